@@ -1,0 +1,49 @@
+# Build everything in-tree:
+#   rust-path-tracer_amd/lib/librpt_hip.so   HIP kernels + C ABI (gfx950, hipcc)
+#   rust-path-tracer_amd/lib/librpt_host.so  host-side dispatch mirror (g++)
+#   oracle/liboracle.so, oracle/liboracle_libm.so   CPU restatement (test infrastructure)
+# -ffp-contract=off everywhere: the parity contract forbids implicit FMA fusion.
+
+PKG      := rust-path-tracer_amd
+LIBDIR   := $(PKG)/lib
+CSRC     := $(PKG)/csrc
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+
+HOST_SRCS := $(CSRC)/host/host_api.cpp $(CSRC)/host/glb_scene.cpp $(CSRC)/host/bvh_build.cpp \
+             $(CSRC)/host/light_table.cpp $(CSRC)/host/bluenoise.cpp
+HIP_SRCS  := $(CSRC)/rpt_hip.hip
+HIP_DEPS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hip) $(wildcard include/rpt/*.h)
+
+CXXFLAGS_COMMON := -std=c++20 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unknown-pragmas
+# -mfma only makes the EXPLICIT __builtin_fma of rpt_math.h a single instruction;
+# implicit contraction stays off.
+ORACLE_FLAGS := $(CXXFLAGS_COMMON) -mfma -msse4.1 -pthread
+HIPFLAGS := --offload-arch=gfx950 -std=c++20 -O3 -fPIC -ffp-contract=off -fno-fast-math \
+            -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero \
+            -Wall -Wno-unused-function
+
+all: host oracle hip
+
+host: $(LIBDIR)/librpt_host.so
+oracle: oracle/liboracle.so oracle/liboracle_libm.so
+hip: $(LIBDIR)/librpt_hip.so
+
+$(LIBDIR)/librpt_host.so: $(HOST_SRCS) $(CSRC)/host/host_internal.h include/rpt/rpt_host.h include/rpt/rpt.h include/rpt/shared_structs.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS_COMMON) -shared -o $@ $(HOST_SRCS) -lz -ldl -pthread
+
+oracle/liboracle.so: oracle/rpt_oracle.cpp $(CSRC)/rpt_math.h $(CSRC)/rpt_math_consts.h include/rpt/shared_structs.h
+	$(CXX) $(ORACLE_FLAGS) -shared -o $@ oracle/rpt_oracle.cpp
+
+oracle/liboracle_libm.so: oracle/rpt_oracle.cpp $(CSRC)/rpt_math.h $(CSRC)/rpt_math_consts.h include/rpt/shared_structs.h
+	$(CXX) $(ORACLE_FLAGS) -DORACLE_USE_LIBM -shared -o $@ oracle/rpt_oracle.cpp -lm
+
+$(LIBDIR)/librpt_hip.so: $(HIP_DEPS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+
+clean:
+	rm -f $(LIBDIR)/*.so oracle/*.so
+
+.PHONY: all host oracle hip clean

@@ -1,0 +1,164 @@
+/*
+ * rpt.h — C ABI of librpt_hip.so, the MI355X (gfx950) wavefront path tracer
+ * that drops in behind the reference's render dispatch.
+ *
+ * Boundary being replaced: `trace_gpu` in the reference, src/trace.rs:136-224,
+ * which today drives one SPIR-V megakernel through gpgpu-rs/wgpu.  Each entry
+ * point below cites the reference call(s) it stands in for.  All functions are
+ * `extern "C"`, take plain pointers and sizes in the `shared_structs` layouts
+ * (include/rpt/shared_structs.h), never throw, never abort, never call exit():
+ * return 0 on success or a negative RPT_E* code, with a message available from
+ * rpt_last_error().
+ *
+ * Ownership: the caller owns every host pointer passed in; the library copies
+ * during the call.  Device memory belongs to the rpt_ctx and is released by
+ * rpt_destroy().  A context is single-caller (the reference uses one render
+ * thread, src/app.rs:157-164); distinct contexts may live on distinct threads.
+ */
+#ifndef RPT_H
+#define RPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "shared_structs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPT_ABI_VERSION 1
+
+enum {
+    RPT_OK = 0,
+    RPT_EINVAL = -1,     /* bad argument / call order                             */
+    RPT_ENODEV = -2,     /* no usable HIP device                                   */
+    RPT_EHIP = -3,       /* a HIP runtime call failed (message has the HIP text)   */
+    RPT_ECONFIG = -4,    /* config the reference itself would panic on (see below) */
+    RPT_ESCENE = -5,     /* scene buffers inconsistent (index out of range, BVH too deep) */
+    RPT_ENOMEM = -6
+};
+
+typedef struct rpt_ctx rpt_ctx;
+
+/* Counters of one context since the last rpt_reset().  Ray counting rule
+ * (SURVEY.md §8d): one extension ray per executed intersect_nearest
+ * (kernels/src/lib.rs:63), one shadow ray per executed intersect_any
+ * (kernels/src/light_pick.rs:141). */
+typedef struct rpt_stats {
+    uint64_t samples;          /* pixel-samples accumulated (W*H*spp on a full image)   */
+    uint64_t extension_rays;
+    uint64_t shadow_rays;
+    uint64_t sky_evals;        /* misses shaded by the procedural / image sky             */
+    uint64_t light_index_clamped; /* gen_r1()==1.0 alias-table overruns clamped (Appendix C) */
+    uint64_t iterations;       /* wavefront iterations executed                           */
+    double   render_ms;        /* wall time of rpt_render calls, host clock               */
+    double   kernel_ms[8];     /* HIP-event time per stage: see RPT_STAGE_*               */
+    uint64_t kernel_launches[8];
+} rpt_stats;
+
+enum {
+    RPT_STAGE_GENERATE = 0,    /* camera rays + accumulate/regenerate */
+    RPT_STAGE_TRAVERSE = 1,    /* nearest-hit BVH traversal           */
+    RPT_STAGE_SHADE = 2,       /* material, BSDF sample, NEE setup    */
+    RPT_STAGE_SHADOW = 3,      /* any-hit traversal + NEE resolve     */
+    RPT_STAGE_SKY = 4,         /* miss shading                        */
+    RPT_STAGE_COUNT = 5
+};
+
+/* Replaces the lazy wgpu framework/adaptor creation, src/trace.rs:3-6,25-38.
+ * device_id is a HIP ordinal. */
+int rpt_create(int device_id, rpt_ctx **out);
+
+/* Multi-GPU tile partition (no reference equivalent: the reference is single
+ * device).  The W x H framebuffer is cut into RPT_TILE x RPT_TILE pixel tiles;
+ * tile t belongs to rank (t mod world_size).  Must be called before
+ * rpt_set_config; default is rank 0 of 1 (whole image). */
+#define RPT_TILE 64
+int rpt_set_partition(rpt_ctx *ctx, uint32_t rank, uint32_t world_size);
+
+/* Replaces World::into_gpu (src/asset.rs:226-235), BVH::into_gpu
+ * (src/bvh.rs:40-43) and the skybox upload (src/trace.rs:144).  Buffers are in
+ * the order the reference binds them (kernels/src/lib.rs:195-202).  atlas and
+ * skybox may be NULL (no textures / procedural sky).  atlas is RGBA8 as in
+ * asset.rs:231 and is sampled with the CPU polyfill's semantics
+ * (shared_structs/src/image_polyfill.rs:38-55; texel = u8/255, alpha = 1,
+ * src/asset.rs:266-273).  skybox is float RGBA, same sampler. */
+int rpt_upload_scene(rpt_ctx *ctx,
+                     const rpt_per_vertex_data *per_vertex, size_t n_vertices,
+                     const rpt_triangle *indices, size_t n_triangles,
+                     const rpt_bvh_node *nodes, size_t n_nodes,
+                     const rpt_material_data *materials, size_t n_materials,
+                     const rpt_light_pick_entry *light_pick, size_t n_light_pick,
+                     const uint8_t *atlas_rgba8, uint32_t atlas_w, uint32_t atlas_h,
+                     const float *skybox_rgba32f, uint32_t sky_w, uint32_t sky_h);
+
+/* Replaces GpuUniformBuffer::from_slice / config_buffer.write
+ * (src/trace.rs:168,219).  Rejects with RPT_ECONFIG what the reference's CPU
+ * path would panic on: more LDS dimensions than the 32-entry table
+ * (kernels/src/rng.rs:20-21), i.e. 2 + max_bounces*(3 + 4*[nee!=0]) +
+ * max(0, max_bounces-1-min_bounces) > 31. Changing width/height invalidates
+ * the accumulator: call rpt_reset afterwards. */
+int rpt_set_config(rpt_ctx *ctx, const rpt_tracing_config *config);
+
+/* Replaces rng_buffer / output_buffer creation and the flush path
+ * (src/trace.rs:164-170, 219-221).  rng_seed has width*height entries, pixel
+ * index y*width + x; accum_init_rgba (nullable) is width*height float4 =
+ * mean * samples for resume (src/trace.rs:163-164), with samples_init the
+ * matching sample count. */
+int rpt_reset(rpt_ctx *ctx, const rpt_rng_state *rng_seed,
+              const float *accum_init_rgba, uint32_t samples_init);
+
+/* Replaces the `for _ in 0..sync_rate { enqueue; poll_blocking }` loop
+ * (src/trace.rs:182-194) — one call renders n_samples more samples for every
+ * pixel of this rank's tiles with no per-sample host round trip.  Per pixel the
+ * effect is exactly n_samples times `output[i] += (radiance, 1); rng[i].x += 1`
+ * (kernels/src/lib.rs:225-226) in sample order. Synchronous on return. */
+int rpt_render(rpt_ctx *ctx, uint32_t n_samples);
+
+/* Replaces output_buffer.read_blocking (src/trace.rs:198).  Writes the SUM
+ * (not the mean) as width*height float4 (r, g, b, sample count) in row-major,
+ * y-down order.  Pixels of tiles owned by other ranks are written as zeros. */
+int rpt_read_accum(rpt_ctx *ctx, float *out_rgba, uint32_t *out_samples);
+
+/* Reads back rng[i] (n, offset) for every pixel (other ranks' pixels: zeros);
+ * lets a caller verify `rng[i].x += 1` semantics (kernels/src/lib.rs:226). */
+int rpt_read_rng(rpt_ctx *ctx, rpt_rng_state *out);
+
+/* --- multi-GPU gather support ---------------------------- */
+/* This rank's accumulators live in ONE contiguous tile-major device block of
+ * rpt_local_pixels() float4 (tiles in ascending tile id, 64x64 row-major
+ * inside a tile, edge tiles clipped).  The caller (one process per GPU) hands
+ * that pointer to its RCCL gather and gives the root the concatenation. */
+int rpt_local_pixels(rpt_ctx *ctx, uint64_t *n_pixels);
+int rpt_local_block_device_ptr(rpt_ctx *ctx, void **dev_ptr);
+/* Pixel count of any rank's block for the current config (for gather sizes). */
+int rpt_rank_pixels(rpt_ctx *ctx, uint32_t rank, uint64_t *n_pixels);
+/* Root side: scatter `world_size` concatenated tile-major blocks (device
+ * memory, sizes rpt_rank_pixels(r)) into a row-major width*height float4 image
+ * in device memory. dev_out_image may be read back with hipMemcpy. */
+int rpt_untile(rpt_ctx *ctx, const void *dev_gathered_blocks, void *dev_out_image);
+
+int rpt_get_stats(rpt_ctx *ctx, rpt_stats *out);
+void rpt_destroy(rpt_ctx *ctx);
+/* ctx may be NULL: returns the last error of a failed rpt_create on this thread. */
+const char *rpt_last_error(rpt_ctx *ctx);
+int rpt_abi_version(void);
+
+/* --- test hooks (not part of the reference boundary) --------------------- */
+/* Evaluate one shared-math function on the DEVICE over n floats so tests can
+ * check bit-equality with the host build of the same header. op: 0 sin, 1 cos,
+ * 2 acos, 3 exp, 4 pow(x,y), 5 asin, 6 atan2(y=x_in, x=y_in), 7 sqrt, 8 div x/y. */
+int rpt_debug_math(rpt_ctx *ctx, int op, const float *x, const float *y, float *out, size_t n);
+/* Same on the HOST build (no device needed, ctx may be NULL). */
+int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size_t n);
+/* Trace n rays through the uploaded BVH on the device. any_hit = 0: nearest
+ * (kernels/src/intersection.rs:169-171) ; 1: any-hit with max_t
+ * (:173-175).  Outputs per ray: t, triangle_index, flags (bit0 hit, bit1 backface). */
+int rpt_debug_trace_rays(rpt_ctx *ctx, int any_hit, size_t n,
+                         const float *origins_xyz, const float *dirs_xyz, const float *max_t,
+                         float *out_t, uint32_t *out_tri, uint32_t *out_flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPT_H */

@@ -1,0 +1,113 @@
+/*
+ * rpt_host.h — C ABI of librpt_host.so: the host side of the render dispatch,
+ * i.e. what sits ABOVE librpt_hip.so and mirrors the reference's own host
+ * interface for this path (names and argument meaning follow the reference).
+ *
+ *   rpt_world_load        <->  World::from_path           src/asset.rs:55-224
+ *   rpt_bvh_build         <->  BVHBuilder::build          src/bvh.rs:59-324
+ *   rpt_light_table_build <->  build_light_pick_table     src/light_pick.rs:24-122
+ *   rpt_blue_noise_seeds  <->  rng_data_blue setup        src/trace.rs:5,149-160
+ *   rpt_tracing_state_*   <->  TracingState               src/trace.rs:40-92
+ *   rpt_setup_trace       <->  setup_trace                src/trace.rs:331-344
+ *   rpt_trace_gpu         <->  trace_gpu                  src/trace.rs:136-224
+ *
+ * The Rust host does not need this library (it already has all of the above
+ * and only needs rpt.h); it exists because this image has no Rust toolchain,
+ * so the host driver is restated in C++ to exercise the C ABI end to end.
+ * Error behaviour follows rpt.h: 0 / negative code, rpt_host_last_error().
+ */
+#ifndef RPT_HOST_H
+#define RPT_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "shared_structs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Borrowed view of a loaded World (src/asset.rs:9-16). Pointers stay valid
+ * until rpt_world_free. atlas is NULL when no material has a texture (the
+ * reference always allocates 4096^2). */
+typedef struct rpt_world_view {
+    const rpt_per_vertex_data *per_vertex; size_t n_vertices;
+    const rpt_triangle *indices; size_t n_triangles;
+    const rpt_bvh_node *nodes; size_t n_nodes;
+    const rpt_material_data *materials; size_t n_materials;
+    const rpt_light_pick_entry *light_pick; size_t n_light_pick;
+    const uint8_t *atlas_rgba8; uint32_t atlas_w, atlas_h;
+    uint32_t bvh_max_depth;       /* root = depth 0 */
+    uint32_t n_emissive_triangles;
+} rpt_world_view;
+
+typedef struct rpt_world rpt_world;
+
+/* World::from_path for glTF-binary (.glb) files: node graph walk with the
+ * reference's (x,z,y) axis swap and (i0,i2,i1) winding (asset.rs:78-128),
+ * materials (135-175), BVH with sah_samples = 128 (196), light pick table on
+ * the reordered indices (201-202), per-vertex packing (206-215).
+ * Returns RPT_HOST_ELOAD when the file cannot be imported (the reference
+ * returns None and trace_gpu silently returns, trace.rs:141-143). */
+int rpt_world_load(const char *path, rpt_world **out);
+/* Build a World from caller-supplied geometry (already in the reference's
+ * post-swap space): runs the same BVH + light-table + packing steps.  Used for
+ * procedural scenes. normals/uvs may be NULL (zero-filled like asset.rs:209-212). */
+int rpt_world_from_buffers(const float *vertices_xyz, const float *normals_xyz, const float *uvs,
+                           size_t n_vertices, const uint32_t *triangles_v0v1v2_mat, size_t n_triangles,
+                           const rpt_material_data *materials, size_t n_materials, rpt_world **out);
+int rpt_world_view_get(const rpt_world *world, rpt_world_view *out);
+void rpt_world_free(rpt_world *world);
+
+/* BVHBuilder::new(vertices, indices).sah_samples(n).build(): reorders
+ * `triangles` in place, writes up to 2*n_triangles-1 nodes, returns the node
+ * count in *n_nodes_out. vertices are Vec4 (xyzw) as in bvh.rs:52. */
+int rpt_bvh_build(const float *vertices_xyzw, size_t n_vertices, rpt_triangle *triangles, size_t n_triangles,
+                  uint32_t sah_samples, rpt_bvh_node *nodes_out, size_t nodes_capacity, size_t *n_nodes_out);
+
+/* compute_emissive_mask + build_light_pick_table (src/light_pick.rs:13-122).
+ * table_out needs capacity >= max(1, n_triangles). */
+int rpt_light_table_build(const float *vertices_xyzw, size_t n_vertices, const rpt_triangle *triangles,
+                          size_t n_triangles, const rpt_material_data *materials, size_t n_materials,
+                          rpt_light_pick_entry *table_out, size_t capacity, size_t *n_entries_out);
+
+/* rng_data_blue (src/trace.rs:150-157): seed(x,y) = (0, u32(f32(b)/255 * 4294967295.0))
+ * with b = 8-bit channel 0 of bluenoise.png at (x % 256, y % 256).
+ * png_path NULL -> fixtures/bluenoise.png next to the library's repo root. */
+int rpt_blue_noise_seeds(const char *png_path, uint32_t width, uint32_t height, rpt_rng_state *out);
+/* The decoded 8-bit blue-noise tile itself (w*h bytes), for KATs. */
+int rpt_blue_noise_tile(const char *png_path, uint8_t *out, size_t capacity, uint32_t *w, uint32_t *h);
+
+/* TracingConfig::default() (shared_structs/src/lib.rs:27-42). */
+void rpt_tracing_config_default(rpt_tracing_config *out);
+
+/* TracingState (src/trace.rs:40-92). Plain struct + functions; `running`,
+ * `samples`, `dirty`, `interacting` may be touched from another thread
+ * (they are accessed with relaxed atomics inside the library). */
+typedef struct rpt_tracing_state rpt_tracing_state;
+rpt_tracing_state *rpt_tracing_state_new(uint32_t width, uint32_t height);   /* TracingState::new */
+void rpt_tracing_state_free(rpt_tracing_state *s);
+rpt_tracing_config *rpt_tracing_state_config(rpt_tracing_state *s);          /* state.config (caller mutates before tracing) */
+const float *rpt_tracing_state_framebuffer(rpt_tracing_state *s, size_t *n_floats); /* W*H*3 mean RGB */
+uint32_t rpt_tracing_state_samples(rpt_tracing_state *s);
+void rpt_tracing_state_set_running(rpt_tracing_state *s, int running);
+void rpt_tracing_state_set_sync_rate(rpt_tracing_state *s, uint32_t sync_rate);
+void rpt_tracing_state_set_dirty(rpt_tracing_state *s, int dirty);
+/* setup_trace(width, height, samples) (src/trace.rs:331-344) — but exact: the
+ * render stops after precisely `samples` samples (the reference's watcher
+ * thread can overshoot). */
+rpt_tracing_state *rpt_setup_trace(uint32_t width, uint32_t height, uint32_t samples);
+
+/* trace_gpu(scene_path, skybox_path, state) (src/trace.rs:136-224) on top of
+ * librpt_hip.so (loaded with dlopen from hip_library_path, or the default
+ * location next to this library when NULL).  device_id selects the GPU. */
+int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_state *state,
+                  int device_id, const char *hip_library_path);
+
+enum { RPT_HOST_ELOAD = -20, RPT_HOST_EPNG = -21, RPT_HOST_EDLOPEN = -22 };
+const char *rpt_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPT_HOST_H */

@@ -1,0 +1,356 @@
+/*
+ * host_api.cpp — C entry points of librpt_host.so: World loading, TracingState,
+ * setup_trace and the trace_gpu render loop driven through the rpt.h C ABI.
+ *
+ * Mirrors (reference): src/trace.rs:40-92 (TracingState), :136-224 (trace_gpu),
+ * :331-344 (setup_trace); src/asset.rs:55-224 (World::from_path);
+ * shared_structs/src/lib.rs:27-42 (TracingConfig::default).
+ */
+#include <dlfcn.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "../../../include/rpt/rpt.h"
+#include "host_internal.h"
+
+namespace rpth {
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+}  // namespace rpth
+
+using namespace rpth;
+
+struct rpt_tracing_state {
+    std::mutex lock;                       /* RwLock<..> stand-in for framebuffer + config */
+    std::vector<float> framebuffer;        /* W*H*3 mean RGB */
+    rpt_tracing_config config;
+    std::atomic<bool> running{false};
+    std::atomic<uint32_t> samples{0};
+    std::atomic<bool> denoise{false};      /* kept for interface parity; OIDN is out of scope */
+    std::atomic<uint32_t> sync_rate{32};
+    std::atomic<bool> use_blue_noise{true};
+    std::atomic<bool> interacting{false};
+    std::atomic<bool> dirty{false};
+    uint32_t target_samples = 0;           /* setup_trace: stop after exactly this many (0 = run until !running) */
+};
+
+extern "C" {
+
+const char *rpt_host_last_error(void) { return g_error.c_str(); }
+
+void rpt_tracing_config_default(rpt_tracing_config *c) {
+    memset(c, 0, sizeof(*c));
+    c->cam_position[0] = 0.0f; c->cam_position[1] = 1.0f; c->cam_position[2] = -5.0f; c->cam_position[3] = 0.0f;
+    c->width = 1280; c->height = 720;
+    c->min_bounces = 3; c->max_bounces = 4;
+    /* Vec3::new(0.5, 1.3, 1.0).normalize().extend(15.0) : v * (1 / sqrt(dot)) */
+    float x = 0.5f, y = 1.3f, z = 1.0f;
+    float inv = 1.0f / std::sqrt((x * x) + (y * y) + (z * z));
+    c->sun_direction[0] = x * inv; c->sun_direction[1] = y * inv; c->sun_direction[2] = z * inv; c->sun_direction[3] = 15.0f;
+    c->nee = 0; c->has_skybox = 0;
+    c->specular_weight_clamp[0] = 0.1f; c->specular_weight_clamp[1] = 0.9f;
+}
+
+/* ------------------------------------------------------------- World ---- */
+int rpt_world_load(const char *path, rpt_world **out) {
+    if (!path || !out) { set_error("null argument"); return RPT_EINVAL; }
+    auto *w = new rpt_world();
+    if (!load_glb(path, w->w)) { delete w; return RPT_HOST_ELOAD; }
+    *out = w;
+    return 0;
+}
+
+int rpt_world_from_buffers(const float *vertices_xyz, const float *normals_xyz, const float *uvs, size_t n_vertices,
+                           const uint32_t *tris, size_t n_triangles, const rpt_material_data *materials,
+                           size_t n_materials, rpt_world **out) {
+    if (!vertices_xyz || !tris || !materials || !out || !n_vertices || !n_triangles || !n_materials) {
+        set_error("null/empty argument");
+        return RPT_EINVAL;
+    }
+    auto *w = new rpt_world();
+    std::vector<Vec4f> vertices(n_vertices), normals, tangents;
+    std::vector<float> uv;
+    for (size_t i = 0; i < n_vertices; ++i) vertices[i] = Vec4f{vertices_xyz[3 * i], vertices_xyz[3 * i + 1], vertices_xyz[3 * i + 2], 1.0f};
+    if (normals_xyz) {
+        normals.resize(n_vertices);
+        for (size_t i = 0; i < n_vertices; ++i) normals[i] = Vec4f{normals_xyz[3 * i], normals_xyz[3 * i + 1], normals_xyz[3 * i + 2], 0.0f};
+    }
+    if (uvs) uv.assign(uvs, uvs + 2 * n_vertices);
+    w->w.indices.resize(n_triangles);
+    for (size_t i = 0; i < n_triangles; ++i) {
+        rpt_triangle t{tris[4 * i], tris[4 * i + 1], tris[4 * i + 2], tris[4 * i + 3]};
+        if (t.v0 >= n_vertices || t.v1 >= n_vertices || t.v2 >= n_vertices || t.material >= n_materials) {
+            delete w;
+            set_error("triangle index out of range");
+            return RPT_ESCENE;
+        }
+        w->w.indices[i] = t;
+    }
+    w->w.materials.assign(materials, materials + n_materials);
+    finish_world(w->w, vertices, normals, tangents, uv);
+    *out = w;
+    return 0;
+}
+
+int rpt_world_view_get(const rpt_world *world, rpt_world_view *v) {
+    if (!world || !v) { set_error("null argument"); return RPT_EINVAL; }
+    const World &w = world->w;
+    v->per_vertex = w.per_vertex.data(); v->n_vertices = w.per_vertex.size();
+    v->indices = w.indices.data(); v->n_triangles = w.indices.size();
+    v->nodes = w.nodes.data(); v->n_nodes = w.nodes.size();
+    v->materials = w.materials.data(); v->n_materials = w.materials.size();
+    v->light_pick = w.light_pick.data(); v->n_light_pick = w.light_pick.size();
+    v->atlas_rgba8 = w.atlas.empty() ? nullptr : w.atlas.data();
+    v->atlas_w = w.atlas_w; v->atlas_h = w.atlas_h;
+    v->bvh_max_depth = w.max_depth;
+    v->n_emissive_triangles = w.n_emissive;
+    return 0;
+}
+
+void rpt_world_free(rpt_world *world) { delete world; }
+
+int rpt_bvh_build(const float *vertices_xyzw, size_t n_vertices, rpt_triangle *triangles, size_t n_triangles,
+                  uint32_t sah_samples, rpt_bvh_node *nodes_out, size_t nodes_capacity, size_t *n_nodes_out) {
+    if (!vertices_xyzw || !triangles || !nodes_out || !n_nodes_out || !n_triangles) { set_error("null/empty argument"); return RPT_EINVAL; }
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].v0 >= n_vertices || triangles[i].v1 >= n_vertices || triangles[i].v2 >= n_vertices) {
+            set_error("triangle index out of range");
+            return RPT_ESCENE;
+        }
+    std::vector<rpt_bvh_node> nodes;
+    size_t n = bvh_build(reinterpret_cast<const Vec4f *>(vertices_xyzw), triangles, n_triangles, sah_samples, nodes);
+    if (n > nodes_capacity) { set_error("node buffer too small"); return RPT_EINVAL; }
+    memcpy(nodes_out, nodes.data(), n * sizeof(rpt_bvh_node));
+    *n_nodes_out = n;
+    return 0;
+}
+
+int rpt_light_table_build(const float *vertices_xyzw, size_t n_vertices, const rpt_triangle *triangles,
+                          size_t n_triangles, const rpt_material_data *materials, size_t n_materials,
+                          rpt_light_pick_entry *table_out, size_t capacity, size_t *n_entries_out) {
+    if (!vertices_xyzw || !triangles || !materials || !table_out || !n_entries_out) { set_error("null argument"); return RPT_EINVAL; }
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].v0 >= n_vertices || triangles[i].v1 >= n_vertices || triangles[i].v2 >= n_vertices ||
+            triangles[i].material >= n_materials) {
+            set_error("triangle index out of range");
+            return RPT_ESCENE;
+        }
+    auto table = build_light_pick_table(reinterpret_cast<const Vec4f *>(vertices_xyzw), triangles, n_triangles, materials, nullptr);
+    if (table.size() > capacity) { set_error("table buffer too small"); return RPT_EINVAL; }
+    memcpy(table_out, table.data(), table.size() * sizeof(rpt_light_pick_entry));
+    *n_entries_out = table.size();
+    return 0;
+}
+
+/* ----------------------------------------------------------- seeds ------ */
+int rpt_blue_noise_tile(const char *png_path, uint8_t *out, size_t capacity, uint32_t *w, uint32_t *h) {
+    std::vector<uint8_t> tile;
+    uint32_t tw, th;
+    std::string p = png_path ? std::string(png_path) : default_fixture_path("bluenoise.png");
+    if (!load_blue_noise(p.c_str(), tile, tw, th)) return RPT_HOST_EPNG;
+    if (w) *w = tw;
+    if (h) *h = th;
+    if (out) {
+        if (capacity < tile.size()) { set_error("tile buffer too small"); return RPT_EINVAL; }
+        memcpy(out, tile.data(), tile.size());
+    }
+    return 0;
+}
+
+int rpt_blue_noise_seeds(const char *png_path, uint32_t width, uint32_t height, rpt_rng_state *out) {
+    if (!out) { set_error("null argument"); return RPT_EINVAL; }
+    std::vector<uint8_t> tile;
+    uint32_t tw, th;
+    std::string p = png_path ? std::string(png_path) : default_fixture_path("bluenoise.png");
+    if (!load_blue_noise(p.c_str(), tile, tw, th)) return RPT_HOST_EPNG;
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) {
+            float pixel = (float)tile[(size_t)(y % th) * tw + (x % tw)] / 255.0f;
+            float scaled = pixel * 4294967295.0f;             /* literal rounds to 2^32 in f32 */
+            uint32_t seed = !(scaled > 0.0f) ? 0u : (scaled >= 4294967296.0f ? 0xffffffffu : (uint32_t)scaled);   /* `as u32` */
+            out[(size_t)y * width + x] = rpt_rng_state{0u, seed};
+        }
+    return 0;
+}
+
+/* ---------------------------------------------------- TracingState ------ */
+rpt_tracing_state *rpt_tracing_state_new(uint32_t width, uint32_t height) {
+    auto *s = new rpt_tracing_state();
+    rpt_tracing_config_default(&s->config);
+    s->config.width = width;
+    s->config.height = height;
+    s->framebuffer.assign((size_t)width * height * 3, 0.0f);
+    return s;
+}
+void rpt_tracing_state_free(rpt_tracing_state *s) { delete s; }
+rpt_tracing_config *rpt_tracing_state_config(rpt_tracing_state *s) { return &s->config; }
+const float *rpt_tracing_state_framebuffer(rpt_tracing_state *s, size_t *n) {
+    if (n) *n = s->framebuffer.size();
+    return s->framebuffer.data();
+}
+uint32_t rpt_tracing_state_samples(rpt_tracing_state *s) { return s->samples.load(std::memory_order_relaxed); }
+void rpt_tracing_state_set_running(rpt_tracing_state *s, int r) { s->running.store(r != 0, std::memory_order_relaxed); }
+void rpt_tracing_state_set_sync_rate(rpt_tracing_state *s, uint32_t r) { s->sync_rate.store(r ? r : 1, std::memory_order_relaxed); }
+void rpt_tracing_state_set_dirty(rpt_tracing_state *s, int d) { s->dirty.store(d != 0, std::memory_order_relaxed); }
+
+rpt_tracing_state *rpt_setup_trace(uint32_t width, uint32_t height, uint32_t samples) {
+    rpt_tracing_state *s = rpt_tracing_state_new(width, height);
+    s->running.store(true, std::memory_order_relaxed);
+    s->target_samples = samples;
+    if (samples == 0) s->running.store(false, std::memory_order_relaxed);   /* "Startup time" benches: 0 samples */
+    return s;
+}
+
+}  // extern "C"
+
+/* ------------------------------------------------------- trace_gpu ------ */
+namespace {
+struct HipApi {
+    void *handle = nullptr;
+    decltype(&rpt_create) create;
+    decltype(&rpt_upload_scene) upload_scene;
+    decltype(&rpt_set_config) set_config;
+    decltype(&rpt_reset) reset;
+    decltype(&rpt_render) render;
+    decltype(&rpt_read_accum) read_accum;
+    decltype(&rpt_destroy) destroy;
+    decltype(&rpt_last_error) last_error;
+};
+template <typename T> bool sym(void *h, const char *name, T &fn) {
+    fn = reinterpret_cast<T>(dlsym(h, name));
+    if (!fn) set_error(std::string("missing symbol ") + name);
+    return fn != nullptr;
+}
+bool load_hip_api(const char *path, HipApi &api) {
+    std::string p;
+    if (path) {
+        p = path;
+    } else {
+        Dl_info info;
+        p = "librpt_hip.so";
+        if (dladdr((void *)&load_hip_api, &info) && info.dli_fname) {
+            std::string self(info.dli_fname);
+            size_t s = self.find_last_of('/');
+            if (s != std::string::npos) p = self.substr(0, s) + "/librpt_hip.so";
+        }
+    }
+    api.handle = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!api.handle) { set_error(std::string("dlopen failed: ") + dlerror()); return false; }
+    return sym(api.handle, "rpt_create", api.create) && sym(api.handle, "rpt_upload_scene", api.upload_scene) &&
+           sym(api.handle, "rpt_set_config", api.set_config) && sym(api.handle, "rpt_reset", api.reset) &&
+           sym(api.handle, "rpt_render", api.render) && sym(api.handle, "rpt_read_accum", api.read_accum) &&
+           sym(api.handle, "rpt_destroy", api.destroy) && sym(api.handle, "rpt_last_error", api.last_error);
+}
+}  // namespace
+
+extern "C" {
+
+int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_state *state, int device_id,
+                  const char *hip_library_path) {
+    if (!scene_path || !state) { set_error("null argument"); return RPT_EINVAL; }
+    if (skybox_path) { set_error("image skyboxes are passed through rpt_upload_scene; file loading is out of scope"); return RPT_EINVAL; }
+
+    rpt_world *world = nullptr;
+    int rc = rpt_world_load(scene_path, &world);
+    if (rc) return rc;                                   /* reference: silent return (trace.rs:141-143) */
+
+    HipApi api;
+    if (!load_hip_api(hip_library_path, api)) { rpt_world_free(world); return RPT_HOST_EDLOPEN; }
+
+    rpt_tracing_config config;
+    { std::lock_guard<std::mutex> g(state->lock); config = state->config; }
+    const uint32_t W = config.width, H = config.height;
+    const size_t pixel_count = (size_t)W * H;
+
+    /* seeds (trace.rs:149-160). Uniform mode uses thread_rng() in the reference
+     * (non-deterministic); here a fixed SplitMix64 stream so runs are repeatable. */
+    std::vector<rpt_rng_state> rng_blue(pixel_count), rng_uniform(pixel_count);
+    if (rpt_blue_noise_seeds(nullptr, W, H, rng_blue.data())) { rpt_world_free(world); dlclose(api.handle); return RPT_HOST_EPNG; }
+    uint64_t sm = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < pixel_count; ++i) {
+        uint64_t z = (sm += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        rng_uniform[i] = rpt_rng_state{(uint32_t)((z ^ (z >> 31)) >> 32), 0u};
+    }
+    auto seeds = [&]() { return state->use_blue_noise.load(std::memory_order_relaxed) ? rng_blue.data() : rng_uniform.data(); };
+
+    /* restore previous state (trace.rs:163-164) */
+    uint32_t samples_init = state->samples.load(std::memory_order_relaxed);
+    std::vector<float> accum_init(pixel_count * 4);
+    {
+        std::lock_guard<std::mutex> g(state->lock);
+        float si = (float)samples_init;
+        for (size_t i = 0; i < pixel_count; ++i) {
+            accum_init[4 * i + 0] = state->framebuffer[3 * i + 0] * si;
+            accum_init[4 * i + 1] = state->framebuffer[3 * i + 1] * si;
+            accum_init[4 * i + 2] = state->framebuffer[3 * i + 2] * si;
+            accum_init[4 * i + 3] = 1.0f * si;
+        }
+    }
+
+    rpt_ctx *ctx = nullptr;
+    auto fail = [&](int code) {
+        set_error(std::string("librpt_hip: ") + api.last_error(ctx));
+        if (ctx) api.destroy(ctx);
+        rpt_world_free(world);
+        dlclose(api.handle);
+        return code;
+    };
+    if ((rc = api.create(device_id, &ctx))) return fail(rc);
+    rpt_world_view v;
+    rpt_world_view_get(world, &v);
+    if ((rc = api.upload_scene(ctx, v.per_vertex, v.n_vertices, v.indices, v.n_triangles, v.nodes, v.n_nodes, v.materials,
+                               v.n_materials, v.light_pick, v.n_light_pick, v.atlas_rgba8, v.atlas_w, v.atlas_h, nullptr, 0, 0)))
+        return fail(rc);
+    if ((rc = api.set_config(ctx, &config))) return fail(rc);
+    if ((rc = api.reset(ctx, seeds(), accum_init.data(), samples_init))) return fail(rc);
+
+    std::vector<float> image_raw(pixel_count * 4), image(pixel_count * 3);
+    while (state->running.load(std::memory_order_relaxed)) {
+        uint32_t n = state->sync_rate.load(std::memory_order_relaxed);
+        if (state->target_samples) {
+            uint32_t done = state->samples.load(std::memory_order_relaxed);
+            uint32_t left = state->target_samples > done ? state->target_samples - done : 0;
+            if (n > left) n = left;
+        }
+        /* the reference polls `interacting | dirty` after every sample
+         * (trace.rs:187); one rpt_render call covers the whole batch, so the
+         * poll happens once per batch */
+        bool flush = state->interacting.load(std::memory_order_relaxed) || state->dirty.load(std::memory_order_relaxed);
+        if (n) {
+            if ((rc = api.render(ctx, n))) return fail(rc);
+            state->samples.fetch_add(n, std::memory_order_relaxed);
+        }
+        uint32_t device_samples = 0;
+        if ((rc = api.read_accum(ctx, image_raw.data(), &device_samples))) return fail(rc);
+        float sample_count = (float)state->samples.load(std::memory_order_relaxed);
+        for (size_t i = 0; i < pixel_count; ++i) {
+            image[3 * i + 0] = image_raw[4 * i + 0] / sample_count;
+            image[3 * i + 1] = image_raw[4 * i + 1] / sample_count;
+            image[3 * i + 2] = image_raw[4 * i + 2] / sample_count;
+        }
+        {
+            std::lock_guard<std::mutex> g(state->lock);
+            state->framebuffer = image;
+        }
+        if (flush) {
+            state->dirty.store(false, std::memory_order_relaxed);
+            state->samples.store(0, std::memory_order_relaxed);
+            { std::lock_guard<std::mutex> g(state->lock); config = state->config; }
+            if ((rc = api.set_config(ctx, &config))) return fail(rc);
+            if ((rc = api.reset(ctx, seeds(), nullptr, 0))) return fail(rc);
+        }
+        if (state->target_samples && state->samples.load(std::memory_order_relaxed) >= state->target_samples)
+            state->running.store(false, std::memory_order_relaxed);
+    }
+    api.destroy(ctx);
+    rpt_world_free(world);
+    dlclose(api.handle);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+/* Internal declarations shared by the librpt_host.so translation units. */
+#ifndef RPT_HOST_INTERNAL_H
+#define RPT_HOST_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/rpt/rpt_host.h"
+
+namespace rpth {
+
+struct Vec4f { float x, y, z, w; };
+
+void set_error(const std::string &msg);
+
+/* src/bvh.rs */
+size_t bvh_build(const Vec4f *vertices, rpt_triangle *triangles, size_t n_triangles, uint32_t sah_samples,
+                 std::vector<rpt_bvh_node> &nodes);
+uint32_t bvh_max_depth(const std::vector<rpt_bvh_node> &nodes);
+
+/* src/light_pick.rs */
+std::vector<rpt_light_pick_entry> build_light_pick_table(const Vec4f *vertices, const rpt_triangle *triangles,
+                                                         size_t n_triangles, const rpt_material_data *materials,
+                                                         uint32_t *n_emissive);
+
+/* bluenoise.png -> 8-bit tile */
+bool load_blue_noise(const char *path, std::vector<uint8_t> &tile, uint32_t &w, uint32_t &h);
+std::string default_fixture_path(const char *name);
+
+struct World {
+    std::vector<rpt_per_vertex_data> per_vertex;
+    std::vector<rpt_triangle> indices;
+    std::vector<rpt_bvh_node> nodes;
+    std::vector<rpt_material_data> materials;
+    std::vector<rpt_light_pick_entry> light_pick;
+    std::vector<uint8_t> atlas;
+    uint32_t atlas_w = 0, atlas_h = 0;
+    uint32_t max_depth = 0, n_emissive = 0;
+};
+
+/* shared tail of World::from_path (src/asset.rs:194-223) */
+void finish_world(World &w, std::vector<Vec4f> &vertices, std::vector<Vec4f> &normals, std::vector<Vec4f> &tangents,
+                  std::vector<float> &uvs);
+
+bool load_glb(const char *path, World &out);
+
+}  // namespace rpth
+
+struct rpt_world { rpth::World w; };
+
+#endif

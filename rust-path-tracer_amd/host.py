@@ -1,0 +1,189 @@
+"""Python face of librpt_host.so — the host side of the render dispatch.
+
+Names follow the reference's host interface for this path:
+  World.from_path          <-> World::from_path      (reference: src/asset.rs:55-224)
+  blue_noise_seeds         <-> rng_data_blue          (reference: src/trace.rs:150-157)
+  TracingConfig defaults   <-> TracingConfig::default (reference: shared_structs/src/lib.rs:27-42)
+  setup_trace / trace_gpu  <-> setup_trace / trace_gpu (reference: src/trace.rs:331-344, 136-224)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (BVH_NODE_DTYPE, LIGHT_PICK_DTYPE, MATERIAL_DTYPE, PER_VERTEX_DTYPE, RNG_DTYPE, TRIANGLE_DTYPE,
+                   TracingConfig, WorldView, ptr)
+
+_lib = None
+
+
+def lib():
+    """Load librpt_host.so (built in-tree by `make host` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        path = os.path.join(_ffi.LIB_DIR, "librpt_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make host` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        L.rpt_host_last_error.restype = C.c_char_p
+        L.rpt_tracing_state_new.restype = C.c_void_p
+        L.rpt_setup_trace.restype = C.c_void_p
+        L.rpt_tracing_state_config.restype = C.POINTER(TracingConfig)
+        L.rpt_tracing_state_config.argtypes = [C.c_void_p]
+        L.rpt_tracing_state_framebuffer.restype = C.POINTER(C.c_float)
+        L.rpt_tracing_state_framebuffer.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.rpt_tracing_state_samples.restype = C.c_uint32
+        L.rpt_tracing_state_samples.argtypes = [C.c_void_p]
+        L.rpt_tracing_state_free.argtypes = [C.c_void_p]
+        L.rpt_tracing_state_set_sync_rate.argtypes = [C.c_void_p, C.c_uint32]
+        L.rpt_trace_gpu.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_char_p]
+        L.rpt_world_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.rpt_world_view_get.argtypes = [C.c_void_p, C.POINTER(WorldView)]
+        L.rpt_world_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise HostError(f"librpt_host error {rc}: {lib().rpt_host_last_error().decode()}")
+
+
+def default_config(width=1280, height=720, **overrides):
+    """TracingConfig::default() with width/height set (TracingState::make_view_dependent_state)."""
+    c = TracingConfig()
+    lib().rpt_tracing_config_default(C.byref(c))
+    c.width, c.height = width, height
+    for k, v in overrides.items():
+        if isinstance(v, (tuple, list)):
+            for i, x in enumerate(v):
+                getattr(c, k)[i] = x
+        else:
+            setattr(c, k, v)
+    return c
+
+
+def _view_array(addr, count, dtype):
+    if not addr or count == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (count * dtype.itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+class World:
+    """The five POD buffers (+ optional atlas) the kernels consume (reference: src/asset.rs:9-16)."""
+
+    def __init__(self, per_vertex, indices, nodes, materials, light_pick, atlas=None, bvh_max_depth=0,
+                 n_emissive_triangles=0):
+        self.per_vertex = np.ascontiguousarray(per_vertex, PER_VERTEX_DTYPE)
+        self.indices = np.ascontiguousarray(indices, TRIANGLE_DTYPE)
+        self.nodes = np.ascontiguousarray(nodes, BVH_NODE_DTYPE)
+        self.materials = np.ascontiguousarray(materials, MATERIAL_DTYPE)
+        self.light_pick = np.ascontiguousarray(light_pick, LIGHT_PICK_DTYPE)
+        self.atlas = atlas  # HxWx4 uint8 or None
+        self.bvh_max_depth = bvh_max_depth
+        self.n_emissive_triangles = n_emissive_triangles
+
+    @classmethod
+    def _from_handle(cls, handle):
+        v = WorldView()
+        _check(lib().rpt_world_view_get(handle, C.byref(v)))
+        atlas = None
+        if v.atlas_rgba8:
+            atlas = _view_array(v.atlas_rgba8, v.atlas_w * v.atlas_h * 4, np.dtype("u1")).reshape(v.atlas_h, v.atlas_w, 4)
+        w = cls(_view_array(v.per_vertex, v.n_vertices, PER_VERTEX_DTYPE),
+                _view_array(v.indices, v.n_triangles, TRIANGLE_DTYPE),
+                _view_array(v.nodes, v.n_nodes, BVH_NODE_DTYPE),
+                _view_array(v.materials, v.n_materials, MATERIAL_DTYPE),
+                _view_array(v.light_pick, v.n_light_pick, LIGHT_PICK_DTYPE),
+                atlas, v.bvh_max_depth, v.n_emissive_triangles)
+        lib().rpt_world_free(handle)
+        return w
+
+    @classmethod
+    def from_path(cls, path):
+        h = C.c_void_p()
+        _check(lib().rpt_world_load(os.fsencode(path), C.byref(h)))
+        return cls._from_handle(h)
+
+    @classmethod
+    def from_buffers(cls, vertices, normals, uvs, triangles, materials):
+        """Procedural scenes: run the reference's BVH / light-table / packing steps on raw geometry."""
+        vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        normals = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        uvs = None if uvs is None else np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
+        triangles = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 4)
+        materials = np.ascontiguousarray(materials, MATERIAL_DTYPE)
+        h = C.c_void_p()
+        _check(lib().rpt_world_from_buffers(ptr(vertices), ptr(normals), ptr(uvs), C.c_size_t(len(vertices)),
+                                            ptr(triangles), C.c_size_t(len(triangles)), ptr(materials),
+                                            C.c_size_t(len(materials)), C.byref(h)))
+        return cls._from_handle(h)
+
+
+def fixture(name):
+    return os.path.join(_ffi.FIXTURES, name)
+
+
+def blue_noise_tile(png_path=None):
+    out = np.zeros(256 * 256, np.uint8)
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib().rpt_blue_noise_tile(os.fsencode(png_path or fixture("bluenoise.png")), ptr(out), C.c_size_t(out.size),
+                                     C.byref(w), C.byref(h)))
+    return out[: w.value * h.value].reshape(h.value, w.value)
+
+
+def blue_noise_seeds(width, height, png_path=None):
+    """rng[i] = (0, seed(x % 256, y % 256)) as a (H*W,) RNG_DTYPE array (reference: src/trace.rs:150-157)."""
+    out = np.zeros(width * height, RNG_DTYPE)
+    _check(lib().rpt_blue_noise_seeds(os.fsencode(png_path or fixture("bluenoise.png")), C.c_uint32(width),
+                                      C.c_uint32(height), ptr(out)))
+    return out
+
+
+class TracingState:
+    """TracingState handle (reference: src/trace.rs:40-92) created by setup_trace."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @property
+    def config(self):
+        return lib().rpt_tracing_state_config(self._h).contents
+
+    @property
+    def samples(self):
+        return lib().rpt_tracing_state_samples(self._h)
+
+    def framebuffer(self):
+        n = C.c_size_t()
+        p = lib().rpt_tracing_state_framebuffer(self._h, C.byref(n))
+        cfg = self.config
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy().reshape(cfg.height, cfg.width, 3)
+
+    def set_sync_rate(self, n):
+        lib().rpt_tracing_state_set_sync_rate(self._h, C.c_uint32(n))
+
+    def close(self):
+        if self._h:
+            lib().rpt_tracing_state_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def setup_trace(width, height, samples):
+    """setup_trace(width, height, samples) (reference: src/trace.rs:331-344), exact sample count."""
+    return TracingState(C.c_void_p(lib().rpt_setup_trace(C.c_uint32(width), C.c_uint32(height), C.c_uint32(samples))))
+
+
+def trace_gpu(scene_path, skybox_path, state, device_id=0):
+    """trace_gpu(scene_path, skybox_path, state) (reference: src/trace.rs:136-224) on librpt_hip.so."""
+    _check(lib().rpt_trace_gpu(os.fsencode(scene_path), None if skybox_path is None else os.fsencode(skybox_path),
+                               state._h, device_id, None))
