@@ -126,9 +126,16 @@ int rpt_read_rng(rpt_ctx *ctx, rpt_rng_state *out);
 
 /* --- multi-GPU gather support ---------------------------- */
 /* This rank's accumulators live in ONE contiguous tile-major device block of
- * rpt_local_pixels() float4 (tiles in ascending tile id, 64x64 row-major
- * inside a tile, edge tiles clipped).  The caller (one process per GPU) hands
- * that pointer to its RCCL gather and gives the root the concatenation. */
+ * rpt_local_pixels() float4: tiles in ascending tile id; inside a tile 8x8
+ * pixel blocks row-major, pixels row-major inside a block; pixels outside the
+ * image skipped (rpt_tile_order gives the exact order).  The caller (one
+ * process per GPU) hands that pointer to its RCCL gather and gives the root
+ * the concatenation. */
+/* Pure function, no context / GPU needed: writes the (x | y << 16) pixel
+ * coordinates of rank's block, in block order, into out_xy (capacity entries)
+ * and the count into *n. out_xy may be NULL to query the count. */
+int rpt_tile_order(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size,
+                   uint32_t *out_xy, size_t capacity, size_t *n);
 int rpt_local_pixels(rpt_ctx *ctx, uint64_t *n_pixels);
 int rpt_local_block_device_ptr(rpt_ctx *ctx, void **dev_ptr);
 /* Pixel count of any rank's block for the current config (for gather sizes). */

@@ -1,0 +1,146 @@
+/*
+ * k_common.h — device-side data layout of the wavefront path tracer.
+ *
+ * One "slot" per pixel owned by this GPU.  A slot carries one path at a time
+ * (sample s of its pixel must finish before sample s+1 starts, so the f32
+ * accumulation order per pixel equals the reference's sample order,
+ * kernels/src/lib.rs:225 / src/trace.rs:295).  All per-slot state is SoA in
+ * 16-byte records so a wave reads 1 KiB per load instruction.
+ *
+ * Queues hold slot ids; they are filled with wave64 ballot + mbcnt prefix
+ * compaction and one atomic per wave (wave_push below).
+ */
+#ifndef RPT_K_COMMON_H
+#define RPT_K_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rpt/shared_structs.h"
+#include "rpt_math.h"
+
+#define RPT_WAVE 64
+#define RPT_BLOCK 256
+
+/* ---- glam-order float3 helpers (device side) ----------------------------- */
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 f3s(float s) { return F3{s, s, s}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return F3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ F3 operator/(F3 a, float s) { return F3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+/* Vec3::dot = (x*x' + y*y') + z*z' ; cross, length, normalize = v * (1/len) */
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) {
+    return F3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+__device__ __forceinline__ float len3(F3 a) { return rptm::sqrtr(dot3(a, a)); }
+__device__ __forceinline__ F3 norm3(F3 a) { return a * (1.0f / len3(a)); }
+__device__ __forceinline__ F3 lerp3(F3 a, F3 b, float s) { return a + ((b - a) * s); }
+__device__ __forceinline__ bool finite3(F3 a) { return rptm::finiter(a.x) && rptm::finiter(a.y) && rptm::finiter(a.z); }
+__device__ __forceinline__ F3 mask_nan3(F3 a) { return finite3(a) ? a : f3s(0.0f); }   /* util.rs:271-277 */
+__device__ __forceinline__ F3 xyz4(float4 v) { return F3{v.x, v.y, v.z}; }
+
+/* ---- scene (read-only) ---------------------------------------------------- */
+struct DevImage {
+    const void *texels;    /* uchar4 (atlas) or float4 (skybox) */
+    uint32_t width, height;
+};
+
+struct DevScene {
+    const float4 *nodes;           /* 2 x float4 per rpt_bvh_node, reference layout */
+    const float4 *tri_geom;        /* 3 x float4 per triangle: (a, e1 = b-a, e2 = c-a), .w unused */
+    const uint4 *indices;          /* rpt_triangle */
+    const float4 *per_vertex;      /* 4 x float4 per rpt_per_vertex_data */
+    const float4 *materials;       /* 6 x float4 per rpt_material_data */
+    const rpt_light_pick_entry *light_pick;
+    uint32_t n_light_pick;
+    uint32_t no_lights;            /* light_pick[0].ratio < 0 */
+    DevImage atlas, skybox;
+};
+
+/* ---- per-slot path state (SoA of float4 records) -------------------------- */
+struct DevState {
+    float4 *ray_a;        /* (ox, oy, oz, dx) */
+    float4 *ray_b;        /* (dy, dz, hit_t, hit_tri bits: bit31 backface, 0xffffffff miss) */
+    float4 *thr_rad;      /* (thr.r, thr.g, thr.b, rad.r) */
+    float4 *rad_misc;     /* (rad.g, rad.b, flags bits, todo bits) */
+    float4 *mis0;         /* (light_area, ln.x, ln.y, ln.z)            nee == MIS only */
+    float4 *mis1;         /* (pick_pdf, em.r, em.g, em.b)                                */
+    float4 *mis2;         /* (light_tri bits, thr_pre.r, thr_pre.g, thr_pre.b)           */
+    float4 *mis3;         /* (bsdf_pdf, spec.r, spec.g, spec.b)                          */
+    uint2 *rng;           /* (n, offset) per pixel, reference rng buffer */
+    float4 *accum;        /* (sum r, sum g, sum b, sum 1), tile-major == slot order */
+    const uint32_t *pixel_xy;   /* x | y << 16 */
+    uint32_t n_slots;
+};
+
+/* flags word: bits 0-7 bounce, bit 8 last sampled lobe (1 = specular), bits 16-21 LDS dimension */
+#define FLAG_BOUNCE(f) ((f) & 0xffu)
+#define FLAG_LOBE_SPEC(f) (((f) >> 8) & 1u)
+#define FLAG_DIM(f) (((f) >> 16) & 0x3fu)
+#define MAKE_FLAGS(bounce, spec, dim) (((bounce) & 0xffu) | ((uint32_t)(spec) << 8) | ((uint32_t)(dim) << 16))
+#define HIT_MISS 0xffffffffu
+
+/* ---- queues ---------------------------------------------------------------- */
+enum { Q_EXT0 = 0, Q_EXT1 = 1, Q_SHADOW = 2, Q_SKY = 3, Q_FIN = 4, Q_COUNT = 8 };
+
+struct DevQueues {
+    uint32_t *ext[2];
+    uint32_t *sky;
+    uint32_t *fin;
+    float4 *sh_o;      /* shadow ray (ox, oy, oz, max_t), indexed by shadow-queue position */
+    float4 *sh_d;      /* (dx, dy, dz, slot bits | bit31 = path ends after this NEE) */
+    float4 *sh_c;      /* (contribution r, g, b if unoccluded, unused) */
+    uint32_t *count;   /* Q_COUNT counters */
+};
+
+struct DevStats {
+    unsigned long long extension_rays, shadow_rays, sky_evals, light_index_clamped, samples;
+};
+
+/* per-render constants derived from TracingConfig on the host */
+struct DevConfig {
+    rpt_tracing_config c;
+    float euler[9];        /* column-major RotY(cam_rotation.y) * RotX(cam_rotation.x) (kernels/src/lib.rs:50) */
+    float sky_rot[9];      /* RotY(atan2(sun.z, sun.x)) for the image skybox (lib.rs:72-73) */
+    uint32_t nee_mode;     /* NextEventEstimation::from_u32 */
+};
+
+/* wave64 ballot + prefix compaction: every lane calls it (converged); lanes with
+ * pred get a dense index in the queue, one atomic per wave. */
+__device__ __forceinline__ uint32_t wave_push(uint32_t *counter, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    uint32_t lane = __lane_id();
+    uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, (int)leader, RPT_WAVE);
+    uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    return base + prefix;
+}
+
+/* ---- stateless LDS sequence (kernels/src/rng.rs:20-32) --------------------- */
+__device__ __constant__ uint32_t c_lds_primes[32] = {
+    0x6a09e667u, 0xbb67ae84u, 0x3c6ef372u, 0xa54ff539u, 0x510e527fu, 0x9b05688au, 0x1f83d9abu, 0x5be0cd18u,
+    0xcbbb9d5cu, 0x629a2929u, 0x91590159u, 0x452fecd8u, 0x67332667u, 0x8eb44a86u, 0xdb0c2e0bu, 0x47b5481du,
+    0xae5f9155u, 0xcf6c85d1u, 0x2f73477du, 0x6d1826cau, 0x8b43d455u, 0xe360b595u, 0x1c456002u, 0x6f196330u,
+    0xd94ebeafu, 0x9cc4a611u, 0x261dc1f2u, 0x5815a7bdu, 0x70b7ed67u, 0xa1513c68u, 0x44f93634u, 0x720dcdfcu};
+
+struct Rng {
+    uint32_t key;     /* n + offset (wrapping) */
+    uint32_t dim;
+    __device__ __forceinline__ float next() {
+        dim += 1u;
+        uint32_t v = c_lds_primes[dim & 31u] * key;
+        return (float)v * (1.0f / 4294967296.0f);
+    }
+};
+
+#endif /* RPT_K_COMMON_H */

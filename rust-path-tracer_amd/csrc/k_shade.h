@@ -1,0 +1,438 @@
+/*
+ * k_shade.h — surface stage of the wavefront pipeline: material fetch, emissive
+ * rules, vertex interpolation, PBR (Lambert + GGX) BSDF sampling, next-event
+ * estimation set-up, throughput / ray update and Russian roulette.
+ *
+ * Reference semantics reproduced (bit-exact f32 operation order):
+ *   hit handling sequence            kernels/src/lib.rs:80-181
+ *   barycentric / interpolation      kernels/src/util.rs:238-251, lib.rs:112-129
+ *   normal map                       lib.rs:132-141
+ *   get_pbr_bsdf / PBR::sample       kernels/src/bsdf.rs:354-387, 272-334
+ *   PBR::evaluate / pdf (NEE side)   bsdf.rs:237-270, 336-351
+ *   sample_direct_lighting           kernels/src/light_pick.rs:100-173
+ *   calculate_bsdf_mis_contribution  light_pick.rs:179-199
+ *   CPU image sampler                shared_structs/src/image_polyfill.rs:32-55
+ *
+ * Wavefront-specific structure: the shadow ray of light_pick.rs:141 is NOT traced
+ * here.  The stage computes the contribution the light sample WOULD add if it
+ * is unoccluded (everything in light_pick.rs:148-160 except the visibility
+ * test depends only on data available here) and emits {ray, max_t,
+ * contribution, slot} into the shadow queue; k_traverse_shadow adds it to the
+ * path's radiance when the any-hit traversal finds nothing — before the next
+ * bounce is shaded, which preserves the reference's f32 summation order of
+ * `radiance` (lib.rs:98,106,164).
+ */
+#ifndef RPT_K_SHADE_H
+#define RPT_K_SHADE_H
+
+#include "k_common.h"
+
+#define RPT_PI_F 3.14159265358979323846f
+#define RPT_EPS 0.001f   /* util.rs:5 */
+
+/* ---- CPU-polyfill image sampling ------------------------------------------ */
+template <bool IS_U8>
+__device__ __forceinline__ float4 image_texel(const DevImage &img, int32_t cx, int32_t cy) {
+    /* `coord.x as usize % width as usize`: i32 sign-extends to 64 bits first */
+    uint64_t x = (uint64_t)(int64_t)cx % (uint64_t)img.width;
+    uint64_t y = (uint64_t)(int64_t)cy % (uint64_t)img.height;
+    uint64_t at = y * (uint64_t)img.width + x;
+    if (IS_U8) {
+        /* Vec4(r, g, b, 255) / 255.0 (src/asset.rs:270) */
+        uchar4 t = reinterpret_cast<const uchar4 *>(img.texels)[at];
+        return make_float4((float)t.x / 255.0f, (float)t.y / 255.0f, (float)t.z / 255.0f, 255.0f / 255.0f);
+    }
+    return reinterpret_cast<const float4 *>(img.texels)[at];
+}
+__device__ __forceinline__ float4 lerp4(float4 a, float4 b, float s) {
+    return make_float4(a.x + ((b.x - a.x) * s), a.y + ((b.y - a.y) * s), a.z + ((b.z - a.z) * s), a.w + ((b.w - a.w) * s));
+}
+template <bool IS_U8>
+__device__ __forceinline__ float4 sample_by_lod(const DevImage &img, float u, float v) {
+    float sx = u * (float)img.width, sy = v * (float)img.height;
+    float fx = rptm::floorr(sx), fy = rptm::floorr(sy);
+    float tx = sx - fx, ty = sy - fy;
+    int32_t ix0 = rptm::f2i32_sat(fx), iy0 = rptm::f2i32_sat(fy);
+    int32_t ix1 = rptm::f2i32_sat(rptm::ceilr(sx)), iy1 = rptm::f2i32_sat(rptm::ceilr(sy));
+    float4 c00 = image_texel<IS_U8>(img, ix0, iy0);
+    float4 c01 = image_texel<IS_U8>(img, ix0, iy1);
+    float4 c10 = image_texel<IS_U8>(img, ix1, iy0);
+    float4 c11 = image_texel<IS_U8>(img, ix1, iy1);
+    float4 a = lerp4(c00, c10, tx);
+    float4 b = lerp4(c01, c11, tx);
+    return lerp4(a, b, ty);
+}
+
+/* ---- microfacet helpers (util.rs live subset) ------------------------------ */
+__device__ __forceinline__ float ggx_d(F3 n, F3 h, float roughness) {
+    float numerator = roughness * roughness;
+    float ndh = rptm::fmaxr(dot3(n, h), 0.0f);
+    float den = (ndh * ndh) * (numerator - 1.0f) + 1.0f;
+    den = rptm::fmaxr(RPT_PI_F * (den * den), RPT_EPS);
+    return numerator / den;
+}
+__device__ __forceinline__ float schlick_g1(F3 n, F3 v, float roughness) {
+    float numerator = rptm::fmaxr(dot3(n, v), 0.0f);
+    float r = (roughness * roughness) / 8.0f;
+    float den = numerator * (1.0f - r) + r;
+    return numerator / den;
+}
+__device__ __forceinline__ F3 fresnel_schlick3(float cos_theta, F3 f0) {
+    return f0 + (f3s(1.0f) - f0) * rptm::powi5(1.0f - cos_theta);
+}
+
+struct Pbr {
+    F3 albedo;
+    float roughness, metallic;
+    float clamp_lo, clamp_hi;
+
+    /* bsdf.rs:275-280 / 244-248 */
+    __device__ __forceinline__ float specular_weight(F3 view, F3 n) const {
+        float c = rptm::fmaxr(dot3(n, view), 0.0f);
+        float f0 = rptm::powi2((1.0f - 1.5f) / (1.0f + 1.5f));
+        float approx_fresnel = f0 + (1.0f - f0) * rptm::powi5(1.0f - c);
+        float w = approx_fresnel * (1.0f - metallic) + 1.0f * metallic;   /* util::lerp(a, 1.0, t) */
+        if (w != 0.0f && w != 1.0f) {
+            if (w < clamp_lo) w = clamp_lo;
+            if (w > clamp_hi) w = clamp_hi;
+        }
+        return w;
+    }
+    __device__ __forceinline__ F3 ks_of(F3 view, F3 halfway) const {
+        const float F0_SQRT = (1.5f - 1.0f) / (1.5f + 1.0f);
+        F3 f0 = lerp3(f3s(F0_SQRT * F0_SQRT), albedo, metallic);
+        return fresnel_schlick3(rptm::fmaxr(dot3(halfway, view), 0.0f), f0);
+    }
+    /* bsdf.rs:193-202 */
+    __device__ __forceinline__ F3 diffuse_term(float cos_theta, float w, F3 ks) const {
+        F3 kd = (f3s(1.0f) - ks) * (1.0f - metallic);
+        F3 diffuse = kd * albedo / RPT_PI_F;
+        return diffuse * cos_theta / (1.0f - w);
+    }
+    /* bsdf.rs:204-219 */
+    __device__ __forceinline__ F3 specular_term(F3 view, F3 n, F3 l, float cos_theta, float d_term, float w, F3 ks) const {
+        float g_term = schlick_g1(n, view, roughness) * schlick_g1(n, l, roughness);
+        F3 num = (d_term * g_term) * ks;
+        float den = 4.0f * rptm::fmaxr(dot3(n, view), 0.0f) * cos_theta;
+        F3 specular = num / rptm::fmaxr(den, RPT_EPS);
+        return specular * cos_theta / w;
+    }
+};
+
+/* material record: 6 float4 (shared_structs/src/lib.rs:44-56) */
+struct Mat {
+    float4 emissive, albedo, roughness, metallic, normals;
+    uint4 has;   /* albedo, metallic, roughness, normal texture flags */
+};
+__device__ __forceinline__ Mat load_material(const DevScene &sc, uint32_t index) {
+    const float4 *p = sc.materials + 6u * index;
+    Mat m;
+    m.emissive = p[0]; m.albedo = p[1]; m.roughness = p[2]; m.metallic = p[3]; m.normals = p[4];
+    float4 f = p[5];
+    m.has = make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
+    return m;
+}
+
+/* destinations a path can leave the shade stage for */
+enum { DEST_NONE = 0, DEST_EXT = 1, DEST_FIN = 2, DEST_SKY = 3 };
+
+__global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t cur,
+                                                     DevStats *stats) {
+    const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    const uint32_t n = q.count[cur];
+    const bool active = i < n;
+    uint32_t dest = DEST_NONE;
+    bool emit_shadow = false;
+    uint32_t slot = 0u;
+    float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
+
+    if (active) {
+        slot = q.ext[cur][i];
+        const float4 ra = st.ray_a[slot];
+        const float4 rb = st.ray_b[slot];
+        const F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
+        const float hit_t = rb.z;
+        const uint32_t hit_tri = __float_as_uint(rb.w);
+        if (hit_tri == HIT_MISS) {
+            dest = DEST_SKY;                         /* lib.rs:66-79: shaded by k_sky */
+        } else {
+            float4 tr = st.thr_rad[slot];
+            float4 rm = st.rad_misc[slot];
+            F3 throughput = f3(tr.x, tr.y, tr.z);
+            F3 radiance = f3(tr.w, rm.x, rm.y);
+            const uint32_t flags = __float_as_uint(rm.z);
+            const uint32_t bounce = FLAG_BOUNCE(flags);
+            const bool last_spec = FLAG_LOBE_SPEC(flags) != 0u;
+            const uint32_t nee_mode = cfg.nee_mode;
+            const bool nee = nee_mode != RPT_NEE_NONE;
+            const bool backface = (hit_tri >> 31) != 0u;
+            const uint32_t tri_index = hit_tri & 0x7fffffffu;
+            const uint4 tri = sc.indices[tri_index];
+            const Mat mat = load_material(sc, tri.w);
+            const F3 hit = ro + rd * hit_t;
+
+            bool done = false;
+            const F3 emissive = xyz4(mat.emissive);
+            if (emissive.x != 0.0f || emissive.y != 0.0f || emissive.z != 0.0f) {       /* lib.rs:86 */
+                if (backface) {
+                    done = true;                                                         /* :88-90 */
+                } else if (!nee || bounce == 0u || last_spec) {                          /* :97-100 */
+                    radiance = radiance + mask_nan3(throughput * emissive);
+                    done = true;
+                } else if (nee_mode == RPT_NEE_MIS) {                                    /* :104-108, last lobe is diffuse here */
+                    float4 m0 = st.mis0[slot], m1 = st.mis1[slot], m2 = st.mis2[slot], m3 = st.mis3[slot];
+                    F3 contribution = f3s(0.0f);
+                    if (tri_index == __float_as_uint(m2.x)) {                            /* light_pick.rs:185 */
+                        F3 light_normal = f3(m0.y, m0.z, m0.w);
+                        float cos_theta = dot3(light_normal, -rd);                      /* last sampled_direction == rd */
+                        float light_pdf = cos_theta <= 0.0f ? 0.0f : rptm::powi2(hit_t) / (m0.x * cos_theta);
+                        if (light_pdf > 0.0f) {
+                            float bsdf_pdf = m3.x;
+                            float p1 = bsdf_pdf * bsdf_pdf;
+                            float weight = p1 / (p1 + light_pdf * light_pdf);
+                            F3 spectrum = f3(m3.y, m3.z, m3.w), emission = f3(m1.y, m1.z, m1.w);
+                            F3 direct = (spectrum * emission * weight / bsdf_pdf) / m1.x;
+                            contribution = f3(m2.y, m2.z, m2.w) * direct;
+                        }
+                    }
+                    radiance = radiance + mask_nan3(contribution);
+                    done = true;
+                }
+                /* nee == direct-only, diffuse bounce > 0: fall through, shade the light as a surface */
+            }
+
+            uint32_t new_flags = flags;
+            F3 new_o = ro, new_d = rd;
+            if (!done) {
+                /* ---- interpolate vertex data (lib.rs:112-129) ---- */
+                const float4 *va = sc.per_vertex + 4u * tri.x;
+                const float4 *vb = sc.per_vertex + 4u * tri.y;
+                const float4 *vc = sc.per_vertex + 4u * tri.z;
+                const F3 pa = xyz4(va[0]), pb = xyz4(vb[0]), pc = xyz4(vc[0]);
+                F3 bary;
+                {
+                    F3 v0 = pb - pa, v1 = pc - pa, v2 = hit - pa;
+                    float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1);
+                    float d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+                    float denom = d00 * d11 - d01 * d01;
+                    float v = (d11 * d20 - d01 * d21) / denom;
+                    float w = (d00 * d21 - d01 * d20) / denom;
+                    bary = f3(1.0f - v - w, v, w);
+                }
+                F3 normal = bary.x * xyz4(va[1]) + bary.y * xyz4(vb[1]) + bary.z * xyz4(vc[1]);
+                const float4 ua = va[3], ub = vb[3], uc = vc[3];
+                float uv_x = (bary.x * ua.x + bary.y * ub.x) + bary.z * uc.x;
+                float uv_y = (bary.x * ua.y + bary.y * ub.y) + bary.z * uc.y;
+                {
+                    float cx = rptm::fminr(rptm::fmaxr(uv_x, 0.0f), 1.0f), cy = rptm::fminr(rptm::fmaxr(uv_y, 0.0f), 1.0f);
+                    if (cx != uv_x || cy != uv_y) {
+                        uv_x = uv_x - rptm::floorr(uv_x);
+                        uv_y = uv_y - rptm::floorr(uv_y);
+                    }
+                }
+                if (mat.has.w != 0u) {                                                   /* lib.rs:132-141 */
+                    float su = mat.normals.x + uv_x * mat.normals.z, sv = mat.normals.y + uv_y * mat.normals.w;
+                    float4 s = sample_by_lod<true>(sc.atlas, su, sv);
+                    F3 nm = f3(s.x * 2.0f - 1.0f, s.y * 2.0f - 1.0f, s.z * 2.0f - 1.0f);
+                    F3 tangent = bary.x * xyz4(va[2]) + bary.y * xyz4(vb[2]) + bary.z * xyz4(vc[2]);
+                    F3 bitangent = cross3(tangent, normal);
+                    F3 r = tangent * nm.x;
+                    r = r + (bitangent * nm.y);
+                    r = r + (normal * nm.z);
+                    normal = norm3(r);
+                }
+
+                /* ---- get_pbr_bsdf (bsdf.rs:354-387) ---- */
+                Pbr bsdf;
+                if (mat.has.x != 0u) {
+                    float4 s = sample_by_lod<true>(sc.atlas, mat.albedo.x + uv_x * mat.albedo.z, mat.albedo.y + uv_y * mat.albedo.w);
+                    bsdf.albedo = f3(s.x, s.y, s.z);
+                } else {
+                    bsdf.albedo = xyz4(mat.albedo);
+                }
+                float roughness = mat.roughness.x, metallic = mat.metallic.x;
+                if (mat.has.z != 0u)
+                    roughness = sample_by_lod<true>(sc.atlas, mat.roughness.x + uv_x * mat.roughness.z, mat.roughness.y + uv_y * mat.roughness.w).x;
+                if (mat.has.y != 0u)
+                    metallic = sample_by_lod<true>(sc.atlas, mat.metallic.x + uv_x * mat.metallic.z, mat.metallic.y + uv_y * mat.metallic.w).x;
+                bsdf.roughness = rptm::fmaxr(roughness, RPT_EPS);
+                bsdf.metallic = rptm::fminr(metallic, 1.0f - RPT_EPS);
+                bsdf.clamp_lo = cfg.c.specular_weight_clamp[0];
+                bsdf.clamp_hi = cfg.c.specular_weight_clamp[1];
+
+                /* ---- PBR::sample (bsdf.rs:272-334) ---- */
+                const uint2 rs = st.rng[slot];
+                Rng rng{rs.x + rs.y, FLAG_DIM(flags)};
+                const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
+                const F3 view = -rd;
+                const float w_spec = bsdf.specular_weight(view, normal);
+                F3 sdir;
+                const bool spec = !(r3 >= w_spec);
+                if (!spec) {
+                    /* create_cartesian(normal) (util.rs:34-40) */
+                    F3 temp_vec = norm3(cross3(normal, f3(0.1f, 0.5f, 0.9f)));
+                    F3 nt = norm3(cross3(temp_vec, normal));       /* right   */
+                    F3 nb = norm3(cross3(normal, nt));             /* forward */
+                    /* cosine_sample_hemisphere (util.rs:24-32) */
+                    float theta = rptm::acosr(rptm::sqrtr(r1));
+                    float phi = 2.0f * RPT_PI_F * r2;
+                    float sin_t, cos_t, sin_p, cos_p;
+                    rptm::sincosr(theta, sin_t, cos_t);
+                    rptm::sincosr(phi, sin_p, cos_p);
+                    F3 s = f3(sin_t * cos_p, cos_t, sin_t * sin_p);
+                    sdir = norm3(f3(s.x * nb.x + s.y * normal.x + s.z * nt.x,
+                                    s.x * nb.y + s.y * normal.y + s.z * nt.y,
+                                    s.x * nb.z + s.y * normal.z + s.z * nt.z));
+                } else {
+                    /* reflect(-view, n) then sample_ggx (util.rs:42-44, 67-85) */
+                    F3 inc = -view;
+                    F3 refl = inc - normal * 2.0f * dot3(inc, normal);
+                    float a = bsdf.roughness * bsdf.roughness;
+                    float phi = 2.0f * RPT_PI_F * r1;
+                    float cos_theta = rptm::sqrtr((1.0f - r2) / (r2 * (a * a - 1.0f) + 1.0f));
+                    float sin_theta = rptm::sqrtr(1.0f - cos_theta * cos_theta);
+                    float sin_p, cos_p;
+                    rptm::sincosr(phi, sin_p, cos_p);
+                    F3 h = f3(cos_p * sin_theta, sin_p * sin_theta, cos_theta);
+                    F3 up = rptm::absr(refl.z) < 0.999f ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
+                    F3 tangent = norm3(cross3(up, refl));
+                    F3 bitangent = cross3(refl, tangent);
+                    sdir = norm3(tangent * h.x + bitangent * h.y + refl * h.z);
+                }
+                const float cos_theta = rptm::fmaxr(dot3(normal, sdir), RPT_EPS);
+                const F3 halfway = norm3(view + sdir);
+                const F3 ks = bsdf.ks_of(view, halfway);
+                float pdf;
+                F3 spectrum;
+                if (!spec) {
+                    pdf = cos_theta / RPT_PI_F;
+                    spectrum = bsdf.diffuse_term(cos_theta, w_spec, ks);
+                } else {
+                    float d_term = ggx_d(normal, halfway, bsdf.roughness);
+                    pdf = (d_term * dot3(normal, halfway)) / (4.0f * dot3(view, halfway));
+                    spectrum = bsdf.specular_term(view, normal, sdir, cos_theta, d_term, w_spec, ks);
+                }
+
+                /* ---- next-event estimation set-up (light_pick.rs:100-173) ---- */
+                if (nee && !spec) {
+                    if (sc.no_lights) {
+                        /* sentinel: DirectLightSample::default() — zero contribution, zeroed carry */
+                        if (nee_mode == RPT_NEE_MIS) {
+                            st.mis0[slot] = make_float4(0, 0, 0, 0);
+                            st.mis1[slot] = make_float4(0, 0, 0, 0);
+                            st.mis2[slot] = make_float4(__uint_as_float(0u), 0, 0, 0);
+                        }
+                    } else {
+                        const float l1 = rng.next(), l2 = rng.next();
+                        uint32_t idx = rptm::f2u32_sat(l1 * (float)sc.n_light_pick);
+                        if (idx >= sc.n_light_pick) {                       /* gen_r1() == 1.0: the reference panics (Appendix C) */
+                            idx = sc.n_light_pick - 1u;
+                            atomicAdd(&stats->light_index_clamped, 1ull);
+                        }
+                        const rpt_light_pick_entry e = sc.light_pick[idx];
+                        const bool pick_a = l2 < e.ratio;
+                        const uint32_t light_index = pick_a ? e.triangle_index_a : e.triangle_index_b;
+                        const float light_area = pick_a ? e.triangle_area_a : e.triangle_area_b;
+                        const float light_pick_pdf = pick_a ? e.triangle_pick_pdf_a : e.triangle_pick_pdf_b;
+                        const uint4 lt = sc.indices[light_index];
+                        const float4 *la = sc.per_vertex + 4u * lt.x;
+                        const float4 *lb = sc.per_vertex + 4u * lt.y;
+                        const float4 *lc = sc.per_vertex + 4u * lt.z;
+                        const F3 light_normal = (xyz4(la[1]) + xyz4(lb[1]) + xyz4(lc[1])) / 3.0f;
+                        const F3 light_emission = xyz4(sc.materials[6u * lt.w]);
+                        const float p1 = rng.next(), p2 = rng.next();
+                        const float r1_sqrt = rptm::sqrtr(p1);
+                        const F3 light_point = (1.0f - r1_sqrt) * xyz4(la[0]) + (r1_sqrt * (1.0f - p2)) * xyz4(lb[0]) +
+                                               (r1_sqrt * p2) * xyz4(lc[0]);
+                        const F3 unorm = light_point - hit;
+                        const float light_distance = len3(unorm);
+                        const F3 light_direction = unorm / light_distance;
+
+                        /* everything after the visibility test, assuming it passes */
+                        F3 direct = f3s(0.0f);
+                        {
+                            float cos_l = dot3(light_normal, -light_direction);
+                            float light_pdf = cos_l <= 0.0f ? 0.0f : rptm::powi2(light_distance) / (light_area * cos_l);
+                            if (light_pdf > 0.0f) {
+                                /* PBR::evaluate(view, n, L, Diffuse) and PBR::pdf(.., Diffuse) */
+                                float w_e = bsdf.specular_weight(view, normal);
+                                float cos_e = rptm::fmaxr(dot3(normal, light_direction), 0.0f);
+                                F3 h_e = norm3(view + light_direction);
+                                F3 ks_e = bsdf.ks_of(view, h_e);
+                                F3 attenuation = bsdf.diffuse_term(cos_e, w_e, ks_e);
+                                float bsdf_pdf = cos_e / RPT_PI_F;
+                                if (bsdf_pdf > 0.0f) {
+                                    float weight = 1.0f;
+                                    if (nee_mode == RPT_NEE_MIS) {
+                                        float q1 = light_pdf * light_pdf;
+                                        weight = q1 / (q1 + bsdf_pdf * bsdf_pdf);
+                                    }
+                                    direct = (attenuation * light_emission * weight / light_pdf) / light_pick_pdf;
+                                }
+                            }
+                        }
+                        const F3 contribution = throughput * direct;
+                        const F3 so = hit + light_direction * RPT_EPS;
+                        emit_shadow = true;
+                        sh_o = make_float4(so.x, so.y, so.z, light_distance - RPT_EPS * 2.0f);
+                        sh_d = make_float4(light_direction.x, light_direction.y, light_direction.z, 0.0f);
+                        sh_c = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+                        if (nee_mode == RPT_NEE_MIS) {
+                            st.mis0[slot] = make_float4(light_area, light_normal.x, light_normal.y, light_normal.z);
+                            st.mis1[slot] = make_float4(light_pick_pdf, light_emission.x, light_emission.y, light_emission.z);
+                            st.mis2[slot] = make_float4(__uint_as_float(light_index), throughput.x, throughput.y, throughput.z);
+                        }
+                    }
+                }
+                if (nee_mode == RPT_NEE_MIS) st.mis3[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
+
+                /* ---- attenuate, respawn, roulette (lib.rs:168-181) ---- */
+                throughput = throughput * (spectrum / pdf);
+                new_d = sdir;
+                new_o = hit + sdir * RPT_EPS;
+                if (bounce > cfg.c.min_bounces) {
+                    float prob = rptm::fmaxr(throughput.x, rptm::fmaxr(throughput.y, throughput.z));
+                    if (rng.next() > prob) {
+                        done = true;
+                    } else {
+                        throughput = throughput * (1.0f / prob);
+                    }
+                }
+                const uint32_t next_bounce = bounce + 1u;
+                if (next_bounce >= cfg.c.max_bounces) done = true;
+                new_flags = MAKE_FLAGS(next_bounce, spec ? 1u : 0u, rng.dim);
+            }
+
+            st.thr_rad[slot] = make_float4(throughput.x, throughput.y, throughput.z, radiance.x);
+            st.rad_misc[slot] = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
+            if (!done) {
+                st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
+                reinterpret_cast<float2 *>(&st.ray_b[slot])[0] = make_float2(new_d.y, new_d.z);
+                dest = DEST_EXT;
+            } else if (emit_shadow) {
+                sh_d.w = __uint_as_float(slot | 0x80000000u);   /* the shadow stage finishes the path */
+                dest = DEST_NONE;
+            } else {
+                dest = DEST_FIN;
+            }
+            if (emit_shadow && !done) sh_d.w = __uint_as_float(slot);
+        }
+    }
+
+    /* ---- converged queue emission: wave64 ballot + prefix compaction ---- */
+    uint32_t at;
+    at = wave_push(&q.count[cur ^ 1u], dest == DEST_EXT);
+    if (dest == DEST_EXT) q.ext[cur ^ 1u][at] = slot;
+    at = wave_push(&q.count[Q_FIN], dest == DEST_FIN);
+    if (dest == DEST_FIN) q.fin[at] = slot;
+    at = wave_push(&q.count[Q_SKY], dest == DEST_SKY);
+    if (dest == DEST_SKY) q.sky[at] = slot;
+    at = wave_push(&q.count[Q_SHADOW], emit_shadow);
+    if (emit_shadow) {
+        q.sh_o[at] = sh_o;
+        q.sh_d[at] = sh_d;
+        q.sh_c[at] = sh_c;
+    }
+}
+
+#endif /* RPT_K_SHADE_H */

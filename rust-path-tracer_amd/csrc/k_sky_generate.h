@@ -1,0 +1,178 @@
+/*
+ * k_sky_generate.h — the two remaining stages of the wavefront pipeline.
+ *
+ *  k_sky       miss shading in its own queue, because the procedural sky is an
+ *              ALU monster (12 march steps, ~108 exp, 4 pow per miss;
+ *              kernels/src/skybox.rs:18-94) that must not share waves with
+ *              cheap surface shading.  Also the image-skybox branch
+ *              (kernels/src/lib.rs:70-78).
+ *  k_generate  accumulate finished paths and regenerate: `output[i] += (rgb, 1)`,
+ *              `rng[i].x += 1` (kernels/src/lib.rs:185, 225-226), then the next
+ *              camera ray of the same pixel (lib.rs:36-60) if samples remain.
+ */
+#ifndef RPT_K_SKY_GENERATE_H
+#define RPT_K_SKY_GENERATE_H
+
+#include "k_shade.h"
+
+/* ---- kernels/src/skybox.rs ------------------------------------------------- */
+#define SKY_EARTH_RADIUS 6360e3f
+#define SKY_ATMOSPHERE_RADIUS 6380e3f
+#define SKY_H_RAY 8e3f
+#define SKY_H_MIE 12e2f
+
+__device__ __forceinline__ float sky_escape(F3 p, F3 d, float r) {
+    F3 v = p - f3(0.0f, -SKY_EARTH_RADIUS, 0.0f);
+    float b = dot3(v, d);
+    float det = b * b - dot3(v, v) + r * r;
+    if (det < 0.0f) return -1.0f;
+    det = rptm::sqrtr(det);
+    float t1 = -b - det;
+    float t2 = -b + det;
+    return t1 >= 0.0f ? t1 : t2;
+}
+__device__ __forceinline__ float2 sky_densities(F3 p) {
+    float h = rptm::fmaxr(len3(p - f3(0.0f, -SKY_EARTH_RADIUS, 0.0f)) - SKY_EARTH_RADIUS, 0.0f);
+    return make_float2(rptm::expr(-h / SKY_H_RAY), rptm::expr(-h / SKY_H_MIE));
+}
+
+__device__ F3 sky_scatter(const float *sun4, F3 origin, F3 direction) {
+    const F3 ray_coeff = f3(58e-7f, 135e-7f, 331e-7f);
+    const F3 mie_scatter = f3(2e-5f, 2e-5f, 2e-5f);
+    const F3 mie_effective = f3(2e-5f * 1.1f, 2e-5f * 1.1f, 2e-5f * 1.1f);
+    const F3 sundir = f3(sun4[0], sun4[1], sun4[2]);
+
+    float depth = sky_escape(origin, direction, SKY_ATMOSPHERE_RADIUS) / (float)12u;
+    F3 i_r = f3s(0.0f), i_m = f3s(0.0f);
+    float total_r = 0.0f, total_m = 0.0f;
+    for (uint32_t i = 0; i < 12u; ++i) {
+        F3 p = origin + direction * (depth * (float)i);
+        float2 dens = sky_densities(p);
+        float d_r = dens.x * depth, d_m = dens.y * depth;
+        total_r = total_r + d_r;
+        total_m = total_m + d_m;
+        /* scatter_depth_int(p, sundir, escape(p, sundir, R_atm)) (skybox.rs:41-44) */
+        float l = sky_escape(p, sundir, SKY_ATMOSPHERE_RADIUS);
+        float2 da = sky_densities(p), db = sky_densities(p + sundir * l);
+        float half_l = l / 2.0f;
+        float sum_r = total_r + (da.x * half_l + db.x * half_l);
+        float sum_m = total_m + (da.y * half_l + db.y * half_l);
+        F3 e = (-ray_coeff) * sum_r - mie_effective * sum_m;
+        F3 a = f3(rptm::expr(e.x), rptm::expr(e.y), rptm::expr(e.z));
+        i_r = i_r + a * d_r;
+        i_m = i_m + a * d_m;
+    }
+    float mu = dot3(direction, sundir);
+    F3 res = (sun4[3] * (1.0f + mu * mu)) *
+             (i_r * ray_coeff * 0.0597f + i_m * mie_scatter * 0.0196f / rptm::powr(1.58f - 1.52f * mu, 1.5f));
+    F3 g = mask_nan3(f3(rptm::sqrtr(res.x), rptm::sqrtr(res.y), rptm::sqrtr(res.z)));
+    return f3(rptm::powr(g.x, 2.2f), rptm::powr(g.y, 2.2f), rptm::powr(g.z, 2.2f));
+}
+
+__device__ __forceinline__ F3 mat3_mul(const float *m, F3 v) {   /* Mat3::mul_vec3, column-major */
+    F3 r = f3(m[0], m[1], m[2]) * v.x;
+    r = r + (f3(m[3], m[4], m[5]) * v.y);
+    r = r + (f3(m[6], m[7], m[8]) * v.z);
+    return r;
+}
+
+__global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats) {
+    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    uint32_t n = q.count[Q_SKY];
+    if (i == 0u && n) atomicAdd(&stats->sky_evals, (unsigned long long)n);
+    bool active = i < n;
+    uint32_t slot = 0u;
+    if (active) {
+        slot = q.sky[i];
+        float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+        F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
+        float4 tr = st.thr_rad[slot], rm = st.rad_misc[slot];
+        F3 throughput = f3(tr.x, tr.y, tr.z), radiance = f3(tr.w, rm.x, rm.y);
+        if (cfg.c.has_skybox == 0u) {
+            radiance = radiance + throughput * sky_scatter(cfg.c.sun_direction, ro, rd);      /* lib.rs:69 */
+        } else {                                                                             /* lib.rs:72-77 */
+            F3 rotated = mat3_mul(cfg.sky_rot, rd);
+            float u = 0.5f + rptm::atan2r(rotated.z, rotated.x) / (2.0f * RPT_PI_F);
+            float v = 1.0f - (0.5f + rptm::asinr(rotated.y) / RPT_PI_F);
+            float intensity = cfg.c.sun_direction[3] * (1.0f / 15.0f);
+            float4 s = sample_by_lod<false>(sc.skybox, u, v);
+            radiance = radiance + throughput * f3(s.x, s.y, s.z) * intensity;
+        }
+        st.thr_rad[slot] = make_float4(tr.x, tr.y, tr.z, radiance.x);
+        st.rad_misc[slot] = make_float4(radiance.y, radiance.z, rm.z, rm.w);
+    }
+    uint32_t at = wave_push(&q.count[Q_FIN], active);
+    if (active) q.fin[at] = slot;
+}
+
+/* camera ray for sample `n` of pixel (x, y) (lib.rs:36-51) */
+__device__ __forceinline__ void camera_ray(const DevConfig &cfg, uint32_t px, uint32_t py, uint32_t key, F3 &ro, F3 &rd) {
+    Rng rng{key, 0u};
+    float j1 = rng.next(), j2 = rng.next();
+    float sx = (float)px + j1, sy = (float)py + j2;
+    float ux = (sx / (float)cfg.c.width) * 2.0f - 1.0f;
+    float uy = (1.0f - sy / (float)cfg.c.height) * 2.0f - 1.0f;
+    uy *= (float)cfg.c.height / (float)cfg.c.width;
+    ro = f3(cfg.c.cam_position[0], cfg.c.cam_position[1], cfg.c.cam_position[2]);
+    rd = mat3_mul(cfg.euler, norm3(f3(ux, uy, 1.0f)));
+}
+
+/* FIRST = true: start of an rpt_render call, every slot begins its first sample.
+ * FIRST = false: slots from the finish queue: accumulate, then regenerate. */
+template <bool FIRST>
+__global__ __launch_bounds__(RPT_BLOCK) void k_generate(DevState st, DevQueues q, DevConfig cfg, uint32_t next,
+                                                        uint32_t n_samples) {
+    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    uint32_t n = FIRST ? st.n_slots : q.count[Q_FIN];
+    bool active = i < n;
+    bool emit = false;
+    uint32_t slot = 0u;
+    if (active) {
+        slot = FIRST ? i : q.fin[i];
+        uint2 rs = st.rng[slot];
+        uint32_t todo;
+        if (FIRST) {
+            todo = n_samples;
+        } else {
+            float4 tr = st.thr_rad[slot], rm = st.rad_misc[slot];
+            float4 acc = st.accum[slot];
+            acc.x += tr.w; acc.y += rm.x; acc.z += rm.y; acc.w += 1.0f;
+            st.accum[slot] = acc;
+            rs.x += 1u;
+            st.rng[slot] = rs;
+            todo = __float_as_uint(rm.w);
+        }
+        if (cfg.c.max_bounces == 0u) {
+            /* the bounce loop never runs (lib.rs:62): every sample adds (0,0,0,1) */
+            float4 acc = st.accum[slot];
+            for (uint32_t s = 0; s < todo; ++s) acc.w += 1.0f;
+            st.accum[slot] = acc;
+            rs.x += todo;
+            st.rng[slot] = rs;
+            todo = 0u;
+        }
+        if (todo > 0u) {
+            uint32_t pxy = st.pixel_xy[slot];
+            F3 ro, rd;
+            camera_ray(cfg, pxy & 0xffffu, pxy >> 16, rs.x + rs.y, ro, rd);
+            st.ray_a[slot] = make_float4(ro.x, ro.y, ro.z, rd.x);
+            reinterpret_cast<float2 *>(&st.ray_b[slot])[0] = make_float2(rd.y, rd.z);
+            st.thr_rad[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            st.rad_misc[slot] = make_float4(0.0f, 0.0f, __uint_as_float(MAKE_FLAGS(0u, 0u, 2u)), __uint_as_float(todo - 1u));
+            emit = true;
+        }
+    }
+    uint32_t at = wave_push(&q.count[next], emit);
+    if (emit) q.ext[next][at] = slot;
+}
+
+/* root-side un-tiling of gathered per-rank blocks into a row-major image */
+__global__ __launch_bounds__(RPT_BLOCK) void k_untile(const float4 *blocks, const uint32_t *pixel_xy_all, uint32_t n_total,
+                                                      uint32_t width, float4 *image) {
+    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (i >= n_total) return;
+    uint32_t pxy = pixel_xy_all[i];
+    image[(size_t)(pxy >> 16) * width + (pxy & 0xffffu)] = blocks[i];
+}
+
+#endif /* RPT_K_SKY_GENERATE_H */

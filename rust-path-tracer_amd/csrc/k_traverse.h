@@ -1,0 +1,198 @@
+/*
+ * k_traverse.h — BVH traversal + ray/triangle intersection stage.
+ *
+ * Produces, per ray, exactly what the reference's stack traversal produces
+ * (kernels/src/intersection.rs:177-234, with intersect_aabb :104-122 and
+ * muller_trumbore :9-54): same visiting order, same strict comparisons, same
+ * f32 operations — so t / triangle index / backface are bit-identical to the
+ * CPU path.  What differs is the machinery:
+ *   - one wave64 lane per ray, rays read as two coalesced float4 records;
+ *   - the traversal stack lives in LDS, laid out [entry][lane] so that every
+ *     ds_read/ds_write of a wave is bank-conflict free regardless of the
+ *     per-lane stack depth (lane l always hits bank l mod 32 of its half);
+ *   - the near child is entered directly (the reference pushes it and pops it
+ *     straight back, :229 then :183), only the far child is pushed;
+ *   - both children of an inner node are adjacent (right = left + 1), so one
+ *     node visit is 4 float4 loads = 64 contiguous bytes;
+ *   - leaf triangles come from a pre-gathered (a, b-a, c-a) array instead of
+ *     index buffer -> 3 x 64-byte vertex records (same f32 subtractions, done
+ *     once at upload).
+ * Traversal order is part of the result (ties in t keep the first triangle
+ * visited), so no reordering / no "max_t" box pruning in any-hit mode (:212-213
+ * prune against result.t only).
+ */
+#ifndef RPT_K_TRAVERSE_H
+#define RPT_K_TRAVERSE_H
+
+#include "k_common.h"
+
+struct HitRecord {
+    float t;
+    uint32_t tri;     /* HIT_MISS or triangle index | backface << 31 */
+};
+
+/* intersection.rs:104-122 — 6 true divisions, NaN-ignoring min/max */
+__device__ __forceinline__ float slab_test(float4 lo, float4 hi, F3 ro, F3 rd, float prev_min_t) {
+    float tx1 = (lo.x - ro.x) / rd.x;
+    float tx2 = (hi.x - ro.x) / rd.x;
+    float tmin = rptm::fminr(tx1, tx2);
+    float tmax = rptm::fmaxr(tx1, tx2);
+    float ty1 = (lo.y - ro.y) / rd.y;
+    float ty2 = (hi.y - ro.y) / rd.y;
+    tmin = rptm::fmaxr(tmin, rptm::fminr(ty1, ty2));
+    tmax = rptm::fminr(tmax, rptm::fmaxr(ty1, ty2));
+    float tz1 = (lo.z - ro.z) / rd.z;
+    float tz2 = (hi.z - ro.z) / rd.z;
+    tmin = rptm::fmaxr(tmin, rptm::fminr(tz1, tz2));
+    tmax = rptm::fminr(tmax, rptm::fmaxr(tz1, tz2));
+    return (tmax >= tmin && tmax > 0.0f && tmin < prev_min_t) ? tmin : __builtin_inff();
+}
+
+/* intersection.rs:9-54 with edge1/edge2 precomputed at upload */
+__device__ __forceinline__ bool moller_trumbore(F3 ro, F3 rd, F3 a, F3 edge1, F3 edge2, float &out_t, bool &backface) {
+    F3 pv = cross3(rd, edge2);
+    float det = dot3(edge1, pv);
+    backface = (rptm::f2u(det) >> 31) != 0u;
+    if (rptm::absr(det) < 1e-6f) return false;
+    float inv_det = 1.0f / det;
+    F3 tv = ro - a;
+    float u = dot3(tv, pv) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    F3 qv = cross3(tv, edge1);
+    float v = dot3(rd, qv) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = dot3(edge2, qv) * inv_det;
+    if (t < 0.0f) return false;
+    out_t = t;
+    return true;
+}
+
+/* One ray through the BVH. `stack` points at this lane's column of the wave's
+ * LDS stack: entry e lives at stack[e * RPT_WAVE]. */
+template <int STACK, bool ANY_HIT>
+__device__ __forceinline__ HitRecord traverse_one(const DevScene &sc, F3 ro, F3 rd, float max_t, uint32_t *stack) {
+    HitRecord res;
+    res.t = 1000000.0f;
+    res.tri = HIT_MISS;
+    int sp = 0;
+    /* current node's metadata (aabb_min.w = triangle_count, aabb_max.w = left/first) */
+    uint32_t cur_count = __float_as_uint(sc.nodes[0].w);
+    uint32_t cur_index = __float_as_uint(sc.nodes[1].w);
+    for (;;) {
+        if (cur_count > 0u) {
+            /* leaf: triangles in index order (:186-205) */
+            for (uint32_t i = 0; i < cur_count; ++i) {
+                uint32_t ti = cur_index + i;
+                F3 a = xyz4(sc.tri_geom[3u * ti]);
+                F3 e1 = xyz4(sc.tri_geom[3u * ti + 1u]);
+                F3 e2 = xyz4(sc.tri_geom[3u * ti + 2u]);
+                float t = 0.0f;
+                bool bf = false;
+                if (moller_trumbore(ro, rd, a, e1, e2, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
+                    res.t = rptm::fminr(res.t, t);
+                    res.tri = ti | (bf ? 0x80000000u : 0u);
+                    if (ANY_HIT) return res;
+                }
+            }
+        } else {
+            /* inner: test both children against the current best t (:207-229) */
+            const float4 *ch = sc.nodes + 2u * cur_index;
+            float4 lmin = ch[0], lmax = ch[1], rmin = ch[2], rmax = ch[3];
+            float dl = slab_test(lmin, lmax, ro, rd, res.t);
+            float dr = slab_test(rmin, rmax, ro, rd, res.t);
+            bool swap = dl > dr;                    /* strict: ties keep left first */
+            float dnear = swap ? dr : dl;
+            float dfar = swap ? dl : dr;
+            if (dnear != __builtin_inff()) {
+                uint32_t near_count = __float_as_uint(swap ? rmin.w : lmin.w);
+                uint32_t near_index = __float_as_uint(swap ? rmax.w : lmax.w);
+                if (dfar != __builtin_inff() && sp < STACK) {
+                    stack[sp * RPT_WAVE] = swap ? cur_index : cur_index + 1u;   /* far child node id */
+                    sp += 1;
+                }
+                cur_count = near_count;
+                cur_index = near_index;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        sp -= 1;
+        uint32_t node = stack[sp * RPT_WAVE];
+        cur_count = __float_as_uint(sc.nodes[2u * node].w);
+        cur_index = __float_as_uint(sc.nodes[2u * node + 1u].w);
+    }
+    return res;
+}
+
+/* Extension rays: queue of slot ids -> hit record written into ray_b.zw */
+template <int STACK>
+__global__ __launch_bounds__(RPT_BLOCK) void k_traverse_nearest(DevScene sc, DevState st, const uint32_t *queue,
+                                                                const uint32_t *queue_count, DevStats *stats) {
+    __shared__ uint32_t lds_stack[RPT_BLOCK / RPT_WAVE][STACK][RPT_WAVE];
+    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    uint32_t n = *queue_count;
+    if (i == 0u && n) atomicAdd(&stats->extension_rays, (unsigned long long)n);
+    if (i >= n) return;
+    uint32_t slot = queue[i];
+    float4 ra = st.ray_a[slot];
+    float4 rb = st.ray_b[slot];
+    F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
+    uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
+    HitRecord h = traverse_one<STACK, false>(sc, ro, rd, 0.0f, stack);
+    float2 *out = reinterpret_cast<float2 *>(&st.ray_b[slot]);
+    out[1] = make_float2(h.t, __uint_as_float(h.tri));
+}
+
+/* Shadow rays (kernels/src/light_pick.rs:141-148): any-hit; if unoccluded the
+ * pre-weighted NEE contribution is added to the path's radiance (lib.rs:164),
+ * and a path that ended at this bounce is handed to the finish queue. */
+template <int STACK>
+__global__ __launch_bounds__(RPT_BLOCK) void k_traverse_shadow(DevScene sc, DevState st, DevQueues q, DevStats *stats) {
+    __shared__ uint32_t lds_stack[RPT_BLOCK / RPT_WAVE][STACK][RPT_WAVE];
+    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    uint32_t n = q.count[Q_SHADOW];
+    if (i == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
+    bool active = i < n;
+    bool finish = false;
+    uint32_t slot = 0u;
+    if (active) {
+        float4 o = q.sh_o[i], d = q.sh_d[i];
+        uint32_t tag = __float_as_uint(d.w);
+        slot = tag & 0x7fffffffu;
+        finish = (tag >> 31) != 0u;
+        uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
+        HitRecord h = traverse_one<STACK, true>(sc, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
+        if (h.tri == HIT_MISS) {
+            float4 c = q.sh_c[i];
+            F3 add = mask_nan3(f3(c.x, c.y, c.z));
+            float4 tr = st.thr_rad[slot];
+            float4 rm = st.rad_misc[slot];
+            tr.w = tr.w + add.x;
+            rm.x = rm.x + add.y;
+            rm.y = rm.y + add.z;
+            st.thr_rad[slot] = tr;
+            st.rad_misc[slot] = rm;
+        }
+    }
+    uint32_t at = wave_push(&q.count[Q_FIN], active && finish);
+    if (active && finish) q.fin[at] = slot;
+}
+
+/* Test hook: plain ray arrays in, hit arrays out (rpt_debug_trace_rays). */
+template <int STACK, bool ANY_HIT>
+__global__ __launch_bounds__(RPT_BLOCK) void k_trace_debug(DevScene sc, uint32_t n, const float *origins, const float *dirs,
+                                                           const float *max_t, float *out_t, uint32_t *out_tri,
+                                                           uint32_t *out_flags) {
+    __shared__ uint32_t lds_stack[RPT_BLOCK / RPT_WAVE][STACK][RPT_WAVE];
+    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    F3 ro = f3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+    F3 rd = f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
+    HitRecord h = traverse_one<STACK, ANY_HIT>(sc, ro, rd, ANY_HIT ? max_t[i] : 0.0f, stack);
+    out_t[i] = h.t;
+    out_tri[i] = (h.tri == HIT_MISS) ? 0u : (h.tri & 0x7fffffffu);
+    out_flags[i] = (h.tri == HIT_MISS) ? 0u : (1u | ((h.tri >> 31) << 1));
+}
+
+#endif /* RPT_K_TRAVERSE_H */

@@ -1,0 +1,740 @@
+/*
+ * rpt_hip.hip — librpt_hip.so: context, upload, wavefront scheduling and the
+ * C ABI of include/rpt/rpt.h (the drop-in replacement of the gpgpu-rs/wgpu
+ * calls in the reference's trace_gpu, src/trace.rs:136-224).
+ *
+ * Wavefront iteration (all queues of slot ids, all state SoA, no host round
+ * trip per sample):
+ *     traverse_nearest -> shade -> [traverse_shadow] -> sky -> generate
+ * The host only learns the size of the next extension queue through a lagged
+ * asynchronous read-back (pinned ring + events), so the GPU never idles on it.
+ */
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rpt/rpt.h"
+#include "k_common.h"
+#include "k_traverse.h"
+#include "k_shade.h"
+#include "k_sky_generate.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+            return RPT_EHIP;                                                                       \
+        }                                                                                          \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (!count) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+constexpr int LAG = 6;           /* iterations between enqueueing and inspecting a queue-size read-back */
+constexpr int RING = 16;
+
+}  // namespace
+
+struct rpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    uint32_t rank = 0, world = 1;
+
+    /* scene */
+    bool has_scene = false;
+    DevBuf<float4> nodes, tri_geom, per_vertex, materials;
+    DevBuf<uint4> indices;
+    DevBuf<rpt_light_pick_entry> light_pick;
+    DevBuf<uchar4> atlas;
+    DevBuf<float4> skybox;
+    DevScene scene{};
+    uint32_t bvh_depth = 0;
+    int stack_cap = 16;
+
+    /* config + partition */
+    bool has_config = false;
+    DevConfig cfg{};
+    uint32_t n_slots = 0;
+    std::vector<uint32_t> pixel_xy_host;
+    DevBuf<uint32_t> pixel_xy;
+
+    /* state */
+    bool has_state = false;
+    DevBuf<float4> ray_a, ray_b, thr_rad, rad_misc, mis0, mis1, mis2, mis3, accum;
+    DevBuf<uint2> rng;
+    DevBuf<uint32_t> q_ext0, q_ext1, q_sky, q_fin, q_count;
+    DevBuf<float4> sh_o, sh_d, sh_c;
+    DevBuf<DevStats> dev_stats;
+    DevState state{};
+    DevQueues queues{};
+    uint32_t samples = 0;
+
+    /* scheduling */
+    uint32_t *pinned_counts = nullptr;   /* RING x Q_COUNT */
+    hipEvent_t ring_events[RING]{};
+    bool events_ready = false;
+
+    /* stats */
+    rpt_stats stats{};
+    bool stage_timing = false;
+    std::vector<hipEvent_t> timing_events;
+};
+
+namespace {
+
+/* rank-local slot order: tiles in ascending id (tile t -> rank t mod world),
+ * inside a tile 8x8 pixel blocks row-major, inside a block row-major; pixels
+ * outside the image are skipped.  One wave = one 8x8 block on full tiles, so
+ * primary rays of a wave are coherent. */
+void build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, std::vector<uint32_t> &out) {
+    out.clear();
+    const uint32_t T = RPT_TILE, B = 8;
+    uint32_t tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+    for (uint32_t t = rank; t < tiles_x * tiles_y; t += world) {
+        uint32_t tx = (t % tiles_x) * T, ty = (t / tiles_x) * T;
+        for (uint32_t by = 0; by < T; by += B)
+            for (uint32_t bx = 0; bx < T; bx += B)
+                for (uint32_t y = 0; y < B; ++y)
+                    for (uint32_t x = 0; x < B; ++x) {
+                        uint32_t px = tx + bx + x, py = ty + by + y;
+                        if (px < W && py < H) out.push_back(px | (py << 16));
+                    }
+    }
+}
+
+int validate_scene(rpt_ctx *ctx, const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt,
+                   const rpt_bvh_node *nodes, size_t nn, const rpt_material_data *mats, size_t nm,
+                   const rpt_light_pick_entry *lp, size_t nlp, uint32_t &max_depth) {
+    (void)pv; (void)mats;
+    if (!nv || !nt || !nn || !nm || !nlp) { ctx->error = "empty scene buffer"; return RPT_ESCENE; }
+    if (nt >= 0x7fffffffull || nn >= 0x7fffffffull) { ctx->error = "scene too large for 31-bit indices"; return RPT_ESCENE; }
+    for (size_t i = 0; i < nt; ++i)
+        if (idx[i].v0 >= nv || idx[i].v1 >= nv || idx[i].v2 >= nv || idx[i].material >= nm) {
+            ctx->error = "index buffer entry out of range";
+            return RPT_ESCENE;
+        }
+    bool sentinel = lp[0].ratio < 0.0f;
+    if (!sentinel)
+        for (size_t i = 0; i < nlp; ++i)
+            if (lp[i].triangle_index_a >= nt || lp[i].triangle_index_b >= nt) {
+                ctx->error = "light pick entry out of range";
+                return RPT_ESCENE;
+            }
+    /* BVH: children in range, every node reached at most once, depth bounded */
+    std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 0u}};
+    size_t visited = 0;
+    max_depth = 0;
+    while (!stack.empty()) {
+        auto [n, d] = stack.back();
+        stack.pop_back();
+        if (++visited > nn) { ctx->error = "BVH is not a tree"; return RPT_ESCENE; }
+        if (d > max_depth) max_depth = d;
+        const rpt_bvh_node &node = nodes[n];
+        if (node.triangle_count > 0) {
+            if ((size_t)node.left_or_first + node.triangle_count > nt) { ctx->error = "BVH leaf range out of bounds"; return RPT_ESCENE; }
+        } else {
+            if ((size_t)node.left_or_first + 1 >= nn) { ctx->error = "BVH child index out of bounds"; return RPT_ESCENE; }
+            stack.push_back({node.left_or_first, d + 1});
+            stack.push_back({node.left_or_first + 1, d + 1});
+        }
+    }
+    if (max_depth > 31) {   /* reference: FixedVec<usize, 32> would overflow (intersection.rs:178) */
+        ctx->error = "BVH deeper than the reference's 32-entry traversal stack";
+        return RPT_ESCENE;
+    }
+    return RPT_OK;
+}
+
+void rotation_y(float angle, float *m) {   /* Mat3::from_rotation_y, column-major */
+    float s, c;
+    rptm::sincosr(angle, s, c);
+    m[0] = c; m[1] = 0.0f; m[2] = -s;
+    m[3] = 0.0f; m[4] = 1.0f; m[5] = 0.0f;
+    m[6] = s; m[7] = 0.0f; m[8] = c;
+}
+void rotation_x(float angle, float *m) {
+    float s, c;
+    rptm::sincosr(angle, s, c);
+    m[0] = 1.0f; m[1] = 0.0f; m[2] = 0.0f;
+    m[3] = 0.0f; m[4] = c; m[5] = s;
+    m[6] = 0.0f; m[7] = -s; m[8] = c;
+}
+void mat3_mul_host(const float *a, const float *b, float *out) {   /* Mat3 * Mat3 = cols a*b.col */
+    for (int c = 0; c < 3; ++c) {
+        float v[3] = {b[3 * c], b[3 * c + 1], b[3 * c + 2]};
+        for (int r = 0; r < 3; ++r) {
+            float acc = a[r] * v[0];
+            acc = acc + a[3 + r] * v[1];
+            acc = acc + a[6 + r] * v[2];
+            out[3 * c + r] = acc;
+        }
+    }
+}
+
+void release_state(rpt_ctx *c) {
+    c->ray_a.release(); c->ray_b.release(); c->thr_rad.release(); c->rad_misc.release();
+    c->mis0.release(); c->mis1.release(); c->mis2.release(); c->mis3.release();
+    c->accum.release(); c->rng.release();
+    c->q_ext0.release(); c->q_ext1.release(); c->q_sky.release(); c->q_fin.release(); c->q_count.release();
+    c->sh_o.release(); c->sh_d.release(); c->sh_c.release();
+    c->pixel_xy.release();
+    c->has_state = false;
+}
+
+int alloc_state(rpt_ctx *c) {
+    size_t n = c->n_slots;
+    HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n));
+    HIP_TRY(c, c->thr_rad.alloc(n)); HIP_TRY(c, c->rad_misc.alloc(n));
+    HIP_TRY(c, c->mis0.alloc(n)); HIP_TRY(c, c->mis1.alloc(n)); HIP_TRY(c, c->mis2.alloc(n)); HIP_TRY(c, c->mis3.alloc(n));
+    HIP_TRY(c, c->accum.alloc(n)); HIP_TRY(c, c->rng.alloc(n));
+    HIP_TRY(c, c->q_ext0.alloc(n)); HIP_TRY(c, c->q_ext1.alloc(n)); HIP_TRY(c, c->q_sky.alloc(n)); HIP_TRY(c, c->q_fin.alloc(n));
+    HIP_TRY(c, c->q_count.alloc(Q_COUNT));
+    HIP_TRY(c, c->sh_o.alloc(n)); HIP_TRY(c, c->sh_d.alloc(n)); HIP_TRY(c, c->sh_c.alloc(n));
+    HIP_TRY(c, c->pixel_xy.alloc(n));
+    if (n) HIP_TRY(c, hipMemcpy(c->pixel_xy.p, c->pixel_xy_host.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t)));
+    DevState &s = c->state;
+    s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.thr_rad = c->thr_rad.p; s.rad_misc = c->rad_misc.p;
+    s.mis0 = c->mis0.p; s.mis1 = c->mis1.p; s.mis2 = c->mis2.p; s.mis3 = c->mis3.p;
+    s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = (uint32_t)n;
+    DevQueues &q = c->queues;
+    q.ext[0] = c->q_ext0.p; q.ext[1] = c->q_ext1.p; q.sky = c->q_sky.p; q.fin = c->q_fin.p;
+    q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p; q.count = c->q_count.p;
+    c->has_state = true;
+    return RPT_OK;
+}
+
+__global__ void k_begin_iteration(uint32_t *count, uint32_t next) {
+    if (threadIdx.x == 0) {
+        count[next] = 0u;
+        count[Q_SHADOW] = 0u;
+        count[Q_SKY] = 0u;
+        count[Q_FIN] = 0u;
+    }
+}
+
+template <int STACK>
+void launch_iteration(rpt_ctx *c, uint32_t cur, uint32_t blocks, bool nee, std::vector<hipEvent_t> *ev, size_t &ev_at) {
+    hipStream_t s = c->stream;
+    auto mark = [&]() {
+        if (ev) (void)hipEventRecord((*ev)[ev_at++], s);
+    };
+    k_begin_iteration<<<1, 64, 0, s>>>(c->queues.count, cur ^ 1u);
+    mark();
+    k_traverse_nearest<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues.ext[cur], c->queues.count + cur, c->dev_stats.p);
+    mark();
+    k_shade<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, cur, c->dev_stats.p);
+    mark();
+    if (nee) k_traverse_shadow<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->dev_stats.p);
+    mark();
+    k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+    mark();
+    k_generate<false><<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, cur ^ 1u, 0u);
+    mark();
+}
+
+constexpr int EVENTS_PER_ITER = 6;
+
+}  // namespace
+
+extern "C" {
+
+int rpt_abi_version(void) { return RPT_ABI_VERSION; }
+
+const char *rpt_last_error(rpt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rpt_create(int device_id, rpt_ctx **out) {
+    if (!out) { g_create_error = "null out pointer"; return RPT_EINVAL; }
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0) {
+        g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return RPT_ENODEV;
+    }
+    if (device_id < 0 || device_id >= n_dev) { g_create_error = "device id out of range"; return RPT_EINVAL; }
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return RPT_EHIP; }
+    auto *c = new rpt_ctx();
+    c->device = device_id;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return RPT_EHIP; }
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->pinned_counts), RING * Q_COUNT * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) { g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return RPT_EHIP; }
+    for (int i = 0; i < RING; ++i) (void)hipEventCreateWithFlags(&c->ring_events[i], hipEventDisableTiming);
+    c->events_ready = true;
+    if (c->dev_stats.alloc(1) != hipSuccess || hipMemset(c->dev_stats.p, 0, sizeof(DevStats)) != hipSuccess) {
+        g_create_error = "device allocation failed";
+        rpt_destroy(c);
+        return RPT_ENOMEM;
+    }
+    const char *env = getenv("RPT_STAGE_TIMING");
+    c->stage_timing = env && env[0] == '1';
+    *out = c;
+    return RPT_OK;
+}
+
+void rpt_destroy(rpt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    release_state(c);
+    c->nodes.release(); c->tri_geom.release(); c->per_vertex.release(); c->materials.release();
+    c->indices.release(); c->light_pick.release(); c->atlas.release(); c->skybox.release();
+    c->dev_stats.release();
+    for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
+    if (c->events_ready)
+        for (int i = 0; i < RING; ++i) (void)hipEventDestroy(c->ring_events[i]);
+    if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rpt_set_partition(rpt_ctx *c, uint32_t rank, uint32_t world_size) {
+    if (!c) return RPT_EINVAL;
+    if (world_size == 0 || rank >= world_size) { c->error = "rank must be < world_size"; return RPT_EINVAL; }
+    c->rank = rank;
+    c->world = world_size;
+    if (c->has_config) {   /* re-derive the slot order for the new partition */
+        rpt_tracing_config cfg = c->cfg.c;
+        c->has_config = false;
+        return rpt_set_config(c, &cfg);
+    }
+    return RPT_OK;
+}
+
+int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt,
+                     const rpt_bvh_node *nodes, size_t nn, const rpt_material_data *mats, size_t nm,
+                     const rpt_light_pick_entry *lp, size_t nlp, const uint8_t *atlas, uint32_t aw, uint32_t ah,
+                     const float *skybox, uint32_t sw, uint32_t sh) {
+    if (!c) return RPT_EINVAL;
+    if (!pv || !idx || !nodes || !mats || !lp) { c->error = "null scene buffer"; return RPT_EINVAL; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t depth = 0;
+    int rc = validate_scene(c, pv, nv, idx, nt, nodes, nn, mats, nm, lp, nlp, depth);
+    if (rc) return rc;
+    for (size_t i = 0; i < nm; ++i)
+        if ((mats[i].has_albedo_texture | mats[i].has_metallic_texture | mats[i].has_roughness_texture | mats[i].has_normal_texture) &&
+            (!atlas || !aw || !ah)) {
+            c->error = "a material references the texture atlas but no atlas was supplied";
+            return RPT_ESCENE;
+        }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->has_scene = false;
+
+    /* derived traversal geometry: (a, b - a, c - a) per triangle — the same f32
+     * subtractions muller_trumbore performs (intersection.rs:13-14), done once */
+    std::vector<float4> geom(3 * nt);
+    for (size_t i = 0; i < nt; ++i) {
+        const float *a = pv[idx[i].v0].vertex, *b = pv[idx[i].v1].vertex, *cc = pv[idx[i].v2].vertex;
+        geom[3 * i + 0] = make_float4(a[0], a[1], a[2], 0.0f);
+        geom[3 * i + 1] = make_float4(b[0] - a[0], b[1] - a[1], b[2] - a[2], 0.0f);
+        geom[3 * i + 2] = make_float4(cc[0] - a[0], cc[1] - a[1], cc[2] - a[2], 0.0f);
+    }
+    HIP_TRY(c, c->nodes.alloc(2 * nn));
+    HIP_TRY(c, c->tri_geom.alloc(3 * nt));
+    HIP_TRY(c, c->per_vertex.alloc(4 * nv));
+    HIP_TRY(c, c->materials.alloc(6 * nm));
+    HIP_TRY(c, c->indices.alloc(nt));
+    HIP_TRY(c, c->light_pick.alloc(nlp));
+    HIP_TRY(c, hipMemcpy(c->nodes.p, nodes, nn * sizeof(rpt_bvh_node), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->tri_geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->per_vertex.p, pv, nv * sizeof(rpt_per_vertex_data), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->materials.p, mats, nm * sizeof(rpt_material_data), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->indices.p, idx, nt * sizeof(rpt_triangle), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->light_pick.p, lp, nlp * sizeof(rpt_light_pick_entry), hipMemcpyHostToDevice));
+
+    static const uint8_t magenta_u8[16] = {255, 0, 255, 255, 255, 0, 255, 255, 255, 0, 255, 255, 255, 0, 255, 255};
+    static const float magenta_f[16] = {1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1};   /* src/asset.rs:283-290 */
+    if (!atlas || !aw || !ah) { atlas = magenta_u8; aw = ah = 2; }
+    if (!skybox || !sw || !sh) { skybox = magenta_f; sw = sh = 2; }
+    HIP_TRY(c, c->atlas.alloc((size_t)aw * ah));
+    HIP_TRY(c, c->skybox.alloc((size_t)sw * sh));
+    HIP_TRY(c, hipMemcpy(c->atlas.p, atlas, (size_t)aw * ah * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->skybox.p, skybox, (size_t)sw * sh * 16, hipMemcpyHostToDevice));
+
+    DevScene &s = c->scene;
+    s.nodes = c->nodes.p; s.tri_geom = c->tri_geom.p; s.indices = c->indices.p; s.per_vertex = c->per_vertex.p;
+    s.materials = c->materials.p; s.light_pick = c->light_pick.p;
+    s.n_light_pick = (uint32_t)nlp;
+    s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
+    s.atlas = DevImage{c->atlas.p, aw, ah};
+    s.skybox = DevImage{c->skybox.p, sw, sh};
+    c->bvh_depth = depth;
+    c->stack_cap = depth <= 15 ? 16 : (depth <= 23 ? 24 : 32);
+    c->has_scene = true;
+    return RPT_OK;
+}
+
+int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
+    if (!c || !cfg) return RPT_EINVAL;
+    if (cfg->width == 0 || cfg->height == 0 || cfg->width > 65535u || cfg->height > 65535u) {
+        c->error = "width/height must be in 1..65535";
+        return RPT_EINVAL;
+    }
+    uint32_t nee_mode = cfg->nee <= 2u ? cfg->nee : 0u;
+    if (cfg->max_bounces > 255u) { c->error = "max_bounces > 255"; return RPT_ECONFIG; }
+    {
+        /* LDS dimension budget (kernels/src/rng.rs:20-21,51-54): the CPU reference panics past 31 */
+        uint64_t per_bounce = 3u + (nee_mode ? 4u : 0u);
+        uint64_t rr = cfg->max_bounces > cfg->min_bounces + 1u ? cfg->max_bounces - 1u - cfg->min_bounces : 0u;
+        uint64_t dims = 2u + (uint64_t)cfg->max_bounces * per_bounce + rr;
+        if (dims > 31u) {
+            c->error = "config needs " + std::to_string(dims) + " LDS dimensions; the reference's table has 31 usable";
+            return RPT_ECONFIG;
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    bool resized = !c->has_config || c->cfg.c.width != cfg->width || c->cfg.c.height != cfg->height;
+    c->cfg.c = *cfg;
+    c->cfg.nee_mode = nee_mode;
+    float ry[9], rx[9];
+    rotation_y(cfg->cam_rotation[1], ry);
+    rotation_x(cfg->cam_rotation[0], rx);
+    mat3_mul_host(ry, rx, c->cfg.euler);
+    rotation_y(rptm::atan2r(cfg->sun_direction[2], cfg->sun_direction[0]), c->cfg.sky_rot);
+    if (resized || !c->has_state) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        release_state(c);
+        build_pixel_order(cfg->width, cfg->height, c->rank, c->world, c->pixel_xy_host);
+        c->n_slots = (uint32_t)c->pixel_xy_host.size();
+        int rc = alloc_state(c);
+        if (rc) return rc;
+        /* fresh accumulators; seeds must come from rpt_reset */
+        if (c->n_slots) {
+            HIP_TRY(c, hipMemset(c->accum.p, 0, c->n_slots * sizeof(float4)));
+            HIP_TRY(c, hipMemset(c->rng.p, 0, c->n_slots * sizeof(uint2)));
+        }
+        c->samples = 0;
+    }
+    c->has_config = true;
+    return RPT_OK;
+}
+
+int rpt_reset(rpt_ctx *c, const rpt_rng_state *seed, const float *accum_init, uint32_t samples_init) {
+    if (!c) return RPT_EINVAL;
+    if (!c->has_config || !c->has_state) { c->error = "rpt_set_config must precede rpt_reset"; return RPT_EINVAL; }
+    if (!seed) { c->error = "null seed buffer"; return RPT_EINVAL; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t W = c->cfg.c.width;
+    size_t n = c->n_slots;
+    std::vector<uint2> rng(n);
+    std::vector<float4> acc(n, make_float4(0, 0, 0, 0));
+    for (size_t s = 0; s < n; ++s) {
+        uint32_t pxy = c->pixel_xy_host[s];
+        size_t i = (size_t)(pxy >> 16) * W + (pxy & 0xffffu);
+        rng[s] = make_uint2(seed[i].n, seed[i].offset);
+        if (accum_init) acc[s] = make_float4(accum_init[4 * i], accum_init[4 * i + 1], accum_init[4 * i + 2], accum_init[4 * i + 3]);
+    }
+    if (n) {
+        HIP_TRY(c, hipMemcpy(c->rng.p, rng.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->accum.p, acc.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(c, hipMemset(c->dev_stats.p, 0, sizeof(DevStats)));
+    c->samples = accum_init ? samples_init : 0u;
+    c->stats = rpt_stats{};
+    return RPT_OK;
+}
+
+int rpt_render(rpt_ctx *c, uint32_t n_samples) {
+    if (!c) return RPT_EINVAL;
+    if (!c->has_scene || !c->has_config || !c->has_state) { c->error = "scene, config and reset must precede rpt_render"; return RPT_EINVAL; }
+    if (n_samples == 0 || c->n_slots == 0) { c->samples += n_samples; return RPT_OK; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto t0 = std::chrono::steady_clock::now();
+    hipStream_t s = c->stream;
+    const uint32_t blocks = (c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK;
+    const bool nee = c->cfg.nee_mode != RPT_NEE_NONE;
+
+    HIP_TRY(c, hipMemsetAsync(c->queues.count, 0, Q_COUNT * sizeof(uint32_t), s));
+    k_generate<true><<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, 0u, n_samples);
+    c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
+
+    std::vector<hipEvent_t> *ev = c->stage_timing ? &c->timing_events : nullptr;
+    size_t ev_at = 0;
+    if (ev) {
+        if (ev->empty()) { ev->resize(1); HIP_TRY(c, hipEventCreate(&(*ev)[0])); }
+        HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s));
+    }
+
+    uint32_t cur = 0;
+    uint64_t it = 0;
+    /* worst case: every sample needs max_bounces iterations, one after another */
+    const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces ? c->cfg.c.max_bounces : 1u) + LAG + 2;
+    for (;;) {
+        if (ev && ev->size() < ev_at + EVENTS_PER_ITER) {
+            size_t old = ev->size();
+            ev->resize(ev_at + EVENTS_PER_ITER * 64);
+            for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
+        }
+        switch (c->stack_cap) {
+            case 16: launch_iteration<16>(c, cur, blocks, nee, ev, ev_at); break;
+            case 24: launch_iteration<24>(c, cur, blocks, nee, ev, ev_at); break;
+            default: launch_iteration<32>(c, cur, blocks, nee, ev, ev_at); break;
+        }
+        int ring = (int)(it % RING);
+        HIP_TRY(c, hipMemcpyAsync(c->pinned_counts + ring * Q_COUNT, c->queues.count, Q_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipEventRecord(c->ring_events[ring], s));
+        cur ^= 1u;
+        it += 1;
+        if (it >= (uint64_t)LAG) {
+            uint64_t j = it - LAG;              /* iteration whose outcome we inspect now */
+            int rj = (int)(j % RING);
+            HIP_TRY(c, hipEventSynchronize(c->ring_events[rj]));
+            uint32_t next_of_j = (uint32_t)((j + 1) & 1u);   /* iteration j wrote its survivors into ext[(j+1)&1] */
+            if (c->pinned_counts[rj * Q_COUNT + next_of_j] == 0u) break;
+        }
+        if (it > it_limit) { c->error = "wavefront did not drain (internal error)"; return RPT_EHIP; }
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    c->stats.iterations += it;
+    c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += it;
+    c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
+    c->stats.kernel_launches[RPT_STAGE_SHADOW] += nee ? it : 0;
+    c->stats.kernel_launches[RPT_STAGE_SKY] += it;
+    c->stats.kernel_launches[RPT_STAGE_GENERATE] += it;
+    if (ev) {
+        /* events per iteration: [begin] trav shade shadow sky gen, preceded by one start event */
+        size_t at = 1;
+        for (uint64_t k = 0; k < it; ++k) {
+            float ms;
+            const int stage_of[EVENTS_PER_ITER] = {-1, RPT_STAGE_TRAVERSE, RPT_STAGE_SHADE, RPT_STAGE_SHADOW, RPT_STAGE_SKY, RPT_STAGE_GENERATE};
+            for (int e = 0; e < EVENTS_PER_ITER; ++e) {
+                if (stage_of[e] >= 0 && hipEventElapsedTime(&ms, (*ev)[at - 1], (*ev)[at]) == hipSuccess)
+                    c->stats.kernel_ms[stage_of[e]] += ms;
+                at += 1;
+            }
+        }
+    }
+    c->samples += n_samples;
+    c->stats.samples += (uint64_t)c->n_slots * n_samples;
+    c->stats.render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RPT_OK;
+}
+
+int rpt_read_accum(rpt_ctx *c, float *out, uint32_t *out_samples) {
+    if (!c || !out) return RPT_EINVAL;
+    if (!c->has_state) { c->error = "nothing to read: no config"; return RPT_EINVAL; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t W = c->cfg.c.width, H = c->cfg.c.height;
+    std::vector<float4> acc(c->n_slots);
+    if (c->n_slots) HIP_TRY(c, hipMemcpy(acc.data(), c->accum.p, c->n_slots * sizeof(float4), hipMemcpyDeviceToHost));
+    memset(out, 0, (size_t)W * H * 4 * sizeof(float));
+    for (size_t s = 0; s < c->n_slots; ++s) {
+        uint32_t pxy = c->pixel_xy_host[s];
+        size_t i = (size_t)(pxy >> 16) * W + (pxy & 0xffffu);
+        out[4 * i] = acc[s].x; out[4 * i + 1] = acc[s].y; out[4 * i + 2] = acc[s].z; out[4 * i + 3] = acc[s].w;
+    }
+    if (out_samples) *out_samples = c->samples;
+    return RPT_OK;
+}
+
+int rpt_read_rng(rpt_ctx *c, rpt_rng_state *out) {
+    if (!c || !out) return RPT_EINVAL;
+    if (!c->has_state) { c->error = "nothing to read: no config"; return RPT_EINVAL; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t W = c->cfg.c.width, H = c->cfg.c.height;
+    std::vector<uint2> rng(c->n_slots);
+    if (c->n_slots) HIP_TRY(c, hipMemcpy(rng.data(), c->rng.p, c->n_slots * sizeof(uint2), hipMemcpyDeviceToHost));
+    memset(out, 0, (size_t)W * H * sizeof(rpt_rng_state));
+    for (size_t s = 0; s < c->n_slots; ++s) {
+        uint32_t pxy = c->pixel_xy_host[s];
+        out[(size_t)(pxy >> 16) * W + (pxy & 0xffffu)] = rpt_rng_state{rng[s].x, rng[s].y};
+    }
+    return RPT_OK;
+}
+
+int rpt_local_pixels(rpt_ctx *c, uint64_t *n) {
+    if (!c || !n) return RPT_EINVAL;
+    if (!c->has_config) { c->error = "no config"; return RPT_EINVAL; }
+    *n = c->n_slots;
+    return RPT_OK;
+}
+
+int rpt_local_block_device_ptr(rpt_ctx *c, void **p) {
+    if (!c || !p) return RPT_EINVAL;
+    if (!c->has_state) { c->error = "no config"; return RPT_EINVAL; }
+    (void)hipStreamSynchronize(c->stream);
+    *p = c->accum.p;
+    return RPT_OK;
+}
+
+int rpt_rank_pixels(rpt_ctx *c, uint32_t rank, uint64_t *n) {
+    if (!c || !n) return RPT_EINVAL;
+    if (!c->has_config || rank >= c->world) { c->error = "no config / bad rank"; return RPT_EINVAL; }
+    std::vector<uint32_t> order;
+    build_pixel_order(c->cfg.c.width, c->cfg.c.height, rank, c->world, order);
+    *n = order.size();
+    return RPT_OK;
+}
+
+int rpt_tile_order(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, uint32_t *out_xy, size_t capacity,
+                   size_t *n) {
+    if (!n || !width || !height || width > 65535u || height > 65535u || !world_size || rank >= world_size) return RPT_EINVAL;
+    std::vector<uint32_t> order;
+    build_pixel_order(width, height, rank, world_size, order);
+    *n = order.size();
+    if (out_xy) {
+        if (capacity < order.size()) return RPT_EINVAL;
+        memcpy(out_xy, order.data(), order.size() * sizeof(uint32_t));
+    }
+    return RPT_OK;
+}
+
+int rpt_untile(rpt_ctx *c, const void *dev_blocks, void *dev_out_image) {
+    if (!c || !dev_blocks || !dev_out_image) return RPT_EINVAL;
+    if (!c->has_config) { c->error = "no config"; return RPT_EINVAL; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint32_t> all, order;
+    for (uint32_t r = 0; r < c->world; ++r) {
+        build_pixel_order(c->cfg.c.width, c->cfg.c.height, r, c->world, order);
+        all.insert(all.end(), order.begin(), order.end());
+    }
+    DevBuf<uint32_t> map;
+    HIP_TRY(c, map.alloc(all.size()));
+    hipError_t e = hipMemcpy(map.p, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        uint32_t n = (uint32_t)all.size();
+        k_untile<<<(n + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, c->stream>>>(reinterpret_cast<const float4 *>(dev_blocks), map.p, n,
+                                                                             c->cfg.c.width, reinterpret_cast<float4 *>(dev_out_image));
+        e = hipStreamSynchronize(c->stream);
+    }
+    map.release();
+    HIP_TRY(c, e);
+    return RPT_OK;
+}
+
+int rpt_get_stats(rpt_ctx *c, rpt_stats *out) {
+    if (!c || !out) return RPT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    DevStats ds;
+    HIP_TRY(c, hipMemcpy(&ds, c->dev_stats.p, sizeof(ds), hipMemcpyDeviceToHost));
+    c->stats.extension_rays = ds.extension_rays;
+    c->stats.shadow_rays = ds.shadow_rays;
+    c->stats.sky_evals = ds.sky_evals;
+    c->stats.light_index_clamped = ds.light_index_clamped;
+    *out = c->stats;
+    return RPT_OK;
+}
+
+/* ------------------------------------------------------------ test hooks -- */
+__global__ void k_debug_math(int op, const float *x, const float *y, float *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+        case 0: r = rptm::sinr(x[i]); break;
+        case 1: r = rptm::cosr(x[i]); break;
+        case 2: r = rptm::acosr(x[i]); break;
+        case 3: r = rptm::expr(x[i]); break;
+        case 4: r = rptm::powr(x[i], y[i]); break;
+        case 5: r = rptm::asinr(x[i]); break;
+        case 6: r = rptm::atan2r(x[i], y[i]); break;
+        case 7: r = rptm::sqrtr(x[i]); break;
+        default: r = x[i] / y[i]; break;
+    }
+    out[i] = r;
+}
+
+int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size_t n) {
+    if (op < 0 || op > 8 || !x || !y || !out) return RPT_EINVAL;
+    for (size_t i = 0; i < n; ++i) {
+        float r;
+        switch (op) {
+            case 0: r = rptm::sinr(x[i]); break;
+            case 1: r = rptm::cosr(x[i]); break;
+            case 2: r = rptm::acosr(x[i]); break;
+            case 3: r = rptm::expr(x[i]); break;
+            case 4: r = rptm::powr(x[i], y[i]); break;
+            case 5: r = rptm::asinr(x[i]); break;
+            case 6: r = rptm::atan2r(x[i], y[i]); break;
+            case 7: r = rptm::sqrtr(x[i]); break;
+            default: r = x[i] / y[i]; break;
+        }
+        out[i] = r;
+    }
+    return RPT_OK;
+}
+
+int rpt_debug_math(rpt_ctx *c, int op, const float *x, const float *y, float *out, size_t n) {
+    if (!c || op < 0 || op > 8 || !x || !y || !out) return RPT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<float> dx, dy, dout;
+    HIP_TRY(c, dx.alloc(n)); HIP_TRY(c, dy.alloc(n)); HIP_TRY(c, dout.alloc(n));
+    hipError_t e = hipMemcpy(dx.p, x, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy.p, y, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_debug_math<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(op, dx.p, dy.p, dout.p, n);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost);
+    dx.release(); dy.release(); dout.release();
+    HIP_TRY(c, e);
+    return RPT_OK;
+}
+
+int rpt_debug_trace_rays(rpt_ctx *c, int any_hit, size_t n, const float *origins, const float *dirs, const float *max_t,
+                         float *out_t, uint32_t *out_tri, uint32_t *out_flags) {
+    if (!c || !origins || !dirs || !out_t || !out_tri || !out_flags || (any_hit && !max_t)) return RPT_EINVAL;
+    if (!c->has_scene) { c->error = "no scene"; return RPT_EINVAL; }
+    if (n == 0) return RPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<float> d_o, d_d, d_m, d_t;
+    DevBuf<uint32_t> d_tri, d_fl;
+    HIP_TRY(c, d_o.alloc(3 * n)); HIP_TRY(c, d_d.alloc(3 * n)); HIP_TRY(c, d_m.alloc(n)); HIP_TRY(c, d_t.alloc(n));
+    HIP_TRY(c, d_tri.alloc(n)); HIP_TRY(c, d_fl.alloc(n));
+    hipError_t e = hipMemcpy(d_o.p, origins, 12 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d.p, dirs, 12 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && max_t) e = hipMemcpy(d_m.p, max_t, 4 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        unsigned blocks = (unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK);
+        hipStream_t s = c->stream;
+#define LAUNCH_DBG(ST)                                                                                                      \
+    if (any_hit) k_trace_debug<ST, true><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p); \
+    else k_trace_debug<ST, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p)
+        switch (c->stack_cap) {
+            case 16: LAUNCH_DBG(16); break;
+            case 24: LAUNCH_DBG(24); break;
+            default: LAUNCH_DBG(32); break;
+        }
+#undef LAUNCH_DBG
+        e = hipStreamSynchronize(s);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out_t, d_t.p, 4 * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_tri, d_tri.p, 4 * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_flags, d_fl.p, 4 * n, hipMemcpyDeviceToHost);
+    d_o.release(); d_d.release(); d_m.release(); d_t.release(); d_tri.release(); d_fl.release();
+    HIP_TRY(c, e);
+    return RPT_OK;
+}
+
+}  // extern "C"

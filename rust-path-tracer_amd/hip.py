@@ -1,0 +1,212 @@
+"""Renderer: ctypes over the rpt.h C ABI of librpt_hip.so (the MI355X wavefront path tracer).
+
+Every method maps 1:1 to a C entry point, which in turn cites the reference
+call it replaces (include/rpt/rpt.h; reference: src/trace.rs:136-224).
+There is deliberately NO fallback: if the HIP library is missing or no GPU is
+present this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import RNG_DTYPE, Stats, TracingConfig, ptr
+
+_lib = None
+
+EXPORTS = [
+    "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
+    "rpt_render", "rpt_read_accum", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
+    "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
+    "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_trace_rays",
+]
+
+
+def lib_path():
+    return os.path.join(_ffi.LIB_DIR, "librpt_hip.so")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make hip` (or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(path)
+        L.rpt_last_error.restype = C.c_char_p
+        L.rpt_last_error.argtypes = [C.c_void_p]
+        L.rpt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.rpt_destroy.argtypes = [C.c_void_p]
+        L.rpt_destroy.restype = None
+        L.rpt_set_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rpt_upload_scene.argtypes = [C.c_void_p] + [C.c_void_p, C.c_size_t] * 5 + [C.c_void_p, C.c_uint32, C.c_uint32] * 2
+        L.rpt_set_config.argtypes = [C.c_void_p, C.POINTER(TracingConfig)]
+        L.rpt_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.rpt_render.argtypes = [C.c_void_p, C.c_uint32]
+        L.rpt_read_accum.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rpt_read_rng.argtypes = [C.c_void_p, C.c_void_p]
+        L.rpt_local_pixels.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.rpt_local_block_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rpt_rank_pixels.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.rpt_untile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpt_tile_order.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]
+        L.rpt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rpt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rpt_debug_math_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rpt_debug_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 6
+        _lib = L
+    return _lib
+
+
+class RptError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"librpt_hip error {code}: {message}")
+        self.code = code
+
+
+class Renderer:
+    """One rpt_ctx on one GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device_id=0, rank=0, world_size=1):
+        self._h = C.c_void_p()
+        rc = lib().rpt_create(device_id, C.byref(self._h))
+        if rc != 0:
+            raise RptError(rc, lib().rpt_last_error(None).decode())
+        self.rank, self.world_size = rank, world_size
+        if world_size != 1:
+            self._check(lib().rpt_set_partition(self._h, rank, world_size))
+        self.config = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RptError(rc, lib().rpt_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rpt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- rpt_upload_scene <-> World::into_gpu (reference: src/asset.rs:226-235)
+    def upload_scene(self, world, skybox_f32=None):
+        atlas = getattr(world, "atlas", None)
+        aw = ah = sw = sh = 0
+        if atlas is not None:
+            atlas = np.ascontiguousarray(atlas, np.uint8)
+            ah, aw = atlas.shape[:2]
+        if skybox_f32 is not None:
+            skybox_f32 = np.ascontiguousarray(skybox_f32, np.float32)
+            sh, sw = skybox_f32.shape[:2]
+        self._check(lib().rpt_upload_scene(
+            self._h, ptr(world.per_vertex), len(world.per_vertex), ptr(world.indices), len(world.indices),
+            ptr(world.nodes), len(world.nodes), ptr(world.materials), len(world.materials),
+            ptr(world.light_pick), len(world.light_pick), ptr(atlas), aw, ah, ptr(skybox_f32), sw, sh))
+
+    # -- rpt_set_config <-> config_buffer write (reference: src/trace.rs:168,219)
+    def set_config(self, config):
+        self._check(lib().rpt_set_config(self._h, C.byref(config)))
+        self.config = config.copy()
+
+    # -- rpt_reset <-> rng/output buffer creation + flush (reference: src/trace.rs:164-170,219-221)
+    def reset(self, rng_seed, accum_init=None, samples_init=0):
+        rng_seed = np.ascontiguousarray(rng_seed, RNG_DTYPE)
+        assert rng_seed.size == self.config.width * self.config.height
+        if accum_init is not None:
+            accum_init = np.ascontiguousarray(accum_init, np.float32)
+            assert accum_init.size == rng_seed.size * 4
+        self._check(lib().rpt_reset(self._h, ptr(rng_seed), ptr(accum_init), samples_init))
+
+    # -- rpt_render <-> the enqueue/poll loop (reference: src/trace.rs:182-194)
+    def render(self, n_samples):
+        self._check(lib().rpt_render(self._h, n_samples))
+
+    # -- rpt_read_accum <-> output_buffer.read_blocking (reference: src/trace.rs:198)
+    def read_accum(self):
+        out = np.zeros((self.config.height, self.config.width, 4), np.float32)
+        samples = C.c_uint32()
+        self._check(lib().rpt_read_accum(self._h, ptr(out), C.byref(samples)))
+        return out, samples.value
+
+    def read_rng(self):
+        out = np.zeros(self.config.height * self.config.width, RNG_DTYPE)
+        self._check(lib().rpt_read_rng(self._h, ptr(out)))
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._check(lib().rpt_get_stats(self._h, C.byref(s)))
+        d = {k: getattr(s, k) for k in ("samples", "extension_rays", "shadow_rays", "sky_evals", "light_index_clamped",
+                                         "iterations", "render_ms")}
+        d["kernel_ms"] = {n: s.kernel_ms[i] for i, n in enumerate(_ffi.STAGE_NAMES)}
+        d["kernel_launches"] = {n: s.kernel_launches[i] for i, n in enumerate(_ffi.STAGE_NAMES)}
+        return d
+
+    # -- multi-GPU gather support
+    def local_pixels(self):
+        n = C.c_uint64()
+        self._check(lib().rpt_local_pixels(self._h, C.byref(n)))
+        return n.value
+
+    def rank_pixels(self, rank):
+        n = C.c_uint64()
+        self._check(lib().rpt_rank_pixels(self._h, rank, C.byref(n)))
+        return n.value
+
+    def local_block_device_ptr(self):
+        p = C.c_void_p()
+        self._check(lib().rpt_local_block_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def untile(self, dev_blocks_ptr, dev_out_ptr):
+        self._check(lib().rpt_untile(self._h, C.c_void_p(dev_blocks_ptr), C.c_void_p(dev_out_ptr)))
+
+    # -- test hooks
+    def debug_math(self, op, x, y=None):
+        x = np.ascontiguousarray(x, np.float32)
+        y = x if y is None else np.ascontiguousarray(y, np.float32)
+        out = np.empty_like(x)
+        self._check(lib().rpt_debug_math(self._h, op, ptr(x), ptr(y), ptr(out), x.size))
+        return out
+
+    def debug_trace_rays(self, any_hit, origins, dirs, max_t=None):
+        origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(origins)
+        max_t = np.zeros(n, np.float32) if max_t is None else np.ascontiguousarray(max_t, np.float32)
+        t = np.zeros(n, np.float32)
+        tri = np.zeros(n, np.uint32)
+        flags = np.zeros(n, np.uint32)
+        self._check(lib().rpt_debug_trace_rays(self._h, int(bool(any_hit)), n, ptr(origins), ptr(dirs), ptr(max_t),
+                                               ptr(t), ptr(tri), ptr(flags)))
+        return t, tri, flags
+
+
+def tile_order(width, height, rank, world_size):
+    """(x | y << 16) of every pixel of `rank`'s tile-major block, in block order (no GPU needed)."""
+    n = C.c_size_t()
+    rc = lib().rpt_tile_order(width, height, rank, world_size, None, 0, C.byref(n))
+    if rc != 0:
+        raise RptError(rc, "rpt_tile_order")
+    out = np.zeros(n.value, np.uint32)
+    rc = lib().rpt_tile_order(width, height, rank, world_size, ptr(out), out.size, C.byref(n))
+    if rc != 0:
+        raise RptError(rc, "rpt_tile_order")
+    return out
+
+
+def debug_math_host(op, x, y=None):
+    """The host build of rpt_math.h inside librpt_hip.so (no GPU needed)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = x if y is None else np.ascontiguousarray(y, np.float32)
+    out = np.empty_like(x)
+    rc = lib().rpt_debug_math_host(op, ptr(x), ptr(y), ptr(out), x.size)
+    if rc != 0:
+        raise RptError(rc, "rpt_debug_math_host")
+    return out

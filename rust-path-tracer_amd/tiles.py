@@ -1,0 +1,69 @@
+"""Framebuffer tile partition + the single per-batch gather (one process per GPU).
+
+The reference has no multi-device path; pixels are independent
+(kernels/src/lib.rs:209-226 touch only output[i] / rng[i]), so the image is cut
+into 64x64 tiles dealt round-robin to ranks and every rank renders its own
+pixels with global coordinates.  There is NO data-path collective while
+rendering; after a sample batch ONE gather moves each rank's contiguous
+tile-major accumulator block to rank 0 (RCCL over xGMI via torch.distributed,
+backend "nccl"; "gloo" in the CPU tests), and rank 0 un-tiles.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+
+def block_sizes(width, height, world_size):
+    return [len(hip.tile_order(width, height, r, world_size)) for r in range(world_size)]
+
+
+def untile_host(blocks, width, height, world_size):
+    """Host reference of rpt_untile: list of per-rank (n_r, 4) arrays -> (H, W, 4) image."""
+    img = np.zeros((height, width, 4), np.float32)
+    for r, blk in enumerate(blocks):
+        xy = hip.tile_order(width, height, r, world_size)
+        img[(xy >> 16).astype(np.int64), (xy & 0xFFFF).astype(np.int64)] = np.asarray(blk, np.float32).reshape(-1, 4)
+    return img
+
+
+def tile_block_from_image(image, rank, world_size):
+    """Extract rank's tile-major block from a full (H, W, 4) image (what a rank would hold)."""
+    h, w = image.shape[:2]
+    xy = hip.tile_order(w, h, rank, world_size)
+    return np.ascontiguousarray(image[(xy >> 16).astype(np.int64), (xy & 0xFFFF).astype(np.int64)], np.float32)
+
+
+def gather_blocks(local_block, width, height, group=None):
+    """The one collective of the multi-GPU path: gather per-rank blocks to rank 0.
+
+    local_block: torch tensor (n_local, 4) float32 on this rank's device (CPU for gloo).
+    Returns on rank 0 the list of per-rank tensors, elsewhere None.  Blocks may
+    differ in size by a few tiles, so they travel padded to the largest block.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = block_sizes(width, height, world)
+    n_max = max(sizes)
+    padded = torch.zeros((n_max, 4), dtype=torch.float32, device=local_block.device)
+    padded[: local_block.shape[0]] = local_block
+    if rank == 0:
+        recv = [torch.empty_like(padded) for _ in range(world)]
+        dist.gather(padded, gather_list=recv, dst=0, group=group)
+        return [recv[r][: sizes[r]] for r in range(world)]
+    dist.gather(padded, gather_list=None, dst=0, group=group)
+    return None
+
+
+def device_block_as_tensor(renderer, device):
+    """Alias the renderer's tile-major accumulator block (device memory owned by librpt_hip) as a torch tensor."""
+    n = renderer.local_pixels()
+    ptr = renderer.local_block_device_ptr()
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
+    return torch.as_tensor(h, device=device)

@@ -1,0 +1,231 @@
+"""GPU parity tests: the HIP wavefront path (through the rpt.h C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): per-pixel relative L2 <= 1e-4 on the mean
+radiance image.  Because rpt_math.h makes both sides bit-identical, the tests
+assert the STRONGER property first (bitwise equal accumulators, equal ray
+counts) and report rel-L2 as the contractual figure.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_REL_L2 = 1e-4   # north_star tolerance
+
+
+def _random_rays(rng, n, world):
+    lo = world.per_vertex["vertex"][:, :3].min(axis=0)
+    hi = world.per_vertex["vertex"][:, :3].max(axis=0)
+    ext = np.maximum(hi - lo, 1e-3)
+    o = (lo - 0.3 * ext + rng.random((n, 3)) * 1.6 * ext).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    # a few axis-aligned directions: exercise the 0-component / inf / NaN slab paths
+    d[: n // 50] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n // 50)] * rng.choice([-1.0, 1.0], (n // 50, 1)).astype(np.float32)
+    return o, d
+
+
+@pytest.mark.parametrize("op,lo,hi", [(0, -10, 10), (1, -10, 10), (2, -1, 1), (3, -100, 30), (5, -1, 1), (7, 0, 1e6)])
+def test_math_bitwise_device_vs_host(renderer, hipmod, oracle, op, lo, hi):
+    rng = np.random.default_rng(op)
+    x = rng.uniform(lo, hi, 1 << 20).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, -1.0, 0.5, -0.5, np.float32(hi), np.float32(lo)]
+    dev = renderer.debug_math(op, x)
+    host = hipmod.debug_math_host(op, x)          # clang host build inside librpt_hip.so
+    orc = oracle.math(op, x)                      # g++ build inside the oracle
+    assert np.array_equal(dev.view(np.uint32), host.view(np.uint32))
+    assert np.array_equal(dev.view(np.uint32), orc.view(np.uint32))
+
+
+def test_math_two_operand_bitwise(renderer, oracle):
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    x = rng.uniform(0, 4, n).astype(np.float32)
+    y = rng.uniform(0.1, 3, n).astype(np.float32)
+    y[: n // 2] = np.float32(2.2)
+    assert np.array_equal(renderer.debug_math(4, x, y).view(np.uint32), oracle.math(4, x, y).view(np.uint32))   # pow
+    a = rng.uniform(-3, 3, n).astype(np.float32)
+    b = rng.uniform(-3, 3, n).astype(np.float32)
+    assert np.array_equal(renderer.debug_math(6, a, b).view(np.uint32), oracle.math(6, a, b).view(np.uint32))   # atan2
+    b[:100] = 0.0   # x / 0, 0 / 0
+    a[:50] = 0.0
+    q_dev, q_cpu = renderer.debug_math(8, a, b), oracle.math(8, a, b)                                          # IEEE divide
+    both_nan = np.isnan(q_dev) & np.isnan(q_cpu)
+    assert np.array_equal(q_dev.view(np.uint32)[~both_nan], q_cpu.view(np.uint32)[~both_nan])
+
+
+@pytest.mark.parametrize("scene", ["DarkCornell", "VeachMIS", "FurnaceTest", "PBRTest"])
+def test_ray_parity_nearest_and_any(renderer, oracle, world, scene):
+    w = world(scene)
+    renderer.upload_scene(w)
+    sc = oracle.scene(w)
+    rng = np.random.default_rng(5)
+    o, d = _random_rays(rng, 200_000, w)
+    t_g, tri_g, fl_g = renderer.debug_trace_rays(False, o, d)
+    t_c, tri_c, fl_c, err = oracle.trace_rays(sc, 0, o, d)
+    assert err == 0
+    assert np.array_equal(fl_g, fl_c)
+    hit = (fl_c & 1) == 1
+    assert hit.sum() > 1000
+    assert np.array_equal(t_g.view(np.uint32), t_c.view(np.uint32))
+    assert np.array_equal(tri_g[hit], tri_c[hit])
+    max_t = (rng.random(len(o)) * 8).astype(np.float32)
+    _, _, afl_g = renderer.debug_trace_rays(True, o, d, max_t)
+    _, _, afl_c, err = oracle.trace_rays(sc, 1, o, d, max_t)
+    assert err == 0
+    assert np.array_equal(afl_g & 1, afl_c & 1)
+
+
+CASES = [
+    # scene, W, H, spp, nee, config overrides
+    ("FurnaceTest", 128, 128, 8, 0, {}),
+    ("FurnaceTest", 128, 128, 8, 1, {}),
+    ("FurnaceTest", 96, 64, 4, 2, {}),
+    ("DarkCornell", 256, 256, 8, 0, {}),
+    ("DarkCornell", 200, 120, 6, 1, {}),                       # ragged: not a multiple of the 64-pixel tile
+    ("DarkCornell", 128, 128, 4, 2, {"min_bounces": 1, "max_bounces": 3}),   # roulette active
+    ("VeachMIS", 192, 108, 4, 1, {}),
+    ("VeachMIS", 160, 90, 4, 0, {"cam_rotation": (0.2, -0.4, 0.0, 0.0), "cam_position": (1.0, 2.0, -6.0, 0.0)}),
+    ("PBRTest", 128, 128, 2, 0, {}),
+    ("PBRTest", 128, 96, 2, 1, {"min_bounces": 0, "max_bounces": 3}),
+]
+
+
+@pytest.mark.parametrize("scene,W,H,spp,nee,over", CASES)
+def test_image_parity_with_oracle(renderer, oracle, rpt, world, scene, W, H, spp, nee, over):
+    w = world(scene)
+    cfg = rpt.default_config(W, H, nee=nee, **over)
+    seeds = rpt.blue_noise_seeds(W, H)
+    renderer.upload_scene(w)
+    renderer.set_config(cfg)
+    renderer.reset(seeds)
+    renderer.render(spp)
+    acc_g, samples = renderer.read_accum()
+    st_g = renderer.stats()
+    acc_c, rng_c, st_c = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    assert samples == spp and st_c.error_flags == 0
+    assert np.all(acc_g[..., 3] == spp)
+    # ray accounting must agree exactly
+    assert st_g["extension_rays"] == st_c.extension_rays
+    assert st_g["shadow_rays"] == st_c.shadow_rays
+    assert st_g["sky_evals"] == st_c.sky_evals
+    # rng[i].x += 1 per sample (kernels/src/lib.rs:226)
+    rng_g = renderer.read_rng()
+    assert np.array_equal(rng_g["n"], rng_c["n"]) and np.array_equal(rng_g["offset"], rng_c["offset"])
+    mean_g, mean_c = acc_g[..., :3] / spp, acc_c[..., :3] / spp
+    err = rel_l2(mean_g, mean_c)
+    n_diff = int((acc_g.view(np.uint32) != acc_c.view(np.uint32)).any(axis=2).sum())
+    print(f"{scene} {W}x{H} spp={spp} nee={nee}: relL2={err:.3e} pixels differing bitwise={n_diff}")
+    assert err <= TOL_REL_L2
+    assert n_diff == 0, "accumulators are expected to be bit-identical to the oracle"
+
+
+def test_render_in_batches_equals_one_batch(renderer, rpt, world):
+    w = world("DarkCornell")
+    cfg = rpt.default_config(96, 96, nee=1)
+    seeds = rpt.blue_noise_seeds(96, 96)
+    renderer.upload_scene(w)
+    renderer.set_config(cfg)
+    renderer.reset(seeds)
+    renderer.render(6)
+    a, _ = renderer.read_accum()
+    renderer.reset(seeds)
+    for n in (1, 2, 3):
+        renderer.render(n)
+    b, s = renderer.read_accum()
+    assert s == 6 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_resume_from_mean_times_samples(renderer, oracle, rpt, world):
+    """accum_init = mean * samples (reference: src/trace.rs:163-164)."""
+    w = world("FurnaceTest")
+    cfg = rpt.default_config(64, 64)
+    seeds = rpt.blue_noise_seeds(64, 64)
+    renderer.upload_scene(w)
+    renderer.set_config(cfg)
+    init = np.full((64, 64, 4), 0.25, np.float32) * np.float32(4.0)
+    init[..., 3] = 4.0
+    renderer.reset(seeds, accum_init=init, samples_init=4)
+    renderer.render(2)
+    acc, samples = renderer.read_accum()
+    acc_c, _, _ = oracle.trace_cpu(cfg, oracle.scene(w), seeds, 2, accum=init)
+    assert samples == 6
+    assert np.array_equal(acc.view(np.uint32), acc_c.view(np.uint32))
+
+
+def test_tile_partition_is_invisible(hipmod, rpt, world, tiles):
+    """Rendering as rank r of 3 gives exactly the pixels of the full render (8e: determinism across GPU counts)."""
+    w = world("DarkCornell")
+    W, H = 200, 136
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+    full = hipmod.Renderer(0)
+    full.upload_scene(w); full.set_config(cfg); full.reset(seeds); full.render(3)
+    ref, _ = full.read_accum()
+    full.close()
+    blocks = []
+    for r in range(3):
+        part = hipmod.Renderer(0, rank=r, world_size=3)
+        part.upload_scene(w); part.set_config(cfg); part.reset(seeds); part.render(3)
+        img, _ = part.read_accum()
+        blk = tiles.tile_block_from_image(img, r, 3)
+        assert part.local_pixels() == len(blk) == part.rank_pixels(r)
+        blocks.append(blk)
+        own = np.zeros((H, W), bool)
+        xy = hipmod.tile_order(W, H, r, 3)
+        own[xy >> 16, xy & 0xFFFF] = True
+        assert np.all(img[~own] == 0)
+        part.close()
+    assert np.array_equal(tiles.untile_host(blocks, W, H, 3).view(np.uint32), ref.view(np.uint32))
+
+
+def test_device_untile_matches_host(hipmod, rpt, world, tiles):
+    import torch
+    w = world("DarkCornell")
+    W, H = 136, 72
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    parts, blocks = [], []
+    for r in range(2):
+        part = hipmod.Renderer(0, rank=r, world_size=2)
+        part.upload_scene(w); part.set_config(cfg); part.reset(seeds); part.render(2)
+        blocks.append(tiles.device_block_as_tensor(part, "cuda:0").clone())
+        parts.append(part)
+    cat = torch.cat(blocks, 0).contiguous()
+    out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    parts[0].untile(cat.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    host = tiles.untile_host([b.cpu().numpy() for b in blocks], W, H, 2)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), host.view(np.uint32))
+    for p in parts:
+        p.close()
+
+
+def test_host_dispatch_trace_gpu_furnace(rpt):
+    """The reference's own test, through the host-side mirror: furnace_test(use_cpu=false, use_mis) —
+    tests/correctness_tests.rs:14-33 — at the reference's settings (128^2, 32 spp, pixel (65,75))."""
+    for use_mis in (False, True):
+        state = rpt.setup_trace(128, 128, 32)
+        if use_mis:
+            state.config.nee = 1
+        rpt.trace_gpu(rpt.fixture("FurnaceTest.glb"), None, state)
+        assert state.samples == 32
+        frame = state.framebuffer()
+        px = frame[75, 65] ** (1.0 / 2.2)
+        assert np.all(np.abs(px - 0.8) < 0.02), px
+        state.close()
+
+
+def test_error_behaviour(hipmod, rpt, world):
+    r = hipmod.Renderer(0)
+    with pytest.raises(hipmod.RptError):           # render before scene/config
+        r.render(1)
+    r.upload_scene(world("DarkCornell"))
+    bad = rpt.default_config(64, 64, nee=1, max_bounces=5)     # 2 + 5*7 > 31 LDS dimensions: reference panics
+    with pytest.raises(hipmod.RptError) as e:
+        r.set_config(bad)
+    assert e.value.code == -4
+    r.close()
