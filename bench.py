@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mrays/s of the MI355X wavefront path tracer.
+
+Workload (BASELINE.json configs[1]): DarkCornell.glb, 1024x1024, 256 spp, default
+TracingConfig (nee = 0, min/max bounces 3/4 — the reference's own bench setting,
+benches/benchmark.rs:17-19), blue-noise seeds.  A "step" is one sample batch:
+`rpt_render(spp_per_step)` over every pixel of this rank's tiles, followed (N > 1)
+by the ONE gather of per-rank tile-major accumulator blocks to rank 0 and the
+root's un-tile.  Default 16 steps x 16 spp = the full 256 spp of the config.
+
+  python bench.py --gpus 1 --steps 16 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = (extension + shadow rays traced by all
+ranks in the K timed steps) / max-over-ranks wall time, scene and state already
+resident in HBM.  Extra objects: `roofline` (dominant kernel, HIP-event timed in
+the same run) and `cpu_baseline` (the CPU oracle — a port of the reference's
+trace_cpu, test infrastructure — timed on this host's cores on a bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene, width, height, total spp of the BASELINE config, config overrides)
+    "darkcornell": ("DarkCornell", 1024, 1024, 256, {}),
+    "darkcornell_mis": ("DarkCornell", 1024, 1024, 256, {"nee": 1}),
+    "veachmis": ("VeachMIS", 1920, 1080, 1024, {"nee": 1}),
+    "pbrtest": ("PBRTest", 2048, 2048, 512, {}),
+    "furnace": ("FurnaceTest", 256, 256, 16, {}),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples):
+    """minimal SoA wavefront traffic, every record written once and read once."""
+    return 128 * n_ext + 96 * n_shadow + 128 * n_mis + 40 * n_samples
+
+
+# bytes the traversal stage itself must move per extension ray: queue slot id 4 R,
+# ray {o 12, d 12} R, hit {t 4, tri|backface 4} W  (its share of the 128 B/ray figure)
+TRAVERSE_BYTES_PER_RAY = 4 + 24 + 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="darkcornell", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    args = ap.parse_args()
+
+    os.environ.setdefault("RPT_STAGE_TIMING", "1")   # HIP events between stage kernels on the render stream
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rpt = importlib.import_module("rust-path-tracer_amd")
+    hip = importlib.import_module("rust-path-tracer_amd.hip")
+    tiles = importlib.import_module("rust-path-tracer_amd.tiles")
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+
+    scene, W, H, total_spp, over = WORKLOADS[args.workload]
+    world = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    cfg = rpt.default_config(W, H, **over)
+    seeds = rpt.blue_noise_seeds(W, H)
+
+    r = hip.Renderer(local_rank, rank=rank, world_size=world_size)
+    r.upload_scene(world)
+    r.set_config(cfg)
+    r.reset(seeds)
+    local_block = tiles.device_block_as_tensor(r, device)
+    image = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        r.render(args.spp_per_step)
+        if world_size > 1:
+            blocks = tiles.gather_blocks(local_block, W, H)          # the single collective per sample batch
+            if rank == 0:
+                cat = torch.cat(blocks, 0).contiguous()
+                r.untile(cat.data_ptr(), image.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    s0 = r.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    s1 = r.stats()
+
+    def delta(key):
+        return s1[key] - s0[key]
+
+    local = torch.tensor([elapsed, float(delta("extension_rays")), float(delta("shadow_rays")), float(delta("samples")),
+                          float(delta("sky_evals"))], dtype=torch.float64, device=device)
+    if world_size > 1:
+        tmax = local[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = local[1:].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        elapsed_max = float(tmax[0])
+        n_ext, n_shadow, n_samples, n_sky = (float(x) for x in sums)
+    else:
+        elapsed_max = elapsed
+        n_ext, n_shadow, n_samples, n_sky = (float(x) for x in local[1:])
+
+    if rank != 0:
+        if world_size > 1:
+            dist.destroy_process_group()
+        return
+
+    rays = n_ext + n_shadow
+    mrays = rays / elapsed_max / 1e6
+    n_mis = n_shadow if cfg.nee == 1 else 0.0
+
+    # --- roofline of the dominant kernel, from the HIP events recorded in this run (rank 0's stream)
+    kms = {k: s1["kernel_ms"][k] - s0["kernel_ms"][k] for k in s1["kernel_ms"]}
+    klaunch = {k: s1["kernel_launches"][k] - s0["kernel_launches"][k] for k in s1["kernel_launches"]}
+    dominant = max(kms, key=lambda k: kms[k])
+    roofline = None
+    if kms[dominant] > 0:
+        avg_ms = kms[dominant] / max(klaunch[dominant], 1)
+        if dominant == "traverse":
+            units = delta("extension_rays") / max(klaunch[dominant], 1)
+            bytes_per_unit = TRAVERSE_BYTES_PER_RAY
+        else:   # report the stage against the whole-pipeline per-ray figure
+            units = delta("extension_rays") / max(klaunch[dominant], 1)
+            bytes_per_unit = 128
+        achieved = bytes_per_unit * units / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("workload") == args.workload and tj.get("kernel") == dominant:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[dominant]),
+                    "units_per_launch": round(units, 1), "algorithmic_bytes_per_unit": bytes_per_unit,
+                    "stage_ms": {k: round(v, 3) for k, v in kms.items()}}
+    pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
+    pipeline_gbs = pipeline_bytes / elapsed_max / 1e9
+
+    # --- CPU baseline: the oracle (a port of trace_cpu) on this host's cores, bounded sample of the same workload
+    cpu = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle_ffi import Oracle
+        orc = Oracle("rpt_math")
+        osc = orc.scene(world)
+        cores = os.cpu_count() or 1
+        rows = max(8, H // 16)
+        rect = (0, (H - rows) // 2, W, (H - rows) // 2 + rows)
+        _, _, st = orc.trace_cpu(cfg, osc, seeds, 1, rect=rect, threads=cores)     # calibration pass
+        rate = (st.extension_rays + st.shadow_rays) / max(st.seconds, 1e-9)
+        spp = 1
+        full_rays_per_spp = (st.extension_rays + st.shadow_rays) * (H / rows)
+        spp = int(max(1, min(64, args.cpu_seconds * rate / max(full_rays_per_spp, 1))))
+        _, _, st = orc.trace_cpu(cfg, osc, seeds, spp, threads=cores)
+        cpu_rays = st.extension_rays + st.shadow_rays
+        cpu = {"value": round(cpu_rays / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
+               "sample": f"{scene}.glb {W}x{H} {spp} spp, same config and seeds, {st.seconds:.1f} s on {st.threads} threads",
+               "samples_per_s": round(st.samples / st.seconds, 1)}
+
+    out = {
+        "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": f"fixtures/{scene}.glb (reference scene file) + blue-noise seeds; no synthetic geometry",
+        "config": {"workload": f"{scene}.glb {W}x{H}, {args.steps}x{args.spp_per_step} spp (config total {total_spp}), "
+                               f"nee={cfg.nee}, bounces {cfg.min_bounces}/{cfg.max_bounces}",
+                   "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU"},
+        "samples_per_s": round(n_samples / elapsed_max, 1),
+        "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
+                 "per_sample": round(rays / max(n_samples, 1), 4)},
+        "roofline": roofline,
+        "pipeline_roofline": {"bound": "hbm", "achieved": round(pipeline_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(pipeline_gbs / HBM_PEAK_GBS, 6),
+                              "formula": "128*N_ext + 96*N_shadow + 128*N_mis + 40*samples (SURVEY.md 8d)"},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
