@@ -1,0 +1,68 @@
+"""Host-side dispatch mirror (librpt_host.so): World::from_path, defaults, error behaviour — no GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+
+def test_default_config_matches_reference(rpt):
+    """TracingConfig::default (shared_structs/src/lib.rs:27-42)."""
+    c = rpt.default_config()
+    assert (c.width, c.height, c.min_bounces, c.max_bounces, c.nee, c.has_skybox) == (1280, 720, 3, 4, 0, 0)
+    assert list(c.cam_position) == [0.0, 1.0, -5.0, 0.0] and list(c.cam_rotation) == [0.0] * 4
+    s = np.array(list(c.sun_direction), np.float32)
+    v = np.array([0.5, 1.3, 1.0], np.float32)
+    assert np.allclose(s[:3], v / np.linalg.norm(v), atol=1e-7) and s[3] == 15.0
+    assert np.allclose(list(c.specular_weight_clamp), [0.1, 0.9])
+
+
+def test_world_load_errors_are_reported_not_fatal(rpt, tmp_path):
+    with pytest.raises(rpt.host.HostError):
+        rpt.World.from_path(str(tmp_path / "missing.glb"))
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"not a glb file at all........")
+    with pytest.raises(rpt.host.HostError):
+        rpt.World.from_path(str(bad))
+
+
+def test_axis_swap_and_winding(rpt, world):
+    """asset.rs:102,106: positions are (x, z, y); DarkCornell's floor must end up at constant world Y."""
+    w = world("DarkCornell")
+    v = w.per_vertex["vertex"]
+    assert np.all(v[:, 3] == 1.0) and np.all(w.per_vertex["normal"][:, 3] == 0.0)
+    n = w.per_vertex["normal"][:, :3]
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-5)
+    # the default camera at (0, 1, -5) looking down +Z must see geometry in front of it
+    assert v[:, 2].max() > 0 and v[:, 1].min() < 1.0 < v[:, 1].max()
+    # emissive triangles face the scene: geometric normal (post winding swap) agrees with the shading normal
+    tri = w.indices
+    em = np.where(w.materials["emissive"][tri["material"]][:, :3].any(axis=1))[0]
+    a, b, c = v[tri["v0"][em], :3], v[tri["v1"][em], :3], v[tri["v2"][em], :3]
+    g = np.cross(b - a, c - a)
+    assert np.all((g * n[tri["v0"][em]]).sum(axis=1) != 0)
+
+
+def test_world_from_buffers_runs_reference_pipeline(rpt):
+    verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [2, 2, 2], [3, 2, 2], [2, 3, 2]], np.float32)
+    tris = np.array([[0, 1, 2, 0], [0, 1, 3, 0], [4, 5, 6, 1]], np.uint32)
+    mats = np.zeros(2, rpt._ffi.MATERIAL_DTYPE)
+    mats["albedo"] = 1.0
+    mats["emissive"][1] = [3, 3, 3, 0]
+    w = rpt.World.from_buffers(verts, None, None, tris, mats)
+    assert len(w.indices) == 3 and w.n_emissive_triangles == 1 and len(w.light_pick) == 1
+    assert w.light_pick["ratio"][0] == 1.0 and w.light_pick["triangle_pick_pdf_a"][0] == 1.0
+    assert np.isclose(w.light_pick["triangle_area_a"][0], 0.5, rtol=1e-6)
+    leaves = w.nodes[w.nodes["triangle_count"] > 0]
+    assert leaves["triangle_count"].sum() == 3
+
+
+def test_trace_gpu_without_device_reports_error(rpt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    state = rpt.setup_trace(32, 32, 1)
+    with pytest.raises(rpt.host.HostError) as e:
+        rpt.trace_gpu(rpt.fixture("DarkCornell.glb"), None, state)
+    assert "no HIP device" in str(e.value)
+    assert state.samples == 0
+    state.close()

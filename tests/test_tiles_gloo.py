@@ -1,0 +1,63 @@
+"""The N > 1 data path on CPU: tile partition -> ONE gather (gloo, world_size 2 and 3) -> un-tile.
+
+Each rank holds exactly what its GPU would hold after a sample batch (its tile-major accumulator block of a
+deterministic image rendered by the CPU oracle); the gathered + un-tiled result on rank 0 must equal the
+single-device image bit for bit (the result is independent of the GPU count)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world_size, port, image_path, out_path):
+    sys.path.insert(0, ROOT)
+    import importlib
+    tiles = importlib.import_module("rust-path-tracer_amd.tiles")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    image = np.load(image_path)
+    H, W = image.shape[:2]
+    local = torch.from_numpy(tiles.tile_block_from_image(image, rank, world_size))
+    blocks = tiles.gather_blocks(local, W, H)
+    if rank == 0:
+        out = tiles.untile_host([b.numpy() for b in blocks], W, H, world_size)
+        np.save(out_path, out)
+    else:
+        assert blocks is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_gather_reassembles_single_device_image(oracle, rpt, world, tmp_path, world_size):
+    W, H = 200, 136          # ragged against the 64-pixel tile: unequal block sizes exercise the padding
+    cfg = rpt.default_config(W, H, nee=1)
+    acc, _, _ = oracle.trace_cpu(cfg, oracle.scene(world("DarkCornell")), rpt.blue_noise_seeds(W, H), 2)
+    img_path, out_path = str(tmp_path / "img.npy"), str(tmp_path / "out.npy")
+    np.save(img_path, acc)
+    mp.spawn(_worker, args=(world_size, _free_port(), img_path, out_path), nprocs=world_size, join=True)
+    out = np.load(out_path)
+    assert np.array_equal(out.view(np.uint32), acc.view(np.uint32))
+
+
+def test_block_sizes_balance(tiles):
+    sizes = tiles.block_sizes(1024, 1024, 8)
+    assert sum(sizes) == 1024 * 1024 and max(sizes) - min(sizes) == 0     # 256 tiles / 8 ranks
+    sizes = tiles.block_sizes(1920, 1080, 8)
+    assert sum(sizes) == 1920 * 1080 and (max(sizes) - min(sizes)) / max(sizes) < 0.06
