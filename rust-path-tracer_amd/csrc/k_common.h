@@ -60,6 +60,7 @@ struct DevScene {
     const rpt_light_pick_entry *light_pick;
     uint32_t n_light_pick;
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */
+    uint32_t fastdiv_ok;           /* every node bound is 0 or in [2^-60, 2^40): exact fast division allowed */
     DevImage atlas, skybox;
 };
 

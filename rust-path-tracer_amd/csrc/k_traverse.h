@@ -25,24 +25,30 @@
 #define RPT_K_TRAVERSE_H
 
 #include "k_common.h"
+#include "rpt_fastdiv.h"
 
 struct HitRecord {
     float t;
     uint32_t tri;     /* HIT_MISS or triangle index | backface << 31 */
 };
 
-/* intersection.rs:104-122 — 6 true divisions, NaN-ignoring min/max */
-__device__ __forceinline__ float slab_test(float4 lo, float4 hi, F3 ro, F3 rd, float prev_min_t) {
-    float tx1 = (lo.x - ro.x) / rd.x;
-    float tx2 = (hi.x - ro.x) / rd.x;
+/* intersection.rs:104-122 — NaN-ignoring min/max, strict comparisons as written */
+template <bool FAST>
+__device__ __forceinline__ float slab_test(float4 lo, float4 hi, F3 ro, F3 rd, F3 ird, float prev_min_t) {
+    float tx1, tx2, ty1, ty2, tz1, tz2;
+    if (FAST) {
+        tx1 = rptm::div_by_rcp(lo.x - ro.x, rd.x, ird.x); tx2 = rptm::div_by_rcp(hi.x - ro.x, rd.x, ird.x);
+        ty1 = rptm::div_by_rcp(lo.y - ro.y, rd.y, ird.y); ty2 = rptm::div_by_rcp(hi.y - ro.y, rd.y, ird.y);
+        tz1 = rptm::div_by_rcp(lo.z - ro.z, rd.z, ird.z); tz2 = rptm::div_by_rcp(hi.z - ro.z, rd.z, ird.z);
+    } else {
+        tx1 = (lo.x - ro.x) / rd.x; tx2 = (hi.x - ro.x) / rd.x;
+        ty1 = (lo.y - ro.y) / rd.y; ty2 = (hi.y - ro.y) / rd.y;
+        tz1 = (lo.z - ro.z) / rd.z; tz2 = (hi.z - ro.z) / rd.z;
+    }
     float tmin = rptm::fminr(tx1, tx2);
     float tmax = rptm::fmaxr(tx1, tx2);
-    float ty1 = (lo.y - ro.y) / rd.y;
-    float ty2 = (hi.y - ro.y) / rd.y;
     tmin = rptm::fmaxr(tmin, rptm::fminr(ty1, ty2));
     tmax = rptm::fminr(tmax, rptm::fmaxr(ty1, ty2));
-    float tz1 = (lo.z - ro.z) / rd.z;
-    float tz2 = (hi.z - ro.z) / rd.z;
     tmin = rptm::fmaxr(tmin, rptm::fminr(tz1, tz2));
     tmax = rptm::fminr(tmax, rptm::fmaxr(tz1, tz2));
     return (tmax >= tmin && tmax > 0.0f && tmin < prev_min_t) ? tmin : __builtin_inff();
@@ -67,10 +73,14 @@ __device__ __forceinline__ bool moller_trumbore(F3 ro, F3 rd, F3 a, F3 edge1, F3
     return true;
 }
 
-/* One ray through the BVH. `stack` points at this lane's column of the wave's
- * LDS stack: entry e lives at stack[e * RPT_WAVE]. */
-template <int STACK, bool ANY_HIT>
-__device__ __forceinline__ HitRecord traverse_one(const DevScene &sc, F3 ro, F3 rd, float max_t, uint32_t *stack) {
+/* One ray through the BVH, "while-while" form: every lane first walks inner
+ * nodes until it stands on a leaf (or has nothing left), then the wave tests
+ * leaf triangles together.  Per lane the sequence of box tests, triangle tests
+ * and the value of the running best t at each of them is exactly the
+ * reference's (intersection.rs:177-234).  `stack` points at this lane's column
+ * of the wave's LDS stack: entry e lives at stack[e * RPT_WAVE]. */
+template <int STACK, bool ANY_HIT, bool FAST>
+__device__ __forceinline__ HitRecord traverse_loop(const DevScene &sc, F3 ro, F3 rd, F3 ird, float max_t, uint32_t *stack) {
     HitRecord res;
     res.t = 1000000.0f;
     res.tri = HIT_MISS;
@@ -78,41 +88,46 @@ __device__ __forceinline__ HitRecord traverse_one(const DevScene &sc, F3 ro, F3 
     /* current node's metadata (aabb_min.w = triangle_count, aabb_max.w = left/first) */
     uint32_t cur_count = __float_as_uint(sc.nodes[0].w);
     uint32_t cur_index = __float_as_uint(sc.nodes[1].w);
+    bool alive = true;
     for (;;) {
-        if (cur_count > 0u) {
-            /* leaf: triangles in index order (:186-205) */
-            for (uint32_t i = 0; i < cur_count; ++i) {
-                uint32_t ti = cur_index + i;
-                F3 a = xyz4(sc.tri_geom[3u * ti]);
-                F3 e1 = xyz4(sc.tri_geom[3u * ti + 1u]);
-                F3 e2 = xyz4(sc.tri_geom[3u * ti + 2u]);
-                float t = 0.0f;
-                bool bf = false;
-                if (moller_trumbore(ro, rd, a, e1, e2, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
-                    res.t = rptm::fminr(res.t, t);
-                    res.tri = ti | (bf ? 0x80000000u : 0u);
-                    if (ANY_HIT) return res;
-                }
-            }
-        } else {
-            /* inner: test both children against the current best t (:207-229) */
+        /* phase 1: inner nodes (:207-229) until a leaf is reached */
+        while (alive && cur_count == 0u) {
             const float4 *ch = sc.nodes + 2u * cur_index;
             float4 lmin = ch[0], lmax = ch[1], rmin = ch[2], rmax = ch[3];
-            float dl = slab_test(lmin, lmax, ro, rd, res.t);
-            float dr = slab_test(rmin, rmax, ro, rd, res.t);
+            float dl = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t);
+            float dr = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t);
             bool swap = dl > dr;                    /* strict: ties keep left first */
             float dnear = swap ? dr : dl;
             float dfar = swap ? dl : dr;
             if (dnear != __builtin_inff()) {
-                uint32_t near_count = __float_as_uint(swap ? rmin.w : lmin.w);
-                uint32_t near_index = __float_as_uint(swap ? rmax.w : lmax.w);
                 if (dfar != __builtin_inff() && sp < STACK) {
                     stack[sp * RPT_WAVE] = swap ? cur_index : cur_index + 1u;   /* far child node id */
                     sp += 1;
                 }
-                cur_count = near_count;
-                cur_index = near_index;
-                continue;
+                cur_count = __float_as_uint(swap ? rmin.w : lmin.w);
+                cur_index = __float_as_uint(swap ? rmax.w : lmax.w);
+            } else if (sp == 0) {
+                alive = false;
+            } else {
+                sp -= 1;
+                uint32_t node = stack[sp * RPT_WAVE];
+                cur_count = __float_as_uint(sc.nodes[2u * node].w);
+                cur_index = __float_as_uint(sc.nodes[2u * node + 1u].w);
+            }
+        }
+        if (!alive) break;
+        /* phase 2: leaf triangles in index order (:186-205) */
+        for (uint32_t i = 0; i < cur_count; ++i) {
+            uint32_t ti = cur_index + i;
+            F3 a = xyz4(sc.tri_geom[3u * ti]);
+            F3 e1 = xyz4(sc.tri_geom[3u * ti + 1u]);
+            F3 e2 = xyz4(sc.tri_geom[3u * ti + 2u]);
+            float t = 0.0f;
+            bool bf = false;
+            if (moller_trumbore(ro, rd, a, e1, e2, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
+                res.t = rptm::fminr(res.t, t);
+                res.tri = ti | (bf ? 0x80000000u : 0u);
+                if (ANY_HIT) return res;
             }
         }
         if (sp == 0) break;
@@ -122,6 +137,17 @@ __device__ __forceinline__ HitRecord traverse_one(const DevScene &sc, F3 ro, F3 
         cur_index = __float_as_uint(sc.nodes[2u * node + 1u].w);
     }
     return res;
+}
+
+template <int STACK, bool ANY_HIT>
+__device__ __forceinline__ HitRecord traverse_one(const DevScene &sc, F3 ro, F3 rd, float max_t, uint32_t *stack) {
+    bool fast = sc.fastdiv_ok != 0u && rptm::fastdiv_divisor_ok(rd.x) && rptm::fastdiv_divisor_ok(rd.y) && rptm::fastdiv_divisor_ok(rd.z) &&
+                rptm::fastdiv_operand_ok(ro.x) && rptm::fastdiv_operand_ok(ro.y) && rptm::fastdiv_operand_ok(ro.z);
+    if (fast) {
+        F3 ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        return traverse_loop<STACK, ANY_HIT, true>(sc, ro, rd, ird, max_t, stack);
+    }
+    return traverse_loop<STACK, ANY_HIT, false>(sc, ro, rd, rd, max_t, stack);
 }
 
 /* Extension rays: queue of slot ids -> hit record written into ray_b.zw */

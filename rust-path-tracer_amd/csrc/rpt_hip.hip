@@ -382,6 +382,11 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     s.materials = c->materials.p; s.light_pick = c->light_pick.p;
     s.n_light_pick = (uint32_t)nlp;
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
+    s.fastdiv_ok = 1u;
+    for (size_t i = 0; i < nn && s.fastdiv_ok; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!rptm::fastdiv_operand_ok(nodes[i].aabb_min[k]) || !rptm::fastdiv_operand_ok(nodes[i].aabb_max[k])) s.fastdiv_ok = 0u;
+    if (const char *env = getenv("RPT_NO_FASTDIV"); env && env[0] == '1') s.fastdiv_ok = 0u;
     s.atlas = DevImage{c->atlas.p, aw, ah};
     s.skybox = DevImage{c->skybox.p, sw, sh};
     c->bvh_depth = depth;
@@ -660,13 +665,14 @@ __global__ void k_debug_math(int op, const float *x, const float *y, float *out,
         case 5: r = rptm::asinr(x[i]); break;
         case 6: r = rptm::atan2r(x[i], y[i]); break;
         case 7: r = rptm::sqrtr(x[i]); break;
+        case 9: r = rptm::slab_quotient(x[i], 0.0f, y[i]); break;
         default: r = x[i] / y[i]; break;
     }
     out[i] = r;
 }
 
 int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size_t n) {
-    if (op < 0 || op > 8 || !x || !y || !out) return RPT_EINVAL;
+    if (op < 0 || op > 9 || !x || !y || !out) return RPT_EINVAL;
     for (size_t i = 0; i < n; ++i) {
         float r;
         switch (op) {
@@ -678,6 +684,7 @@ int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size
             case 5: r = rptm::asinr(x[i]); break;
             case 6: r = rptm::atan2r(x[i], y[i]); break;
             case 7: r = rptm::sqrtr(x[i]); break;
+            case 9: r = rptm::slab_quotient(x[i], 0.0f, y[i]); break;
             default: r = x[i] / y[i]; break;
         }
         out[i] = r;
@@ -686,7 +693,7 @@ int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size
 }
 
 int rpt_debug_math(rpt_ctx *c, int op, const float *x, const float *y, float *out, size_t n) {
-    if (!c || op < 0 || op > 8 || !x || !y || !out) return RPT_EINVAL;
+    if (!c || op < 0 || op > 9 || !x || !y || !out) return RPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf<float> dx, dy, dout;
     HIP_TRY(c, dx.alloc(n)); HIP_TRY(c, dy.alloc(n)); HIP_TRY(c, dout.alloc(n));
