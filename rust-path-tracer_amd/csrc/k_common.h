@@ -53,7 +53,10 @@ struct DevImage {
 
 struct DevScene {
     const float4 *nodes;           /* 2 x float4 per rpt_bvh_node, reference layout */
-    const float4 *tri_geom;        /* 3 x float4 per triangle: (a, e1 = b-a, e2 = c-a), .w unused */
+    const float4 *tri_geom;        /* 3 x float4 per triangle: (a | d00), (e1 = b-a | d01), (e2 = c-a | d11);
+                                      dNN = the triangle-constant dot products of util::barycentric */
+    const float4 *tri_shade;       /* 4 x float4 per triangle: (na | uva.x) (nb | uva.y) (nc | material) (uvb, uvc) */
+    const float4 *mat_lite;        /* 2 x float4 per material: (emissive.rgb | roughness.x) (albedo.rgb | metallic.x) */
     const uint4 *indices;          /* rpt_triangle */
     const float4 *per_vertex;      /* 4 x float4 per rpt_per_vertex_data */
     const float4 *materials;       /* 6 x float4 per rpt_material_data */
@@ -61,6 +64,7 @@ struct DevScene {
     uint32_t n_light_pick;
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */
     uint32_t fastdiv_ok;           /* every node bound is 0 or in [2^-60, 2^40): exact fast division allowed */
+    uint32_t textured;             /* some material has a texture flag set */
     DevImage atlas, skybox;
 };
 
@@ -88,16 +92,17 @@ struct DevState {
 #define HIT_MISS 0xffffffffu
 
 /* ---- queues ---------------------------------------------------------------- */
-enum { Q_EXT0 = 0, Q_EXT1 = 1, Q_SHADOW = 2, Q_SKY = 3, Q_FIN = 4, Q_COUNT = 8 };
+enum { Q_EXT0 = 0, Q_EXT1 = 1, Q_SHADOW = 2, Q_SKY = 3, Q_COUNT = 8 };
 
 struct DevQueues {
     uint32_t *ext[2];
     uint32_t *sky;
-    uint32_t *fin;
     float4 *sh_o;      /* shadow ray (ox, oy, oz, max_t), indexed by shadow-queue position */
     float4 *sh_d;      /* (dx, dy, dz, slot bits | bit31 = path ends after this NEE) */
     float4 *sh_c;      /* (contribution r, g, b if unoccluded, unused) */
     uint32_t *count;   /* Q_COUNT counters */
+    unsigned long long *host_ring;   /* mapped pinned host memory: (iteration + 1) << 32 | extension-queue size */
+    uint32_t ring_mask;
 };
 
 struct DevStats {

@@ -26,6 +26,7 @@
 #define RPT_K_SHADE_H
 
 #include "k_common.h"
+#include "k_path.h"
 
 #define RPT_PI_F 3.14159265358979323846f
 #define RPT_EPS 0.001f   /* util.rs:5 */
@@ -124,18 +125,35 @@ struct Mat {
     float4 emissive, albedo, roughness, metallic, normals;
     uint4 has;   /* albedo, metallic, roughness, normal texture flags */
 };
+template <bool TEXTURED>
 __device__ __forceinline__ Mat load_material(const DevScene &sc, uint32_t index) {
-    const float4 *p = sc.materials + 6u * index;
     Mat m;
-    m.emissive = p[0]; m.albedo = p[1]; m.roughness = p[2]; m.metallic = p[3]; m.normals = p[4];
-    float4 f = p[5];
-    m.has = make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
+    if (TEXTURED) {
+        const float4 *p = sc.materials + 6u * index;
+        m.emissive = p[0]; m.albedo = p[1]; m.roughness = p[2]; m.metallic = p[3]; m.normals = p[4];
+        float4 f = p[5];
+        m.has = make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
+    } else {
+        /* untextured scene: everything the BSDF needs sits in 32 bytes */
+        const float4 *p = sc.mat_lite + 2u * index;
+        float4 a = p[0], b = p[1];
+        m.emissive = make_float4(a.x, a.y, a.z, 0.0f);
+        m.albedo = make_float4(b.x, b.y, b.z, 0.0f);
+        m.roughness = make_float4(a.w, 0, 0, 0);
+        m.metallic = make_float4(b.w, 0, 0, 0);
+        m.normals = make_float4(0, 0, 0, 0);
+        m.has = make_uint4(0u, 0u, 0u, 0u);
+    }
     return m;
 }
 
 /* destinations a path can leave the shade stage for */
-enum { DEST_NONE = 0, DEST_EXT = 1, DEST_FIN = 2, DEST_SKY = 3 };
+enum { DEST_NONE = 0, DEST_EXT = 1, DEST_SKY = 2 };
 
+/* NEE = NextEventEstimation mode (0 none, 1 MIS, 2 direct only), TEXTURED = the
+ * scene has at least one texture flag.  Specialising removes the dead halves of
+ * the stage (and their registers) for the common untextured / no-NEE case. */
+template <int NEE, bool TEXTURED>
 __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t cur,
                                                      DevStats *stats) {
     const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
@@ -163,12 +181,13 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             const uint32_t flags = __float_as_uint(rm.z);
             const uint32_t bounce = FLAG_BOUNCE(flags);
             const bool last_spec = FLAG_LOBE_SPEC(flags) != 0u;
-            const uint32_t nee_mode = cfg.nee_mode;
-            const bool nee = nee_mode != RPT_NEE_NONE;
+            constexpr bool nee = NEE != RPT_NEE_NONE;
             const bool backface = (hit_tri >> 31) != 0u;
             const uint32_t tri_index = hit_tri & 0x7fffffffu;
-            const uint4 tri = sc.indices[tri_index];
-            const Mat mat = load_material(sc, tri.w);
+            /* per-triangle shading record: normals, uvs, material in 64 contiguous bytes */
+            const float4 *ts = sc.tri_shade + 4u * tri_index;
+            const float4 s0 = ts[0], s1 = ts[1], s2 = ts[2];
+            const Mat mat = load_material<TEXTURED>(sc, __float_as_uint(s2.w));
             const F3 hit = ro + rd * hit_t;
 
             bool done = false;
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                 } else if (!nee || bounce == 0u || last_spec) {                          /* :97-100 */
                     radiance = radiance + mask_nan3(throughput * emissive);
                     done = true;
-                } else if (nee_mode == RPT_NEE_MIS) {                                    /* :104-108, last lobe is diffuse here */
+                } else if (NEE == RPT_NEE_MIS) {                                         /* :104-108, last lobe is diffuse here */
                     float4 m0 = st.mis0[slot], m1 = st.mis1[slot], m2 = st.mis2[slot], m3 = st.mis3[slot];
                     F3 contribution = f3s(0.0f);
                     if (tri_index == __float_as_uint(m2.x)) {                            /* light_pick.rs:185 */
@@ -204,57 +223,59 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             uint32_t new_flags = flags;
             F3 new_o = ro, new_d = rd;
             if (!done) {
-                /* ---- interpolate vertex data (lib.rs:112-129) ---- */
-                const float4 *va = sc.per_vertex + 4u * tri.x;
-                const float4 *vb = sc.per_vertex + 4u * tri.y;
-                const float4 *vc = sc.per_vertex + 4u * tri.z;
-                const F3 pa = xyz4(va[0]), pb = xyz4(vb[0]), pc = xyz4(vc[0]);
+                /* ---- interpolate vertex data (lib.rs:112-129); d00/d01/d11 are triangle constants ---- */
+                const float4 *tg = sc.tri_geom + 3u * tri_index;
+                const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
                 F3 bary;
                 {
-                    F3 v0 = pb - pa, v1 = pc - pa, v2 = hit - pa;
-                    float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1);
+                    F3 v0 = xyz4(g1), v1 = xyz4(g2), v2 = hit - xyz4(g0);
+                    float d00 = g0.w, d01 = g1.w, d11 = g2.w;
                     float d20 = dot3(v2, v0), d21 = dot3(v2, v1);
                     float denom = d00 * d11 - d01 * d01;
                     float v = (d11 * d20 - d01 * d21) / denom;
                     float w = (d00 * d21 - d01 * d20) / denom;
                     bary = f3(1.0f - v - w, v, w);
                 }
-                F3 normal = bary.x * xyz4(va[1]) + bary.y * xyz4(vb[1]) + bary.z * xyz4(vc[1]);
-                const float4 ua = va[3], ub = vb[3], uc = vc[3];
-                float uv_x = (bary.x * ua.x + bary.y * ub.x) + bary.z * uc.x;
-                float uv_y = (bary.x * ua.y + bary.y * ub.y) + bary.z * uc.y;
-                {
+                F3 normal = bary.x * xyz4(s0) + bary.y * xyz4(s1) + bary.z * xyz4(s2);
+                float uv_x = 0.0f, uv_y = 0.0f;
+                if (TEXTURED) {
+                    const float4 s3 = ts[3];     /* (uvb.x, uvb.y, uvc.x, uvc.y); uva in s0.w, s1.w */
+                    uv_x = (bary.x * s0.w + bary.y * s3.x) + bary.z * s3.z;
+                    uv_y = (bary.x * s1.w + bary.y * s3.y) + bary.z * s3.w;
                     float cx = rptm::fminr(rptm::fmaxr(uv_x, 0.0f), 1.0f), cy = rptm::fminr(rptm::fmaxr(uv_y, 0.0f), 1.0f);
                     if (cx != uv_x || cy != uv_y) {
                         uv_x = uv_x - rptm::floorr(uv_x);
                         uv_y = uv_y - rptm::floorr(uv_y);
                     }
-                }
-                if (mat.has.w != 0u) {                                                   /* lib.rs:132-141 */
-                    float su = mat.normals.x + uv_x * mat.normals.z, sv = mat.normals.y + uv_y * mat.normals.w;
-                    float4 s = sample_by_lod<true>(sc.atlas, su, sv);
-                    F3 nm = f3(s.x * 2.0f - 1.0f, s.y * 2.0f - 1.0f, s.z * 2.0f - 1.0f);
-                    F3 tangent = bary.x * xyz4(va[2]) + bary.y * xyz4(vb[2]) + bary.z * xyz4(vc[2]);
-                    F3 bitangent = cross3(tangent, normal);
-                    F3 r = tangent * nm.x;
-                    r = r + (bitangent * nm.y);
-                    r = r + (normal * nm.z);
-                    normal = norm3(r);
+                    if (mat.has.w != 0u) {                                               /* lib.rs:132-141 */
+                        float su = mat.normals.x + uv_x * mat.normals.z, sv = mat.normals.y + uv_y * mat.normals.w;
+                        float4 s = sample_by_lod<true>(sc.atlas, su, sv);
+                        F3 nm = f3(s.x * 2.0f - 1.0f, s.y * 2.0f - 1.0f, s.z * 2.0f - 1.0f);
+                        const uint4 tri = sc.indices[tri_index];
+                        F3 tangent = bary.x * xyz4(sc.per_vertex[4u * tri.x + 2u]) + bary.y * xyz4(sc.per_vertex[4u * tri.y + 2u]) +
+                                     bary.z * xyz4(sc.per_vertex[4u * tri.z + 2u]);
+                        F3 bitangent = cross3(tangent, normal);
+                        F3 r = tangent * nm.x;
+                        r = r + (bitangent * nm.y);
+                        r = r + (normal * nm.z);
+                        normal = norm3(r);
+                    }
                 }
 
                 /* ---- get_pbr_bsdf (bsdf.rs:354-387) ---- */
                 Pbr bsdf;
-                if (mat.has.x != 0u) {
-                    float4 s = sample_by_lod<true>(sc.atlas, mat.albedo.x + uv_x * mat.albedo.z, mat.albedo.y + uv_y * mat.albedo.w);
-                    bsdf.albedo = f3(s.x, s.y, s.z);
-                } else {
-                    bsdf.albedo = xyz4(mat.albedo);
-                }
+                bsdf.albedo = xyz4(mat.albedo);
                 float roughness = mat.roughness.x, metallic = mat.metallic.x;
-                if (mat.has.z != 0u)
-                    roughness = sample_by_lod<true>(sc.atlas, mat.roughness.x + uv_x * mat.roughness.z, mat.roughness.y + uv_y * mat.roughness.w).x;
-                if (mat.has.y != 0u)
-                    metallic = sample_by_lod<true>(sc.atlas, mat.metallic.x + uv_x * mat.metallic.z, mat.metallic.y + uv_y * mat.metallic.w).x;
+                if (TEXTURED) {
+                    if (mat.has.x != 0u) {
+                        float4 s = sample_by_lod<true>(sc.atlas, mat.albedo.x + uv_x * mat.albedo.z, mat.albedo.y + uv_y * mat.albedo.w);
+                        bsdf.albedo = f3(s.x, s.y, s.z);
+                    }
+                    if (mat.has.z != 0u)
+                        roughness = sample_by_lod<true>(sc.atlas, mat.roughness.x + uv_x * mat.roughness.z, mat.roughness.y + uv_y * mat.roughness.w).x;
+                    if (mat.has.y != 0u)
+                        metallic = sample_by_lod<true>(sc.atlas, mat.metallic.x + uv_x * mat.metallic.z, mat.metallic.y + uv_y * mat.metallic.w).x;
+                }
                 bsdf.roughness = rptm::fmaxr(roughness, RPT_EPS);
                 bsdf.metallic = rptm::fminr(metallic, 1.0f - RPT_EPS);
                 bsdf.clamp_lo = cfg.c.specular_weight_clamp[0];
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                 if (nee && !spec) {
                     if (sc.no_lights) {
                         /* sentinel: DirectLightSample::default() — zero contribution, zeroed carry */
-                        if (nee_mode == RPT_NEE_MIS) {
+                        if (NEE == RPT_NEE_MIS) {
                             st.mis0[slot] = make_float4(0, 0, 0, 0);
                             st.mis1[slot] = make_float4(0, 0, 0, 0);
                             st.mis2[slot] = make_float4(__uint_as_float(0u), 0, 0, 0);
@@ -363,7 +384,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                                 float bsdf_pdf = cos_e / RPT_PI_F;
                                 if (bsdf_pdf > 0.0f) {
                                     float weight = 1.0f;
-                                    if (nee_mode == RPT_NEE_MIS) {
+                                    if (NEE == RPT_NEE_MIS) {
                                         float q1 = light_pdf * light_pdf;
                                         weight = q1 / (q1 + bsdf_pdf * bsdf_pdf);
                                     }
@@ -377,14 +398,14 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                         sh_o = make_float4(so.x, so.y, so.z, light_distance - RPT_EPS * 2.0f);
                         sh_d = make_float4(light_direction.x, light_direction.y, light_direction.z, 0.0f);
                         sh_c = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
-                        if (nee_mode == RPT_NEE_MIS) {
+                        if (NEE == RPT_NEE_MIS) {
                             st.mis0[slot] = make_float4(light_area, light_normal.x, light_normal.y, light_normal.z);
                             st.mis1[slot] = make_float4(light_pick_pdf, light_emission.x, light_emission.y, light_emission.z);
                             st.mis2[slot] = make_float4(__uint_as_float(light_index), throughput.x, throughput.y, throughput.z);
                         }
                     }
                 }
-                if (nee_mode == RPT_NEE_MIS) st.mis3[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
+                if (NEE == RPT_NEE_MIS) st.mis3[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
 
                 /* ---- attenuate, respawn, roulette (lib.rs:168-181) ---- */
                 throughput = throughput * (spectrum / pdf);
@@ -403,19 +424,21 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                 new_flags = MAKE_FLAGS(next_bounce, spec ? 1u : 0u, rng.dim);
             }
 
-            st.thr_rad[slot] = make_float4(throughput.x, throughput.y, throughput.z, radiance.x);
-            st.rad_misc[slot] = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
-            if (!done) {
-                st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
-                reinterpret_cast<float2 *>(&st.ray_b[slot])[0] = make_float2(new_d.y, new_d.z);
-                dest = DEST_EXT;
-            } else if (emit_shadow) {
-                sh_d.w = __uint_as_float(slot | 0x80000000u);   /* the shadow stage finishes the path */
-                dest = DEST_NONE;
+            if (done && !emit_shadow) {
+                /* the path ends here with nothing pending: accumulate + regenerate in place */
+                if (finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w))) dest = DEST_EXT;
             } else {
-                dest = DEST_FIN;
+                st.thr_rad[slot] = make_float4(throughput.x, throughput.y, throughput.z, radiance.x);
+                st.rad_misc[slot] = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
+                if (!done) {
+                    st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
+                    reinterpret_cast<float2 *>(&st.ray_b[slot])[0] = make_float2(new_d.y, new_d.z);
+                    dest = DEST_EXT;
+                    sh_d.w = __uint_as_float(slot);
+                } else {
+                    sh_d.w = __uint_as_float(slot | 0x80000000u);   /* the shadow stage finishes the path */
+                }
             }
-            if (emit_shadow && !done) sh_d.w = __uint_as_float(slot);
         }
     }
 
@@ -423,15 +446,15 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     uint32_t at;
     at = wave_push(&q.count[cur ^ 1u], dest == DEST_EXT);
     if (dest == DEST_EXT) q.ext[cur ^ 1u][at] = slot;
-    at = wave_push(&q.count[Q_FIN], dest == DEST_FIN);
-    if (dest == DEST_FIN) q.fin[at] = slot;
     at = wave_push(&q.count[Q_SKY], dest == DEST_SKY);
     if (dest == DEST_SKY) q.sky[at] = slot;
-    at = wave_push(&q.count[Q_SHADOW], emit_shadow);
-    if (emit_shadow) {
-        q.sh_o[at] = sh_o;
-        q.sh_d[at] = sh_d;
-        q.sh_c[at] = sh_c;
+    if (NEE != RPT_NEE_NONE) {
+        at = wave_push(&q.count[Q_SHADOW], emit_shadow);
+        if (emit_shadow) {
+            q.sh_o[at] = sh_o;
+            q.sh_d[at] = sh_d;
+            q.sh_c[at] = sh_c;
+        }
     }
 }
 

@@ -6,9 +6,9 @@
  *              kernels/src/skybox.rs:18-94) that must not share waves with
  *              cheap surface shading.  Also the image-skybox branch
  *              (kernels/src/lib.rs:70-78).
- *  k_generate  accumulate finished paths and regenerate: `output[i] += (rgb, 1)`,
- *              `rng[i].x += 1` (kernels/src/lib.rs:185, 225-226), then the next
- *              camera ray of the same pixel (lib.rs:36-60) if samples remain.
+ *  k_generate_first  first camera ray of every slot at the start of rpt_render
+ *              (lib.rs:36-60).  Finished paths are accumulated and regenerated
+ *              in place by whichever stage ends them (k_path.h).
  */
 #ifndef RPT_K_SKY_GENERATE_H
 #define RPT_K_SKY_GENERATE_H
@@ -69,18 +69,13 @@ __device__ F3 sky_scatter(const float *sun4, F3 origin, F3 direction) {
     return f3(rptm::powr(g.x, 2.2f), rptm::powr(g.y, 2.2f), rptm::powr(g.z, 2.2f));
 }
 
-__device__ __forceinline__ F3 mat3_mul(const float *m, F3 v) {   /* Mat3::mul_vec3, column-major */
-    F3 r = f3(m[0], m[1], m[2]) * v.x;
-    r = r + (f3(m[3], m[4], m[5]) * v.y);
-    r = r + (f3(m[6], m[7], m[8]) * v.z);
-    return r;
-}
-
-__global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats) {
+__global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t cur,
+                                                   DevStats *stats) {
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
     uint32_t n = q.count[Q_SKY];
     if (i == 0u && n) atomicAdd(&stats->sky_evals, (unsigned long long)n);
     bool active = i < n;
+    bool emit = false;
     uint32_t slot = 0u;
     if (active) {
         slot = q.sky[i];
@@ -98,72 +93,34 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
             float4 s = sample_by_lod<false>(sc.skybox, u, v);
             radiance = radiance + throughput * f3(s.x, s.y, s.z) * intensity;
         }
-        st.thr_rad[slot] = make_float4(tr.x, tr.y, tr.z, radiance.x);
-        st.rad_misc[slot] = make_float4(radiance.y, radiance.z, rm.z, rm.w);
+        /* a miss always ends the path (lib.rs:79) */
+        emit = finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
     }
-    uint32_t at = wave_push(&q.count[Q_FIN], active);
-    if (active) q.fin[at] = slot;
+    uint32_t at = wave_push(&q.count[cur ^ 1u], emit);
+    if (emit) q.ext[cur ^ 1u][at] = slot;
 }
 
-/* camera ray for sample `n` of pixel (x, y) (lib.rs:36-51) */
-__device__ __forceinline__ void camera_ray(const DevConfig &cfg, uint32_t px, uint32_t py, uint32_t key, F3 &ro, F3 &rd) {
-    Rng rng{key, 0u};
-    float j1 = rng.next(), j2 = rng.next();
-    float sx = (float)px + j1, sy = (float)py + j2;
-    float ux = (sx / (float)cfg.c.width) * 2.0f - 1.0f;
-    float uy = (1.0f - sy / (float)cfg.c.height) * 2.0f - 1.0f;
-    uy *= (float)cfg.c.height / (float)cfg.c.width;
-    ro = f3(cfg.c.cam_position[0], cfg.c.cam_position[1], cfg.c.cam_position[2]);
-    rd = mat3_mul(cfg.euler, norm3(f3(ux, uy, 1.0f)));
-}
-
-/* FIRST = true: start of an rpt_render call, every slot begins its first sample.
- * FIRST = false: slots from the finish queue: accumulate, then regenerate. */
-template <bool FIRST>
-__global__ __launch_bounds__(RPT_BLOCK) void k_generate(DevState st, DevQueues q, DevConfig cfg, uint32_t next,
-                                                        uint32_t n_samples) {
+/* Start of an rpt_render call: every slot begins the first of its n_samples samples. */
+__global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQueues q, DevConfig cfg, uint32_t n_samples) {
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    uint32_t n = FIRST ? st.n_slots : q.count[Q_FIN];
-    bool active = i < n;
+    bool active = i < st.n_slots;
     bool emit = false;
-    uint32_t slot = 0u;
     if (active) {
-        slot = FIRST ? i : q.fin[i];
-        uint2 rs = st.rng[slot];
-        uint32_t todo;
-        if (FIRST) {
-            todo = n_samples;
-        } else {
-            float4 tr = st.thr_rad[slot], rm = st.rad_misc[slot];
-            float4 acc = st.accum[slot];
-            acc.x += tr.w; acc.y += rm.x; acc.z += rm.y; acc.w += 1.0f;
-            st.accum[slot] = acc;
-            rs.x += 1u;
-            st.rng[slot] = rs;
-            todo = __float_as_uint(rm.w);
-        }
+        uint2 rs = st.rng[i];
         if (cfg.c.max_bounces == 0u) {
             /* the bounce loop never runs (lib.rs:62): every sample adds (0,0,0,1) */
-            float4 acc = st.accum[slot];
-            for (uint32_t s = 0; s < todo; ++s) acc.w += 1.0f;
-            st.accum[slot] = acc;
-            rs.x += todo;
-            st.rng[slot] = rs;
-            todo = 0u;
-        }
-        if (todo > 0u) {
-            uint32_t pxy = st.pixel_xy[slot];
-            F3 ro, rd;
-            camera_ray(cfg, pxy & 0xffffu, pxy >> 16, rs.x + rs.y, ro, rd);
-            st.ray_a[slot] = make_float4(ro.x, ro.y, ro.z, rd.x);
-            reinterpret_cast<float2 *>(&st.ray_b[slot])[0] = make_float2(rd.y, rd.z);
-            st.thr_rad[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            st.rad_misc[slot] = make_float4(0.0f, 0.0f, __uint_as_float(MAKE_FLAGS(0u, 0u, 2u)), __uint_as_float(todo - 1u));
+            float4 acc = st.accum[i];
+            for (uint32_t s = 0; s < n_samples; ++s) acc.w += 1.0f;
+            st.accum[i] = acc;
+            rs.x += n_samples;
+            st.rng[i] = rs;
+        } else {
+            start_path(st, cfg, i, rs, n_samples - 1u);
             emit = true;
         }
     }
-    uint32_t at = wave_push(&q.count[next], emit);
-    if (emit) q.ext[next][at] = slot;
+    uint32_t at = wave_push(&q.count[0], emit);
+    if (emit) q.ext[0][at] = i;
 }
 
 /* root-side un-tiling of gathered per-rank blocks into a row-major image */

@@ -53,8 +53,8 @@ template <typename T> struct DevBuf {
     }
 };
 
-constexpr int LAG = 6;           /* iterations between enqueueing and inspecting a queue-size read-back */
-constexpr int RING = 16;
+constexpr int LAG = 6;           /* iterations the host may run ahead of the queue-size report it inspects */
+constexpr int RING = 16;         /* power of two, > LAG */
 
 }  // namespace
 
@@ -66,7 +66,7 @@ struct rpt_ctx {
 
     /* scene */
     bool has_scene = false;
-    DevBuf<float4> nodes, tri_geom, per_vertex, materials;
+    DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials;
     DevBuf<uint4> indices;
     DevBuf<rpt_light_pick_entry> light_pick;
     DevBuf<uchar4> atlas;
@@ -86,17 +86,16 @@ struct rpt_ctx {
     bool has_state = false;
     DevBuf<float4> ray_a, ray_b, thr_rad, rad_misc, mis0, mis1, mis2, mis3, accum;
     DevBuf<uint2> rng;
-    DevBuf<uint32_t> q_ext0, q_ext1, q_sky, q_fin, q_count;
+    DevBuf<uint32_t> q_ext0, q_ext1, q_sky, q_count;
     DevBuf<float4> sh_o, sh_d, sh_c;
     DevBuf<DevStats> dev_stats;
     DevState state{};
     DevQueues queues{};
     uint32_t samples = 0;
 
-    /* scheduling */
-    uint32_t *pinned_counts = nullptr;   /* RING x Q_COUNT */
-    hipEvent_t ring_events[RING]{};
-    bool events_ready = false;
+    /* scheduling: the traversal kernel reports each iteration's queue size into mapped pinned memory */
+    unsigned long long *host_ring = nullptr;       /* host view, RING entries */
+    unsigned long long *host_ring_dev = nullptr;   /* device view of the same memory */
 
     /* stats */
     rpt_stats stats{};
@@ -199,7 +198,7 @@ void release_state(rpt_ctx *c) {
     c->ray_a.release(); c->ray_b.release(); c->thr_rad.release(); c->rad_misc.release();
     c->mis0.release(); c->mis1.release(); c->mis2.release(); c->mis3.release();
     c->accum.release(); c->rng.release();
-    c->q_ext0.release(); c->q_ext1.release(); c->q_sky.release(); c->q_fin.release(); c->q_count.release();
+    c->q_ext0.release(); c->q_ext1.release(); c->q_sky.release(); c->q_count.release();
     c->sh_o.release(); c->sh_d.release(); c->sh_c.release();
     c->pixel_xy.release();
     c->has_state = false;
@@ -211,7 +210,7 @@ int alloc_state(rpt_ctx *c) {
     HIP_TRY(c, c->thr_rad.alloc(n)); HIP_TRY(c, c->rad_misc.alloc(n));
     HIP_TRY(c, c->mis0.alloc(n)); HIP_TRY(c, c->mis1.alloc(n)); HIP_TRY(c, c->mis2.alloc(n)); HIP_TRY(c, c->mis3.alloc(n));
     HIP_TRY(c, c->accum.alloc(n)); HIP_TRY(c, c->rng.alloc(n));
-    HIP_TRY(c, c->q_ext0.alloc(n)); HIP_TRY(c, c->q_ext1.alloc(n)); HIP_TRY(c, c->q_sky.alloc(n)); HIP_TRY(c, c->q_fin.alloc(n));
+    HIP_TRY(c, c->q_ext0.alloc(n)); HIP_TRY(c, c->q_ext1.alloc(n)); HIP_TRY(c, c->q_sky.alloc(n));
     HIP_TRY(c, c->q_count.alloc(Q_COUNT));
     HIP_TRY(c, c->sh_o.alloc(n)); HIP_TRY(c, c->sh_d.alloc(n)); HIP_TRY(c, c->sh_c.alloc(n));
     HIP_TRY(c, c->pixel_xy.alloc(n));
@@ -222,42 +221,49 @@ int alloc_state(rpt_ctx *c) {
     s.mis0 = c->mis0.p; s.mis1 = c->mis1.p; s.mis2 = c->mis2.p; s.mis3 = c->mis3.p;
     s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = (uint32_t)n;
     DevQueues &q = c->queues;
-    q.ext[0] = c->q_ext0.p; q.ext[1] = c->q_ext1.p; q.sky = c->q_sky.p; q.fin = c->q_fin.p;
+    q.ext[0] = c->q_ext0.p; q.ext[1] = c->q_ext1.p; q.sky = c->q_sky.p;
     q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p; q.count = c->q_count.p;
+    q.host_ring = c->host_ring_dev; q.ring_mask = RING - 1;
     c->has_state = true;
     return RPT_OK;
 }
 
-__global__ void k_begin_iteration(uint32_t *count, uint32_t next) {
-    if (threadIdx.x == 0) {
-        count[next] = 0u;
-        count[Q_SHADOW] = 0u;
-        count[Q_SKY] = 0u;
-        count[Q_FIN] = 0u;
-    }
-}
-
-template <int STACK>
-void launch_iteration(rpt_ctx *c, uint32_t cur, uint32_t blocks, bool nee, std::vector<hipEvent_t> *ev, size_t &ev_at) {
+template <int STACK, int NEE, bool TEXTURED>
+void launch_iteration(rpt_ctx *c, uint32_t cur, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
     hipStream_t s = c->stream;
     auto mark = [&]() {
         if (ev) (void)hipEventRecord((*ev)[ev_at++], s);
     };
-    k_begin_iteration<<<1, 64, 0, s>>>(c->queues.count, cur ^ 1u);
+    k_traverse_nearest<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, cur, iteration, c->dev_stats.p);
     mark();
-    k_traverse_nearest<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues.ext[cur], c->queues.count + cur, c->dev_stats.p);
+    k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, cur, c->dev_stats.p);
     mark();
-    k_shade<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, cur, c->dev_stats.p);
+    if (NEE != RPT_NEE_NONE) k_traverse_shadow<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, cur, c->dev_stats.p);
     mark();
-    if (nee) k_traverse_shadow<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->dev_stats.p);
-    mark();
-    k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
-    mark();
-    k_generate<false><<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, cur ^ 1u, 0u);
+    k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, cur, c->dev_stats.p);
     mark();
 }
 
-constexpr int EVENTS_PER_ITER = 6;
+template <int STACK>
+void launch_iteration_stack(rpt_ctx *c, uint32_t cur, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
+    const bool tex = c->scene.textured != 0u;
+    switch (c->cfg.nee_mode) {
+        case RPT_NEE_MIS:
+            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, cur, iteration, blocks, ev, ev_at);
+            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, cur, iteration, blocks, ev, ev_at);
+            break;
+        case RPT_NEE_DIRECT:
+            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, cur, iteration, blocks, ev, ev_at);
+            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, cur, iteration, blocks, ev, ev_at);
+            break;
+        default:
+            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, cur, iteration, blocks, ev, ev_at);
+            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, cur, iteration, blocks, ev, ev_at);
+            break;
+    }
+}
+
+constexpr int EVENTS_PER_ITER = 4;   /* after traverse, shade, shadow, sky */
 
 }  // namespace
 
@@ -283,10 +289,10 @@ int rpt_create(int device_id, rpt_ctx **out) {
     c->device = device_id;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return RPT_EHIP; }
-    e = hipHostMalloc(reinterpret_cast<void **>(&c->pinned_counts), RING * Q_COUNT * sizeof(uint32_t), hipHostMallocDefault);
-    if (e != hipSuccess) { g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return RPT_EHIP; }
-    for (int i = 0; i < RING; ++i) (void)hipEventCreateWithFlags(&c->ring_events[i], hipEventDisableTiming);
-    c->events_ready = true;
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->host_ring), RING * sizeof(unsigned long long), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->host_ring_dev), c->host_ring, 0);
+    if (e != hipSuccess) { g_create_error = std::string("hipHostMalloc(mapped): ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return RPT_EHIP; }
+    memset(c->host_ring, 0, RING * sizeof(unsigned long long));
     if (c->dev_stats.alloc(1) != hipSuccess || hipMemset(c->dev_stats.p, 0, sizeof(DevStats)) != hipSuccess) {
         g_create_error = "device allocation failed";
         rpt_destroy(c);
@@ -303,13 +309,12 @@ void rpt_destroy(rpt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release_state(c);
-    c->nodes.release(); c->tri_geom.release(); c->per_vertex.release(); c->materials.release();
+    c->nodes.release(); c->tri_geom.release(); c->tri_shade.release(); c->mat_lite.release();
+    c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->atlas.release(); c->skybox.release();
     c->dev_stats.release();
     for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
-    if (c->events_ready)
-        for (int i = 0; i < RING; ++i) (void)hipEventDestroy(c->ring_events[i]);
-    if (c->pinned_counts) (void)hipHostFree(c->pinned_counts);
+    if (c->host_ring) (void)hipHostFree(c->host_ring);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -346,17 +351,41 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;
 
-    /* derived traversal geometry: (a, b - a, c - a) per triangle — the same f32
-     * subtractions muller_trumbore performs (intersection.rs:13-14), done once */
-    std::vector<float4> geom(3 * nt);
+    /* derived per-triangle records, computed with the very f32 operations the reference performs per hit:
+     *   tri_geom : a, e1 = b - a, e2 = c - a (muller_trumbore, intersection.rs:13-14; barycentric v0, v1, util.rs:239-240)
+     *              with d00 = e1.e1, d01 = e1.e2, d11 = e2.e2 (util.rs:242-244) in the .w lanes
+     *   tri_shade: the three vertex normals, the three uv0 pairs and the material index in 64 contiguous bytes
+     *   mat_lite : emissive / albedo colours + roughness.x / metallic.x in 32 bytes (untextured scenes) */
+    auto dot = [](const float *u, const float *v) { return (u[0] * v[0]) + (u[1] * v[1]) + (u[2] * v[2]); };
+    std::vector<float4> geom(3 * nt), shade(4 * nt), lite(2 * nm);
     for (size_t i = 0; i < nt; ++i) {
-        const float *a = pv[idx[i].v0].vertex, *b = pv[idx[i].v1].vertex, *cc = pv[idx[i].v2].vertex;
-        geom[3 * i + 0] = make_float4(a[0], a[1], a[2], 0.0f);
-        geom[3 * i + 1] = make_float4(b[0] - a[0], b[1] - a[1], b[2] - a[2], 0.0f);
-        geom[3 * i + 2] = make_float4(cc[0] - a[0], cc[1] - a[1], cc[2] - a[2], 0.0f);
+        const rpt_per_vertex_data &A = pv[idx[i].v0], &B = pv[idx[i].v1], &C = pv[idx[i].v2];
+        const float *a = A.vertex, *b = B.vertex, *cc = C.vertex;
+        float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+        float e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};
+        geom[3 * i + 0] = make_float4(a[0], a[1], a[2], dot(e1, e1));
+        geom[3 * i + 1] = make_float4(e1[0], e1[1], e1[2], dot(e1, e2));
+        geom[3 * i + 2] = make_float4(e2[0], e2[1], e2[2], dot(e2, e2));
+        uint32_t m = idx[i].material;
+        float mf;
+        memcpy(&mf, &m, 4);
+        shade[4 * i + 0] = make_float4(A.normal[0], A.normal[1], A.normal[2], A.uv0[0]);
+        shade[4 * i + 1] = make_float4(B.normal[0], B.normal[1], B.normal[2], A.uv0[1]);
+        shade[4 * i + 2] = make_float4(C.normal[0], C.normal[1], C.normal[2], mf);
+        shade[4 * i + 3] = make_float4(B.uv0[0], B.uv0[1], C.uv0[0], C.uv0[1]);
+    }
+    uint32_t textured = 0;
+    for (size_t i = 0; i < nm; ++i) {
+        lite[2 * i + 0] = make_float4(mats[i].emissive[0], mats[i].emissive[1], mats[i].emissive[2], mats[i].roughness[0]);
+        lite[2 * i + 1] = make_float4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].metallic[0]);
+        if (mats[i].has_albedo_texture | mats[i].has_metallic_texture | mats[i].has_roughness_texture | mats[i].has_normal_texture) textured = 1;
     }
     HIP_TRY(c, c->nodes.alloc(2 * nn));
     HIP_TRY(c, c->tri_geom.alloc(3 * nt));
+    HIP_TRY(c, c->tri_shade.alloc(4 * nt));
+    HIP_TRY(c, c->mat_lite.alloc(2 * nm));
+    HIP_TRY(c, hipMemcpy(c->tri_shade.p, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->mat_lite.p, lite.data(), lite.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(c, c->per_vertex.alloc(4 * nv));
     HIP_TRY(c, c->materials.alloc(6 * nm));
     HIP_TRY(c, c->indices.alloc(nt));
@@ -378,7 +407,9 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, hipMemcpy(c->skybox.p, skybox, (size_t)sw * sh * 16, hipMemcpyHostToDevice));
 
     DevScene &s = c->scene;
-    s.nodes = c->nodes.p; s.tri_geom = c->tri_geom.p; s.indices = c->indices.p; s.per_vertex = c->per_vertex.p;
+    s.nodes = c->nodes.p; s.tri_geom = c->tri_geom.p; s.tri_shade = c->tri_shade.p; s.mat_lite = c->mat_lite.p;
+    s.textured = textured;
+    s.indices = c->indices.p; s.per_vertex = c->per_vertex.p;
     s.materials = c->materials.p; s.light_pick = c->light_pick.p;
     s.n_light_pick = (uint32_t)nlp;
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
@@ -474,10 +505,10 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
     const uint32_t blocks = (c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK;
-    const bool nee = c->cfg.nee_mode != RPT_NEE_NONE;
 
     HIP_TRY(c, hipMemsetAsync(c->queues.count, 0, Q_COUNT * sizeof(uint32_t), s));
-    k_generate<true><<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, 0u, n_samples);
+    for (int k = 0; k < RING; ++k) __atomic_store_n(&c->host_ring[k], 0ull, __ATOMIC_RELAXED);
+    k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples);
     c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
 
     std::vector<hipEvent_t> *ev = c->stage_timing ? &c->timing_events : nullptr;
@@ -489,50 +520,57 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
 
     uint32_t cur = 0;
     uint64_t it = 0;
+    bool drained = c->cfg.c.max_bounces == 0u;
     /* worst case: every sample needs max_bounces iterations, one after another */
     const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces ? c->cfg.c.max_bounces : 1u) + LAG + 2;
-    for (;;) {
+    while (!drained) {
         if (ev && ev->size() < ev_at + EVENTS_PER_ITER) {
             size_t old = ev->size();
             ev->resize(ev_at + EVENTS_PER_ITER * 64);
             for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
         }
         switch (c->stack_cap) {
-            case 16: launch_iteration<16>(c, cur, blocks, nee, ev, ev_at); break;
-            case 24: launch_iteration<24>(c, cur, blocks, nee, ev, ev_at); break;
-            default: launch_iteration<32>(c, cur, blocks, nee, ev, ev_at); break;
+            case 16: launch_iteration_stack<16>(c, cur, (uint32_t)it, blocks, ev, ev_at); break;
+            case 24: launch_iteration_stack<24>(c, cur, (uint32_t)it, blocks, ev, ev_at); break;
+            default: launch_iteration_stack<32>(c, cur, (uint32_t)it, blocks, ev, ev_at); break;
         }
-        int ring = (int)(it % RING);
-        HIP_TRY(c, hipMemcpyAsync(c->pinned_counts + ring * Q_COUNT, c->queues.count, Q_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipEventRecord(c->ring_events[ring], s));
         cur ^= 1u;
         it += 1;
         if (it >= (uint64_t)LAG) {
-            uint64_t j = it - LAG;              /* iteration whose outcome we inspect now */
-            int rj = (int)(j % RING);
-            HIP_TRY(c, hipEventSynchronize(c->ring_events[rj]));
-            uint32_t next_of_j = (uint32_t)((j + 1) & 1u);   /* iteration j wrote its survivors into ext[(j+1)&1] */
-            if (c->pinned_counts[rj * Q_COUNT + next_of_j] == 0u) break;
+            /* the traversal kernel of iteration j published (j + 1) << 32 | queue size when it started */
+            uint64_t j = it - LAG;
+            volatile unsigned long long *slot = &c->host_ring[j & (RING - 1)];
+            unsigned long long v;
+            uint64_t spins = 0;
+            while (((v = *slot) >> 32) != ((j + 1) & 0xffffffffull)) {
+                if (++spins > 2000000000ull || hipStreamQuery(s) == hipSuccess) {
+                    v = *slot;
+                    if ((v >> 32) == ((j + 1) & 0xffffffffull)) break;
+                    HIP_TRY(c, hipGetLastError());
+                    c->error = "wavefront progress report never arrived (internal error)";
+                    return RPT_EHIP;
+                }
+            }
+            if ((uint32_t)v == 0u) drained = true;       /* iteration j found an empty extension queue: everything after it is a no-op */
         }
         if (it > it_limit) { c->error = "wavefront did not drain (internal error)"; return RPT_EHIP; }
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
+    const bool nee = c->cfg.nee_mode != RPT_NEE_NONE;
     c->stats.iterations += it;
     c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += it;
     c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
     c->stats.kernel_launches[RPT_STAGE_SHADOW] += nee ? it : 0;
     c->stats.kernel_launches[RPT_STAGE_SKY] += it;
-    c->stats.kernel_launches[RPT_STAGE_GENERATE] += it;
     if (ev) {
-        /* events per iteration: [begin] trav shade shadow sky gen, preceded by one start event */
+        /* one start event, then per iteration: traverse, shade, shadow, sky */
         size_t at = 1;
+        const int stage_of[EVENTS_PER_ITER] = {RPT_STAGE_TRAVERSE, RPT_STAGE_SHADE, RPT_STAGE_SHADOW, RPT_STAGE_SKY};
         for (uint64_t k = 0; k < it; ++k) {
-            float ms;
-            const int stage_of[EVENTS_PER_ITER] = {-1, RPT_STAGE_TRAVERSE, RPT_STAGE_SHADE, RPT_STAGE_SHADOW, RPT_STAGE_SKY, RPT_STAGE_GENERATE};
             for (int e = 0; e < EVENTS_PER_ITER; ++e) {
-                if (stage_of[e] >= 0 && hipEventElapsedTime(&ms, (*ev)[at - 1], (*ev)[at]) == hipSuccess)
-                    c->stats.kernel_ms[stage_of[e]] += ms;
+                float ms;
+                if (hipEventElapsedTime(&ms, (*ev)[at - 1], (*ev)[at]) == hipSuccess) c->stats.kernel_ms[stage_of[e]] += ms;
                 at += 1;
             }
         }

@@ -57,6 +57,19 @@ def test_math_two_operand_bitwise(renderer, oracle):
     assert np.array_equal(q_dev.view(np.uint32)[~both_nan], q_cpu.view(np.uint32)[~both_nan])
 
 
+def test_fast_division_on_device_equals_ieee(renderer):
+    """rpt_fastdiv.h on gfx950: guarded reciprocal division == IEEE division (modulo the sign of a zero quotient)."""
+    rng = np.random.default_rng(23)
+    n = 1 << 22
+    y = rng.uniform(-1, 1, n).astype(np.float32)
+    y[: n // 8] = (rng.uniform(-1, 1, n // 8) * 10.0 ** rng.uniform(-12, 0, n // 8)).astype(np.float32)
+    x = (rng.uniform(-50, 50, n) - rng.uniform(-50, 50, n)).astype(np.float32)
+    x[:64] = 0.0
+    fast, true = renderer.debug_math(9, x, y), renderer.debug_math(8, x, y)
+    ok = (np.isnan(fast) & np.isnan(true)) | ((fast == 0) & (true == 0))
+    assert np.array_equal(fast.view(np.uint32)[~ok], true.view(np.uint32)[~ok])
+
+
 @pytest.mark.parametrize("scene", ["DarkCornell", "VeachMIS", "FurnaceTest", "PBRTest"])
 def test_ray_parity_nearest_and_any(renderer, oracle, world, scene):
     w = world(scene)
