@@ -7,8 +7,18 @@
  * kernels/src/lib.rs:225 / src/trace.rs:295).  All per-slot state is SoA in
  * 16-byte records so a wave reads 1 KiB per load instruction.
  *
- * Queues hold slot ids; they are filled with wave64 ballot + mbcnt prefix
- * compaction and one atomic per wave (wave_push below).
+ * Extension rays need no queue: a finished path is regenerated in place, so
+ * (except in the last few iterations of a render call) every slot always has
+ * a ray in flight and thread i simply owns slot i — perfectly coalesced, no
+ * index indirection, no atomics, and a wave is one 8x8 pixel block for ever.
+ * The slot's stage is the hit word of its ray record (HIT_PENDING -> traverse,
+ * a hit / HIT_MISS -> shade, HIT_PARKED -> nothing).
+ * The two side stages that only SOME paths need — sky shading of misses and
+ * shadow rays — are fed by compacted queues built with wave64 ballot + mbcnt
+ * prefix sums, aggregated per workgroup through LDS so that one atomic serves
+ * 256 lanes (a single queue counter sustains only ~90 returning atomics/us on
+ * MI355X — MI355X_MICROARCH.md "dequeue" — which at one atomic per wave was
+ * the measured bottleneck of the first version of the shade stage).
  */
 #ifndef RPT_K_COMMON_H
 #define RPT_K_COMMON_H
@@ -89,18 +99,22 @@ struct DevState {
 #define FLAG_LOBE_SPEC(f) (((f) >> 8) & 1u)
 #define FLAG_DIM(f) (((f) >> 16) & 0x3fu)
 #define MAKE_FLAGS(bounce, spec, dim) (((bounce) & 0xffu) | ((uint32_t)(spec) << 8) | ((uint32_t)(dim) << 16))
-#define HIT_MISS 0xffffffffu
+#define HIT_MISS 0xffffffffu      /* traversed, nothing hit                          -> shade sends it to the sky queue */
+#define HIT_PENDING 0xfffffffeu   /* a ray is waiting for the traversal stage                                          */
+#define HIT_PARKED 0xfffffffdu    /* nothing to do: waiting in the sky / shadow queue, or the slot is out of samples   */
 
 /* ---- queues ---------------------------------------------------------------- */
-enum { Q_EXT0 = 0, Q_EXT1 = 1, Q_SHADOW = 2, Q_SKY = 3, Q_COUNT = 8 };
+enum { Q_SHADOW = 0, Q_SKY = 1, Q_ALIVE0 = 2, Q_ALIVE1 = 3, Q_COUNT = 8 };
+#define RPT_STAT_SHARDS 64        /* sharded 64-bit counters, one 128-byte line each */
+#define RPT_STAT_STRIDE 16
 
 struct DevQueues {
-    uint32_t *ext[2];
     uint32_t *sky;
     float4 *sh_o;      /* shadow ray (ox, oy, oz, max_t), indexed by shadow-queue position */
     float4 *sh_d;      /* (dx, dy, dz, slot bits | bit31 = path ends after this NEE) */
     float4 *sh_c;      /* (contribution r, g, b if unoccluded, unused) */
-    uint32_t *count;   /* Q_COUNT counters */
+    uint32_t *count;   /* Q_COUNT words: shadow / sky queue sizes, alive flags of even / odd iterations */
+    unsigned long long *ray_shards;  /* RPT_STAT_SHARDS x RPT_STAT_STRIDE: extension rays traced */
     unsigned long long *host_ring;   /* mapped pinned host memory: (iteration + 1) << 32 | extension-queue size */
     uint32_t ring_mask;
 };
@@ -129,6 +143,27 @@ __device__ __forceinline__ uint32_t wave_push(uint32_t *counter, bool pred) {
     if (lane == leader) base = atomicAdd(counter, total);
     base = (uint32_t)__shfl((int)base, (int)leader, RPT_WAVE);
     uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    return base + prefix;
+}
+
+/* Workgroup-aggregated variant: one atomic per 256 lanes.  Every thread of the
+ * block must call it (two barriers inside).  `scratch` is RPT_BLOCK/RPT_WAVE + 1 words of LDS. */
+__device__ __forceinline__ uint32_t block_push(uint32_t *counter, bool pred, uint32_t *scratch) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
+    constexpr uint32_t NW = RPT_BLOCK / RPT_WAVE;
+    unsigned long long mask = __ballot(pred);
+    if (lane == 0u) scratch[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t total = 0u;
+        for (uint32_t w = 0; w < NW; ++w) total += scratch[w];
+        scratch[NW] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = scratch[NW];
+    for (uint32_t w = 0; w < wave; ++w) base += scratch[w];
+    uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    __syncthreads();     /* scratch may be reused by the next push */
     return base + prefix;
 }
 

@@ -35,7 +35,7 @@ __device__ __forceinline__ void start_path(const DevState &st, const DevConfig &
     F3 ro, rd;
     camera_ray(cfg, pxy & 0xffffu, pxy >> 16, rs.x + rs.y, ro, rd);
     st.ray_a[slot] = make_float4(ro.x, ro.y, ro.z, rd.x);
-    reinterpret_cast<float2 *>(&st.ray_b[slot])[0] = make_float2(rd.y, rd.z);
+    st.ray_b[slot] = make_float4(rd.y, rd.z, 0.0f, __uint_as_float(HIT_PENDING));
     st.thr_rad[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     st.rad_misc[slot] = make_float4(0.0f, 0.0f, __uint_as_float(MAKE_FLAGS(0u, 0u, 2u)), __uint_as_float(todo_after));
 }
@@ -43,8 +43,8 @@ __device__ __forceinline__ void start_path(const DevState &st, const DevConfig &
 /* A path of `slot` ended with `radiance`: accumulate it (sample order per pixel is
  * preserved because a slot carries one sample at a time), advance the pixel's rng
  * state, and start the pixel's next sample if this render call still owes one.
- * Returns true when a new path was written (caller pushes the slot to the next
- * extension queue). */
+ * Returns true when a new path was written (its ray record is then marked
+ * HIT_PENDING for the next traversal pass); otherwise the slot stays parked. */
 __device__ __forceinline__ bool finish_and_regenerate(const DevState &st, const DevConfig &cfg, uint32_t slot, F3 radiance,
                                                       uint32_t todo) {
     float4 acc = st.accum[slot];
@@ -53,7 +53,10 @@ __device__ __forceinline__ bool finish_and_regenerate(const DevState &st, const 
     uint2 rs = st.rng[slot];
     rs.x += 1u;
     st.rng[slot] = rs;
-    if (todo == 0u) return false;
+    if (todo == 0u) {
+        reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+        return false;
+    }
     start_path(st, cfg, slot, rs, todo - 1u);
     return true;
 }

@@ -147,32 +147,38 @@ __device__ __forceinline__ Mat load_material(const DevScene &sc, uint32_t index)
     return m;
 }
 
-/* destinations a path can leave the shade stage for */
-enum { DEST_NONE = 0, DEST_EXT = 1, DEST_SKY = 2 };
 
 /* NEE = NextEventEstimation mode (0 none, 1 MIS, 2 direct only), TEXTURED = the
  * scene has at least one texture flag.  Specialising removes the dead halves of
  * the stage (and their registers) for the common untextured / no-NEE case. */
 template <int NEE, bool TEXTURED>
-__global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t cur,
+__global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
                                                      DevStats *stats) {
-    const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    const uint32_t n = q.count[cur];
-    const bool active = i < n;
-    uint32_t dest = DEST_NONE;
+    __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
+    const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (slot == 0u) {
+        /* progress report for the host: did the traversal pass of this iteration find any ray?  Also clear
+         * the flag the NEXT iteration's traversal will raise (it last belonged to iteration - 1). */
+        uint32_t alive = q.count[Q_ALIVE0 + (iteration & 1u)];
+        q.count[Q_ALIVE0 + ((iteration + 1u) & 1u)] = 0u;
+        __hip_atomic_store(&q.host_ring[iteration & q.ring_mask], ((unsigned long long)(iteration + 1u) << 32) | alive,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    bool to_sky = false;
     bool emit_shadow = false;
-    uint32_t slot = 0u;
     float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
+    float4 rb = make_float4(0, 0, 0, __uint_as_float(HIT_PARKED));
+    if (slot < st.n_slots) rb = st.ray_b[slot];
+    const uint32_t hit_tri = __float_as_uint(rb.w);
+    const bool active = hit_tri != HIT_PENDING && hit_tri != HIT_PARKED;     /* traversed in this iteration */
 
     if (active) {
-        slot = q.ext[cur][i];
         const float4 ra = st.ray_a[slot];
-        const float4 rb = st.ray_b[slot];
         const F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
         const float hit_t = rb.z;
-        const uint32_t hit_tri = __float_as_uint(rb.w);
         if (hit_tri == HIT_MISS) {
-            dest = DEST_SKY;                         /* lib.rs:66-79: shaded by k_sky */
+            to_sky = true;                           /* lib.rs:66-79: shaded by k_sky, which also ends the path */
+            reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
         } else {
             float4 tr = st.thr_rad[slot];
             float4 rm = st.rad_misc[slot];
@@ -426,30 +432,32 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
 
             if (done && !emit_shadow) {
                 /* the path ends here with nothing pending: accumulate + regenerate in place */
-                if (finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w))) dest = DEST_EXT;
+                finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
             } else {
                 st.thr_rad[slot] = make_float4(throughput.x, throughput.y, throughput.z, radiance.x);
                 st.rad_misc[slot] = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
                 if (!done) {
                     st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
-                    reinterpret_cast<float2 *>(&st.ray_b[slot])[0] = make_float2(new_d.y, new_d.z);
-                    dest = DEST_EXT;
+                    st.ray_b[slot] = make_float4(new_d.y, new_d.z, 0.0f, __uint_as_float(HIT_PENDING));
                     sh_d.w = __uint_as_float(slot);
                 } else {
-                    sh_d.w = __uint_as_float(slot | 0x80000000u);   /* the shadow stage finishes the path */
+                    /* the shadow stage adds the NEE term and then finishes the path */
+                    reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+                    sh_d.w = __uint_as_float(slot | 0x80000000u);
                 }
             }
         }
     }
 
-    /* ---- converged queue emission: wave64 ballot + prefix compaction ---- */
+    /* ---- side-queue emission: wave64 ballot + mbcnt prefix, one atomic per workgroup ---- */
+    /* (block-uniform early outs keep the barriers inside block_push legal) */
     uint32_t at;
-    at = wave_push(&q.count[cur ^ 1u], dest == DEST_EXT);
-    if (dest == DEST_EXT) q.ext[cur ^ 1u][at] = slot;
-    at = wave_push(&q.count[Q_SKY], dest == DEST_SKY);
-    if (dest == DEST_SKY) q.sky[at] = slot;
-    if (NEE != RPT_NEE_NONE) {
-        at = wave_push(&q.count[Q_SHADOW], emit_shadow);
+    if (__syncthreads_or(to_sky)) {
+        at = block_push(&q.count[Q_SKY], to_sky, push_scratch);
+        if (to_sky) q.sky[at] = slot;
+    }
+    if (NEE != RPT_NEE_NONE && __syncthreads_or(emit_shadow)) {
+        at = block_push(&q.count[Q_SHADOW], emit_shadow, push_scratch);
         if (emit_shadow) {
             q.sh_o[at] = sh_o;
             q.sh_d[at] = sh_d;

@@ -69,16 +69,12 @@ __device__ F3 sky_scatter(const float *sun4, F3 origin, F3 direction) {
     return f3(rptm::powr(g.x, 2.2f), rptm::powr(g.y, 2.2f), rptm::powr(g.z, 2.2f));
 }
 
-__global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t cur,
-                                                   DevStats *stats) {
+__global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats) {
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
     uint32_t n = q.count[Q_SKY];
     if (i == 0u && n) atomicAdd(&stats->sky_evals, (unsigned long long)n);
-    bool active = i < n;
-    bool emit = false;
-    uint32_t slot = 0u;
-    if (active) {
-        slot = q.sky[i];
+    if (i < n) {
+        uint32_t slot = q.sky[i];
         float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
         F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
         float4 tr = st.thr_rad[slot], rm = st.rad_misc[slot];
@@ -94,18 +90,14 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
             radiance = radiance + throughput * f3(s.x, s.y, s.z) * intensity;
         }
         /* a miss always ends the path (lib.rs:79) */
-        emit = finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
+        finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
     }
-    uint32_t at = wave_push(&q.count[cur ^ 1u], emit);
-    if (emit) q.ext[cur ^ 1u][at] = slot;
 }
 
 /* Start of an rpt_render call: every slot begins the first of its n_samples samples. */
 __global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQueues q, DevConfig cfg, uint32_t n_samples) {
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    bool active = i < st.n_slots;
-    bool emit = false;
-    if (active) {
+    if (i < st.n_slots) {
         uint2 rs = st.rng[i];
         if (cfg.c.max_bounces == 0u) {
             /* the bounce loop never runs (lib.rs:62): every sample adds (0,0,0,1) */
@@ -114,13 +106,11 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQu
             st.accum[i] = acc;
             rs.x += n_samples;
             st.rng[i] = rs;
+            reinterpret_cast<float2 *>(&st.ray_b[i])[1] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
         } else {
             start_path(st, cfg, i, rs, n_samples - 1u);
-            emit = true;
         }
     }
-    uint32_t at = wave_push(&q.count[0], emit);
-    if (emit) q.ext[0][at] = i;
 }
 
 /* root-side un-tiling of gathered per-rank blocks into a row-major image */

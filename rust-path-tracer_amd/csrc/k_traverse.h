@@ -151,31 +151,34 @@ __device__ __forceinline__ HitRecord traverse_one(const DevScene &sc, F3 ro, F3 
     return traverse_loop<STACK, ANY_HIT, false>(sc, ro, rd, rd, max_t, stack);
 }
 
-/* Extension rays: queue of slot ids -> hit record written into ray_b.zw.
- * Thread 0 also does the per-iteration bookkeeping that needs no kernel of its
- * own: it clears the three counters the later stages of THIS iteration will
- * fill (they were consumed by the previous iteration's kernels, which have all
- * retired — same stream), and reports the size of this iteration's queue to the
- * host through mapped pinned memory so the host can stop launching iterations
- * without ever synchronising with the stream. */
+/* Extension rays.  Thread i owns slot i; it traces the slot's ray if one is
+ * pending (HIT_PENDING) and writes the hit record into ray_b.zw.  A wave that
+ * found work raises this iteration's alive flag (plain store, every writer
+ * stores the same value), which the shade stage reports to the host. */
 template <int STACK>
-__global__ __launch_bounds__(RPT_BLOCK) void k_traverse_nearest(DevScene sc, DevState st, DevQueues q, uint32_t cur,
-                                                                uint32_t iteration, DevStats *stats) {
+__global__ __launch_bounds__(RPT_BLOCK) void k_traverse_nearest(DevScene sc, DevState st, DevQueues q, uint32_t iteration) {
     __shared__ uint32_t lds_stack[RPT_BLOCK / RPT_WAVE][STACK][RPT_WAVE];
-    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    uint32_t n = q.count[cur];
-    if (i == 0u) {
-        q.count[cur ^ 1u] = 0u;
+    const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (slot == 0u) {
+        /* the side queues were consumed by the previous iteration's sky / shadow kernels (same stream) */
         q.count[Q_SHADOW] = 0u;
         q.count[Q_SKY] = 0u;
-        if (n) atomicAdd(&stats->extension_rays, (unsigned long long)n);
-        __hip_atomic_store(&q.host_ring[iteration & q.ring_mask], ((unsigned long long)(iteration + 1u) << 32) | n,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (i >= n) return;
-    uint32_t slot = q.ext[cur][i];
+    float4 rb = make_float4(0, 0, 0, 0);
+    bool pending = false;
+    if (slot < st.n_slots) {
+        rb = st.ray_b[slot];
+        pending = __float_as_uint(rb.w) == HIT_PENDING;
+    }
+    unsigned long long active = __ballot(pending);
+    if (active == 0ull) return;
+    if (__lane_id() == (uint32_t)__ffsll((long long)active) - 1u) {
+        q.count[Q_ALIVE0 + (iteration & 1u)] = 1u;
+        /* ray accounting: sharded, non-returning atomics (nobody waits for them) */
+        atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)__popcll(active));
+    }
+    if (!pending) return;
     float4 ra = st.ray_a[slot];
-    float4 rb = st.ray_b[slot];
     F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
     uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
     HitRecord h = traverse_one<STACK, false>(sc, ro, rd, 0.0f, stack);
@@ -183,47 +186,42 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_traverse_nearest(DevScene sc, Dev
     out[1] = make_float2(h.t, __uint_as_float(h.tri));
 }
 
-/* Shadow rays (kernels/src/light_pick.rs:141-148): any-hit; if unoccluded the
- * pre-weighted NEE contribution is added to the path's radiance (lib.rs:164).
- * A path that ended at this bounce (bit 31 of the tag) is finished here:
- * accumulated and, if samples remain, regenerated into the next extension queue. */
+/* Shadow rays (kernels/src/light_pick.rs:141-148): any-hit over the compacted
+ * shadow queue; if unoccluded the pre-weighted NEE contribution is added to the
+ * path's radiance (lib.rs:164).  A path that ended at this bounce (bit 31 of
+ * the tag) is finished here: accumulated and, if samples remain, regenerated
+ * in place (its slot becomes HIT_PENDING again). */
 template <int STACK>
-__global__ __launch_bounds__(RPT_BLOCK) void k_traverse_shadow(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t cur,
+__global__ __launch_bounds__(RPT_BLOCK) void k_traverse_shadow(DevScene sc, DevState st, DevQueues q, DevConfig cfg,
                                                                DevStats *stats) {
     __shared__ uint32_t lds_stack[RPT_BLOCK / RPT_WAVE][STACK][RPT_WAVE];
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
     uint32_t n = q.count[Q_SHADOW];
     if (i == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
-    bool active = i < n;
-    bool emit = false;
-    uint32_t slot = 0u;
-    if (active) {
-        float4 o = q.sh_o[i], d = q.sh_d[i];
-        uint32_t tag = __float_as_uint(d.w);
-        slot = tag & 0x7fffffffu;
-        bool finish = (tag >> 31) != 0u;
-        uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-        HitRecord h = traverse_one<STACK, true>(sc, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
-        bool visible = h.tri == HIT_MISS;
-        if (visible || finish) {
-            float4 tr = st.thr_rad[slot];
-            float4 rm = st.rad_misc[slot];
-            F3 radiance = f3(tr.w, rm.x, rm.y);
-            if (visible) {
-                float4 c = q.sh_c[i];
-                radiance = radiance + mask_nan3(f3(c.x, c.y, c.z));
-            }
-            if (finish) {
-                emit = finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
-            } else {
-                tr.w = radiance.x; rm.x = radiance.y; rm.y = radiance.z;
-                st.thr_rad[slot] = tr;
-                st.rad_misc[slot] = rm;
-            }
+    if (i >= n) return;
+    float4 o = q.sh_o[i], d = q.sh_d[i];
+    uint32_t tag = __float_as_uint(d.w);
+    uint32_t slot = tag & 0x7fffffffu;
+    bool finish = (tag >> 31) != 0u;
+    uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
+    HitRecord h = traverse_one<STACK, true>(sc, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
+    bool visible = h.tri == HIT_MISS;
+    if (visible || finish) {
+        float4 tr = st.thr_rad[slot];
+        float4 rm = st.rad_misc[slot];
+        F3 radiance = f3(tr.w, rm.x, rm.y);
+        if (visible) {
+            float4 c = q.sh_c[i];
+            radiance = radiance + mask_nan3(f3(c.x, c.y, c.z));
+        }
+        if (finish) {
+            finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
+        } else {
+            tr.w = radiance.x; rm.x = radiance.y; rm.y = radiance.z;
+            st.thr_rad[slot] = tr;
+            st.rad_misc[slot] = rm;
         }
     }
-    uint32_t at = wave_push(&q.count[cur ^ 1u], emit);
-    if (emit) q.ext[cur ^ 1u][at] = slot;
 }
 
 /* Test hook: plain ray arrays in, hit arrays out (rpt_debug_trace_rays). */

@@ -86,7 +86,8 @@ struct rpt_ctx {
     bool has_state = false;
     DevBuf<float4> ray_a, ray_b, thr_rad, rad_misc, mis0, mis1, mis2, mis3, accum;
     DevBuf<uint2> rng;
-    DevBuf<uint32_t> q_ext0, q_ext1, q_sky, q_count;
+    DevBuf<uint32_t> q_sky, q_count;
+    DevBuf<unsigned long long> ray_shards;
     DevBuf<float4> sh_o, sh_d, sh_c;
     DevBuf<DevStats> dev_stats;
     DevState state{};
@@ -198,7 +199,7 @@ void release_state(rpt_ctx *c) {
     c->ray_a.release(); c->ray_b.release(); c->thr_rad.release(); c->rad_misc.release();
     c->mis0.release(); c->mis1.release(); c->mis2.release(); c->mis3.release();
     c->accum.release(); c->rng.release();
-    c->q_ext0.release(); c->q_ext1.release(); c->q_sky.release(); c->q_count.release();
+    c->q_sky.release(); c->q_count.release(); c->ray_shards.release();
     c->sh_o.release(); c->sh_d.release(); c->sh_c.release();
     c->pixel_xy.release();
     c->has_state = false;
@@ -210,7 +211,9 @@ int alloc_state(rpt_ctx *c) {
     HIP_TRY(c, c->thr_rad.alloc(n)); HIP_TRY(c, c->rad_misc.alloc(n));
     HIP_TRY(c, c->mis0.alloc(n)); HIP_TRY(c, c->mis1.alloc(n)); HIP_TRY(c, c->mis2.alloc(n)); HIP_TRY(c, c->mis3.alloc(n));
     HIP_TRY(c, c->accum.alloc(n)); HIP_TRY(c, c->rng.alloc(n));
-    HIP_TRY(c, c->q_ext0.alloc(n)); HIP_TRY(c, c->q_ext1.alloc(n)); HIP_TRY(c, c->q_sky.alloc(n));
+    HIP_TRY(c, c->q_sky.alloc(n));
+    HIP_TRY(c, c->ray_shards.alloc(RPT_STAT_SHARDS * RPT_STAT_STRIDE));
+    HIP_TRY(c, hipMemset(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(c, c->q_count.alloc(Q_COUNT));
     HIP_TRY(c, c->sh_o.alloc(n)); HIP_TRY(c, c->sh_d.alloc(n)); HIP_TRY(c, c->sh_c.alloc(n));
     HIP_TRY(c, c->pixel_xy.alloc(n));
@@ -221,7 +224,7 @@ int alloc_state(rpt_ctx *c) {
     s.mis0 = c->mis0.p; s.mis1 = c->mis1.p; s.mis2 = c->mis2.p; s.mis3 = c->mis3.p;
     s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = (uint32_t)n;
     DevQueues &q = c->queues;
-    q.ext[0] = c->q_ext0.p; q.ext[1] = c->q_ext1.p; q.sky = c->q_sky.p;
+    q.sky = c->q_sky.p; q.ray_shards = c->ray_shards.p;
     q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p; q.count = c->q_count.p;
     q.host_ring = c->host_ring_dev; q.ring_mask = RING - 1;
     c->has_state = true;
@@ -229,36 +232,36 @@ int alloc_state(rpt_ctx *c) {
 }
 
 template <int STACK, int NEE, bool TEXTURED>
-void launch_iteration(rpt_ctx *c, uint32_t cur, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
+void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
     hipStream_t s = c->stream;
     auto mark = [&]() {
         if (ev) (void)hipEventRecord((*ev)[ev_at++], s);
     };
-    k_traverse_nearest<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, cur, iteration, c->dev_stats.p);
+    k_traverse_nearest<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, iteration);
     mark();
-    k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, cur, c->dev_stats.p);
+    k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
-    if (NEE != RPT_NEE_NONE) k_traverse_shadow<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, cur, c->dev_stats.p);
+    if (NEE != RPT_NEE_NONE) k_traverse_shadow<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
     mark();
-    k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, cur, c->dev_stats.p);
+    k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
     mark();
 }
 
 template <int STACK>
-void launch_iteration_stack(rpt_ctx *c, uint32_t cur, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
+void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
     const bool tex = c->scene.textured != 0u;
     switch (c->cfg.nee_mode) {
         case RPT_NEE_MIS:
-            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, cur, iteration, blocks, ev, ev_at);
-            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, cur, iteration, blocks, ev, ev_at);
+            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, iteration, blocks, ev, ev_at);
+            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, iteration, blocks, ev, ev_at);
             break;
         case RPT_NEE_DIRECT:
-            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, cur, iteration, blocks, ev, ev_at);
-            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, cur, iteration, blocks, ev, ev_at);
+            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, iteration, blocks, ev, ev_at);
+            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, iteration, blocks, ev, ev_at);
             break;
         default:
-            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, cur, iteration, blocks, ev, ev_at);
-            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, cur, iteration, blocks, ev, ev_at);
+            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, iteration, blocks, ev, ev_at);
+            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, iteration, blocks, ev, ev_at);
             break;
     }
 }
@@ -492,6 +495,7 @@ int rpt_reset(rpt_ctx *c, const rpt_rng_state *seed, const float *accum_init, ui
         HIP_TRY(c, hipMemcpy(c->accum.p, acc.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     }
     HIP_TRY(c, hipMemset(c->dev_stats.p, 0, sizeof(DevStats)));
+    HIP_TRY(c, hipMemset(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long)));
     c->samples = accum_init ? samples_init : 0u;
     c->stats = rpt_stats{};
     return RPT_OK;
@@ -518,7 +522,6 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
         HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s));
     }
 
-    uint32_t cur = 0;
     uint64_t it = 0;
     bool drained = c->cfg.c.max_bounces == 0u;
     /* worst case: every sample needs max_bounces iterations, one after another */
@@ -530,14 +533,13 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
             for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
         }
         switch (c->stack_cap) {
-            case 16: launch_iteration_stack<16>(c, cur, (uint32_t)it, blocks, ev, ev_at); break;
-            case 24: launch_iteration_stack<24>(c, cur, (uint32_t)it, blocks, ev, ev_at); break;
-            default: launch_iteration_stack<32>(c, cur, (uint32_t)it, blocks, ev, ev_at); break;
+            case 16: launch_iteration_stack<16>(c, (uint32_t)it, blocks, ev, ev_at); break;
+            case 24: launch_iteration_stack<24>(c, (uint32_t)it, blocks, ev, ev_at); break;
+            default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at); break;
         }
-        cur ^= 1u;
         it += 1;
         if (it >= (uint64_t)LAG) {
-            /* the traversal kernel of iteration j published (j + 1) << 32 | queue size when it started */
+            /* the shade kernel of iteration j published (j + 1) << 32 | "traversal j found a pending ray" */
             uint64_t j = it - LAG;
             volatile unsigned long long *slot = &c->host_ring[j & (RING - 1)];
             unsigned long long v;
@@ -551,7 +553,7 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
                     return RPT_EHIP;
                 }
             }
-            if ((uint32_t)v == 0u) drained = true;       /* iteration j found an empty extension queue: everything after it is a no-op */
+            if ((uint32_t)v == 0u) drained = true;       /* iteration j found no ray at all: everything after it is a no-op */
         }
         if (it > it_limit) { c->error = "wavefront did not drain (internal error)"; return RPT_EHIP; }
     }
@@ -681,6 +683,10 @@ int rpt_get_stats(rpt_ctx *c, rpt_stats *out) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     DevStats ds;
     HIP_TRY(c, hipMemcpy(&ds, c->dev_stats.p, sizeof(ds), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> shards(RPT_STAT_SHARDS * RPT_STAT_STRIDE, 0ull);
+    if (c->ray_shards.p) HIP_TRY(c, hipMemcpy(shards.data(), c->ray_shards.p, shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    ds.extension_rays = 0;
+    for (int k = 0; k < RPT_STAT_SHARDS; ++k) ds.extension_rays += shards[(size_t)k * RPT_STAT_STRIDE];
     c->stats.extension_rays = ds.extension_rays;
     c->stats.shadow_rays = ds.shadow_rays;
     c->stats.sky_evals = ds.sky_evals;
