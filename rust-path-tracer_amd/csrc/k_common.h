@@ -72,6 +72,8 @@ struct DevScene {
     const float4 *materials;       /* 6 x float4 per rpt_material_data */
     const rpt_light_pick_entry *light_pick;
     uint32_t n_light_pick;
+    uint32_t n_nodes, n_triangles;
+    uint32_t lds_scene;            /* nodes + tri_geom fit in RPT_LDS_SCENE_BYTES: traverse out of LDS */
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */
     uint32_t fastdiv_ok;           /* every node bound is 0 or in [2^-60, 2^40): exact fast division allowed */
     uint32_t textured;             /* some material has a texture flag set */

@@ -81,19 +81,20 @@ __device__ __forceinline__ bool moller_trumbore(F3 ro, F3 rd, F3 a, F3 edge1, F3
  * reference's (intersection.rs:177-234).  `stack` points at this lane's column
  * of the wave's LDS stack: entry e lives at stack[e * RPT_WAVE]. */
 template <int STACK, bool ANY_HIT, bool FAST>
-__device__ __forceinline__ HitRecord traverse_loop(const DevScene &sc, F3 ro, F3 rd, F3 ird, float max_t, uint32_t *stack) {
+__device__ __forceinline__ HitRecord traverse_loop(const float4 *nodes, const float4 *tri_geom, F3 ro, F3 rd, F3 ird, float max_t,
+                                                   uint32_t *stack) {
     HitRecord res;
     res.t = 1000000.0f;
     res.tri = HIT_MISS;
     int sp = 0;
     /* current node's metadata (aabb_min.w = triangle_count, aabb_max.w = left/first) */
-    uint32_t cur_count = __float_as_uint(sc.nodes[0].w);
-    uint32_t cur_index = __float_as_uint(sc.nodes[1].w);
+    uint32_t cur_count = __float_as_uint(nodes[0].w);
+    uint32_t cur_index = __float_as_uint(nodes[1].w);
     bool alive = true;
     for (;;) {
         /* phase 1: inner nodes (:207-229) until a leaf is reached */
         while (alive && cur_count == 0u) {
-            const float4 *ch = sc.nodes + 2u * cur_index;
+            const float4 *ch = nodes + 2u * cur_index;
             float4 lmin = ch[0], lmax = ch[1], rmin = ch[2], rmax = ch[3];
             float dl = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t);
             float dr = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t);
@@ -112,17 +113,17 @@ __device__ __forceinline__ HitRecord traverse_loop(const DevScene &sc, F3 ro, F3
             } else {
                 sp -= 1;
                 uint32_t node = stack[sp * RPT_WAVE];
-                cur_count = __float_as_uint(sc.nodes[2u * node].w);
-                cur_index = __float_as_uint(sc.nodes[2u * node + 1u].w);
+                cur_count = __float_as_uint(nodes[2u * node].w);
+                cur_index = __float_as_uint(nodes[2u * node + 1u].w);
             }
         }
         if (!alive) break;
         /* phase 2: leaf triangles in index order (:186-205) */
         for (uint32_t i = 0; i < cur_count; ++i) {
             uint32_t ti = cur_index + i;
-            F3 a = xyz4(sc.tri_geom[3u * ti]);
-            F3 e1 = xyz4(sc.tri_geom[3u * ti + 1u]);
-            F3 e2 = xyz4(sc.tri_geom[3u * ti + 2u]);
+            F3 a = xyz4(tri_geom[3u * ti]);
+            F3 e1 = xyz4(tri_geom[3u * ti + 1u]);
+            F3 e2 = xyz4(tri_geom[3u * ti + 2u]);
             float t = 0.0f;
             bool bf = false;
             if (moller_trumbore(ro, rd, a, e1, e2, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
@@ -134,31 +135,55 @@ __device__ __forceinline__ HitRecord traverse_loop(const DevScene &sc, F3 ro, F3
         if (sp == 0) break;
         sp -= 1;
         uint32_t node = stack[sp * RPT_WAVE];
-        cur_count = __float_as_uint(sc.nodes[2u * node].w);
-        cur_index = __float_as_uint(sc.nodes[2u * node + 1u].w);
+        cur_count = __float_as_uint(nodes[2u * node].w);
+        cur_index = __float_as_uint(nodes[2u * node + 1u].w);
     }
     return res;
 }
 
 template <int STACK, bool ANY_HIT>
-__device__ __forceinline__ HitRecord traverse_one(const DevScene &sc, F3 ro, F3 rd, float max_t, uint32_t *stack) {
-    bool fast = sc.fastdiv_ok != 0u && rptm::fastdiv_divisor_ok(rd.x) && rptm::fastdiv_divisor_ok(rd.y) && rptm::fastdiv_divisor_ok(rd.z) &&
+__device__ __forceinline__ HitRecord traverse_one(const float4 *nodes, const float4 *tri_geom, uint32_t fastdiv_ok, F3 ro, F3 rd,
+                                                  float max_t, uint32_t *stack) {
+    bool fast = fastdiv_ok != 0u && rptm::fastdiv_divisor_ok(rd.x) && rptm::fastdiv_divisor_ok(rd.y) && rptm::fastdiv_divisor_ok(rd.z) &&
                 rptm::fastdiv_operand_ok(ro.x) && rptm::fastdiv_operand_ok(ro.y) && rptm::fastdiv_operand_ok(ro.z);
     if (fast) {
         F3 ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-        return traverse_loop<STACK, ANY_HIT, true>(sc, ro, rd, ird, max_t, stack);
+        return traverse_loop<STACK, ANY_HIT, true>(nodes, tri_geom, ro, rd, ird, max_t, stack);
     }
-    return traverse_loop<STACK, ANY_HIT, false>(sc, ro, rd, rd, max_t, stack);
+    return traverse_loop<STACK, ANY_HIT, false>(nodes, tri_geom, ro, rd, rd, max_t, stack);
+}
+
+/* Small scenes live in LDS: when nodes + triangle geometry fit in RPT_LDS_SCENE_BYTES
+ * every workgroup copies them in once and traverses out of LDS (ds_read_b128,
+ * ~64-cycle latency, no pressure on the CU's single vector-memory address unit —
+ * the measured limiter once the divisions were gone: ~380 divergent 16-byte
+ * wave-loads per wave through one TA per CU).  Larger scenes read through L1/L2. */
+#define RPT_LDS_SCENE_BYTES 24576
+extern __shared__ __attribute__((aligned(16))) float4 rpt_lds_dyn[];   /* sized at launch to the scene (LDS variants only) */
+template <bool LDS_SCENE, int THREADS>
+__device__ __forceinline__ void stage_scene(const DevScene &sc, float4 *lds_scene, const float4 *&nodes, const float4 *&tri_geom) {
+    if (LDS_SCENE) {
+        const uint32_t n_node_vec = 2u * sc.n_nodes, n_tri_vec = 3u * sc.n_triangles;
+        for (uint32_t k = threadIdx.x; k < n_node_vec; k += THREADS) lds_scene[k] = sc.nodes[k];
+        for (uint32_t k = threadIdx.x; k < n_tri_vec; k += THREADS) lds_scene[n_node_vec + k] = sc.tri_geom[k];
+        __syncthreads();
+        nodes = lds_scene;
+        tri_geom = lds_scene + n_node_vec;
+    } else {
+        nodes = sc.nodes;
+        tri_geom = sc.tri_geom;
+    }
 }
 
 /* Extension rays.  Thread i owns slot i; it traces the slot's ray if one is
  * pending (HIT_PENDING) and writes the hit record into ray_b.zw.  A wave that
  * found work raises this iteration's alive flag (plain store, every writer
  * stores the same value), which the shade stage reports to the host. */
-template <int STACK>
-__global__ __launch_bounds__(RPT_BLOCK) void k_traverse_nearest(DevScene sc, DevState st, DevQueues q, uint32_t iteration) {
-    __shared__ uint32_t lds_stack[RPT_BLOCK / RPT_WAVE][STACK][RPT_WAVE];
-    const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
+template <int STACK, bool LDS_SCENE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevState st, DevQueues q, uint32_t iteration) {
+    __shared__ uint32_t lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
+    float4 *lds_scene = rpt_lds_dyn;
+    const uint32_t slot = blockIdx.x * THREADS + threadIdx.x;
     if (slot == 0u) {
         /* the side queues were consumed by the previous iteration's sky / shadow kernels (same stream) */
         q.count[Q_SHADOW] = 0u;
@@ -170,6 +195,9 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_traverse_nearest(DevScene sc, Dev
         rb = st.ray_b[slot];
         pending = __float_as_uint(rb.w) == HIT_PENDING;
     }
+    if (LDS_SCENE && !__syncthreads_or(pending)) return;      /* block-uniform: nothing to trace here */
+    const float4 *nodes, *tri_geom;
+    stage_scene<LDS_SCENE, THREADS>(sc, lds_scene, nodes, tri_geom);
     unsigned long long active = __ballot(pending);
     if (active == 0ull) return;
     if (__lane_id() == (uint32_t)__ffsll((long long)active) - 1u) {
@@ -181,7 +209,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_traverse_nearest(DevScene sc, Dev
     float4 ra = st.ray_a[slot];
     F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
     uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, false>(sc, ro, rd, 0.0f, stack);
+    HitRecord h = traverse_one<STACK, false>(nodes, tri_geom, sc.fastdiv_ok, ro, rd, 0.0f, stack);
     float2 *out = reinterpret_cast<float2 *>(&st.ray_b[slot]);
     out[1] = make_float2(h.t, __uint_as_float(h.tri));
 }
@@ -191,20 +219,23 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_traverse_nearest(DevScene sc, Dev
  * path's radiance (lib.rs:164).  A path that ended at this bounce (bit 31 of
  * the tag) is finished here: accumulated and, if samples remain, regenerated
  * in place (its slot becomes HIT_PENDING again). */
-template <int STACK>
-__global__ __launch_bounds__(RPT_BLOCK) void k_traverse_shadow(DevScene sc, DevState st, DevQueues q, DevConfig cfg,
-                                                               DevStats *stats) {
-    __shared__ uint32_t lds_stack[RPT_BLOCK / RPT_WAVE][STACK][RPT_WAVE];
-    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+template <int STACK, bool LDS_SCENE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats) {
+    __shared__ uint32_t lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
+    float4 *lds_scene = rpt_lds_dyn;
+    uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     uint32_t n = q.count[Q_SHADOW];
     if (i == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
+    if (blockIdx.x * THREADS >= n) return;                     /* block-uniform */
+    const float4 *nodes, *tri_geom;
+    stage_scene<LDS_SCENE, THREADS>(sc, lds_scene, nodes, tri_geom);
     if (i >= n) return;
     float4 o = q.sh_o[i], d = q.sh_d[i];
     uint32_t tag = __float_as_uint(d.w);
     uint32_t slot = tag & 0x7fffffffu;
     bool finish = (tag >> 31) != 0u;
     uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, true>(sc, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
+    HitRecord h = traverse_one<STACK, true>(nodes, tri_geom, sc.fastdiv_ok, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
     bool visible = h.tri == HIT_MISS;
     if (visible || finish) {
         float4 tr = st.thr_rad[slot];
@@ -225,17 +256,19 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_traverse_shadow(DevScene sc, DevS
 }
 
 /* Test hook: plain ray arrays in, hit arrays out (rpt_debug_trace_rays). */
-template <int STACK, bool ANY_HIT>
-__global__ __launch_bounds__(RPT_BLOCK) void k_trace_debug(DevScene sc, uint32_t n, const float *origins, const float *dirs,
-                                                           const float *max_t, float *out_t, uint32_t *out_tri,
-                                                           uint32_t *out_flags) {
-    __shared__ uint32_t lds_stack[RPT_BLOCK / RPT_WAVE][STACK][RPT_WAVE];
-    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+template <int STACK, bool ANY_HIT, bool LDS_SCENE, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_trace_debug(DevScene sc, uint32_t n, const float *origins, const float *dirs,
+                                                         const float *max_t, float *out_t, uint32_t *out_tri, uint32_t *out_flags) {
+    __shared__ uint32_t lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
+    float4 *lds_scene = rpt_lds_dyn;
+    uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+    const float4 *nodes, *tri_geom;
+    stage_scene<LDS_SCENE, THREADS>(sc, lds_scene, nodes, tri_geom);
     if (i >= n) return;
     F3 ro = f3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
     F3 rd = f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
     uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, ANY_HIT>(sc, ro, rd, ANY_HIT ? max_t[i] : 0.0f, stack);
+    HitRecord h = traverse_one<STACK, ANY_HIT>(nodes, tri_geom, sc.fastdiv_ok, ro, rd, ANY_HIT ? max_t[i] : 0.0f, stack);
     out_t[i] = h.t;
     out_tri[i] = (h.tri == HIT_MISS) ? 0u : (h.tri & 0x7fffffffu);
     out_flags[i] = (h.tri == HIT_MISS) ? 0u : (1u | ((h.tri >> 31) << 1));

@@ -231,17 +231,29 @@ int alloc_state(rpt_ctx *c) {
     return RPT_OK;
 }
 
+constexpr int LDS_THREADS = 512;     /* workgroup size of the LDS-resident-scene traversal variants */
+
 template <int STACK, int NEE, bool TEXTURED>
 void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
     hipStream_t s = c->stream;
     auto mark = [&]() {
         if (ev) (void)hipEventRecord((*ev)[ev_at++], s);
     };
-    k_traverse_nearest<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, iteration);
+    const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
+    const size_t lds_bytes = (size_t)c->scene.n_nodes * 32 + (size_t)c->scene.n_triangles * 48;
+    if (STACK == 16 && c->scene.lds_scene)
+        k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
+    else
+        k_traverse_nearest<STACK, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, iteration);
     mark();
     k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
-    if (NEE != RPT_NEE_NONE) k_traverse_shadow<STACK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+    if (NEE != RPT_NEE_NONE) {
+        if (STACK == 16 && c->scene.lds_scene)
+            k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+        else
+            k_traverse_shadow<STACK, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+    }
     mark();
     k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
     mark();
@@ -415,6 +427,10 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     s.indices = c->indices.p; s.per_vertex = c->per_vertex.p;
     s.materials = c->materials.p; s.light_pick = c->light_pick.p;
     s.n_light_pick = (uint32_t)nlp;
+    s.n_nodes = (uint32_t)nn;
+    s.n_triangles = (uint32_t)nt;
+    s.lds_scene = (nn * 32 + nt * 48 <= RPT_LDS_SCENE_BYTES && depth <= 15) ? 1u : 0u;
+    if (const char *env = getenv("RPT_NO_LDS_SCENE"); env && env[0] == '1') s.lds_scene = 0u;
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
     s.fastdiv_ok = 1u;
     for (size_t i = 0; i < nn && s.fastdiv_ok; ++i)
@@ -770,10 +786,18 @@ int rpt_debug_trace_rays(rpt_ctx *c, int any_hit, size_t n, const float *origins
         unsigned blocks = (unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK);
         hipStream_t s = c->stream;
 #define LAUNCH_DBG(ST)                                                                                                      \
-    if (any_hit) k_trace_debug<ST, true><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p); \
-    else k_trace_debug<ST, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p)
+    if (any_hit) k_trace_debug<ST, true, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p); \
+    else k_trace_debug<ST, false, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p)
         switch (c->stack_cap) {
-            case 16: LAUNCH_DBG(16); break;
+            case 16:
+                if (c->scene.lds_scene) {
+                    unsigned bl = (unsigned)((n + LDS_THREADS - 1) / LDS_THREADS);
+                    if (any_hit) k_trace_debug<16, true, true, LDS_THREADS><<<bl, LDS_THREADS, (size_t)c->scene.n_nodes * 32 + (size_t)c->scene.n_triangles * 48, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
+                    else k_trace_debug<16, false, true, LDS_THREADS><<<bl, LDS_THREADS, (size_t)c->scene.n_nodes * 32 + (size_t)c->scene.n_triangles * 48, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
+                } else {
+                    LAUNCH_DBG(16);
+                }
+                break;
             case 24: LAUNCH_DBG(24); break;
             default: LAUNCH_DBG(32); break;
         }
