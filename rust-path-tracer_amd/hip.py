@@ -24,7 +24,8 @@ EXPORTS = [
 
 
 def lib_path():
-    return os.path.join(_ffi.LIB_DIR, "librpt_hip.so")
+    # RPT_HIP_LIB: developer override used for A/B runs of differently tuned builds
+    return os.environ.get("RPT_HIP_LIB") or os.path.join(_ffi.LIB_DIR, "librpt_hip.so")
 
 
 def lib():
