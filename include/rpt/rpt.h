@@ -76,6 +76,14 @@ int rpt_create(int device_id, rpt_ctx **out);
 #define RPT_TILE 64
 int rpt_set_partition(rpt_ctx *ctx, uint32_t rank, uint32_t world_size);
 
+/* Tuning knob without reference equivalent: how many samples of one pixel are kept
+ * in flight (rounded up to a power of two, <= 32).  0 = automatic (enough to give
+ * the GPU ~0.75 M concurrent paths when this rank owns few pixels).  The result
+ * does not depend on it: finished samples are added to a pixel's accumulator in
+ * sample order whatever the value.  Invalidates the accumulator like a resize:
+ * call before rpt_set_config or re-run rpt_reset afterwards. */
+int rpt_set_samples_in_flight(rpt_ctx *ctx, int samples);
+
 /* Replaces World::into_gpu (src/asset.rs:226-235), BVH::into_gpu
  * (src/bvh.rs:40-43) and the skybox upload (src/trace.rs:144).  Buffers are in
  * the order the reference binds them (kernels/src/lib.rs:195-202).  atlas and

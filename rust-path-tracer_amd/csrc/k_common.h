@@ -7,6 +7,13 @@
  * kernels/src/lib.rs:225 / src/trace.rs:295).  All per-slot state is SoA in
  * 16-byte records so a wave reads 1 KiB per load instruction.
  *
+ * Several samples of one pixel may be in flight at once (S = 2^group_shift slots
+ * per pixel, adjacent lanes of one wave) so that a GPU owning only a few tiles
+ * still fills its 256 CUs.  Slot k takes samples k, k+S, k+2S, ...; the S samples
+ * of a "generation" are summed into the accumulator in k order by one lane once
+ * all of them have finished, which reproduces the reference's sample-order f32 sum
+ * bit for bit whatever S is (k_path.h: complete_generations).
+ *
  * Extension rays need no queue: a finished path is regenerated in place, so
  * (except in the last few iterations of a render call) every slot always has
  * a ray in flight and thread i simply owns slot i — perfectly coalesced, no
@@ -90,10 +97,13 @@ struct DevState {
     float4 *mis1;         /* (pick_pdf, em.r, em.g, em.b)                                */
     float4 *mis2;         /* (light_tri bits, thr_pre.r, thr_pre.g, thr_pre.b)           */
     float4 *mis3;         /* (bsdf_pdf, spec.r, spec.g, spec.b)                          */
-    uint2 *rng;           /* (n, offset) per pixel, reference rng buffer */
-    float4 *accum;        /* (sum r, sum g, sum b, sum 1), tile-major == slot order */
+    /* per PIXEL (pixel = slot >> group_shift): */
+    uint2 *rng;           /* (n, offset), the reference's rng buffer */
+    float4 *accum;        /* (sum r, sum g, sum b, sum 1), tile-major == pixel order */
     const uint32_t *pixel_xy;   /* x | y << 16 */
     uint32_t n_slots;
+    uint32_t n_pixels;
+    uint32_t group_shift; /* log2 S, S = samples of one pixel in flight (slots per pixel) */
 };
 
 /* flags word: bits 0-7 bounce, bit 8 last sampled lobe (1 = specular), bits 16-21 LDS dimension */
@@ -103,7 +113,9 @@ struct DevState {
 #define MAKE_FLAGS(bounce, spec, dim) (((bounce) & 0xffu) | ((uint32_t)(spec) << 8) | ((uint32_t)(dim) << 16))
 #define HIT_MISS 0xffffffffu      /* traversed, nothing hit                          -> shade sends it to the sky queue */
 #define HIT_PENDING 0xfffffffeu   /* a ray is waiting for the traversal stage                                          */
-#define HIT_PARKED 0xfffffffdu    /* nothing to do: waiting in the sky / shadow queue, or the slot is out of samples   */
+#define HIT_PARKED 0xfffffffdu    /* waiting in the sky / shadow queue                                                 */
+#define HIT_DONE 0xfffffffcu      /* sample finished, radiance final in thr_rad.w / rad_misc.xy; waits for its siblings */
+#define HIT_IDLE 0xfffffffbu      /* the slot has no sample left to take in this render call                           */
 
 /* ---- queues ---------------------------------------------------------------- */
 enum { Q_SHADOW = 0, Q_SKY = 1, Q_ALIVE0 = 2, Q_ALIVE1 = 3, Q_COUNT = 8 };

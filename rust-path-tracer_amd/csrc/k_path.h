@@ -29,36 +29,89 @@ __device__ __forceinline__ void camera_ray(const DevConfig &cfg, uint32_t px, ui
     rd = mat3_mul(cfg.euler, norm3(f3(ux, uy, 1.0f)));
 }
 
-/* write a fresh path into slot: throughput 1, radiance 0, bounce 0, LDS dimension 2 (jitter consumed) */
-__device__ __forceinline__ void start_path(const DevState &st, const DevConfig &cfg, uint32_t slot, uint2 rs, uint32_t todo_after) {
-    uint32_t pxy = st.pixel_xy[slot];
+/* write a fresh path into slot: throughput 1, radiance 0, bounce 0, LDS dimension 2 (jitter consumed).
+ * `n` is the sample's own sequence number (pixel's rng.n + k), `offset` the pixel's LDS offset. */
+__device__ __forceinline__ void start_path(const DevState &st, const DevConfig &cfg, uint32_t slot, uint32_t n, uint32_t offset,
+                                           uint32_t todo_after) {
+    uint32_t pxy = st.pixel_xy[slot >> st.group_shift];
     F3 ro, rd;
-    camera_ray(cfg, pxy & 0xffffu, pxy >> 16, rs.x + rs.y, ro, rd);
+    camera_ray(cfg, pxy & 0xffffu, pxy >> 16, n + offset, ro, rd);
     st.ray_a[slot] = make_float4(ro.x, ro.y, ro.z, rd.x);
     st.ray_b[slot] = make_float4(rd.y, rd.z, 0.0f, __uint_as_float(HIT_PENDING));
     st.thr_rad[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     st.rad_misc[slot] = make_float4(0.0f, 0.0f, __uint_as_float(MAKE_FLAGS(0u, 0u, 2u)), __uint_as_float(todo_after));
 }
 
-/* A path of `slot` ended with `radiance`: accumulate it (sample order per pixel is
- * preserved because a slot carries one sample at a time), advance the pixel's rng
- * state, and start the pixel's next sample if this render call still owes one.
- * Returns true when a new path was written (its ray record is then marked
- * HIT_PENDING for the next traversal pass); otherwise the slot stays parked. */
-__device__ __forceinline__ bool finish_and_regenerate(const DevState &st, const DevConfig &cfg, uint32_t slot, F3 radiance,
-                                                      uint32_t todo) {
-    float4 acc = st.accum[slot];
-    acc.x += radiance.x; acc.y += radiance.y; acc.z += radiance.z; acc.w += 1.0f;
-    st.accum[slot] = acc;
-    uint2 rs = st.rng[slot];
-    rs.x += 1u;
-    st.rng[slot] = rs;
-    if (todo == 0u) {
-        reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
-        return false;
+/* A path ended in a side stage (sky / shadow).  With one slot per pixel the sample is accumulated and the
+ * next one started on the spot; with several, the finished radiance is parked (HIT_DONE) and the shade
+ * stage of the next iteration — where the pixel's slots sit in adjacent lanes — completes the generation. */
+__device__ __forceinline__ void finish_in_side_stage(const DevState &st, const DevConfig &cfg, uint32_t slot, F3 radiance,
+                                                     float4 tr, float4 rm) {
+    if (st.group_shift == 0u) {
+        float4 acc = st.accum[slot];
+        acc.x += radiance.x; acc.y += radiance.y; acc.z += radiance.z; acc.w += 1.0f;
+        st.accum[slot] = acc;
+        uint2 rs = st.rng[slot];
+        rs.x += 1u;
+        st.rng[slot] = rs;
+        uint32_t todo = __float_as_uint(rm.w);
+        if (todo == 0u) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+        else start_path(st, cfg, slot, rs.x, rs.y, todo - 1u);
+    } else {
+        st.thr_rad[slot] = make_float4(tr.x, tr.y, tr.z, radiance.x);
+        st.rad_misc[slot] = make_float4(radiance.y, radiance.z, rm.z, rm.w);
+        reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_DONE));
     }
-    start_path(st, cfg, slot, rs, todo - 1u);
-    return true;
+}
+
+/* End of the shade stage, every lane of the wave (converged): lanes whose sample is finished (`done`,
+ * radiance in registers) or whose slot has nothing left (`idle`) vote; when all S slots of a pixel are
+ * done/idle the group's first lane adds the finished radiances to the accumulator IN SLOT ORDER (= sample
+ * order, kernels/src/lib.rs:225, src/trace.rs:295), advances the pixel's rng.n by the number of samples
+ * (lib.rs:226), and every done lane starts its next sample (lib.rs:36-60).  Lanes finished earlier than
+ * their siblings write their radiance back and wait as HIT_DONE.  `fresh` = the sample finished in this
+ * kernel (its state is not in memory yet). */
+__device__ __forceinline__ void complete_generations(const DevState &st, const DevConfig &cfg, uint32_t slot, bool done, bool idle,
+                                                     bool fresh, F3 radiance, float4 tr, float4 rm) {
+    const uint32_t shift = st.group_shift, S = 1u << shift;
+    const uint32_t lane = __lane_id();
+    const uint32_t g0 = lane & ~(S - 1u);
+    const unsigned long long done_m = __ballot(done), idle_m = __ballot(idle);
+    if (done_m == 0ull) return;
+    const unsigned long long gm = (S >= 64u ? ~0ull : ((1ull << S) - 1ull)) << g0;
+    const bool complete = (((done_m | idle_m) & gm) == gm) && ((done_m & gm) != 0ull);
+    const bool leader = complete && lane == g0;
+    const uint32_t pix = slot >> shift;
+    float4 acc = make_float4(0, 0, 0, 0);
+    uint2 rs = make_uint2(0u, 0u);
+    if (leader) {
+        acc = st.accum[pix];
+        rs = st.rng[pix];
+    }
+    for (uint32_t k = 0; k < S; ++k) {                 /* wave-uniform trip count */
+        int src = (int)(g0 + k);
+        float rx = __shfl(radiance.x, src, RPT_WAVE), ry = __shfl(radiance.y, src, RPT_WAVE), rz = __shfl(radiance.z, src, RPT_WAVE);
+        if (leader && ((done_m >> (g0 + k)) & 1ull)) {
+            acc.x += rx; acc.y += ry; acc.z += rz; acc.w += 1.0f;
+        }
+    }
+    if (leader) {
+        st.accum[pix] = acc;
+        rs.x += (uint32_t)__popcll(done_m & gm);
+        st.rng[pix] = rs;
+    }
+    const uint32_t new_n = (uint32_t)__shfl((int)rs.x, (int)g0, RPT_WAVE);
+    const uint32_t offset = (uint32_t)__shfl((int)rs.y, (int)g0, RPT_WAVE);
+    if (!done) return;
+    if (complete) {
+        uint32_t todo = __float_as_uint(rm.w);
+        if (todo == 0u) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+        else start_path(st, cfg, slot, new_n + (lane - g0), offset, todo - 1u);
+    } else if (fresh) {
+        st.thr_rad[slot] = make_float4(tr.x, tr.y, tr.z, radiance.x);
+        st.rad_misc[slot] = make_float4(radiance.y, radiance.z, rm.z, rm.w);
+        reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_DONE));
+    }
 }
 
 #endif /* RPT_K_PATH_H */

@@ -170,7 +170,18 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     float4 rb = make_float4(0, 0, 0, __uint_as_float(HIT_PARKED));
     if (slot < st.n_slots) rb = st.ray_b[slot];
     const uint32_t hit_tri = __float_as_uint(rb.w);
-    const bool active = hit_tri != HIT_PENDING && hit_tri != HIT_PARKED;     /* traversed in this iteration */
+    const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;            /* traversed in this iteration */
+    /* generation bookkeeping (k_path.h: complete_generations) */
+    bool g_done = false, g_fresh = false;
+    const bool g_idle = hit_tri == HIT_IDLE;
+    F3 g_radiance = f3s(0.0f);
+    float4 g_tr = make_float4(0, 0, 0, 0), g_rm = g_tr;
+    if (hit_tri == HIT_DONE) {                       /* finished earlier (sky / shadow stage, or before its siblings) */
+        g_tr = st.thr_rad[slot];
+        g_rm = st.rad_misc[slot];
+        g_radiance = f3(g_tr.w, g_rm.x, g_rm.y);
+        g_done = true;
+    }
 
     if (active) {
         const float4 ra = st.ray_a[slot];
@@ -288,8 +299,8 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                 bsdf.clamp_hi = cfg.c.specular_weight_clamp[1];
 
                 /* ---- PBR::sample (bsdf.rs:272-334) ---- */
-                const uint2 rs = st.rng[slot];
-                Rng rng{rs.x + rs.y, FLAG_DIM(flags)};
+                const uint2 rs = st.rng[slot >> st.group_shift];
+                Rng rng{rs.x + (slot & ((1u << st.group_shift) - 1u)) + rs.y, FLAG_DIM(flags)};
                 const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
                 const F3 view = -rd;
                 const float w_spec = bsdf.specular_weight(view, normal);
@@ -431,8 +442,11 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             }
 
             if (done && !emit_shadow) {
-                /* the path ends here with nothing pending: accumulate + regenerate in place */
-                finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
+                /* the path ends here with nothing pending: its generation may complete below */
+                g_done = g_fresh = true;
+                g_radiance = radiance;
+                g_tr = make_float4(throughput.x, throughput.y, throughput.z, radiance.x);
+                g_rm = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
             } else {
                 st.thr_rad[slot] = make_float4(throughput.x, throughput.y, throughput.z, radiance.x);
                 st.rad_misc[slot] = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
@@ -448,6 +462,9 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             }
         }
     }
+
+    /* ---- accumulate finished generations in sample order and start the next samples ---- */
+    complete_generations(st, cfg, slot, g_done, g_idle, g_fresh, g_radiance, g_tr, g_rm);
 
     /* ---- side-queue emission: wave64 ballot + mbcnt prefix, one atomic per workgroup ---- */
     /* (block-uniform early outs keep the barriers inside block_push legal) */

@@ -90,27 +90,32 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
             radiance = radiance + throughput * f3(s.x, s.y, s.z) * intensity;
         }
         /* a miss always ends the path (lib.rs:79) */
-        finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
+        finish_in_side_stage(st, cfg, slot, radiance, tr, rm);
     }
 }
 
-/* Start of an rpt_render call: every slot begins the first of its n_samples samples. */
+/* Start of an rpt_render call: slot k of every pixel begins sample k; it will take samples k, k+S, ... of
+ * the n_samples this call owes the pixel. */
 __global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQueues q, DevConfig cfg, uint32_t n_samples) {
-    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    if (i < st.n_slots) {
-        uint2 rs = st.rng[i];
-        if (cfg.c.max_bounces == 0u) {
-            /* the bounce loop never runs (lib.rs:62): every sample adds (0,0,0,1) */
-            float4 acc = st.accum[i];
+    uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (slot >= st.n_slots) return;
+    const uint32_t S = 1u << st.group_shift, k = slot & (S - 1u), pix = slot >> st.group_shift;
+    uint2 rs = st.rng[pix];
+    if (cfg.c.max_bounces == 0u) {
+        /* the bounce loop never runs (lib.rs:62): every sample adds (0,0,0,1) */
+        if (k == 0u) {
+            float4 acc = st.accum[pix];
             for (uint32_t s = 0; s < n_samples; ++s) acc.w += 1.0f;
-            st.accum[i] = acc;
+            st.accum[pix] = acc;
             rs.x += n_samples;
-            st.rng[i] = rs;
-            reinterpret_cast<float2 *>(&st.ray_b[i])[1] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
-        } else {
-            start_path(st, cfg, i, rs, n_samples - 1u);
+            st.rng[pix] = rs;
         }
+        reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+        return;
     }
+    uint32_t count = n_samples > k ? (n_samples - k + S - 1u) / S : 0u;
+    if (count == 0u) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+    else start_path(st, cfg, slot, rs.x + k, rs.y, count - 1u);
 }
 
 /* root-side un-tiling of gathered per-rank blocks into a row-major image */

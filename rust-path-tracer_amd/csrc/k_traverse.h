@@ -246,7 +246,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
             radiance = radiance + mask_nan3(f3(c.x, c.y, c.z));
         }
         if (finish) {
-            finish_and_regenerate(st, cfg, slot, radiance, __float_as_uint(rm.w));
+            finish_in_side_stage(st, cfg, slot, radiance, tr, rm);
         } else {
             tr.w = radiance.x; rm.x = radiance.y; rm.y = radiance.z;
             st.thr_rad[slot] = tr;

@@ -78,7 +78,10 @@ struct rpt_ctx {
     /* config + partition */
     bool has_config = false;
     DevConfig cfg{};
-    uint32_t n_slots = 0;
+    uint32_t n_slots = 0;       /* n_pixels << group_shift */
+    uint32_t n_pixels = 0;      /* pixels of this rank's tiles */
+    uint32_t group_shift = 0;   /* log2 of the samples of one pixel kept in flight */
+    int samples_in_flight_request = 0;   /* 0 = automatic */
     std::vector<uint32_t> pixel_xy_host;
     DevBuf<uint32_t> pixel_xy;
 
@@ -131,7 +134,7 @@ int validate_scene(rpt_ctx *ctx, const rpt_per_vertex_data *pv, size_t nv, const
                    const rpt_light_pick_entry *lp, size_t nlp, uint32_t &max_depth) {
     (void)pv; (void)mats;
     if (!nv || !nt || !nn || !nm || !nlp) { ctx->error = "empty scene buffer"; return RPT_ESCENE; }
-    if (nt >= 0x7fffffffull || nn >= 0x7fffffffull) { ctx->error = "scene too large for 31-bit indices"; return RPT_ESCENE; }
+    if (nt >= 0x7ffffff0ull || nn >= 0x7ffffff0ull) { ctx->error = "scene too large for 31-bit indices"; return RPT_ESCENE; }
     for (size_t i = 0; i < nt; ++i)
         if (idx[i].v0 >= nv || idx[i].v1 >= nv || idx[i].v2 >= nv || idx[i].material >= nm) {
             ctx->error = "index buffer entry out of range";
@@ -206,23 +209,24 @@ void release_state(rpt_ctx *c) {
 }
 
 int alloc_state(rpt_ctx *c) {
-    size_t n = c->n_slots;
+    size_t n = c->n_slots, np = c->n_pixels;
     HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n));
     HIP_TRY(c, c->thr_rad.alloc(n)); HIP_TRY(c, c->rad_misc.alloc(n));
     HIP_TRY(c, c->mis0.alloc(n)); HIP_TRY(c, c->mis1.alloc(n)); HIP_TRY(c, c->mis2.alloc(n)); HIP_TRY(c, c->mis3.alloc(n));
-    HIP_TRY(c, c->accum.alloc(n)); HIP_TRY(c, c->rng.alloc(n));
+    HIP_TRY(c, c->accum.alloc(np)); HIP_TRY(c, c->rng.alloc(np));
     HIP_TRY(c, c->q_sky.alloc(n));
     HIP_TRY(c, c->ray_shards.alloc(RPT_STAT_SHARDS * RPT_STAT_STRIDE));
     HIP_TRY(c, hipMemset(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(c, c->q_count.alloc(Q_COUNT));
     HIP_TRY(c, c->sh_o.alloc(n)); HIP_TRY(c, c->sh_d.alloc(n)); HIP_TRY(c, c->sh_c.alloc(n));
-    HIP_TRY(c, c->pixel_xy.alloc(n));
-    if (n) HIP_TRY(c, hipMemcpy(c->pixel_xy.p, c->pixel_xy_host.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, c->pixel_xy.alloc(np));
+    if (np) HIP_TRY(c, hipMemcpy(c->pixel_xy.p, c->pixel_xy_host.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemset(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t)));
     DevState &s = c->state;
     s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.thr_rad = c->thr_rad.p; s.rad_misc = c->rad_misc.p;
     s.mis0 = c->mis0.p; s.mis1 = c->mis1.p; s.mis2 = c->mis2.p; s.mis3 = c->mis3.p;
     s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = (uint32_t)n;
+    s.n_pixels = (uint32_t)np; s.group_shift = c->group_shift;
     DevQueues &q = c->queues;
     q.sky = c->q_sky.p; q.ray_shards = c->ray_shards.p;
     q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p; q.count = c->q_count.p;
@@ -476,13 +480,23 @@ int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         release_state(c);
         build_pixel_order(cfg->width, cfg->height, c->rank, c->world, c->pixel_xy_host);
-        c->n_slots = (uint32_t)c->pixel_xy_host.size();
+        c->n_pixels = (uint32_t)c->pixel_xy_host.size();
+        /* samples of one pixel in flight: enough slots to fill 256 CUs even when this rank owns few tiles */
+        uint32_t S = 1;
+        if (c->samples_in_flight_request > 0) {
+            while (S < (uint32_t)c->samples_in_flight_request && S < 32u) S <<= 1;
+        } else {
+            while (S < 16u && (uint64_t)c->n_pixels * S < 786432ull) S <<= 1;
+        }
+        c->group_shift = 0;
+        while ((1u << c->group_shift) < S) c->group_shift += 1;
+        c->n_slots = c->n_pixels << c->group_shift;
         int rc = alloc_state(c);
         if (rc) return rc;
         /* fresh accumulators; seeds must come from rpt_reset */
-        if (c->n_slots) {
-            HIP_TRY(c, hipMemset(c->accum.p, 0, c->n_slots * sizeof(float4)));
-            HIP_TRY(c, hipMemset(c->rng.p, 0, c->n_slots * sizeof(uint2)));
+        if (c->n_pixels) {
+            HIP_TRY(c, hipMemset(c->accum.p, 0, c->n_pixels * sizeof(float4)));
+            HIP_TRY(c, hipMemset(c->rng.p, 0, c->n_pixels * sizeof(uint2)));
         }
         c->samples = 0;
     }
@@ -497,7 +511,7 @@ int rpt_reset(rpt_ctx *c, const rpt_rng_state *seed, const float *accum_init, ui
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t W = c->cfg.c.width;
-    size_t n = c->n_slots;
+    size_t n = c->n_pixels;
     std::vector<uint2> rng(n);
     std::vector<float4> acc(n, make_float4(0, 0, 0, 0));
     for (size_t s = 0; s < n; ++s) {
@@ -521,6 +535,7 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     if (!c) return RPT_EINVAL;
     if (!c->has_scene || !c->has_config || !c->has_state) { c->error = "scene, config and reset must precede rpt_render"; return RPT_EINVAL; }
     if (n_samples == 0 || c->n_slots == 0) { c->samples += n_samples; return RPT_OK; }
+    if ((uint64_t)n_samples + (1u << c->group_shift) >= 0x100000000ull) { c->error = "n_samples too large"; return RPT_EINVAL; }
     HIP_TRY(c, hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
@@ -541,7 +556,7 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     uint64_t it = 0;
     bool drained = c->cfg.c.max_bounces == 0u;
     /* worst case: every sample needs max_bounces iterations, one after another */
-    const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces ? c->cfg.c.max_bounces : 1u) + LAG + 2;
+    const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces + 2u) + LAG + 2;
     while (!drained) {
         if (ev && ev->size() < ev_at + EVENTS_PER_ITER) {
             size_t old = ev->size();
@@ -594,7 +609,7 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
         }
     }
     c->samples += n_samples;
-    c->stats.samples += (uint64_t)c->n_slots * n_samples;
+    c->stats.samples += (uint64_t)c->n_pixels * n_samples;
     c->stats.render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RPT_OK;
 }
@@ -605,10 +620,10 @@ int rpt_read_accum(rpt_ctx *c, float *out, uint32_t *out_samples) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t W = c->cfg.c.width, H = c->cfg.c.height;
-    std::vector<float4> acc(c->n_slots);
-    if (c->n_slots) HIP_TRY(c, hipMemcpy(acc.data(), c->accum.p, c->n_slots * sizeof(float4), hipMemcpyDeviceToHost));
+    std::vector<float4> acc(c->n_pixels);
+    if (c->n_pixels) HIP_TRY(c, hipMemcpy(acc.data(), c->accum.p, c->n_pixels * sizeof(float4), hipMemcpyDeviceToHost));
     memset(out, 0, (size_t)W * H * 4 * sizeof(float));
-    for (size_t s = 0; s < c->n_slots; ++s) {
+    for (size_t s = 0; s < c->n_pixels; ++s) {
         uint32_t pxy = c->pixel_xy_host[s];
         size_t i = (size_t)(pxy >> 16) * W + (pxy & 0xffffu);
         out[4 * i] = acc[s].x; out[4 * i + 1] = acc[s].y; out[4 * i + 2] = acc[s].z; out[4 * i + 3] = acc[s].w;
@@ -623,10 +638,10 @@ int rpt_read_rng(rpt_ctx *c, rpt_rng_state *out) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t W = c->cfg.c.width, H = c->cfg.c.height;
-    std::vector<uint2> rng(c->n_slots);
-    if (c->n_slots) HIP_TRY(c, hipMemcpy(rng.data(), c->rng.p, c->n_slots * sizeof(uint2), hipMemcpyDeviceToHost));
+    std::vector<uint2> rng(c->n_pixels);
+    if (c->n_pixels) HIP_TRY(c, hipMemcpy(rng.data(), c->rng.p, c->n_pixels * sizeof(uint2), hipMemcpyDeviceToHost));
     memset(out, 0, (size_t)W * H * sizeof(rpt_rng_state));
-    for (size_t s = 0; s < c->n_slots; ++s) {
+    for (size_t s = 0; s < c->n_pixels; ++s) {
         uint32_t pxy = c->pixel_xy_host[s];
         out[(size_t)(pxy >> 16) * W + (pxy & 0xffffu)] = rpt_rng_state{rng[s].x, rng[s].y};
     }
@@ -636,7 +651,19 @@ int rpt_read_rng(rpt_ctx *c, rpt_rng_state *out) {
 int rpt_local_pixels(rpt_ctx *c, uint64_t *n) {
     if (!c || !n) return RPT_EINVAL;
     if (!c->has_config) { c->error = "no config"; return RPT_EINVAL; }
-    *n = c->n_slots;
+    *n = c->n_pixels;
+    return RPT_OK;
+}
+
+int rpt_set_samples_in_flight(rpt_ctx *c, int s) {
+    if (!c) return RPT_EINVAL;
+    if (s < 0 || s > 32) { c->error = "samples in flight must be 0 (automatic) or 1..32"; return RPT_EINVAL; }
+    c->samples_in_flight_request = s;
+    if (c->has_config) {   /* re-derive the slot count */
+        rpt_tracing_config cfg = c->cfg.c;
+        c->has_config = false;
+        return rpt_set_config(c, &cfg);
+    }
     return RPT_OK;
 }
 

@@ -16,7 +16,7 @@ from ._ffi import RNG_DTYPE, Stats, TracingConfig, ptr
 _lib = None
 
 EXPORTS = [
-    "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
+    "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_set_samples_in_flight", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
     "rpt_render", "rpt_read_accum", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
     "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
     "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_trace_rays",
@@ -41,6 +41,7 @@ def lib():
         L.rpt_destroy.argtypes = [C.c_void_p]
         L.rpt_destroy.restype = None
         L.rpt_set_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rpt_set_samples_in_flight.argtypes = [C.c_void_p, C.c_int]
         L.rpt_upload_scene.argtypes = [C.c_void_p] + [C.c_void_p, C.c_size_t] * 5 + [C.c_void_p, C.c_uint32, C.c_uint32] * 2
         L.rpt_set_config.argtypes = [C.c_void_p, C.POINTER(TracingConfig)]
         L.rpt_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -94,6 +95,10 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+    def set_samples_in_flight(self, samples):
+        """0 = automatic. Never changes the result (tests/test_gpu_parity.py::test_samples_in_flight_invisible)."""
+        self._check(lib().rpt_set_samples_in_flight(self._h, samples))
 
     # -- rpt_upload_scene <-> World::into_gpu (reference: src/asset.rs:226-235)
     def upload_scene(self, world, skybox_f32=None):

@@ -190,6 +190,30 @@ def test_full_size_baseline_config_properties(hipmod, oracle, rpt, world):
     r.close()
 
 
+@pytest.mark.parametrize("scene,nee,spp", [("DarkCornell", 0, 7), ("VeachMIS", 1, 5), ("PBRTest", 2, 3)])
+def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp):
+    """Any number of samples of a pixel in flight gives the sequential sample-order sum, bit for bit
+    (k_path.h: complete_generations) — including sample counts that are not a multiple of it."""
+    w = world(scene)
+    W, H = 96, 80
+    cfg = rpt.default_config(W, H, nee=nee)
+    seeds = rpt.blue_noise_seeds(W, H)
+    ref, rng_ref, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    for s_in_flight in (1, 2, 4, 16, 32, 0):
+        r = hipmod.Renderer(0)
+        r.set_samples_in_flight(s_in_flight)
+        r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+        r.render(spp - 2)
+        r.render(2)
+        acc, n = r.read_accum()
+        assert n == spp
+        assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"samples in flight = {s_in_flight}"
+        g = r.stats()
+        assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays
+        assert np.array_equal(r.read_rng()["n"], rng_ref["n"])
+        r.close()
+
+
 def test_render_in_batches_equals_one_batch(renderer, rpt, world):
     w = world("DarkCornell")
     cfg = rpt.default_config(96, 96, nee=1)
