@@ -96,6 +96,7 @@ def main():
     r.reset(seeds)
     local_block = tiles.device_block_as_tensor(r, device)
     image = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
+    gatherer = tiles.Gatherer(W, H, device) if world_size > 1 else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -106,10 +107,11 @@ def main():
     def step():
         r.render(args.spp_per_step)
         if world_size > 1:
-            blocks = tiles.gather_blocks(local_block, W, H)          # the single collective per sample batch
+            torch.cuda.current_stream().synchronize()
+            recv = gatherer.gather(local_block)                      # the single collective per sample batch
             if rank == 0:
-                cat = torch.cat(blocks, 0).contiguous()
-                r.untile(cat.data_ptr(), image.data_ptr())
+                torch.cuda.current_stream().synchronize()
+                r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)
 
     for _ in range(args.warmup):
         step()

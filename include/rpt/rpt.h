@@ -148,10 +148,11 @@ int rpt_local_pixels(rpt_ctx *ctx, uint64_t *n_pixels);
 int rpt_local_block_device_ptr(rpt_ctx *ctx, void **dev_ptr);
 /* Pixel count of any rank's block for the current config (for gather sizes). */
 int rpt_rank_pixels(rpt_ctx *ctx, uint32_t rank, uint64_t *n_pixels);
-/* Root side: scatter `world_size` concatenated tile-major blocks (device
- * memory, sizes rpt_rank_pixels(r)) into a row-major width*height float4 image
- * in device memory. dev_out_image may be read back with hipMemcpy. */
-int rpt_untile(rpt_ctx *ctx, const void *dev_gathered_blocks, void *dev_out_image);
+/* Root side: scatter the `world_size` gathered tile-major blocks (device memory)
+ * into a row-major width*height float4 image in device memory.  Block r starts at
+ * element r * block_stride_pixels (a gather into equal-sized padded slots), or the
+ * blocks are tightly concatenated when block_stride_pixels == 0. */
+int rpt_untile(rpt_ctx *ctx, const void *dev_gathered_blocks, uint64_t block_stride_pixels, void *dev_out_image);
 
 int rpt_get_stats(rpt_ctx *ctx, rpt_stats *out);
 void rpt_destroy(rpt_ctx *ctx);

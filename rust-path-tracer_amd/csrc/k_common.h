@@ -118,7 +118,13 @@ struct DevState {
 #define HIT_IDLE 0xfffffffbu      /* the slot has no sample left to take in this render call                           */
 
 /* ---- queues ---------------------------------------------------------------- */
-enum { Q_SHADOW = 0, Q_SKY = 1, Q_ALIVE0 = 2, Q_ALIVE1 = 3, Q_COUNT = 8 };
+/* counter words: sizes of the two side queues; per iteration parity, "the traversal pass traced a ray" and
+ * "the shade pass started a new sample" (together with a non-empty sky queue: work remains) */
+/* each word sits in its own 128-byte line: queue counters take atomics while flags are polled and raised
+ * by every wave, and sharing a line made the two serialise against each other in L2 */
+#define Q_LINE 32
+enum { Q_SHADOW = 0 * Q_LINE, Q_SKY = 1 * Q_LINE, Q_ALIVE0 = 2 * Q_LINE, Q_ALIVE1 = 3 * Q_LINE, Q_REGEN0 = 4 * Q_LINE,
+       Q_REGEN1 = 5 * Q_LINE, Q_COUNT = 8 * Q_LINE };
 #define RPT_STAT_SHARDS 64        /* sharded 64-bit counters, one 128-byte line each */
 #define RPT_STAT_STRIDE 16
 
@@ -127,7 +133,8 @@ struct DevQueues {
     float4 *sh_o;      /* shadow ray (ox, oy, oz, max_t), indexed by shadow-queue position */
     float4 *sh_d;      /* (dx, dy, dz, slot bits | bit31 = path ends after this NEE) */
     float4 *sh_c;      /* (contribution r, g, b if unoccluded, unused) */
-    uint32_t *count;   /* Q_COUNT words: shadow / sky queue sizes, alive flags of even / odd iterations */
+    uint32_t *count;   /* Q_COUNT words, see the enum above */
+    uint32_t sky_threshold;   /* the sky stage runs once this many misses are queued (or nothing else is left) */
     unsigned long long *ray_shards;  /* RPT_STAT_SHARDS x RPT_STAT_STRIDE: extension rays traced */
     unsigned long long *host_ring;   /* mapped pinned host memory: (iteration + 1) << 32 | extension-queue size */
     uint32_t ring_mask;
@@ -158,6 +165,14 @@ __device__ __forceinline__ uint32_t wave_push(uint32_t *counter, bool pred) {
     base = (uint32_t)__shfl((int)base, (int)leader, RPT_WAVE);
     uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     return base + prefix;
+}
+
+/* Raise a kernel-wide boolean.  Thousands of waves storing to ONE address serialise in L2 (measured: a
+ * per-wave plain store of 1 to a single word cost 36..150 us per launch of the shade stage), so look first:
+ * after the first few writers everybody reads 1 from L1/L2 and skips the store.  (L1 is invalidated at
+ * kernel start, so a stale 0 only costs a redundant store, never a lost flag.) */
+__device__ __forceinline__ void raise_flag(uint32_t *flag) {
+    if (*flag == 0u) *flag = 1u;
 }
 
 /* Workgroup-aggregated variant: one atomic per 256 lanes.  Every thread of the

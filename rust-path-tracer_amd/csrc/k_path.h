@@ -71,10 +71,32 @@ __device__ __forceinline__ void finish_in_side_stage(const DevState &st, const D
  * (lib.rs:226), and every done lane starts its next sample (lib.rs:36-60).  Lanes finished earlier than
  * their siblings write their radiance back and wait as HIT_DONE.  `fresh` = the sample finished in this
  * kernel (its state is not in memory yet). */
-__device__ __forceinline__ void complete_generations(const DevState &st, const DevConfig &cfg, uint32_t slot, bool done, bool idle,
-                                                     bool fresh, F3 radiance, float4 tr, float4 rm) {
+__device__ __forceinline__ void complete_generations(const DevState &st, const DevConfig &cfg, uint32_t *regen_flag, uint32_t slot,
+                                                     bool done, bool idle, bool fresh, F3 radiance, float4 tr, float4 rm) {
     const uint32_t shift = st.group_shift, S = 1u << shift;
     const uint32_t lane = __lane_id();
+    if (shift == 0u) {
+        /* one slot per pixel: a finished sample is its own generation — no votes, no shuffles */
+        bool started = false;
+        if (done) {
+            float4 acc = st.accum[slot];
+            acc.x += radiance.x; acc.y += radiance.y; acc.z += radiance.z; acc.w += 1.0f;
+            st.accum[slot] = acc;
+            uint2 rs1 = st.rng[slot];
+            rs1.x += 1u;
+            st.rng[slot] = rs1;
+            uint32_t todo = __float_as_uint(rm.w);
+            if (todo == 0u) {
+                reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+            } else {
+                start_path(st, cfg, slot, rs1.x, rs1.y, todo - 1u);
+                started = true;
+            }
+        }
+        unsigned long long any = __ballot(started);
+        if (any != 0ull && lane == (uint32_t)__ffsll((long long)any) - 1u) raise_flag(regen_flag);
+        return;
+    }
     const uint32_t g0 = lane & ~(S - 1u);
     const unsigned long long done_m = __ballot(done), idle_m = __ballot(idle);
     if (done_m == 0ull) return;
@@ -102,6 +124,10 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
     }
     const uint32_t new_n = (uint32_t)__shfl((int)rs.x, (int)g0, RPT_WAVE);
     const uint32_t offset = (uint32_t)__shfl((int)rs.y, (int)g0, RPT_WAVE);
+    {   /* tell the host that new samples were started (one plain store per wave, every writer stores 1) */
+        unsigned long long started = __ballot(done && complete && __float_as_uint(rm.w) != 0u);
+        if (started != 0ull && lane == (uint32_t)__ffsll((long long)started) - 1u) raise_flag(regen_flag);
+    }
     if (!done) return;
     if (complete) {
         uint32_t todo = __float_as_uint(rm.w);

@@ -156,14 +156,6 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                                                      DevStats *stats) {
     __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
     const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    if (slot == 0u) {
-        /* progress report for the host: did the traversal pass of this iteration find any ray?  Also clear
-         * the flag the NEXT iteration's traversal will raise (it last belonged to iteration - 1). */
-        uint32_t alive = q.count[Q_ALIVE0 + (iteration & 1u)];
-        q.count[Q_ALIVE0 + ((iteration + 1u) & 1u)] = 0u;
-        __hip_atomic_store(&q.host_ring[iteration & q.ring_mask], ((unsigned long long)(iteration + 1u) << 32) | alive,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
     bool to_sky = false;
     bool emit_shadow = false;
     float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
@@ -464,7 +456,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     }
 
     /* ---- accumulate finished generations in sample order and start the next samples ---- */
-    complete_generations(st, cfg, slot, g_done, g_idle, g_fresh, g_radiance, g_tr, g_rm);
+    complete_generations(st, cfg, &q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE], slot, g_done, g_idle, g_fresh, g_radiance, g_tr, g_rm);
 
     /* ---- side-queue emission: wave64 ballot + mbcnt prefix, one atomic per workgroup ---- */
     /* (block-uniform early outs keep the barriers inside block_push legal) */

@@ -69,9 +69,24 @@ __device__ F3 sky_scatter(const float *sun4, F3 origin, F3 direction) {
     return f3(rptm::powr(g.x, 2.2f), rptm::powr(g.y, 2.2f), rptm::powr(g.z, 2.2f));
 }
 
-__global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats) {
+/* The sky stage is LAZY: misses pile up in the queue over several iterations and are shaded once
+ * q.sky_threshold of them are waiting, or when the traversal pass of this iteration found no ray at all
+ * (so nothing else can make progress).  On closed scenes a handful of misses per iteration would otherwise
+ * cost a full, latency-bound 12-step march every iteration (measured: 24 us x 280 launches = 10 % of the
+ * DarkCornell run).  It is also the last kernel of an iteration, so its first thread reports progress to
+ * the host through mapped pinned memory: work remains iff a ray was traced, a sample was started, or
+ * misses are waiting. */
+__global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
+                                                   DevStats *stats) {
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    uint32_t n = q.count[Q_SKY];
+    const uint32_t n = q.count[Q_SKY];
+    const uint32_t alive = q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE];
+    if (i == 0u) {
+        uint32_t busy = alive | q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE] | (n != 0u ? 1u : 0u);
+        __hip_atomic_store(&q.host_ring[iteration & q.ring_mask], ((unsigned long long)(iteration + 1u) << 32) | busy,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (n < q.sky_threshold && alive != 0u) return;          /* not worth a pass yet (same test as k_traverse_nearest) */
     if (i == 0u && n) atomicAdd(&stats->sky_evals, (unsigned long long)n);
     if (i < n) {
         uint32_t slot = q.sky[i];
@@ -124,6 +139,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_untile(const float4 *blocks, cons
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
     if (i >= n_total) return;
     uint32_t pxy = pixel_xy_all[i];
+    if (pxy == 0xffffffffu) return;          /* padding between strided blocks */
     image[(size_t)(pxy >> 16) * width + (pxy & 0xffffu)] = blocks[i];
 }
 

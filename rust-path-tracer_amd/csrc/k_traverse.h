@@ -185,9 +185,15 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     float4 *lds_scene = rpt_lds_dyn;
     const uint32_t slot = blockIdx.x * THREADS + threadIdx.x;
     if (slot == 0u) {
-        /* the side queues were consumed by the previous iteration's sky / shadow kernels (same stream) */
+        /* Per-iteration bookkeeping that needs no kernel of its own.  The shadow queue was consumed by the
+         * previous iteration's shadow kernel (same stream).  The sky stage is lazy (k_sky): it drained its
+         * queue last iteration only if enough misses had piled up or nothing else was left — the same
+         * decision is re-derived here from the same, still unmodified words. */
+        const uint32_t prev = (iteration + 1u) & 1u;
         q.count[Q_SHADOW] = 0u;
-        q.count[Q_SKY] = 0u;
+        if (q.count[Q_SKY] >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q.count[Q_SKY] = 0u;
+        q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
+        q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
     }
     float4 rb = make_float4(0, 0, 0, 0);
     bool pending = false;
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     unsigned long long active = __ballot(pending);
     if (active == 0ull) return;
     if (__lane_id() == (uint32_t)__ffsll((long long)active) - 1u) {
-        q.count[Q_ALIVE0 + (iteration & 1u)] = 1u;
+        raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
         /* ray accounting: sharded, non-returning atomics (nobody waits for them) */
         atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)__popcll(active));
     }

@@ -11,6 +11,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -231,6 +232,11 @@ int alloc_state(rpt_ctx *c) {
     q.sky = c->q_sky.p; q.ray_shards = c->ray_shards.p;
     q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p; q.count = c->q_count.p;
     q.host_ring = c->host_ring_dev; q.ring_mask = RING - 1;
+    /* 1 = shade misses in the iteration that found them.  Letting them pile up (threshold ~ n/64) removes most
+     * of the near-empty sky launches on closed scenes, but the parked pixels finish later and lengthen the tail:
+     * measured DarkCornell 3650 Mrays/s deferred vs 3928 eager — so eager is the default. */
+    q.sky_threshold = 1u;
+    if (const char *env = getenv("RPT_SKY_THRESHOLD")) q.sky_threshold = (uint32_t)std::max(1, atoi(env));
     c->has_state = true;
     return RPT_OK;
 }
@@ -259,7 +265,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             k_traverse_shadow<STACK, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
     }
     mark();
-    k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+    k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
 }
 
@@ -556,7 +562,8 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     uint64_t it = 0;
     bool drained = c->cfg.c.max_bounces == 0u;
     /* worst case: every sample needs max_bounces iterations, one after another */
-    const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces + 2u) + LAG + 2;
+    /* safety net against a stuck pipeline (a bug), far above what deferral of sky work can cost */
+    const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces + 2u) * 16u + 4096u;
     while (!drained) {
         if (ev && ev->size() < ev_at + EVENTS_PER_ITER) {
             size_t old = ev->size();
@@ -570,7 +577,7 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
         }
         it += 1;
         if (it >= (uint64_t)LAG) {
-            /* the shade kernel of iteration j published (j + 1) << 32 | "traversal j found a pending ray" */
+            /* the sky kernel of iteration j published (j + 1) << 32 | "work remains after iteration j" */
             uint64_t j = it - LAG;
             volatile unsigned long long *slot = &c->host_ring[j & (RING - 1)];
             unsigned long long v;
@@ -584,7 +591,7 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
                     return RPT_EHIP;
                 }
             }
-            if ((uint32_t)v == 0u) drained = true;       /* iteration j found no ray at all: everything after it is a no-op */
+            if ((uint32_t)v == 0u) drained = true;       /* no ray traced, no sample started, no miss waiting: all later iterations are no-ops */
         }
         if (it > it_limit) { c->error = "wavefront did not drain (internal error)"; return RPT_EHIP; }
     }
@@ -697,13 +704,18 @@ int rpt_tile_order(uint32_t width, uint32_t height, uint32_t rank, uint32_t worl
     return RPT_OK;
 }
 
-int rpt_untile(rpt_ctx *c, const void *dev_blocks, void *dev_out_image) {
+int rpt_untile(rpt_ctx *c, const void *dev_blocks, uint64_t block_stride_pixels, void *dev_out_image) {
     if (!c || !dev_blocks || !dev_out_image) return RPT_EINVAL;
     if (!c->has_config) { c->error = "no config"; return RPT_EINVAL; }
     HIP_TRY(c, hipSetDevice(c->device));
+    /* map[i] = destination pixel of element i of the gathered buffer (0xffffffff = padding) */
     std::vector<uint32_t> all, order;
     for (uint32_t r = 0; r < c->world; ++r) {
         build_pixel_order(c->cfg.c.width, c->cfg.c.height, r, c->world, order);
+        if (block_stride_pixels) {
+            if (order.size() > block_stride_pixels) { c->error = "block stride smaller than a rank's block"; return RPT_EINVAL; }
+            all.resize((size_t)r * block_stride_pixels, 0xffffffffu);
+        }
         all.insert(all.end(), order.begin(), order.end());
     }
     DevBuf<uint32_t> map;

@@ -51,7 +51,7 @@ def lib():
         L.rpt_local_pixels.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.rpt_local_block_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.rpt_rank_pixels.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
-        L.rpt_untile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rpt_untile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.rpt_tile_order.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_size_t)]
         L.rpt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -170,8 +170,8 @@ class Renderer:
         self._check(lib().rpt_local_block_device_ptr(self._h, C.byref(p)))
         return p.value
 
-    def untile(self, dev_blocks_ptr, dev_out_ptr):
-        self._check(lib().rpt_untile(self._h, C.c_void_p(dev_blocks_ptr), C.c_void_p(dev_out_ptr)))
+    def untile(self, dev_blocks_ptr, dev_out_ptr, block_stride_pixels=0):
+        self._check(lib().rpt_untile(self._h, C.c_void_p(dev_blocks_ptr), block_stride_pixels, C.c_void_p(dev_out_ptr)))
 
     # -- test hooks
     def debug_math(self, op, x, y=None):

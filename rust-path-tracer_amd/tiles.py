@@ -35,6 +35,32 @@ def tile_block_from_image(image, rank, world_size):
     return np.ascontiguousarray(image[(xy >> 16).astype(np.int64), (xy & 0xFFFF).astype(np.int64)], np.float32)
 
 
+class Gatherer:
+    """Pre-allocated form of gather_blocks for the per-batch hot loop: every rank's block lands in its own
+    equal-sized slot of ONE contiguous tensor on rank 0 (slot stride = the largest block), which rpt_untile
+    consumes directly (block_stride_pixels = stride) — no per-step allocation, padding copy or concatenation."""
+
+    def __init__(self, width, height, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.sizes = block_sizes(width, height, self.world)
+        self.stride = max(self.sizes)
+        self.send = torch.zeros((self.stride, 4), dtype=torch.float32, device=device)
+        self.recv = torch.zeros((self.world, self.stride, 4), dtype=torch.float32, device=device) if self.rank == 0 else None
+        self.recv_list = [self.recv[r] for r in range(self.world)] if self.rank == 0 else None
+
+    def gather(self, local_block):
+        """local_block: (n_local, 4) tensor aliasing the renderer's accumulator block. Returns recv on rank 0."""
+        n = self.sizes[self.rank]
+        src = local_block if n == self.stride else None
+        if src is None:
+            self.send[:n].copy_(local_block)
+            src = self.send
+        dist.gather(src, gather_list=self.recv_list, dst=0, group=self.group)
+        return self.recv
+
+
 def gather_blocks(local_block, width, height, group=None):
     """The one collective of the multi-GPU path: gather per-rank blocks to rank 0.
 

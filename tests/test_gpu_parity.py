@@ -291,6 +291,15 @@ def test_device_untile_matches_host(hipmod, rpt, world, tiles):
     torch.cuda.synchronize()
     host = tiles.untile_host([b.cpu().numpy() for b in blocks], W, H, 2)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), host.view(np.uint32))
+    # strided form (equal-sized gather slots, as bench.py uses)
+    stride = max(len(b) for b in blocks) + 5
+    padded = torch.full((2, stride, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+    for r_, b in enumerate(blocks):
+        padded[r_, : len(b)] = b
+    out2 = torch.zeros_like(out)
+    parts[0].untile(padded.data_ptr(), out2.data_ptr(), stride)
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy().view(np.uint32), host.view(np.uint32))
     for p in parts:
         p.close()
 

@@ -35,11 +35,15 @@ def _worker(rank, world_size, port, image_path, out_path):
     H, W = image.shape[:2]
     local = torch.from_numpy(tiles.tile_block_from_image(image, rank, world_size))
     blocks = tiles.gather_blocks(local, W, H)
+    g = tiles.Gatherer(W, H, "cpu")
+    recv = g.gather(local)                       # the pre-allocated form bench.py uses
     if rank == 0:
         out = tiles.untile_host([b.numpy() for b in blocks], W, H, world_size)
+        out2 = tiles.untile_host([recv[r_, : g.sizes[r_]].numpy() for r_ in range(world_size)], W, H, world_size)
+        assert np.array_equal(out.view(np.uint32), out2.view(np.uint32))
         np.save(out_path, out)
     else:
-        assert blocks is None
+        assert blocks is None and recv is None
     dist.barrier()
     dist.destroy_process_group()
 
