@@ -272,6 +272,14 @@ inline float intersect_aabb(V3 bmin, V3 bmax, V3 ro, V3 rd, float prev_min_t) {
     return INFINITY;
 }
 
+/* optional event log for tools/traversal_sim.py: one byte per node visit, 0 = inner node, 1 = leaf */
+thread_local uint8_t *g_event_log = nullptr;
+thread_local uint32_t g_event_cap = 0, g_event_len = 0;
+inline void log_event(uint8_t e) {
+    if (g_event_log && g_event_len < g_event_cap) g_event_log[g_event_len] = e;
+    g_event_len += 1;
+}
+
 template <bool NEAREST_HIT>
 TraceResult intersect_front_to_back(const Scene &sc, V3 ro, V3 rd, float max_t, Counters &cnt) {
     uint32_t stack[32];
@@ -282,6 +290,7 @@ TraceResult intersect_front_to_back(const Scene &sc, V3 ro, V3 rd, float max_t, 
         uint32_t node_index = stack[--len];
         const rpt_bvh_node &node = sc.nodes[node_index];
         cnt.node_pops++;
+        log_event(node.triangle_count > 0 ? 1 : 0);
         if (node.triangle_count > 0) {
             for (uint32_t i = 0; i < node.triangle_count; ++i) {
                 uint32_t triangle_index = node.left_or_first + i;
@@ -705,6 +714,11 @@ inline V3 sky_scatter(const float *sundir4, V3 origin, V3 direction) {
 /* ------------------------------------------------------------------------ */
 struct PixelResult { V4 radiance; uint32_t next_n, next_offset; };
 
+/* optional dump of the extension ray of one chosen bounce (analysis hook) */
+thread_local float *g_ray_dump = nullptr;      /* 6 floats: origin, direction */
+thread_local uint32_t g_ray_dump_bounce = 0;
+thread_local bool g_ray_dump_hit = false;
+
 PixelResult trace_pixel(uint32_t id_x, uint32_t id_y, const rpt_tracing_config &config, rpt_rng_state rng,
                         const Scene &sc, Counters &cnt) {
     uint32_t nee_mode = config.nee <= 2 ? config.nee : 0;   /* NextEventEstimation::from_u32 */
@@ -728,6 +742,11 @@ PixelResult trace_pixel(uint32_t id_x, uint32_t id_y, const rpt_tracing_config &
 
     for (uint32_t bounce = 0; bounce < config.max_bounces; ++bounce) {
         cnt.extension_rays++;
+        if (g_ray_dump && bounce == g_ray_dump_bounce) {
+            g_ray_dump[0] = ray_origin.x; g_ray_dump[1] = ray_origin.y; g_ray_dump[2] = ray_origin.z;
+            g_ray_dump[3] = ray_direction.x; g_ray_dump[4] = ray_direction.y; g_ray_dump[5] = ray_direction.z;
+            g_ray_dump_hit = true;
+        }
         TraceResult trace_result = intersect_front_to_back<true>(sc, ray_origin, ray_direction, 0.0f, cnt);
         V3 hit = ray_origin + ray_direction * trace_result.t;
 
@@ -944,6 +963,41 @@ int oracle_trace_rays(const oracle_scene *scene, int mode, size_t n, const float
         out_flags[i] = (r.hit ? 1u : 0u) | (r.backface ? 2u : 0u);
     }
     return (int)cnt.error_flags;
+}
+
+/* Analysis hook: per-ray sequence of node visits (0 inner / 1 leaf) of the reference traversal, and the rays
+ * (origin, direction) each bounce of each pixel-sample produces, for tools/traversal_sim.py. */
+int oracle_trace_events(const oracle_scene *scene, size_t n, const float *origins, const float *dirs, uint8_t *events,
+                        uint32_t max_events, uint32_t *lengths) {
+    Scene sc = make_scene(scene);
+    Counters cnt;
+    for (size_t i = 0; i < n; ++i) {
+        g_event_log = events + i * (size_t)max_events;
+        g_event_cap = max_events;
+        g_event_len = 0;
+        intersect_front_to_back<true>(sc, xyz(origins + 3 * i), xyz(dirs + 3 * i), 0.0f, cnt);
+        lengths[i] = g_event_len;
+    }
+    g_event_log = nullptr;
+    return 0;
+}
+
+/* rays[(y*W + x)*6..] = extension ray of bounce `bounce` of sample rng[i] of every pixel; valid[i] = 0 if the path ended earlier */
+int oracle_dump_rays(const rpt_tracing_config *config, const oracle_scene *scene, const rpt_rng_state *rng, uint32_t bounce,
+                     float *rays, uint8_t *valid) {
+    Scene sc = make_scene(scene);
+    Counters cnt;
+    for (uint32_t y = 0; y < config->height; ++y)
+        for (uint32_t x = 0; x < config->width; ++x) {
+            size_t i = (size_t)y * config->width + x;
+            g_ray_dump = rays + 6 * i;
+            g_ray_dump_bounce = bounce;
+            g_ray_dump_hit = false;
+            trace_pixel(x, y, *config, rng[i], sc, cnt);
+            valid[i] = g_ray_dump_hit ? 1 : 0;
+        }
+    g_ray_dump = nullptr;
+    return 0;
 }
 
 float oracle_lds(uint32_t n, uint32_t dimension, uint32_t offset, uint32_t *out_product) {

@@ -74,12 +74,21 @@ __device__ __forceinline__ bool moller_trumbore(F3 ro, F3 rd, F3 a, F3 edge1, F3
     return true;
 }
 
-/* One ray through the BVH, "while-while" form: every lane first walks inner
- * nodes until it stands on a leaf (or has nothing left), then the wave tests
- * leaf triangles together.  Per lane the sequence of box tests, triangle tests
- * and the value of the running best t at each of them is exactly the
- * reference's (intersection.rs:177-234).  `stack` points at this lane's column
- * of the wave's LDS stack: entry e lives at stack[e * RPT_WAVE]. */
+/* One ray per lane through the BVH.  Per lane the sequence of box tests, triangle tests and the value of the
+ * running best t at each of them is exactly the reference's (intersection.rs:177-234); what is scheduled is
+ * WHEN a lane takes its next step.  Each trip of the loop, lanes standing on an inner node take one box step;
+ * lanes standing on a leaf WAIT until at least RPT_LEAF_K lanes of the wave are waiting (or nobody is left at
+ * an inner node), then the wave issues the triangle body once for all of them.
+ * Why: after the first bounce the rays of a wave are incoherent.  A replay of the reference traversal on real
+ * DarkCornell bounce rays (tools/traversal_sim.py) gives, in issue slots per ray: classic while-while 148
+ * (lanes at a leaf wait for the slowest lane of every round), one-step-per-trip "if-if" 113 (the leaf body,
+ * 14 % of the steps, is issued on almost every trip), deferred leaves with K = 12..16: 106; ideal 38.  Measured on MI355X the gain is smaller (LDS/latency share the
+ * bill with VALU issue): traverse 23.7 -> 22.4..22.8 ms for K = 8..16, 25.9 ms for K = 64 (= while-while); K = 8 is
+ * also the best for VeachMIS.
+ * `stack` points at this lane's column of the wave's LDS stack: entry e lives at stack[e * RPT_WAVE]. */
+#ifndef RPT_LEAF_K
+#define RPT_LEAF_K 8
+#endif
 template <int STACK, bool ANY_HIT, bool FAST>
 __device__ __forceinline__ HitRecord traverse_loop(const float4 *nodes, const float4 *tri_geom, F3 ro, F3 rd, F3 ird, float max_t,
                                                    uint32_t *stack) {
@@ -92,8 +101,12 @@ __device__ __forceinline__ HitRecord traverse_loop(const float4 *nodes, const fl
     uint32_t cur_index = __float_as_uint(nodes[1].w);
     bool alive = true;
     for (;;) {
-        /* phase 1: inner nodes (:207-229) until a leaf is reached */
-        while (alive && cur_count == 0u) {
+        const bool at_inner = alive && cur_count == 0u;
+        const bool at_leaf = alive && cur_count != 0u;
+        const unsigned long long inner_m = __ballot(at_inner), leaf_m = __ballot(at_leaf);
+        if ((inner_m | leaf_m) == 0ull) break;
+        if (at_inner) {
+            /* inner node (:207-229): test both children against the current best t */
             const float4 *ch = nodes + 2u * cur_index;
             float4 lmin = ch[0], lmax = ch[1], rmin = ch[2], rmax = ch[3];
             float dl = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t);
@@ -117,26 +130,31 @@ __device__ __forceinline__ HitRecord traverse_loop(const float4 *nodes, const fl
                 cur_index = __float_as_uint(nodes[2u * node + 1u].w);
             }
         }
-        if (!alive) break;
-        /* phase 2: leaf triangles in index order (:186-205) */
-        for (uint32_t i = 0; i < cur_count; ++i) {
-            uint32_t ti = cur_index + i;
-            F3 a = xyz4(tri_geom[3u * ti]);
-            F3 e1 = xyz4(tri_geom[3u * ti + 1u]);
-            F3 e2 = xyz4(tri_geom[3u * ti + 2u]);
-            float t = 0.0f;
-            bool bf = false;
-            if (moller_trumbore(ro, rd, a, e1, e2, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
-                res.t = rptm::fminr(res.t, t);
-                res.tri = ti | (bf ? 0x80000000u : 0u);
-                if (ANY_HIT) return res;
+        if (at_leaf && ((uint32_t)__popcll(leaf_m) >= (uint32_t)RPT_LEAF_K || inner_m == 0ull)) {
+            /* leaf triangles in index order (:186-205) */
+            bool accepted = false;
+            for (uint32_t i = 0; i < cur_count; ++i) {
+                uint32_t ti = cur_index + i;
+                F3 a = xyz4(tri_geom[3u * ti]);
+                F3 e1 = xyz4(tri_geom[3u * ti + 1u]);
+                F3 e2 = xyz4(tri_geom[3u * ti + 2u]);
+                float t = 0.0f;
+                bool bf = false;
+                if (moller_trumbore(ro, rd, a, e1, e2, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
+                    res.t = rptm::fminr(res.t, t);
+                    res.tri = ti | (bf ? 0x80000000u : 0u);
+                    if (ANY_HIT) { accepted = true; break; }
+                }
+            }
+            if ((ANY_HIT && accepted) || sp == 0) {
+                alive = false;
+            } else {
+                sp -= 1;
+                uint32_t node = stack[sp * RPT_WAVE];
+                cur_count = __float_as_uint(nodes[2u * node].w);
+                cur_index = __float_as_uint(nodes[2u * node + 1u].w);
             }
         }
-        if (sp == 0) break;
-        sp -= 1;
-        uint32_t node = stack[sp * RPT_WAVE];
-        cur_count = __float_as_uint(nodes[2u * node].w);
-        cur_index = __float_as_uint(nodes[2u * node + 1u].w);
     }
     return res;
 }

@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Analysis tool (CPU only): how well does a wave64 keep its lanes busy while traversing?
+
+Uses the oracle's event log (per ray: the sequence of inner-node / leaf visits of the reference traversal) on
+rays dumped from real paths, groups rays into waves the way the GPU does (8x8 pixel blocks) and replays loop
+structures as SIMT schedules.  Output: steps per wave and lane utilisation for each structure.
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from oracle_ffi import Oracle  # noqa: E402
+
+rpt = importlib.import_module("rust-path-tracer_amd")
+hip = importlib.import_module("rust-path-tracer_amd.hip")
+
+COST_INNER, COST_LEAF = 100.0, 75.0      # VALU instructions per step (from the ISA)
+
+
+def events_for(orc, sc, o, d, cap=256):
+    n = len(o)
+    ev = np.zeros((n, cap), np.uint8)
+    ln = np.zeros(n, np.uint32)
+    orc.lib.oracle_trace_events(C.byref(sc), C.c_size_t(n), o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                ev.ctypes.data_as(C.c_void_p), C.c_uint32(cap), ln.ctypes.data_as(C.c_void_p))
+    assert ln.max() <= cap
+    return ev, ln
+
+
+def sim_while_while(ev, ln):
+    """All lanes walk inner nodes until each stands on a leaf (or is done), then leaves are tested together."""
+    pos = np.zeros(len(ln), np.int64)
+    inner_steps = leaf_steps = 0
+    inner_lane = leaf_lane = 0
+    while np.any(pos < ln):
+        while True:
+            at_inner = (pos < ln) & (ev[np.arange(len(ln)), np.minimum(pos, ev.shape[1] - 1)] == 0)
+            if not at_inner.any():
+                break
+            inner_steps += 1
+            inner_lane += int(at_inner.sum())
+            pos[at_inner] += 1
+        at_leaf = pos < ln
+        if at_leaf.any():
+            leaf_steps += 1
+            leaf_lane += int(at_leaf.sum())
+            pos[at_leaf] += 1
+    return inner_steps, leaf_steps, inner_lane, leaf_lane
+
+
+def sim_if_if(ev, ln):
+    """One loop, each iteration every live lane takes ONE step; both bodies are issued when both kinds are present."""
+    pos = np.zeros(len(ln), np.int64)
+    inner_steps = leaf_steps = inner_lane = leaf_lane = 0
+    while np.any(pos < ln):
+        live = pos < ln
+        kind = ev[np.arange(len(ln)), np.minimum(pos, ev.shape[1] - 1)]
+        a = live & (kind == 0)
+        b = live & (kind == 1)
+        if a.any():
+            inner_steps += 1
+            inner_lane += int(a.sum())
+        if b.any():
+            leaf_steps += 1
+            leaf_lane += int(b.sum())
+        pos[live] += 1
+    return inner_steps, leaf_steps, inner_lane, leaf_lane
+
+
+def report(name, results, n_rays):
+    i_s = sum(r[0] for r in results); l_s = sum(r[1] for r in results)
+    i_l = sum(r[2] for r in results); l_l = sum(r[3] for r in results)
+    cost = i_s * COST_INNER + l_s * COST_LEAF
+    useful = (i_l * COST_INNER + l_l * COST_LEAF) / 64.0
+    print(f"  {name:28s} inner steps/wave {i_s/len(results):6.1f} leaf steps/wave {l_s/len(results):5.1f}  "
+          f"lane util inner {i_l/(64*max(i_s,1)):.2f} leaf {l_l/(64*max(l_s,1)):.2f}  overall {useful/cost:.2f}  "
+          f"cost/ray {cost/n_rays:7.1f}")
+
+
+def main():
+    scene = sys.argv[1] if len(sys.argv) > 1 else "DarkCornell"
+    W = H = 128
+    orc = Oracle()
+    w = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    sc = orc.scene(w)
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    order = hip.tile_order(W, H, 0, 1)          # slot order: 8x8 blocks
+    px = (order >> 16).astype(np.int64) * W + (order & 0xFFFF).astype(np.int64)
+    for bounce in range(4):
+        rays = np.zeros((W * H, 6), np.float32)
+        valid = np.zeros(W * H, np.uint8)
+        orc.lib.oracle_dump_rays(C.byref(cfg), C.byref(sc), seeds.ctypes.data_as(C.c_void_p), C.c_uint32(bounce),
+                                 rays.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+        rays, valid = rays[px], valid[px]
+        o = np.ascontiguousarray(rays[:, :3]); d = np.ascontiguousarray(rays[:, 3:])
+        ev, ln = events_for(orc, sc, o, d)
+        ln = np.where(valid == 1, ln, 0)
+        n_rays = int(valid.sum())
+        print(f"{scene} bounce {bounce}: {n_rays} rays, node visits/ray mean {ln[valid==1].mean():.1f} max {ln.max()} "
+              f"leaf visits/ray {ev[valid==1].sum(axis=1).mean():.2f}")
+        waves = [(ev[i:i + 64], ln[i:i + 64]) for i in range(0, len(ln), 64)]
+        waves = [wv for wv in waves if wv[1].max() > 0]
+        report("while-while", [sim_while_while(*wv) for wv in waves], n_rays)
+        report("if-if (one step per iter)", [sim_if_if(*wv) for wv in waves], n_rays)
+
+
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold")):
+    main()
+
+
+def sim_refill(ev, ln, valid, chunk, thresh, cost_refill=60.0, mode="ifif"):
+    """Persistent lanes: a wave owns `chunk` consecutive rays; idle lanes are refilled when >= thresh are idle.
+    Returns total cost (instruction issue slots) for all rays."""
+    total = 0.0
+    n = len(ln)
+    for base in range(0, n, chunk):
+        idx = [i for i in range(base, min(base + chunk, n)) if valid[i]]
+        nxt = 0
+        lane_ray = [-1] * 64
+        lane_pos = [0] * 64
+        while True:
+            idle = [l for l in range(64) if lane_ray[l] < 0]
+            if nxt < len(idx) and (len(idle) >= thresh or len(idle) == 64):
+                for l in idle:
+                    if nxt < len(idx):
+                        lane_ray[l] = idx[nxt]; lane_pos[l] = 0; nxt += 1
+                total += cost_refill
+            live = [l for l in range(64) if lane_ray[l] >= 0]
+            if not live:
+                break
+            if mode == "ifif":
+                kinds = [ev[lane_ray[l], lane_pos[l]] for l in live]
+                if 0 in kinds: total += COST_INNER
+                if 1 in kinds: total += COST_LEAF
+                for l in live:
+                    lane_pos[l] += 1
+                    if lane_pos[l] >= ln[lane_ray[l]]: lane_ray[l] = -1
+            else:   # while-while
+                while True:
+                    inner = [l for l in live if lane_ray[l] >= 0 and ev[lane_ray[l], lane_pos[l]] == 0]
+                    if not inner: break
+                    total += COST_INNER
+                    for l in inner:
+                        lane_pos[l] += 1
+                        if lane_pos[l] >= ln[lane_ray[l]]: lane_ray[l] = -1
+                leaf = [l for l in live if lane_ray[l] >= 0]
+                if leaf:
+                    total += COST_LEAF
+                    for l in leaf:
+                        lane_pos[l] += 1
+                        if lane_pos[l] >= ln[lane_ray[l]]: lane_ray[l] = -1
+    return total
+
+
+def main_refill():
+    scene = sys.argv[2] if len(sys.argv) > 2 else "DarkCornell"
+    W = H = 128
+    orc = Oracle()
+    w = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    sc = orc.scene(w)
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    order = hip.tile_order(W, H, 0, 1)
+    px = (order >> 16).astype(np.int64) * W + (order & 0xFFFF).astype(np.int64)
+    bounce = 2
+    rays = np.zeros((W * H, 6), np.float32)
+    valid = np.zeros(W * H, np.uint8)
+    orc.lib.oracle_dump_rays(C.byref(cfg), C.byref(sc), seeds.ctypes.data_as(C.c_void_p), C.c_uint32(bounce),
+                             rays.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+    rays, valid = rays[px], valid[px]
+    ev, ln = events_for(orc, sc, np.ascontiguousarray(rays[:, :3]), np.ascontiguousarray(rays[:, 3:]))
+    ln = np.where(valid == 1, ln, 0)
+    sub = slice(0, 4096)
+    evs, lns, vs = ev[sub], ln[sub], valid[sub]
+    n_rays = int(vs.sum())
+    ideal = (float((evs[:, :] == 0)[np.arange(len(lns))[:, None], :][..., :0].sum()))  # placeholder
+    inner_total = sum(int((evs[i, :lns[i]] == 0).sum()) for i in range(len(lns)))
+    leaf_total = sum(int((evs[i, :lns[i]] == 1).sum()) for i in range(len(lns)))
+    print(f"{scene} bounce {bounce}: ideal cost/ray {(inner_total*COST_INNER+leaf_total*COST_LEAF)/64/n_rays:.1f}")
+    for mode in ("ifif", "whilewhile"):
+        for chunk, thresh in [(64, 64), (128, 16), (256, 16), (256, 8), (256, 32), (512, 16), (1024, 16)]:
+            c = sim_refill(evs, lns, vs, chunk, thresh, mode=mode)
+            print(f"  {mode:10s} chunk {chunk:5d} refill>= {thresh:2d}: cost/ray {c/n_rays:7.1f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "refill":
+    main_refill()
+
+
+def sim_threshold(ev, ln, valid, chunk, refill_thresh, leaf_k, cost_refill=60.0):
+    """if-if with deferred leaves: lanes standing on a leaf wait until >= leaf_k lanes wait (or nobody is at an inner
+    node); lanes at inner nodes step every iteration.  Optional refill from a chunk (chunk == 64: none)."""
+    total = 0.0
+    n = len(ln)
+    for base in range(0, n, chunk):
+        idx = [i for i in range(base, min(base + chunk, n)) if valid[i]]
+        nxt = 0
+        lane_ray = [-1] * 64
+        lane_pos = [0] * 64
+        while True:
+            idle = [l for l in range(64) if lane_ray[l] < 0]
+            if nxt < len(idx) and (len(idle) >= refill_thresh or len(idle) == 64):
+                for l in idle:
+                    if nxt < len(idx):
+                        lane_ray[l] = idx[nxt]; lane_pos[l] = 0; nxt += 1
+                total += cost_refill
+            live = [l for l in range(64) if lane_ray[l] >= 0]
+            if not live:
+                break
+            inner = [l for l in live if ev[lane_ray[l], lane_pos[l]] == 0]
+            leaf = [l for l in live if ev[lane_ray[l], lane_pos[l]] == 1]
+            step = []
+            if inner:
+                total += COST_INNER
+                step += inner
+            if leaf and (len(leaf) >= leaf_k or not inner):
+                total += COST_LEAF
+                step += leaf
+            for l in step:
+                lane_pos[l] += 1
+                if lane_pos[l] >= ln[lane_ray[l]]: lane_ray[l] = -1
+    return total
+
+
+def main_threshold():
+    scene = sys.argv[2] if len(sys.argv) > 2 else "DarkCornell"
+    W = H = 128
+    orc = Oracle()
+    w = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    sc = orc.scene(w)
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    order = hip.tile_order(W, H, 0, 1)
+    px = (order >> 16).astype(np.int64) * W + (order & 0xFFFF).astype(np.int64)
+    for bounce in (0, 2):
+        rays = np.zeros((W * H, 6), np.float32)
+        valid = np.zeros(W * H, np.uint8)
+        orc.lib.oracle_dump_rays(C.byref(cfg), C.byref(sc), seeds.ctypes.data_as(C.c_void_p), C.c_uint32(bounce),
+                                 rays.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+        rays, valid = rays[px], valid[px]
+        ev, ln = events_for(orc, sc, np.ascontiguousarray(rays[:, :3]), np.ascontiguousarray(rays[:, 3:]))
+        ln = np.where(valid == 1, ln, 0)
+        sub = slice(0, 4096)
+        evs, lns, vs = ev[sub], ln[sub], valid[sub]
+        n_rays = int(vs.sum())
+        print(f"{scene} bounce {bounce}")
+        for chunk, rt in [(64, 64), (256, 16)]:
+            for k in (1, 4, 8, 12, 16, 24, 32, 64):
+                c = sim_threshold(evs, lns, vs, chunk, rt, k)
+                print(f"  chunk {chunk:4d} leaf_k {k:2d}: cost/ray {c/n_rays:7.1f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "threshold":
+    main_threshold()
