@@ -135,6 +135,7 @@ struct DevQueues {
     float4 *sh_c;      /* (contribution r, g, b if unoccluded, unused) */
     uint32_t *count;   /* Q_COUNT words, see the enum above */
     uint32_t sky_threshold;   /* the sky stage runs once this many misses are queued (or nothing else is left) */
+    uint32_t sky_wide_limit;  /* up to this many queued misses the sky march runs 16 lanes per miss */
     unsigned long long *ray_shards;  /* RPT_STAT_SHARDS x RPT_STAT_STRIDE: extension rays traced */
     unsigned long long *host_ring;   /* mapped pinned host memory: (iteration + 1) << 32 | extension-queue size */
     uint32_t ring_mask;

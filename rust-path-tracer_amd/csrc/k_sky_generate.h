@@ -69,6 +69,50 @@ __device__ F3 sky_scatter(const float *sun4, F3 origin, F3 direction) {
     return f3(rptm::powr(g.x, 2.2f), rptm::powr(g.y, 2.2f), rptm::powr(g.z, 2.2f));
 }
 
+/* The same march with its 12 steps spread over 12 lanes of a 16-lane group (all lanes of a group hold the same
+ * miss).  Only the two running sums are order dependent: they are rebuilt in exactly the sequential order
+ * (total_k = ((0 + d_0) + d_1) + ... + d_k ; i_r = ((0 + t_0) + t_1) + ...) from lane-to-lane broadcasts, so
+ * the result is bit-identical to sky_scatter.  Used when few misses are queued: the march is then latency
+ * bound (one wave, 12 dependent steps of f64 exp/sqrt chains ~ 24 us) and this cuts the chain 12-fold. */
+__device__ F3 sky_scatter_wide(const float *sun4, F3 origin, F3 direction, uint32_t j, uint32_t g0) {
+    const F3 ray_coeff = f3(58e-7f, 135e-7f, 331e-7f);
+    const F3 mie_scatter = f3(2e-5f, 2e-5f, 2e-5f);
+    const F3 mie_effective = f3(2e-5f * 1.1f, 2e-5f * 1.1f, 2e-5f * 1.1f);
+    const F3 sundir = f3(sun4[0], sun4[1], sun4[2]);
+
+    float depth = sky_escape(origin, direction, SKY_ATMOSPHERE_RADIUS) / (float)12u;
+    F3 p = origin + direction * (depth * (float)j);
+    float2 dens = sky_densities(p);
+    float d_r = dens.x * depth, d_m = dens.y * depth;
+    float total_r = 0.0f, total_m = 0.0f;
+    for (uint32_t k = 0; k < 12u; ++k) {
+        float vr = __shfl(d_r, (int)(g0 + k), RPT_WAVE), vm = __shfl(d_m, (int)(g0 + k), RPT_WAVE);
+        if (j >= k) {
+            total_r = total_r + vr;
+            total_m = total_m + vm;
+        }
+    }
+    float l = sky_escape(p, sundir, SKY_ATMOSPHERE_RADIUS);
+    float2 db = sky_densities(p + sundir * l);
+    float half_l = l / 2.0f;
+    float sum_r = total_r + (dens.x * half_l + db.x * half_l);
+    float sum_m = total_m + (dens.y * half_l + db.y * half_l);
+    F3 e = (-ray_coeff) * sum_r - mie_effective * sum_m;
+    F3 a = f3(rptm::expr(e.x), rptm::expr(e.y), rptm::expr(e.z));
+    F3 t_r = a * d_r, t_m = a * d_m;
+    F3 i_r = f3s(0.0f), i_m = f3s(0.0f);
+    for (uint32_t k = 0; k < 12u; ++k) {
+        int src = (int)(g0 + k);
+        i_r = i_r + f3(__shfl(t_r.x, src, RPT_WAVE), __shfl(t_r.y, src, RPT_WAVE), __shfl(t_r.z, src, RPT_WAVE));
+        i_m = i_m + f3(__shfl(t_m.x, src, RPT_WAVE), __shfl(t_m.y, src, RPT_WAVE), __shfl(t_m.z, src, RPT_WAVE));
+    }
+    float mu = dot3(direction, sundir);
+    F3 res = (sun4[3] * (1.0f + mu * mu)) *
+             (i_r * ray_coeff * 0.0597f + i_m * mie_scatter * 0.0196f / rptm::powr(1.58f - 1.52f * mu, 1.5f));
+    F3 g = mask_nan3(f3(rptm::sqrtr(res.x), rptm::sqrtr(res.y), rptm::sqrtr(res.z)));
+    return f3(rptm::powr(g.x, 2.2f), rptm::powr(g.y, 2.2f), rptm::powr(g.z, 2.2f));
+}
+
 /* The sky stage is LAZY: misses pile up in the queue over several iterations and are shaded once
  * q.sky_threshold of them are waiting, or when the traversal pass of this iteration found no ray at all
  * (so nothing else can make progress).  On closed scenes a handful of misses per iteration would otherwise
@@ -88,6 +132,24 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
     }
     if (n < q.sky_threshold && alive != 0u) return;          /* not worth a pass yet (same test as k_traverse_nearest) */
     if (i == 0u && n) atomicAdd(&stats->sky_evals, (unsigned long long)n);
+    if (cfg.c.has_skybox == 0u && n <= q.sky_wide_limit) {
+        /* few misses: 16 lanes per miss (block-uniform branch) */
+        const uint32_t m = i >> 4;
+        if (m < n) {
+            const uint32_t slot = q.sky[m];
+            const uint32_t lane = __lane_id(), g0 = lane & ~15u, j = lane & 15u;
+            float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+            F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
+            F3 sky = sky_scatter_wide(cfg.c.sun_direction, ro, rd, j, g0);
+            if (j == 0u) {
+                float4 tr = st.thr_rad[slot], rm = st.rad_misc[slot];
+                F3 throughput = f3(tr.x, tr.y, tr.z), radiance = f3(tr.w, rm.x, rm.y);
+                radiance = radiance + throughput * sky;                                       /* lib.rs:69 */
+                finish_in_side_stage(st, cfg, slot, radiance, tr, rm);
+            }
+        }
+        return;
+    }
     if (i < n) {
         uint32_t slot = q.sky[i];
         float4 ra = st.ray_a[slot], rb = st.ray_b[slot];

@@ -235,6 +235,8 @@ int alloc_state(rpt_ctx *c) {
     /* 1 = shade misses in the iteration that found them.  Letting them pile up (threshold ~ n/64) removes most
      * of the near-empty sky launches on closed scenes, but the parked pixels finish later and lengthen the tail:
      * measured DarkCornell 3650 Mrays/s deferred vs 3928 eager — so eager is the default. */
+    q.sky_wide_limit = (uint32_t)std::min<size_t>(n / 16, 32768);
+    if (const char *env = getenv("RPT_SKY_WIDE_LIMIT")) q.sky_wide_limit = (uint32_t)std::min<size_t>(n / 16, (size_t)std::max(0, atoi(env)));
     q.sky_threshold = 1u;
     if (const char *env = getenv("RPT_SKY_THRESHOLD")) q.sky_threshold = (uint32_t)std::max(1, atoi(env));
     c->has_state = true;
