@@ -44,9 +44,9 @@ def algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples):
     return 128 * n_ext + 96 * n_shadow + 128 * n_mis + 40 * n_samples
 
 
-# bytes the traversal stage itself must move per extension ray: queue slot id 4 R,
-# ray {o 12, d 12} R, hit {t 4, tri|backface 4} W  (its share of the 128 B/ray figure)
-TRAVERSE_BYTES_PER_RAY = 4 + 24 + 8
+# bytes the traversal stage itself must move per extension ray: the two 16-byte ray records
+# {origin, direction, stage word} read, the 8-byte hit record {t, triangle|backface} written
+TRAVERSE_BYTES_PER_RAY = 32 + 8
 
 
 def main():
@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo (host-staged gather) only exists to exercise the N>1 logic on a box with one GPU")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="testing aid for --dist-backend gloo")
     args = ap.parse_args()
 
     os.environ.setdefault("RPT_STAGE_TIMING", "1")   # HIP events between stage kernels on the render stream
@@ -79,11 +82,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device(device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
 
     scene, W, H, total_spp, over = WORKLOADS[args.workload]
     world = rpt.World.from_path(rpt.fixture(scene + ".glb"))
@@ -96,7 +104,10 @@ def main():
     r.reset(seeds)
     local_block = tiles.device_block_as_tensor(r, device)
     image = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
-    gatherer = tiles.Gatherer(W, H, device) if world_size > 1 else None
+    comm_device = device if args.dist_backend == "nccl" else "cpu"
+    gatherer = tiles.Gatherer(W, H, comm_device) if world_size > 1 else None
+    staged = torch.zeros((world_size, gatherer.stride, 4), dtype=torch.float32, device=device) \
+        if (world_size > 1 and rank == 0 and comm_device == "cpu") else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -110,6 +121,9 @@ def main():
             torch.cuda.current_stream().synchronize()
             recv = gatherer.gather(local_block)                      # the single collective per sample batch
             if rank == 0:
+                if staged is not None:
+                    staged.copy_(recv)
+                    recv = staged
                 torch.cuda.current_stream().synchronize()
                 r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)
 
@@ -128,7 +142,7 @@ def main():
         return s1[key] - s0[key]
 
     local = torch.tensor([elapsed, float(delta("extension_rays")), float(delta("shadow_rays")), float(delta("samples")),
-                          float(delta("sky_evals"))], dtype=torch.float64, device=device)
+                          float(delta("sky_evals"))], dtype=torch.float64, device=comm_device if world_size > 1 else device)
     if world_size > 1:
         tmax = local[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

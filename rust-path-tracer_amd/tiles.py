@@ -53,11 +53,10 @@ class Gatherer:
     def gather(self, local_block):
         """local_block: (n_local, 4) tensor aliasing the renderer's accumulator block. Returns recv on rank 0."""
         n = self.sizes[self.rank]
-        src = local_block if n == self.stride else None
-        if src is None:
-            self.send[:n].copy_(local_block)
-            src = self.send
-        dist.gather(src, gather_list=self.recv_list, dst=0, group=self.group)
+        # always stage through a torch-owned buffer: the collective then never sees memory it did not allocate
+        # (2 MiB per rank at 1024^2 — noise next to a sample batch); also moves to the host for the gloo tests
+        self.send[:n].copy_(local_block)
+        dist.gather(self.send, gather_list=self.recv_list, dst=0, group=self.group)
         return self.recv
 
 
