@@ -11,7 +11,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 
 HOST_SRCS := $(CSRC)/host/host_api.cpp $(CSRC)/host/glb_scene.cpp $(CSRC)/host/bvh_build.cpp \
-             $(CSRC)/host/light_table.cpp $(CSRC)/host/bluenoise.cpp
+             $(CSRC)/host/light_table.cpp $(CSRC)/host/bluenoise.cpp $(CSRC)/host/image_io.cpp
 HIP_SRCS  := $(CSRC)/rpt_hip.hip
 HIP_DEPS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hip) $(wildcard include/rpt/*.h)
 
@@ -29,7 +29,7 @@ host: $(LIBDIR)/librpt_host.so
 oracle: oracle/liboracle.so oracle/liboracle_libm.so
 hip: $(LIBDIR)/librpt_hip.so
 
-$(LIBDIR)/librpt_host.so: $(HOST_SRCS) $(CSRC)/host/host_internal.h include/rpt/rpt_host.h include/rpt/rpt.h include/rpt/shared_structs.h
+$(LIBDIR)/librpt_host.so: $(HOST_SRCS) $(CSRC)/host/host_internal.h $(CSRC)/rpt_math.h include/rpt/rpt_host.h include/rpt/rpt.h include/rpt/shared_structs.h
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS_COMMON) -shared -o $@ $(HOST_SRCS) -lz -ldl -pthread
 

@@ -128,6 +128,13 @@ int rpt_render(rpt_ctx *ctx, uint32_t n_samples);
  * y-down order.  Pixels of tiles owned by other ranks are written as zeros. */
 int rpt_read_accum(rpt_ctx *ctx, float *out_rgba, uint32_t *out_samples);
 
+/* Post-accumulation step on the device: mean = sum / samples
+ * (src/trace.rs:199-204) then tonemap operator 0..6 exactly as the display shader
+ * numbers them (src/resources/render.wgsl:131-153: 0 none, 1 Reinhard, 2 ACES
+ * Narkowicz x0.6, 3 ACES Narkowicz, 4 ACES Hill, 5 Neutral, 6 Uncharted).  Writes
+ * width*height*3 floats, row-major; other ranks' pixels are zero. */
+int rpt_resolve(rpt_ctx *ctx, uint32_t tonemap_op, float *out_rgb);
+
 /* Reads back rng[i] (n, offset) for every pixel (other ranks' pixels: zeros);
  * lets a caller verify `rng[i].x += 1` semantics (kernels/src/lib.rs:226). */
 int rpt_read_rng(rpt_ctx *ctx, rpt_rng_state *out);

@@ -57,6 +57,15 @@ int rpt_world_from_buffers(const float *vertices_xyz, const float *normals_xyz, 
                            size_t n_vertices, const uint32_t *triangles_v0v1v2_mat, size_t n_triangles,
                            const rpt_material_data *materials, size_t n_materials, rpt_world **out);
 int rpt_world_view_get(const rpt_world *world, rpt_world_view *out);
+/* ".rptscene": the World's five POD buffers (+ atlas) in one flat little-endian file, so the
+ * Rust host (which has assimp) and this backend can exchange byte-identical inputs:
+ *   header { "RPTSCN01", u64 n_vertices, n_triangles, n_nodes, n_materials, n_light_pick, u32 atlas_w, atlas_h }
+ *   then PerVertexData[], UVec4 index[], BVHNode[], MaterialData[], LightPickEntry[], RGBA8 atlas. */
+int rpt_world_save(const rpt_world *world, const char *path);
+int rpt_world_load_cache(const char *path, rpt_world **out);
+/* 8-bit RGBA PNG of a resolved frame (width*height*3 floats).  srgb_encode != 0 applies the sRGB transfer
+ * function the reference's save path gets from its sRGB surface format (src/app.rs:759-845). */
+int rpt_write_png(const char *path, const float *rgb, uint32_t width, uint32_t height, int srgb_encode);
 void rpt_world_free(rpt_world *world);
 
 /* BVHBuilder::new(vertices, indices).sah_samples(n).build(): reorders

@@ -107,6 +107,13 @@ class Oracle:
                                          _p(t), _p(tri), _p(flags))
         return t, tri, flags, err
 
+    def resolve(self, accum, sample_count, op):
+        """mean + display tonemap (reference: src/trace.rs:303-308, src/resources/render.wgsl:36-153)."""
+        accum = np.ascontiguousarray(accum, np.float32)
+        out = np.zeros(accum.shape[:-1] + (3,), np.float32)
+        self.lib.oracle_resolve(_p(accum), C.c_size_t(accum.size // 4), C.c_float(sample_count), C.c_uint32(op), _p(out))
+        return out
+
     def lds(self, n, dim, offset):
         prod = C.c_uint32()
         v = self.lib.oracle_lds(C.c_uint32(n), C.c_uint32(dim), C.c_uint32(offset), C.byref(prod))

@@ -1000,6 +1000,56 @@ int oracle_dump_rays(const rpt_tracing_config *config, const oracle_scene *scene
     return 0;
 }
 
+/* Post-accumulation step: mean = sum / sample_count (src/trace.rs:303-308) followed by display tonemap operator `op`
+ * (src/resources/render.wgsl:36-153; 0 none, 1 Reinhard, 2 ACES Narkowicz x0.6, 3 ACES Narkowicz, 4 ACES Hill,
+ * 5 Neutral, 6 Uncharted).  WGSL leaves the association of mat*vec and of a*b+c to the implementation; this
+ * restatement fixes them as written (left to right, matrix product accumulated column by column). */
+static V3 wg_div(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+static V3 wg_sat(V3 a) { return V3{m_min(m_max(a.x, 0.0f), 1.0f), m_min(m_max(a.y, 0.0f), 1.0f), m_min(m_max(a.z, 0.0f), 1.0f)}; }
+static V3 wg_aces_narkowicz(V3 x) {
+    float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return wg_sat(wg_div(x * (a * x + splat3(b)), x * (c * x + splat3(d)) + splat3(e)));
+}
+static V3 wg_aces_hill(V3 x) {
+    V3 color = v3(0.59719f, 0.07600f, 0.02840f) * x.x + v3(0.35458f, 0.90834f, 0.13383f) * x.y + v3(0.04823f, 0.01566f, 0.83777f) * x.z;
+    V3 a = color * (color + splat3(0.0245786f)) - splat3(0.000090537f);
+    V3 b = color * (0.983729f * color + splat3(0.4329510f)) + splat3(0.238081f);
+    color = wg_div(a, b);
+    color = v3(1.60475f, -0.10208f, -0.00327f) * color.x + v3(-0.53108f, 1.10813f, -0.07276f) * color.y +
+            v3(-0.07367f, -0.00605f, 1.07602f) * color.z;
+    return wg_sat(color);
+}
+static V3 wg_curve(V3 x, float a, float b, float c, float d, float e, float f) {
+    return wg_div(x * (a * x + splat3(c * b)) + splat3(d * e), x * (a * x + splat3(b)) + splat3(d * f)) - splat3(e / f);
+}
+int oracle_resolve(const float *accum_rgba, size_t n_pixels, float sample_count, uint32_t op, float *out_rgb) {
+    for (size_t i = 0; i < n_pixels; ++i) {
+        V3 x = v3(accum_rgba[4 * i] / sample_count, accum_rgba[4 * i + 1] / sample_count, accum_rgba[4 * i + 2] / sample_count);
+        V3 r = x;
+        switch (op) {
+            case 1: r = wg_div(x, x + splat3(1.0f)); break;
+            case 2: r = wg_aces_narkowicz(x * 0.6f); break;
+            case 3: r = wg_aces_narkowicz(x); break;
+            case 4: r = wg_aces_hill(x); break;
+            case 5: {
+                V3 white_scale = wg_div(splat3(1.0f), wg_curve(splat3(5.3f), 0.2f, 0.29f, 0.24f, 0.272f, 0.02f, 0.3f));
+                r = wg_curve(x * white_scale, 0.2f, 0.29f, 0.24f, 0.272f, 0.02f, 0.3f) * white_scale;
+                r = wg_div(r, splat3(1.0f));
+                break;
+            }
+            case 6: {
+                V3 curr = wg_curve(x * 2.0f, 0.15f, 0.50f, 0.10f, 0.20f, 0.02f, 0.30f);
+                V3 white_scale = wg_div(splat3(1.0f), wg_curve(splat3(11.2f), 0.15f, 0.50f, 0.10f, 0.20f, 0.02f, 0.30f));
+                r = curr * white_scale;
+                break;
+            }
+            default: break;
+        }
+        out_rgb[3 * i] = r.x; out_rgb[3 * i + 1] = r.y; out_rgb[3 * i + 2] = r.z;
+    }
+    return 0;
+}
+
 float oracle_lds(uint32_t n, uint32_t dimension, uint32_t offset, uint32_t *out_product) {
     if (out_product) *out_product = LDS_PRIMES[dimension & 31u] * (n + offset);
     return lds(n, dimension, offset);

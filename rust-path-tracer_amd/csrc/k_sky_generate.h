@@ -205,4 +205,62 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_untile(const float4 *blocks, cons
     image[(size_t)(pxy >> 16) * width + (pxy & 0xffffu)] = blocks[i];
 }
 
+/* ---- post-accumulation step --------------------------------------------------------
+ * mean = sum / sample_count (src/trace.rs:199-204) followed by one of the display tonemappers of
+ * src/resources/render.wgsl:36-117 (operator selection :131-153).  Pure f32 rational curves, written in
+ * the shader's operation order; input = the tile-major accumulator block, output = row-major RGB. */
+__device__ __forceinline__ float tm_clamp01(float x) { return rptm::fminr(rptm::fmaxr(x, 0.0f), 1.0f); }
+__device__ __forceinline__ F3 tm_aces_narkowicz(F3 x) {                       /* render.wgsl:36-43 */
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    F3 num = x * (a * x + f3s(b));
+    F3 den = x * (c * x + f3s(d)) + f3s(e);
+    return f3(tm_clamp01(num.x / den.x), tm_clamp01(num.y / den.y), tm_clamp01(num.z / den.z));
+}
+__device__ __forceinline__ F3 tm_aces_hill(F3 x) {                            /* render.wgsl:46-69 */
+    /* transpose(mat3x3(rows)) * v  ==  rows dotted with v, accumulated column by column (x, then y, then z) */
+    F3 color = f3(0.59719f, 0.07600f, 0.02840f) * x.x + f3(0.35458f, 0.90834f, 0.13383f) * x.y + f3(0.04823f, 0.01566f, 0.83777f) * x.z;
+    F3 a = color * (color + f3s(0.0245786f)) - f3s(0.000090537f);
+    F3 b = color * (0.983729f * color + f3s(0.4329510f)) + f3s(0.238081f);
+    color = f3(a.x / b.x, a.y / b.y, a.z / b.z);
+    color = f3(1.60475f, -0.10208f, -0.00327f) * color.x + f3(-0.53108f, 1.10813f, -0.07276f) * color.y +
+            f3(-0.07367f, -0.00605f, 1.07602f) * color.z;
+    return f3(tm_clamp01(color.x), tm_clamp01(color.y), tm_clamp01(color.z));
+}
+__device__ __forceinline__ F3 tm_curve(F3 x, float a, float b, float c, float d, float e, float f) {   /* :75-77, :103-111 */
+    F3 num = x * (a * x + f3s(c * b)) + f3s(d * e);
+    F3 den = x * (a * x + f3s(b)) + f3s(d * f);
+    return f3(num.x / den.x, num.y / den.y, num.z / den.z) - f3s(e / f);
+}
+__device__ __forceinline__ F3 tonemap(uint32_t op, F3 x) {
+    switch (op) {
+        case 1u: return f3(x.x / (x.x + 1.0f), x.y / (x.y + 1.0f), x.z / (x.z + 1.0f));     /* Reinhard :71-73 */
+        case 2u: return tm_aces_narkowicz(x * 0.6f);
+        case 3u: return tm_aces_narkowicz(x);
+        case 4u: return tm_aces_hill(x);
+        case 5u: {                                                                           /* Neutral :79-101 */
+            F3 w = tm_curve(f3s(5.3f), 0.2f, 0.29f, 0.24f, 0.272f, 0.02f, 0.3f);
+            F3 white_scale = f3(1.0f / w.x, 1.0f / w.y, 1.0f / w.z);
+            F3 y = tm_curve(x * white_scale, 0.2f, 0.29f, 0.24f, 0.272f, 0.02f, 0.3f) * white_scale;
+            return f3(y.x / 1.0f, y.y / 1.0f, y.z / 1.0f);
+        }
+        case 6u: {                                                                           /* Uncharted :113-121 */
+            F3 curr = tm_curve(x * 2.0f, 0.15f, 0.50f, 0.10f, 0.20f, 0.02f, 0.30f);
+            F3 w = tm_curve(f3s(11.2f), 0.15f, 0.50f, 0.10f, 0.20f, 0.02f, 0.30f);
+            return curr * f3(1.0f / w.x, 1.0f / w.y, 1.0f / w.z);
+        }
+        default: return x;
+    }
+}
+__global__ __launch_bounds__(RPT_BLOCK) void k_resolve(const float4 *accum, const uint32_t *pixel_xy, uint32_t n_pixels, uint32_t width,
+                                                       float sample_count, uint32_t op, float *out_rgb) {
+    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 a = accum[i];
+    F3 mean = f3(a.x / sample_count, a.y / sample_count, a.z / sample_count);
+    F3 c = tonemap(op, mean);
+    uint32_t pxy = pixel_xy[i];
+    size_t at = ((size_t)(pxy >> 16) * width + (pxy & 0xffffu)) * 3u;
+    out_rgb[at] = c.x; out_rgb[at + 1] = c.y; out_rgb[at + 2] = c.z;
+}
+
 #endif /* RPT_K_SKY_GENERATE_H */

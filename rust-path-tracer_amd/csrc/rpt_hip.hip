@@ -734,6 +734,27 @@ int rpt_untile(rpt_ctx *c, const void *dev_blocks, uint64_t block_stride_pixels,
     return RPT_OK;
 }
 
+int rpt_resolve(rpt_ctx *c, uint32_t tonemap_op, float *out_rgb) {
+    if (!c || !out_rgb) return RPT_EINVAL;
+    if (!c->has_state) { c->error = "nothing to resolve: no config"; return RPT_EINVAL; }
+    if (tonemap_op > 6u) { c->error = "tonemap operator must be 0..6"; return RPT_EINVAL; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n_out = (size_t)c->cfg.c.width * c->cfg.c.height * 3;
+    DevBuf<float> dev;
+    HIP_TRY(c, dev.alloc(n_out));
+    hipError_t e = hipMemsetAsync(dev.p, 0, n_out * sizeof(float), c->stream);
+    if (e == hipSuccess && c->n_pixels) {
+        k_resolve<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, c->stream>>>(c->accum.p, c->pixel_xy.p, c->n_pixels, c->cfg.c.width,
+                                                                                      (float)c->samples, tonemap_op, dev.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_rgb, dev.p, n_out * sizeof(float), hipMemcpyDeviceToHost);
+    dev.release();
+    HIP_TRY(c, e);
+    return RPT_OK;
+}
+
 int rpt_get_stats(rpt_ctx *c, rpt_stats *out) {
     if (!c || !out) return RPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));

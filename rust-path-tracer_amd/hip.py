@@ -17,7 +17,7 @@ _lib = None
 
 EXPORTS = [
     "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_set_samples_in_flight", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
-    "rpt_render", "rpt_read_accum", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
+    "rpt_render", "rpt_read_accum", "rpt_resolve", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
     "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
     "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_trace_rays",
 ]
@@ -48,6 +48,7 @@ def lib():
         L.rpt_render.argtypes = [C.c_void_p, C.c_uint32]
         L.rpt_read_accum.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.rpt_read_rng.argtypes = [C.c_void_p, C.c_void_p]
+        L.rpt_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.rpt_local_pixels.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.rpt_local_block_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.rpt_rank_pixels.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
@@ -139,6 +140,12 @@ class Renderer:
         samples = C.c_uint32()
         self._check(lib().rpt_read_accum(self._h, ptr(out), C.byref(samples)))
         return out, samples.value
+
+    def resolve(self, tonemap_op=0):
+        """mean radiance (+ display tonemap 0..6, reference: src/resources/render.wgsl:131-153) as (H, W, 3) float32."""
+        out = np.zeros((self.config.height, self.config.width, 3), np.float32)
+        self._check(lib().rpt_resolve(self._h, tonemap_op, ptr(out)))
+        return out
 
     def read_rng(self):
         out = np.zeros(self.config.height * self.config.width, RNG_DTYPE)

@@ -41,6 +41,11 @@ def lib():
         L.rpt_world_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.rpt_world_view_get.argtypes = [C.c_void_p, C.POINTER(WorldView)]
         L.rpt_world_free.argtypes = [C.c_void_p]
+        L.rpt_world_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.rpt_world_load_cache.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.rpt_world_from_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.c_size_t, C.POINTER(C.c_void_p)]
+        L.rpt_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
         _lib = L
     return _lib
 
@@ -112,6 +117,28 @@ class World:
         return cls._from_handle(h)
 
     @classmethod
+    def from_cache(cls, path):
+        """Load a ".rptscene" file (the five POD buffers written by World.save / the Rust host)."""
+        h = C.c_void_p()
+        _check(lib().rpt_world_load_cache(os.fsencode(path), C.byref(h)))
+        return cls._from_handle(h)
+
+    def save(self, path):
+        """Write this World's buffers as ".rptscene" (byte-identical exchange format, include/rpt/rpt_host.h)."""
+        header = np.zeros(1, np.dtype([("magic", "S8"), ("n", "<u8", 5), ("aw", "<u4"), ("ah", "<u4")]))
+        header["magic"] = b"RPTSCN01"
+        header["n"] = [len(self.per_vertex), len(self.indices), len(self.nodes), len(self.materials), len(self.light_pick)]
+        atlas = b""
+        if self.atlas is not None:
+            header["ah"], header["aw"] = self.atlas.shape[:2]
+            atlas = np.ascontiguousarray(self.atlas, np.uint8).tobytes()
+        with open(path, "wb") as f:
+            f.write(header.tobytes())
+            for a in (self.per_vertex, self.indices, self.nodes, self.materials, self.light_pick):
+                f.write(a.tobytes())
+            f.write(atlas)
+
+    @classmethod
     def from_buffers(cls, vertices, normals, uvs, triangles, materials):
         """Procedural scenes: run the reference's BVH / light-table / packing steps on raw geometry."""
         vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
@@ -128,6 +155,12 @@ class World:
 
 def fixture(name):
     return os.path.join(_ffi.FIXTURES, name)
+
+
+def write_png(path, rgb, srgb=True):
+    """8-bit PNG of a resolved (H, W, 3) float frame, sRGB-encoded like the reference's saved renders."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    _check(lib().rpt_write_png(os.fsencode(path), ptr(rgb), C.c_uint32(rgb.shape[1]), C.c_uint32(rgb.shape[0]), int(bool(srgb))))
 
 
 def blue_noise_tile(png_path=None):

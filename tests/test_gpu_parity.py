@@ -214,6 +214,25 @@ def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp
         r.close()
 
 
+def test_resolve_and_tonemap_parity(renderer, oracle, rpt, world):
+    """mean + the six display tonemappers (render.wgsl:36-153) on the device == oracle, bitwise."""
+    w = world("VeachMIS")
+    W, H, spp = 160, 96, 6
+    cfg = rpt.default_config(W, H, nee=1)
+    renderer.upload_scene(w)
+    renderer.set_config(cfg)
+    renderer.reset(rpt.blue_noise_seeds(W, H))
+    renderer.render(spp)
+    acc, n = renderer.read_accum()
+    for op in range(7):
+        got = renderer.resolve(op)
+        want = oracle.resolve(acc, float(n), op)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"tonemap op {op}"
+        if op in (1, 2, 3, 4):
+            assert got.min() >= 0.0 and got.max() <= 1.0
+    assert np.array_equal(renderer.resolve(0), acc[..., :3] / np.float32(n))
+
+
 def test_render_in_batches_equals_one_batch(renderer, rpt, world):
     w = world("DarkCornell")
     cfg = rpt.default_config(96, 96, nee=1)

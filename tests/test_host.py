@@ -66,3 +66,36 @@ def test_trace_gpu_without_device_reports_error(rpt):
     assert "no HIP device" in str(e.value)
     assert state.samples == 0
     state.close()
+
+
+def test_rptscene_cache_roundtrip_is_byte_identical(rpt, world, tmp_path):
+    """the five POD buffers survive save/load bit for bit (Python writer and C loader agree)."""
+    for name in ("DarkCornell", "PBRTest"):
+        w = world(name)
+        path = str(tmp_path / (name + ".rptscene"))
+        w.save(path)
+        w2 = rpt.World.from_cache(path)
+        for k in ("per_vertex", "indices", "nodes", "materials", "light_pick"):
+            assert np.array_equal(getattr(w, k).view(np.uint8), getattr(w2, k).view(np.uint8)), k
+        assert w2.bvh_max_depth == w.bvh_max_depth and w2.n_emissive_triangles == w.n_emissive_triangles
+    bad = tmp_path / "bad.rptscene"
+    bad.write_bytes(b"RPTSCN01" + b"\x00" * 20)
+    with pytest.raises(rpt.host.HostError):
+        rpt.World.from_cache(str(bad))
+
+
+def test_png_writer_srgb(rpt, tmp_path):
+    from PIL import Image
+    img = np.zeros((4, 5, 3), np.float32)
+    img[0, 0] = [0.0, 0.5, 1.0]
+    img[1, 1] = [0.0031308, 2.0, -1.0]
+    img[2, 2] = [np.nan, 0.2140, 0.0]
+    path = str(tmp_path / "a.png")
+    rpt.host.write_png(path, img)
+    px = np.array(Image.open(path))
+    assert px.shape == (4, 5, 4) and np.all(px[..., 3] == 255)
+    assert list(px[0, 0, :3]) == [0, 188, 255]          # 0.5 linear -> 0.7354 sRGB -> 188
+    assert list(px[1, 1, :3]) == [10, 255, 0]           # 0.0031308 * 12.92 * 255 = 10.3 ; clamps
+    assert list(px[2, 2, :3]) == [0, 127, 0]            # NaN -> 0 ; 0.214 -> ~0.5
+    rpt.host.write_png(path, img, srgb=False)
+    assert list(np.array(Image.open(path))[0, 0, :3]) == [0, 128, 255]
