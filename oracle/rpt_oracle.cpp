@@ -196,6 +196,8 @@ struct Counters {
     uint64_t node_pops = 0, box_tests = 0, tri_tests = 0;
     uint32_t max_stack = 0;
     uint32_t error_flags = 0;   /* bit0 stack overflow, bit1 rng dimension overflow */
+    uint8_t *event_log = nullptr;   /* analysis hook, see log_event */
+    uint32_t event_cap = 0, event_len = 0;
 };
 
 /* ------------------------------------------------------------------------ */
@@ -273,11 +275,10 @@ inline float intersect_aabb(V3 bmin, V3 bmax, V3 ro, V3 rd, float prev_min_t) {
 }
 
 /* optional event log for tools/traversal_sim.py: one byte per node visit, 0 = inner node, 1 = leaf */
-thread_local uint8_t *g_event_log = nullptr;
-thread_local uint32_t g_event_cap = 0, g_event_len = 0;
-inline void log_event(uint8_t e) {
-    if (g_event_log && g_event_len < g_event_cap) g_event_log[g_event_len] = e;
-    g_event_len += 1;
+inline void log_event(Counters &cnt, uint8_t e) {
+    if (!cnt.event_log) return;
+    if (cnt.event_len < cnt.event_cap) cnt.event_log[cnt.event_len] = e;
+    cnt.event_len += 1;
 }
 
 template <bool NEAREST_HIT>
@@ -290,7 +291,7 @@ TraceResult intersect_front_to_back(const Scene &sc, V3 ro, V3 rd, float max_t, 
         uint32_t node_index = stack[--len];
         const rpt_bvh_node &node = sc.nodes[node_index];
         cnt.node_pops++;
-        log_event(node.triangle_count > 0 ? 1 : 0);
+        log_event(cnt, node.triangle_count > 0 ? 1 : 0);
         if (node.triangle_count > 0) {
             for (uint32_t i = 0; i < node.triangle_count; ++i) {
                 uint32_t triangle_index = node.left_or_first + i;
@@ -972,13 +973,12 @@ int oracle_trace_events(const oracle_scene *scene, size_t n, const float *origin
     Scene sc = make_scene(scene);
     Counters cnt;
     for (size_t i = 0; i < n; ++i) {
-        g_event_log = events + i * (size_t)max_events;
-        g_event_cap = max_events;
-        g_event_len = 0;
+        cnt.event_log = events + i * (size_t)max_events;
+        cnt.event_cap = max_events;
+        cnt.event_len = 0;
         intersect_front_to_back<true>(sc, xyz(origins + 3 * i), xyz(dirs + 3 * i), 0.0f, cnt);
-        lengths[i] = g_event_len;
+        lengths[i] = cnt.event_len;
     }
-    g_event_log = nullptr;
     return 0;
 }
 
