@@ -28,6 +28,9 @@
 #include "k_path.h"
 #include "rpt_fastdiv.h"
 
+template <bool LDS_SCENE> struct StackElem { typedef uint32_t type; };
+template <> struct StackElem<true> { typedef uint16_t type; };
+
 struct HitRecord {
     float t;
     uint32_t tri;     /* HIT_MISS or triangle index | backface << 31 */
@@ -89,9 +92,9 @@ __device__ __forceinline__ bool moller_trumbore(F3 ro, F3 rd, F3 a, F3 edge1, F3
 #ifndef RPT_LEAF_K
 #define RPT_LEAF_K 8
 #endif
-template <int STACK, bool ANY_HIT, bool FAST>
+template <int STACK, bool ANY_HIT, bool FAST, typename StackT>
 __device__ __forceinline__ HitRecord traverse_loop(const float4 *nodes, const float4 *tri_geom, F3 ro, F3 rd, F3 ird, float max_t,
-                                                   uint32_t *stack) {
+                                                   StackT *stack) {
     HitRecord res;
     res.t = 1000000.0f;
     res.tri = HIT_MISS;
@@ -116,7 +119,7 @@ __device__ __forceinline__ HitRecord traverse_loop(const float4 *nodes, const fl
             float dfar = swap ? dl : dr;
             if (dnear != __builtin_inff()) {
                 if (dfar != __builtin_inff() && sp < STACK) {
-                    stack[sp * RPT_WAVE] = swap ? cur_index : cur_index + 1u;   /* far child node id */
+                    stack[sp * RPT_WAVE] = (StackT)(swap ? cur_index : cur_index + 1u);   /* far child node id */
                     sp += 1;
                 }
                 cur_count = __float_as_uint(swap ? rmin.w : lmin.w);
@@ -159,16 +162,16 @@ __device__ __forceinline__ HitRecord traverse_loop(const float4 *nodes, const fl
     return res;
 }
 
-template <int STACK, bool ANY_HIT>
+template <int STACK, bool ANY_HIT, typename StackT>
 __device__ __forceinline__ HitRecord traverse_one(const float4 *nodes, const float4 *tri_geom, uint32_t fastdiv_ok, F3 ro, F3 rd,
-                                                  float max_t, uint32_t *stack) {
+                                                  float max_t, StackT *stack) {
     bool fast = fastdiv_ok != 0u && rptm::fastdiv_divisor_ok(rd.x) && rptm::fastdiv_divisor_ok(rd.y) && rptm::fastdiv_divisor_ok(rd.z) &&
                 rptm::fastdiv_operand_ok(ro.x) && rptm::fastdiv_operand_ok(ro.y) && rptm::fastdiv_operand_ok(ro.z);
     if (fast) {
         F3 ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-        return traverse_loop<STACK, ANY_HIT, true>(nodes, tri_geom, ro, rd, ird, max_t, stack);
+        return traverse_loop<STACK, ANY_HIT, true, StackT>(nodes, tri_geom, ro, rd, ird, max_t, stack);
     }
-    return traverse_loop<STACK, ANY_HIT, false>(nodes, tri_geom, ro, rd, rd, max_t, stack);
+    return traverse_loop<STACK, ANY_HIT, false, StackT>(nodes, tri_geom, ro, rd, rd, max_t, stack);
 }
 
 /* Small scenes live in LDS: when nodes + triangle geometry fit in RPT_LDS_SCENE_BYTES
@@ -199,7 +202,10 @@ __device__ __forceinline__ void stage_scene(const DevScene &sc, float4 *lds_scen
  * stores the same value), which the shade stage reports to the host. */
 template <int STACK, bool LDS_SCENE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevState st, DevQueues q, uint32_t iteration) {
-    __shared__ uint32_t lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
+    /* an LDS-resident scene has < 768 nodes: 16-bit stack entries halve the stack (36 KB per 512-thread
+     * workgroup with the scene -> 4 workgroups = 32 waves per CU instead of 24) */
+    typedef typename StackElem<LDS_SCENE>::type StackT;
+    __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
     const uint32_t slot = blockIdx.x * THREADS + threadIdx.x;
     if (slot == 0u) {
@@ -232,8 +238,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     if (!pending) return;
     float4 ra = st.ray_a[slot];
     F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
-    uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, false>(nodes, tri_geom, sc.fastdiv_ok, ro, rd, 0.0f, stack);
+    StackT *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
+    HitRecord h = traverse_one<STACK, false, StackT>(nodes, tri_geom, sc.fastdiv_ok, ro, rd, 0.0f, stack);
     float2 *out = reinterpret_cast<float2 *>(&st.ray_b[slot]);
     out[1] = make_float2(h.t, __uint_as_float(h.tri));
 }
@@ -245,7 +251,10 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
  * in place (its slot becomes HIT_PENDING again). */
 template <int STACK, bool LDS_SCENE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats) {
-    __shared__ uint32_t lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
+    /* an LDS-resident scene has < 768 nodes: 16-bit stack entries halve the stack (36 KB per 512-thread
+     * workgroup with the scene -> 4 workgroups = 32 waves per CU instead of 24) */
+    typedef typename StackElem<LDS_SCENE>::type StackT;
+    __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
     uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     uint32_t n = q.count[Q_SHADOW];
@@ -258,8 +267,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
     uint32_t tag = __float_as_uint(d.w);
     uint32_t slot = tag & 0x7fffffffu;
     bool finish = (tag >> 31) != 0u;
-    uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, true>(nodes, tri_geom, sc.fastdiv_ok, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
+    StackT *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
+    HitRecord h = traverse_one<STACK, true, StackT>(nodes, tri_geom, sc.fastdiv_ok, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
     bool visible = h.tri == HIT_MISS;
     if (visible || finish) {
         float4 tr = st.thr_rad[slot];
@@ -283,7 +292,10 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
 template <int STACK, bool ANY_HIT, bool LDS_SCENE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_trace_debug(DevScene sc, uint32_t n, const float *origins, const float *dirs,
                                                          const float *max_t, float *out_t, uint32_t *out_tri, uint32_t *out_flags) {
-    __shared__ uint32_t lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
+    /* an LDS-resident scene has < 768 nodes: 16-bit stack entries halve the stack (36 KB per 512-thread
+     * workgroup with the scene -> 4 workgroups = 32 waves per CU instead of 24) */
+    typedef typename StackElem<LDS_SCENE>::type StackT;
+    __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
     uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     const float4 *nodes, *tri_geom;
@@ -291,8 +303,8 @@ __global__ __launch_bounds__(THREADS) void k_trace_debug(DevScene sc, uint32_t n
     if (i >= n) return;
     F3 ro = f3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
     F3 rd = f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
-    uint32_t *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, ANY_HIT>(nodes, tri_geom, sc.fastdiv_ok, ro, rd, ANY_HIT ? max_t[i] : 0.0f, stack);
+    StackT *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
+    HitRecord h = traverse_one<STACK, ANY_HIT, StackT>(nodes, tri_geom, sc.fastdiv_ok, ro, rd, ANY_HIT ? max_t[i] : 0.0f, stack);
     out_t[i] = h.t;
     out_tri[i] = (h.tri == HIT_MISS) ? 0u : (h.tri & 0x7fffffffu);
     out_flags[i] = (h.tri == HIT_MISS) ? 0u : (1u | ((h.tri >> 31) << 1));

@@ -111,7 +111,7 @@ def main():
         report("if-if (one step per iter)", [sim_if_if(*wv) for wv in waves], n_rays)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold", "sort")):
     main()
 
 
@@ -259,3 +259,43 @@ def main_threshold():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "threshold":
     main_threshold()
+
+
+def main_sort():
+    """Does regrouping the rays of a 512-thread workgroup by direction (octant / finer) help a wave's coherence?"""
+    scene = sys.argv[2] if len(sys.argv) > 2 else "DarkCornell"
+    W = H = 128
+    orc = Oracle()
+    w = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    sc = orc.scene(w)
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    order = hip.tile_order(W, H, 0, 1)
+    px = (order >> 16).astype(np.int64) * W + (order & 0xFFFF).astype(np.int64)
+    bounce = 2
+    rays = np.zeros((W * H, 6), np.float32)
+    valid = np.zeros(W * H, np.uint8)
+    orc.lib.oracle_dump_rays(C.byref(cfg), C.byref(sc), seeds.ctypes.data_as(C.c_void_p), C.c_uint32(bounce),
+                             rays.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+    rays, valid = rays[px], valid[px]
+    ev, ln = events_for(orc, sc, np.ascontiguousarray(rays[:, :3]), np.ascontiguousarray(rays[:, 3:]))
+    ln = np.where(valid == 1, ln, 0)
+    n = 8192
+    d = rays[:n, 3:]
+    for name, keyfn in [("none", None),
+                        ("octant", lambda d: (d[:, 0] > 0) * 4 + (d[:, 1] > 0) * 2 + (d[:, 2] > 0)),
+                        ("octant+major axis", lambda d: ((d[:, 0] > 0) * 4 + (d[:, 1] > 0) * 2 + (d[:, 2] > 0)) * 3 + np.argmax(np.abs(d), axis=1)),
+                        ("path length (oracle knowledge)", "len")]:
+        for group in (512, 2048):
+            perm = np.arange(n)
+            if keyfn is not None:
+                for b in range(0, n, group):
+                    sl = slice(b, b + group)
+                    key = ln[sl] if keyfn == "len" else keyfn(d[sl])
+                    perm[sl] = b + np.argsort(key, kind="stable")
+            c = sim_threshold(ev[perm], ln[perm], valid[:n][perm], 64, 64, 8)
+            print(f"  regroup by {name:32s} within {group:5d}: cost/ray {c/int(valid[:n].sum()):7.1f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sort":
+    main_sort()
