@@ -233,6 +233,59 @@ def test_resolve_and_tonemap_parity(renderer, oracle, rpt, world):
     assert np.array_equal(renderer.resolve(0), acc[..., :3] / np.float32(n))
 
 
+EDGE_CASES = [
+    # W, H, spp, config overrides — degenerate sizes and bounce settings
+    (1, 1, 5, {}),
+    (3, 5, 4, {"nee": 1}),
+    (65, 64, 3, {}),                                          # one pixel column spills into a second tile
+    (40, 40, 3, {"max_bounces": 0}),                          # the bounce loop never runs: black image, w = spp
+    (40, 40, 3, {"max_bounces": 1}),
+    (40, 40, 4, {"min_bounces": 0, "max_bounces": 4}),        # roulette from bounce 1 on
+    (40, 40, 4, {"min_bounces": 9, "max_bounces": 2, "nee": 2}),
+    (40, 40, 3, {"nee": 7}),                                  # NextEventEstimation::from_u32(7) == None
+    (40, 40, 3, {"specular_weight_clamp": (0.0, 1.0)}),
+    (48, 32, 3, {"cam_position": (0.0, 1.0, 0.5, 0.0)}),     # camera inside the geometry
+]
+
+
+@pytest.mark.parametrize("W,H,spp,over", EDGE_CASES)
+def test_edge_configurations(renderer, oracle, rpt, world, W, H, spp, over):
+    for scene in ("DarkCornell", "VeachMIS"):
+        w = world(scene)
+        cfg = rpt.default_config(W, H, **over)
+        seeds = rpt.blue_noise_seeds(W, H)
+        renderer.upload_scene(w)
+        renderer.set_config(cfg)
+        renderer.reset(seeds)
+        renderer.render(0)                                    # a zero-sample batch is a no-op
+        renderer.render(spp)
+        acc, n = renderer.read_accum()
+        ref, rng_ref, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+        assert n == spp and st.error_flags == 0
+        assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), (scene, over)
+        assert np.array_equal(renderer.read_rng()["n"], rng_ref["n"])
+        g = renderer.stats()
+        assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays
+
+
+def test_uniform_seed_mode(renderer, oracle, rpt, world):
+    """rng_data_uniform (reference: src/trace.rs:158): n = random u32, offset = 0 — caller-supplied here."""
+    W, H, spp = 64, 48, 4
+    w = world("DarkCornell")
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = np.zeros(W * H, rpt._ffi.RNG_DTYPE)
+    seeds["n"] = np.random.default_rng(99).integers(0, 2 ** 32, W * H, dtype=np.uint64).astype(np.uint32)
+    seeds["n"][:4] = [0xFFFFFFFF, 0xFFFFFFFE, 0, 1]           # n + 1 wraps
+    renderer.upload_scene(w)
+    renderer.set_config(cfg)
+    renderer.reset(seeds)
+    renderer.render(spp)
+    acc, _ = renderer.read_accum()
+    ref, rng_ref, _ = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(renderer.read_rng()["n"], rng_ref["n"])
+
+
 def test_render_in_batches_equals_one_batch(renderer, rpt, world):
     w = world("DarkCornell")
     cfg = rpt.default_config(96, 96, nee=1)
