@@ -52,6 +52,19 @@ def algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples):
 TRAVERSE_BYTES_PER_RAY = 32 + 8
 
 
+def usable_cores():
+    """Host threads this process may actually run: affinity mask, capped by the cgroup CPU quota (the GPU box
+    shows 256 hardware threads but cpu.max = 16 CPUs; more threads than that only adds throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +223,7 @@ def main():
         from oracle_ffi import Oracle
         orc = Oracle("rpt_math")
         osc = orc.scene(world)
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         rows = max(8, H // 16)
         rect = (0, (H - rows) // 2, W, (H - rows) // 2 + rows)
         _, _, st = orc.trace_cpu(cfg, osc, seeds, 1, rect=rect, threads=cores)     # calibration pass

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""The reference's own criterion benches (benches/benchmark.rs:8-25), re-run through the host-side dispatch mirror:
+
+  "160 samples (GPU)":  trace_gpu("scenes/DarkCornell.glb", None, setup_trace(1280, 720, 160))   reference comment: 2.408 s
+  "32 samples (CPU)":   trace_cpu(same scene, setup_trace(1280, 720, 32))                        reference comment: 12.891 s
+  "Startup time (GPU)": trace_gpu(scene, setup_trace(1280, 720, 0)) — BreakTime.glb is missing, so DarkCornell and the
+                        1 M-triangle stand-in are timed instead.
+
+Wall time INCLUDES scene import, BVH build, light table, upload and (GPU) context creation, like the originals.
+The CPU row uses the oracle (test infrastructure) on all host cores.  Hardware of the reference numbers is unstated.
+"""
+import importlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+rpt = importlib.import_module("rust-path-tracer_amd")
+
+
+def gpu_run(samples, reps=3):
+    best = 1e9
+    for _ in range(reps):
+        t = time.perf_counter()
+        state = rpt.setup_trace(1280, 720, samples)
+        rpt.trace_gpu(rpt.fixture("DarkCornell.glb"), None, state)
+        dt = time.perf_counter() - t
+        assert state.samples == samples
+        state.close()
+        best = min(best, dt)
+    return best
+
+
+def cpu_run(samples):
+    from oracle_ffi import Oracle
+    t = time.perf_counter()
+    world = rpt.World.from_path(rpt.fixture("DarkCornell.glb"))
+    orc = Oracle()
+    cfg = rpt.default_config(1280, 720)
+    import bench
+    acc, _, st = orc.trace_cpu(cfg, orc.scene(world), rpt.blue_noise_seeds(1280, 720), samples, threads=bench.usable_cores())
+    return time.perf_counter() - t, st.threads
+
+
+if __name__ == "__main__":
+    print(f"160 samples (GPU), DarkCornell 1280x720 incl. startup: {gpu_run(160):.3f} s   (reference comment: 2.408 s)")
+    print(f"Startup time (GPU), DarkCornell, 0 samples:            {gpu_run(0):.3f} s   (reference: 3.021 s on BreakTime.glb)")
+    dt, th = cpu_run(32)
+    print(f"32 samples (CPU oracle, {th} threads) incl. startup:       {dt:.3f} s   (reference comment: 12.891 s)")
