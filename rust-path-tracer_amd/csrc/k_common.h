@@ -68,6 +68,10 @@ struct DevImage {
     uint32_t width, height;
 };
 
+/* wave64 ballot of a bool that already lives in an SGPR mask: HIP's __ballot(int) first materialises the
+ * predicate as 0/1 in a VGPR and compares it again (two extra VALU instructions per ballot). */
+__device__ __forceinline__ unsigned long long rpt_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 struct DevScene {
     const float4 *nodes;           /* 2 x float4 per rpt_bvh_node, reference layout */
     const float4 *tri_geom;        /* 3 x float4 per triangle: (a | d00), (e1 = b-a | d01), (e2 = c-a | d11);
@@ -81,6 +85,8 @@ struct DevScene {
     uint32_t n_light_pick;
     uint32_t n_nodes, n_triangles;
     uint32_t lds_scene;            /* nodes + tri_geom fit in RPT_LDS_SCENE_BYTES: traverse out of LDS */
+    const float4 *lds_image;       /* LDS-resident traversal image (k_traverse.h SceneViewLds), lds_vecs float4 */
+    uint32_t lds_pairs, lds_vecs, lds_root;
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */
     uint32_t fastdiv_ok;           /* every node bound is 0 or in [2^-60, 2^40): exact fast division allowed */
     uint32_t textured;             /* some material has a texture flag set */
@@ -156,7 +162,7 @@ struct DevConfig {
 /* wave64 ballot + prefix compaction: every lane calls it (converged); lanes with
  * pred get a dense index in the queue, one atomic per wave. */
 __device__ __forceinline__ uint32_t wave_push(uint32_t *counter, bool pred) {
-    unsigned long long mask = __ballot(pred);
+    unsigned long long mask = rpt_ballot(pred);
     if (mask == 0ull) return 0u;
     uint32_t lane = __lane_id();
     uint32_t total = (uint32_t)__popcll(mask);
@@ -181,7 +187,7 @@ __device__ __forceinline__ void raise_flag(uint32_t *flag) {
 __device__ __forceinline__ uint32_t block_push(uint32_t *counter, bool pred, uint32_t *scratch) {
     const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
     constexpr uint32_t NW = RPT_BLOCK / RPT_WAVE;
-    unsigned long long mask = __ballot(pred);
+    unsigned long long mask = rpt_ballot(pred);
     if (lane == 0u) scratch[wave] = (uint32_t)__popcll(mask);
     __syncthreads();
     if (threadIdx.x == 0u) {

@@ -93,12 +93,12 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
                 started = true;
             }
         }
-        unsigned long long any = __ballot(started);
+        unsigned long long any = rpt_ballot(started);
         if (any != 0ull && lane == (uint32_t)__ffsll((long long)any) - 1u) raise_flag(regen_flag);
         return;
     }
     const uint32_t g0 = lane & ~(S - 1u);
-    const unsigned long long done_m = __ballot(done), idle_m = __ballot(idle);
+    const unsigned long long done_m = rpt_ballot(done), idle_m = rpt_ballot(idle);
     if (done_m == 0ull) return;
     const unsigned long long gm = (S >= 64u ? ~0ull : ((1ull << S) - 1ull)) << g0;
     const bool complete = (((done_m | idle_m) & gm) == gm) && ((done_m & gm) != 0ull);
@@ -125,7 +125,7 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
     const uint32_t new_n = (uint32_t)__shfl((int)rs.x, (int)g0, RPT_WAVE);
     const uint32_t offset = (uint32_t)__shfl((int)rs.y, (int)g0, RPT_WAVE);
     {   /* tell the host that new samples were started (one plain store per wave, every writer stores 1) */
-        unsigned long long started = __ballot(done && complete && __float_as_uint(rm.w) != 0u);
+        unsigned long long started = rpt_ballot(done && complete && __float_as_uint(rm.w) != 0u);
         if (started != 0ull && lane == (uint32_t)__ffsll((long long)started) - 1u) raise_flag(regen_flag);
     }
     if (!done) return;

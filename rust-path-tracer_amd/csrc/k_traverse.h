@@ -36,9 +36,12 @@ struct HitRecord {
     uint32_t tri;     /* HIT_MISS or triangle index | backface << 31 */
 };
 
-/* intersection.rs:104-122 — NaN-ignoring min/max, strict comparisons as written */
+/* intersection.rs:104-122 — NaN-ignoring min/max, strict comparisons as written.  The reference returns
+ * tmin or +inf; callers only ever compare that value, so it is kept as (hit, tmin): a hit has a non-NaN
+ * tmin < prev_min_t < inf, and "dl > dr" on the inf-encoded values (intersection.rs:216) is
+ * hit_r && (!hit_l || tmin_l > tmin_r) — predicates that stay in scalar mask registers. */
 template <bool FAST>
-__device__ __forceinline__ float slab_test(float4 lo, float4 hi, F3 ro, F3 rd, F3 ird, float prev_min_t) {
+__device__ __forceinline__ bool slab_test(float4 lo, float4 hi, F3 ro, F3 rd, F3 ird, float prev_min_t, float &tmin_out) {
     float tx1, tx2, ty1, ty2, tz1, tz2;
     if (FAST) {
         tx1 = rptm::div_by_rcp(lo.x - ro.x, rd.x, ird.x); tx2 = rptm::div_by_rcp(hi.x - ro.x, rd.x, ird.x);
@@ -55,17 +58,91 @@ __device__ __forceinline__ float slab_test(float4 lo, float4 hi, F3 ro, F3 rd, F
     tmax = rptm::fminr(tmax, rptm::fmaxr(ty1, ty2));
     tmin = rptm::fmaxr(tmin, rptm::fminr(tz1, tz2));
     tmax = rptm::fminr(tmax, rptm::fmaxr(tz1, tz2));
-    return (tmax >= tmin && tmax > 0.0f && tmin < prev_min_t) ? tmin : __builtin_inff();
+    tmin_out = tmin;
+    return tmax >= tmin && tmax > 0.0f && tmin < prev_min_t;
 }
 
-/* intersection.rs:9-54 with edge1/edge2 precomputed at upload */
-__device__ __forceinline__ bool moller_trumbore(F3 ro, F3 rd, F3 a, F3 edge1, F3 edge2, float &out_t, bool &backface) {
+/* How a traversal reads the scene.  Two images of the same BVH:
+ *
+ * SceneViewGlobal — the uploaded node array as is (children adjacent, one visit = 64 contiguous bytes = half a
+ *   cache line through L1/L2) and the (a, e1, e2) triangle records.
+ *
+ * SceneViewLds — the LDS-resident image of a small scene, built once at upload (rpt_hip.hip, build_lds_image).
+ *   ds_read_b128 serves a wave in four groups of 16 lanes and banks by (addr/4) mod 64, i.e. 16 slots of 16 bytes.
+ *   In the uploaded layout chunk j of child pair p sits at slot (4p + j) mod 16: for a given load instruction the
+ *   16 lanes of a group can only ever land on 4 of the 16 slots, so incoherent rays serialise 3-4 deep and the
+ *   LDS array, not the VALU, sets the pace (4 loads x 4 groups x conflicts > the ~110 VALU cycles of a visit).
+ *   The image is therefore stored as four arrays indexed by pair — left.min | right.min | left.max | right.max —
+ *   so that instruction j of pair p lands on slot (const_j + p) mod 16: all 16 slots in play.  Triangles likewise
+ *   (a[] | e1[] | e2[]).  The .w lane of a min chunk carries the child's packed descriptor
+ *   (triangle_count << 16 | first_triangle, or the pair index of an inner child), so entering or popping a node
+ *   is one dword instead of two.  Pair p holds nodes 2p+1 and 2p+2 (the builder allocates children in pairs
+ *   from node 1, bvh.rs:296-299); a node array that is not shaped like that simply is not given an LDS image. */
+struct SceneViewGlobal {
+    const float4 *nodes, *tri_geom;
+    typedef uint2 Cur;                                      /* x = triangle_count, y = left child / first triangle */
+    __device__ __forceinline__ Cur root() const { return make_uint2(__float_as_uint(nodes[0].w), __float_as_uint(nodes[1].w)); }
+    /* a finished lane carries count = 0x80000000: both predicates are single compares on the register (a ballot
+     * of a compare is the compare itself; a ballot of a loop-carried bool costs two more VALU instructions) */
+    __device__ __forceinline__ static bool is_inner(Cur c) { return c.x == 0u; }
+    __device__ __forceinline__ static bool is_leaf(Cur c) { return (int32_t)c.x > 0; }
+    __device__ __forceinline__ static Cur dead() { return make_uint2(0x80000000u, 0u); }
+    __device__ __forceinline__ static uint32_t leaf_count(Cur c) { return c.x; }
+    __device__ __forceinline__ static uint32_t leaf_first(Cur c) { return c.y; }
+    __device__ __forceinline__ void children(Cur c, float4 &lmin, float4 &lmax, float4 &rmin, float4 &rmax) const {
+        const float4 *ch = nodes + 2u * c.y;
+        lmin = ch[0]; lmax = ch[1]; rmin = ch[2]; rmax = ch[3];
+    }
+    __device__ __forceinline__ static Cur enter(bool right, float4 lmin, float4 lmax, float4 rmin, float4 rmax) {
+        return make_uint2(__float_as_uint(right ? rmin.w : lmin.w), __float_as_uint(right ? rmax.w : lmax.w));
+    }
+    __device__ __forceinline__ uint32_t far_entry(Cur c, bool far_is_left) const { return far_is_left ? c.y : c.y + 1u; }
+    __device__ __forceinline__ Cur from_entry(uint32_t e) const {
+        return make_uint2(__float_as_uint(nodes[2u * e].w), __float_as_uint(nodes[2u * e + 1u].w));
+    }
+    __device__ __forceinline__ void edges(uint32_t ti, F3 &e1, F3 &e2) const { e1 = xyz4(tri_geom[3u * ti + 1u]); e2 = xyz4(tri_geom[3u * ti + 2u]); }
+    __device__ __forceinline__ F3 corner(uint32_t ti) const { return xyz4(tri_geom[3u * ti]); }
+};
+
+struct SceneViewLds {
+    const float4 *img;
+    uint32_t pairs, tris, root_word;
+    typedef uint32_t Cur;                                   /* count << 16 | first triangle; count == 0: pair index */
+    __device__ __forceinline__ Cur root() const { return root_word; }
+    __device__ __forceinline__ static bool is_inner(Cur c) { return c < 0x10000u; }
+    __device__ __forceinline__ static bool is_leaf(Cur c) { return (int32_t)c > 0xffff; }
+    __device__ __forceinline__ static Cur dead() { return 0x80000000u; }
+    __device__ __forceinline__ static uint32_t leaf_count(Cur c) { return c >> 16; }
+    __device__ __forceinline__ static uint32_t leaf_first(Cur c) { return c & 0xffffu; }
+    __device__ __forceinline__ void children(Cur c, float4 &lmin, float4 &lmax, float4 &rmin, float4 &rmax) const {
+        const float4 *ch = img + c;
+        lmin = ch[0]; rmin = ch[pairs]; lmax = ch[2u * pairs]; rmax = ch[3u * pairs];
+    }
+    __device__ __forceinline__ static Cur enter(bool right, float4 lmin, float4, float4 rmin, float4) {
+        return __float_as_uint(right ? rmin.w : lmin.w);
+    }
+    /* stack entries index the two min arrays directly: left of pair p = p, right = pairs + p */
+    __device__ __forceinline__ uint32_t far_entry(Cur c, bool far_is_left) const { return far_is_left ? c : c + pairs; }
+    __device__ __forceinline__ Cur from_entry(uint32_t e) const { return __float_as_uint(img[e].w); }
+    __device__ __forceinline__ void edges(uint32_t ti, F3 &e1, F3 &e2) const {
+        const float4 *t = img + 4u * pairs + ti;
+        e1 = xyz4(t[tris]); e2 = xyz4(t[2u * tris]);
+    }
+    __device__ __forceinline__ F3 corner(uint32_t ti) const { return xyz4(img[4u * pairs + ti]); }
+};
+
+/* intersection.rs:9-54 with edge1/edge2 precomputed at upload; the corner is fetched only by lanes that get
+ * past the determinant test */
+template <typename View>
+__device__ __forceinline__ bool moller_trumbore_view(const View &view, uint32_t ti, F3 ro, F3 rd, float &out_t, bool &backface) {
+    F3 edge1, edge2;
+    view.edges(ti, edge1, edge2);
     F3 pv = cross3(rd, edge2);
     float det = dot3(edge1, pv);
     backface = (rptm::f2u(det) >> 31) != 0u;
     if (rptm::absr(det) < 1e-6f) return false;
     float inv_det = 1.0f / det;
-    F3 tv = ro - a;
+    F3 tv = ro - view.corner(ti);
     float u = dot3(tv, pv) * inv_det;
     if (u < 0.0f || u > 1.0f) return false;
     F3 qv = cross3(tv, edge1);
@@ -92,108 +169,96 @@ __device__ __forceinline__ bool moller_trumbore(F3 ro, F3 rd, F3 a, F3 edge1, F3
 #ifndef RPT_LEAF_K
 #define RPT_LEAF_K 8
 #endif
-template <int STACK, bool ANY_HIT, bool FAST, typename StackT>
-__device__ __forceinline__ HitRecord traverse_loop(const float4 *nodes, const float4 *tri_geom, F3 ro, F3 rd, F3 ird, float max_t,
-                                                   StackT *stack) {
+template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackT>
+__device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 rd, F3 ird, float max_t, StackT *stack) {
+    typedef typename View::Cur Cur;
     HitRecord res;
     res.t = 1000000.0f;
     res.tri = HIT_MISS;
     int sp = 0;
-    /* current node's metadata (aabb_min.w = triangle_count, aabb_max.w = left/first) */
-    uint32_t cur_count = __float_as_uint(nodes[0].w);
-    uint32_t cur_index = __float_as_uint(nodes[1].w);
-    bool alive = true;
+    Cur cur = view.root();
     for (;;) {
-        const bool at_inner = alive && cur_count == 0u;
-        const bool at_leaf = alive && cur_count != 0u;
-        const unsigned long long inner_m = __ballot(at_inner), leaf_m = __ballot(at_leaf);
+        const bool at_inner = View::is_inner(cur);
+        const bool at_leaf = View::is_leaf(cur);
+        const unsigned long long inner_m = rpt_ballot(at_inner), leaf_m = rpt_ballot(at_leaf);
         if ((inner_m | leaf_m) == 0ull) break;
         if (at_inner) {
             /* inner node (:207-229): test both children against the current best t */
-            const float4 *ch = nodes + 2u * cur_index;
-            float4 lmin = ch[0], lmax = ch[1], rmin = ch[2], rmax = ch[3];
-            float dl = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t);
-            float dr = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t);
-            bool swap = dl > dr;                    /* strict: ties keep left first */
-            float dnear = swap ? dr : dl;
-            float dfar = swap ? dl : dr;
-            if (dnear != __builtin_inff()) {
-                if (dfar != __builtin_inff() && sp < STACK) {
-                    stack[sp * RPT_WAVE] = (StackT)(swap ? cur_index : cur_index + 1u);   /* far child node id */
+            float4 lmin, lmax, rmin, rmax;
+            view.children(cur, lmin, lmax, rmin, rmax);
+            float tl, tr;
+            const bool hit_l = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t, tl);
+            const bool hit_r = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t, tr);
+            const bool swap = hit_r && (!hit_l || tl > tr);     /* strict: ties keep left first */
+            if (hit_l || hit_r) {
+                if (hit_l && hit_r && sp < STACK) {
+                    stack[sp * RPT_WAVE] = (StackT)view.far_entry(cur, swap);
                     sp += 1;
                 }
-                cur_count = __float_as_uint(swap ? rmin.w : lmin.w);
-                cur_index = __float_as_uint(swap ? rmax.w : lmax.w);
+                cur = View::enter(swap, lmin, lmax, rmin, rmax);
             } else if (sp == 0) {
-                alive = false;
+                cur = View::dead();
             } else {
                 sp -= 1;
-                uint32_t node = stack[sp * RPT_WAVE];
-                cur_count = __float_as_uint(nodes[2u * node].w);
-                cur_index = __float_as_uint(nodes[2u * node + 1u].w);
+                cur = view.from_entry(stack[sp * RPT_WAVE]);
             }
         }
         if (at_leaf && ((uint32_t)__popcll(leaf_m) >= (uint32_t)RPT_LEAF_K || inner_m == 0ull)) {
             /* leaf triangles in index order (:186-205) */
             bool accepted = false;
-            for (uint32_t i = 0; i < cur_count; ++i) {
-                uint32_t ti = cur_index + i;
-                F3 a = xyz4(tri_geom[3u * ti]);
-                F3 e1 = xyz4(tri_geom[3u * ti + 1u]);
-                F3 e2 = xyz4(tri_geom[3u * ti + 2u]);
+            const uint32_t count = View::leaf_count(cur), first = View::leaf_first(cur);
+            for (uint32_t i = 0; i < count; ++i) {
+                uint32_t ti = first + i;
                 float t = 0.0f;
                 bool bf = false;
-                if (moller_trumbore(ro, rd, a, e1, e2, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
+                if (moller_trumbore_view(view, ti, ro, rd, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
                     res.t = rptm::fminr(res.t, t);
                     res.tri = ti | (bf ? 0x80000000u : 0u);
                     if (ANY_HIT) { accepted = true; break; }
                 }
             }
             if ((ANY_HIT && accepted) || sp == 0) {
-                alive = false;
+                cur = View::dead();
             } else {
                 sp -= 1;
-                uint32_t node = stack[sp * RPT_WAVE];
-                cur_count = __float_as_uint(nodes[2u * node].w);
-                cur_index = __float_as_uint(nodes[2u * node + 1u].w);
+                cur = view.from_entry(stack[sp * RPT_WAVE]);
             }
         }
     }
     return res;
 }
 
-template <int STACK, bool ANY_HIT, typename StackT>
-__device__ __forceinline__ HitRecord traverse_one(const float4 *nodes, const float4 *tri_geom, uint32_t fastdiv_ok, F3 ro, F3 rd,
-                                                  float max_t, StackT *stack) {
+template <int STACK, bool ANY_HIT, typename View, typename StackT>
+__device__ __forceinline__ HitRecord traverse_one(const View &view, uint32_t fastdiv_ok, F3 ro, F3 rd, float max_t, StackT *stack) {
     bool fast = fastdiv_ok != 0u && rptm::fastdiv_divisor_ok(rd.x) && rptm::fastdiv_divisor_ok(rd.y) && rptm::fastdiv_divisor_ok(rd.z) &&
                 rptm::fastdiv_operand_ok(ro.x) && rptm::fastdiv_operand_ok(ro.y) && rptm::fastdiv_operand_ok(ro.z);
     if (fast) {
         F3 ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-        return traverse_loop<STACK, ANY_HIT, true, StackT>(nodes, tri_geom, ro, rd, ird, max_t, stack);
+        return traverse_loop<STACK, ANY_HIT, true>(view, ro, rd, ird, max_t, stack);
     }
-    return traverse_loop<STACK, ANY_HIT, false, StackT>(nodes, tri_geom, ro, rd, rd, max_t, stack);
+    return traverse_loop<STACK, ANY_HIT, false>(view, ro, rd, rd, max_t, stack);
 }
 
 /* Small scenes live in LDS: when nodes + triangle geometry fit in RPT_LDS_SCENE_BYTES
- * every workgroup copies them in once and traverses out of LDS (ds_read_b128,
- * ~64-cycle latency, no pressure on the CU's single vector-memory address unit —
- * the measured limiter once the divisions were gone: ~380 divergent 16-byte
+ * every workgroup copies the upload-time LDS image in once and traverses out of LDS
+ * (ds_read_b128, ~64-cycle latency, no pressure on the CU's single vector-memory address
+ * unit — the measured limiter once the divisions were gone: ~380 divergent 16-byte
  * wave-loads per wave through one TA per CU).  Larger scenes read through L1/L2. */
 #define RPT_LDS_SCENE_BYTES 24576
 extern __shared__ __attribute__((aligned(16))) float4 rpt_lds_dyn[];   /* sized at launch to the scene (LDS variants only) */
+template <bool LDS_SCENE> struct SceneViewOf { typedef SceneViewGlobal type; };
+template <> struct SceneViewOf<true> { typedef SceneViewLds type; };
+
+template <int THREADS>
+__device__ __forceinline__ SceneViewLds stage_scene_lds(const DevScene &sc, float4 *lds_scene) {
+    for (uint32_t k = threadIdx.x; k < sc.lds_vecs; k += THREADS) lds_scene[k] = sc.lds_image[k];
+    __syncthreads();
+    return SceneViewLds{lds_scene, sc.lds_pairs, sc.n_triangles, sc.lds_root};
+}
 template <bool LDS_SCENE, int THREADS>
-__device__ __forceinline__ void stage_scene(const DevScene &sc, float4 *lds_scene, const float4 *&nodes, const float4 *&tri_geom) {
-    if (LDS_SCENE) {
-        const uint32_t n_node_vec = 2u * sc.n_nodes, n_tri_vec = 3u * sc.n_triangles;
-        for (uint32_t k = threadIdx.x; k < n_node_vec; k += THREADS) lds_scene[k] = sc.nodes[k];
-        for (uint32_t k = threadIdx.x; k < n_tri_vec; k += THREADS) lds_scene[n_node_vec + k] = sc.tri_geom[k];
-        __syncthreads();
-        nodes = lds_scene;
-        tri_geom = lds_scene + n_node_vec;
-    } else {
-        nodes = sc.nodes;
-        tri_geom = sc.tri_geom;
-    }
+__device__ __forceinline__ typename SceneViewOf<LDS_SCENE>::type stage_scene(const DevScene &sc, float4 *lds_scene) {
+    if constexpr (LDS_SCENE) return stage_scene_lds<THREADS>(sc, lds_scene);
+    else return SceneViewGlobal{sc.nodes, sc.tri_geom};
 }
 
 /* Extension rays.  Thread i owns slot i; it traces the slot's ray if one is
@@ -226,9 +291,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
         pending = __float_as_uint(rb.w) == HIT_PENDING;
     }
     if (LDS_SCENE && !__syncthreads_or(pending)) return;      /* block-uniform: nothing to trace here */
-    const float4 *nodes, *tri_geom;
-    stage_scene<LDS_SCENE, THREADS>(sc, lds_scene, nodes, tri_geom);
-    unsigned long long active = __ballot(pending);
+    const auto view = stage_scene<LDS_SCENE, THREADS>(sc, lds_scene);
+    unsigned long long active = rpt_ballot(pending);
     if (active == 0ull) return;
     if (__lane_id() == (uint32_t)__ffsll((long long)active) - 1u) {
         raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
@@ -239,7 +303,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     float4 ra = st.ray_a[slot];
     F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
     StackT *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, false, StackT>(nodes, tri_geom, sc.fastdiv_ok, ro, rd, 0.0f, stack);
+    HitRecord h = traverse_one<STACK, false>(view, sc.fastdiv_ok, ro, rd, 0.0f, stack);
     float2 *out = reinterpret_cast<float2 *>(&st.ray_b[slot]);
     out[1] = make_float2(h.t, __uint_as_float(h.tri));
 }
@@ -260,15 +324,14 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
     uint32_t n = q.count[Q_SHADOW];
     if (i == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
     if (blockIdx.x * THREADS >= n) return;                     /* block-uniform */
-    const float4 *nodes, *tri_geom;
-    stage_scene<LDS_SCENE, THREADS>(sc, lds_scene, nodes, tri_geom);
+    const auto view = stage_scene<LDS_SCENE, THREADS>(sc, lds_scene);
     if (i >= n) return;
     float4 o = q.sh_o[i], d = q.sh_d[i];
     uint32_t tag = __float_as_uint(d.w);
     uint32_t slot = tag & 0x7fffffffu;
     bool finish = (tag >> 31) != 0u;
     StackT *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, true, StackT>(nodes, tri_geom, sc.fastdiv_ok, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
+    HitRecord h = traverse_one<STACK, true>(view, sc.fastdiv_ok, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
     bool visible = h.tri == HIT_MISS;
     if (visible || finish) {
         float4 tr = st.thr_rad[slot];
@@ -298,13 +361,12 @@ __global__ __launch_bounds__(THREADS) void k_trace_debug(DevScene sc, uint32_t n
     __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
     uint32_t i = blockIdx.x * THREADS + threadIdx.x;
-    const float4 *nodes, *tri_geom;
-    stage_scene<LDS_SCENE, THREADS>(sc, lds_scene, nodes, tri_geom);
+    const auto view = stage_scene<LDS_SCENE, THREADS>(sc, lds_scene);
     if (i >= n) return;
     F3 ro = f3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
     F3 rd = f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
     StackT *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
-    HitRecord h = traverse_one<STACK, ANY_HIT, StackT>(nodes, tri_geom, sc.fastdiv_ok, ro, rd, ANY_HIT ? max_t[i] : 0.0f, stack);
+    HitRecord h = traverse_one<STACK, ANY_HIT>(view, sc.fastdiv_ok, ro, rd, ANY_HIT ? max_t[i] : 0.0f, stack);
     out_t[i] = h.t;
     out_tri[i] = (h.tri == HIT_MISS) ? 0u : (h.tri & 0x7fffffffu);
     out_flags[i] = (h.tri == HIT_MISS) ? 0u : (1u | ((h.tri >> 31) << 1));

@@ -67,7 +67,7 @@ struct rpt_ctx {
 
     /* scene */
     bool has_scene = false;
-    DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials;
+    DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials, lds_image;
     DevBuf<uint4> indices;
     DevBuf<rpt_light_pick_entry> light_pick;
     DevBuf<uchar4> atlas;
@@ -243,6 +243,45 @@ int alloc_state(rpt_ctx *c) {
     return RPT_OK;
 }
 
+/* The LDS-resident traversal image of a small scene (k_traverse.h, SceneViewLds):
+ *   [left.min | desc] x P, [right.min | desc] x P, [left.max] x P, [right.max] x P, a[] , e1[], e2[]
+ * with pair p = nodes (2p+1, 2p+2) and desc = triangle_count << 16 | first_triangle for a leaf child, the child's own
+ * pair index for an inner child.  Returns false when the node array is not pair-shaped (children of every inner
+ * node at an odd index l and l+1, all nodes reachable slots used): such a scene traverses from global memory. */
+bool build_lds_image(const rpt_bvh_node *nodes, size_t nn, const std::vector<float4> &geom, size_t nt,
+                     std::vector<float4> &image, uint32_t &pairs, uint32_t &root) {
+    if (nn == 0 || (nn & 1u) == 0u || nt >= 65536 || nn >= 65536) return false;
+    auto desc = [&](const rpt_bvh_node &n, uint32_t &out) {
+        if (n.triangle_count != 0u) {
+            if (n.triangle_count >= 32768u || n.left_or_first >= 65536u) return false;   /* bit 31 of a descriptor = finished lane */
+            out = (n.triangle_count << 16) | n.left_or_first;
+            return true;
+        }
+        uint32_t l = n.left_or_first;
+        if ((l & 1u) == 0u || (size_t)l + 1 >= nn) return false;
+        out = l >> 1;
+        return true;
+    };
+    if (!desc(nodes[0], root)) return false;
+    const size_t P = (nn - 1) / 2;
+    pairs = (uint32_t)P;
+    image.assign(4 * P + 3 * nt, make_float4(0, 0, 0, 0));
+    for (size_t p = 0; p < P; ++p) {
+        const rpt_bvh_node &L = nodes[2 * p + 1], &R = nodes[2 * p + 2];
+        uint32_t dl, dr;
+        if (!desc(L, dl) || !desc(R, dr)) return false;
+        float fl, fr;
+        memcpy(&fl, &dl, 4); memcpy(&fr, &dr, 4);
+        image[p] = make_float4(L.aabb_min[0], L.aabb_min[1], L.aabb_min[2], fl);
+        image[P + p] = make_float4(R.aabb_min[0], R.aabb_min[1], R.aabb_min[2], fr);
+        image[2 * P + p] = make_float4(L.aabb_max[0], L.aabb_max[1], L.aabb_max[2], 0.0f);
+        image[3 * P + p] = make_float4(R.aabb_max[0], R.aabb_max[1], R.aabb_max[2], 0.0f);
+    }
+    for (size_t t = 0; t < nt; ++t)
+        for (int j = 0; j < 3; ++j) image[4 * P + (size_t)j * nt + t] = geom[3 * t + j];
+    return true;
+}
+
 constexpr int LDS_THREADS = 512;     /* workgroup size of the LDS-resident-scene traversal variants */
 
 template <int STACK, int NEE, bool TEXTURED>
@@ -252,7 +291,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         if (ev) (void)hipEventRecord((*ev)[ev_at++], s);
     };
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
-    const size_t lds_bytes = (size_t)c->scene.n_nodes * 32 + (size_t)c->scene.n_triangles * 48;
+    const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else
@@ -336,7 +375,7 @@ void rpt_destroy(rpt_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release_state(c);
-    c->nodes.release(); c->tri_geom.release(); c->tri_shade.release(); c->mat_lite.release();
+    c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->atlas.release(); c->skybox.release();
     c->dev_stats.release();
@@ -441,7 +480,18 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     s.n_light_pick = (uint32_t)nlp;
     s.n_nodes = (uint32_t)nn;
     s.n_triangles = (uint32_t)nt;
-    s.lds_scene = (nn * 32 + nt * 48 <= RPT_LDS_SCENE_BYTES && depth <= 15) ? 1u : 0u;
+    s.lds_scene = 0u; s.lds_image = nullptr; s.lds_pairs = s.lds_vecs = s.lds_root = 0u;
+    if (nn * 32 + nt * 48 <= RPT_LDS_SCENE_BYTES && depth <= 15) {
+        std::vector<float4> image;
+        uint32_t pairs = 0, root = 0;
+        if (build_lds_image(nodes, nn, geom, nt, image, pairs, root)) {
+            HIP_TRY(c, c->lds_image.alloc(std::max<size_t>(1, image.size())));
+            if (!image.empty())
+                HIP_TRY(c, hipMemcpy(c->lds_image.p, image.data(), image.size() * sizeof(float4), hipMemcpyHostToDevice));
+            s.lds_scene = 1u; s.lds_image = c->lds_image.p;
+            s.lds_pairs = pairs; s.lds_vecs = (uint32_t)image.size(); s.lds_root = root;
+        }
+    }
     if (const char *env = getenv("RPT_NO_LDS_SCENE"); env && env[0] == '1') s.lds_scene = 0u;
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
     s.fastdiv_ok = 1u;
@@ -854,8 +904,8 @@ int rpt_debug_trace_rays(rpt_ctx *c, int any_hit, size_t n, const float *origins
             case 16:
                 if (c->scene.lds_scene) {
                     unsigned bl = (unsigned)((n + LDS_THREADS - 1) / LDS_THREADS);
-                    if (any_hit) k_trace_debug<16, true, true, LDS_THREADS><<<bl, LDS_THREADS, (size_t)c->scene.n_nodes * 32 + (size_t)c->scene.n_triangles * 48, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
-                    else k_trace_debug<16, false, true, LDS_THREADS><<<bl, LDS_THREADS, (size_t)c->scene.n_nodes * 32 + (size_t)c->scene.n_triangles * 48, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
+                    if (any_hit) k_trace_debug<16, true, true, LDS_THREADS><<<bl, LDS_THREADS, (size_t)c->scene.lds_vecs * sizeof(float4), s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
+                    else k_trace_debug<16, false, true, LDS_THREADS><<<bl, LDS_THREADS, (size_t)c->scene.lds_vecs * sizeof(float4), s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
                 } else {
                     LAUNCH_DBG(16);
                 }

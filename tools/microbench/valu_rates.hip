@@ -1,0 +1,136 @@
+// Issue cost of VALU instructions on gfx950, in SIMD cycles per wave64 instruction.
+// Build: hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip ; run on the GPU box.
+// Each kernel runs ITER trips of a 32-instruction unrolled body on 8 independent destination registers;
+// grid = 256 CUs x 4 SIMDs x WPS waves.  cycles = time * f_clk * n_simd * / wave-instructions; the clock is
+// calibrated on v_fma_f32 (assumed 4.0 cycles: 16 lanes per SIMD cycle).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <string>
+
+#define ITER 16384
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define BODY4(X) REP8(X) REP8(X) REP8(X) REP8(X)
+
+#define DEFINE_KERNEL(NAME, ASM_LINE, CLOBBER)                                                              \
+    __global__ __launch_bounds__(256) void NAME(float *out) {                                               \
+        float a = threadIdx.x * 1e-3f + 1.0f, b = 1.0001f, c = 0.5f;                                        \
+        for (int i = 0; i < ITER; ++i) {                                                                    \
+            asm volatile(ASM_LINE : "+v"(a) : "v"(b), "v"(c) : CLOBBER);                                    \
+        }                                                                                                   \
+        if (a == 12345.678f) out[0] = a;                                                                    \
+    }
+
+// 32 instructions per asm block, destination registers v[40..47] (+pairs up to v[40..55]) clobbered
+#define R8(fmt_pre, fmt_post) \
+    fmt_pre "40" fmt_post "\n" fmt_pre "41" fmt_post "\n" fmt_pre "42" fmt_post "\n" fmt_pre "43" fmt_post "\n" \
+    fmt_pre "44" fmt_post "\n" fmt_pre "45" fmt_post "\n" fmt_pre "46" fmt_post "\n" fmt_pre "47" fmt_post "\n"
+#define R32(p, q) R8(p, q) R8(p, q) R8(p, q) R8(p, q)
+#define P8(fmt_pre, fmt_post) \
+    fmt_pre "[40:41]" fmt_post "\n" fmt_pre "[42:43]" fmt_post "\n" fmt_pre "[44:45]" fmt_post "\n" fmt_pre "[46:47]" fmt_post "\n" \
+    fmt_pre "[48:49]" fmt_post "\n" fmt_pre "[50:51]" fmt_post "\n" fmt_pre "[52:53]" fmt_post "\n" fmt_pre "[54:55]" fmt_post "\n"
+#define P32(p, q) P8(p, q) P8(p, q) P8(p, q) P8(p, q)
+#define CL "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s40","s41","s42","s43"
+
+DEFINE_KERNEL(k_fma_f32, R32("v_fma_f32 v", ", %0, %1, %2"), CL)
+DEFINE_KERNEL(k_mul_f32, R32("v_mul_f32 v", ", %0, %1"), CL)
+DEFINE_KERNEL(k_add_f32, R32("v_add_f32 v", ", %0, %1"), CL)
+DEFINE_KERNEL(k_min_f32, R32("v_min_f32 v", ", %0, %1"), CL)
+DEFINE_KERNEL(k_max3_f32, R32("v_max3_f32 v", ", %0, %1, %2"), CL)
+DEFINE_KERNEL(k_mov_b32, R32("v_mov_b32 v", ", %0"), CL)
+DEFINE_KERNEL(k_cndmask, R32("v_cndmask_b32 v", ", %0, %1, vcc"), CL)
+DEFINE_KERNEL(k_cndmask_sgpr, R32("v_cndmask_b32 v", ", %0, %1, s[42:43]"), CL)
+DEFINE_KERNEL(k_cmp_vcc, R32("v_cmp_lt_f32 vcc, %0, v", ""), CL)
+DEFINE_KERNEL(k_cmp_sgpr, R32("v_cmp_lt_f32 s[40:41], %0, v", ""), CL)
+DEFINE_KERNEL(k_and_b32, R32("v_and_b32 v", ", %0, %1"), CL)
+DEFINE_KERNEL(k_lshl_add, R32("v_lshl_add_u32 v", ", %0, 3, %1"), CL)
+DEFINE_KERNEL(k_bfe, R32("v_bfe_u32 v", ", %0, 3, 8"), CL)
+DEFINE_KERNEL(k_mul_lo_u32, R32("v_mul_lo_u32 v", ", %0, %1"), CL)
+DEFINE_KERNEL(k_rcp_f32, R32("v_rcp_f32 v", ", %0"), CL)
+DEFINE_KERNEL(k_sqrt_f32, R32("v_sqrt_f32 v", ", %0"), CL)
+DEFINE_KERNEL(k_div_scale, R32("v_div_scale_f32 v", ", vcc, %0, %1, %0"), CL)
+DEFINE_KERNEL(k_div_fmas, R32("v_div_fmas_f32 v", ", %0, %1, %2"), CL)
+DEFINE_KERNEL(k_div_fixup, R32("v_div_fixup_f32 v", ", %0, %1, %2"), CL)
+DEFINE_KERNEL(k_cvt_f64_f32, P32("v_cvt_f64_f32 v", ", %0"), CL)
+DEFINE_KERNEL(k_pk_fma_f32, P32("v_pk_fma_f32 v", ", v[56:57], v[58:59], v[56:57]"), CL)
+DEFINE_KERNEL(k_pk_mul_f32, P32("v_pk_mul_f32 v", ", v[56:57], v[58:59]"), CL)
+DEFINE_KERNEL(k_pk_add_f32, P32("v_pk_add_f32 v", ", v[56:57], v[58:59]"), CL)
+DEFINE_KERNEL(k_pk_mov_b32, P32("v_pk_mov_b32 v", ", v[56:57], v[58:59]"), CL)
+DEFINE_KERNEL(k_fma_f64, P32("v_fma_f64 v", ", v[56:57], v[58:59], v[56:57]"), CL)
+DEFINE_KERNEL(k_mul_f64, P32("v_mul_f64 v", ", v[56:57], v[58:59]"), CL)
+DEFINE_KERNEL(k_add_f64, P32("v_add_f64 v", ", v[56:57], v[58:59]"), CL)
+DEFINE_KERNEL(k_rcp_f64, P32("v_rcp_f64 v", ", v[56:57]"), CL)
+DEFINE_KERNEL(k_cvt_f32_f64, R32("v_cvt_f32_f64 v", ", v[56:57]"), CL)
+DEFINE_KERNEL(k_mad_u64_u32, P32("v_mad_u64_u32 v", ", vcc, %0, %1, v[56:57]"), CL)
+DEFINE_KERNEL(k_lshl_add_u64, P32("v_lshl_add_u64 v", ", v[56:57], 3, v[58:59]"), CL)
+DEFINE_KERNEL(k_ds_bpermute, R32("ds_bpermute_b32 v", ", %0, %1"), CL)
+DEFINE_KERNEL(k_readlane, R32("v_readlane_b32 s42, %0, 3 ; v", ""), CL)
+DEFINE_KERNEL(k_mbcnt, R32("v_mbcnt_lo_u32_b32 v", ", -1, 0"), CL)
+DEFINE_KERNEL(k_s_and, R32("s_and_b64 s[40:41], s[42:43], exec ; v", ""), CL)
+
+
+#define PAIR8(a, b) a "40" b "40, %0, %1, " "\n" a "41" b "41, %0, %1, " "\n"
+DEFINE_KERNEL(k_cmp_cnd_vcc, R8("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 v", ", %0, %1, vcc") R8("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 v", ", %0, %1, vcc"), CL)
+DEFINE_KERNEL(k_cmp_cnd_sgpr, R8("v_cmp_lt_f32 s[40:41], %0, %1\n v_cndmask_b32 v", ", %0, %1, s[40:41]") R8("v_cmp_lt_f32 s[40:41], %0, %1\n v_cndmask_b32 v", ", %0, %1, s[40:41]"), CL)
+DEFINE_KERNEL(k_cnd_e64_vcc, R32("v_cndmask_b32_e64 v", ", %0, %1, vcc"), CL)
+DEFINE_KERNEL(k_cnd_after_cmp, "v_cmp_lt_f32 vcc, %0, %1\n" R32("v_cndmask_b32 v", ", %0, %1, vcc"), CL)
+DEFINE_KERNEL(k_cnd_exec_full, "s_mov_b64 vcc, exec\n" R32("v_cndmask_b32 v", ", %0, %1, vcc"), CL)
+DEFINE_KERNEL(k_cnd_zero, "s_mov_b64 vcc, 0\n" R32("v_cndmask_b32 v", ", %0, %1, vcc"), CL)
+DEFINE_KERNEL(k_min_fma_mix, R8("v_min_f32 v", ", %0, %1\n v_fma_f32 v48, %0, %1, %2\n v_fma_f32 v49, %0, %1, %2\n v_fma_f32 v50, %0, %1, %2") , CL)
+DEFINE_KERNEL(k_fma_x32_dep, R32("v_fma_f32 %0, %0, %1, %2 ; v", ""), CL)
+
+
+#define CMPV "v_cmp_lt_f32 vcc, %0, %1\n"
+#define CND(n) "v_cndmask_b32 v" #n ", %0, %1, vcc\n"
+#define FMA(n) "v_fma_f32 v" #n ", %0, %1, %2\n"
+#define MIN(n) "v_min_f32 v" #n ", %0, %1\n"
+// 8 x (cmp + 3 cnd) = 32 instr
+DEFINE_KERNEL(k_cmp_3cnd, CMPV CND(40) CND(41) CND(42) CMPV CND(43) CND(44) CND(45) CMPV CND(46) CND(47) CND(40) CMPV CND(41) CND(42) CND(43) CMPV CND(44) CND(45) CND(46) CMPV CND(47) CND(40) CND(41) CMPV CND(42) CND(43) CND(44) CMPV CND(45) CND(46) CND(47), CL)
+// 10 x (cmp + 2 cnd) + 2 fma = 32
+DEFINE_KERNEL(k_cmp_2cnd, CMPV CND(40) CND(41) CMPV CND(42) CND(43) CMPV CND(44) CND(45) CMPV CND(46) CND(47) CMPV CND(40) CND(41) CMPV CND(42) CND(43) CMPV CND(44) CND(45) CMPV CND(46) CND(47) CMPV CND(40) CND(41) CMPV CND(42) CND(43) FMA(44) FMA(45), CL)
+// 16 x (cnd, fma)
+DEFINE_KERNEL(k_cnd_fma, CND(40) FMA(48) CND(41) FMA(49) CND(42) FMA(50) CND(43) FMA(51) CND(44) FMA(48) CND(45) FMA(49) CND(46) FMA(50) CND(47) FMA(51) CND(40) FMA(48) CND(41) FMA(49) CND(42) FMA(50) CND(43) FMA(51) CND(44) FMA(48) CND(45) FMA(49) CND(46) FMA(50) CND(47) FMA(51), CL)
+// 16 x (cnd, min)
+DEFINE_KERNEL(k_cnd_min, CND(40) MIN(48) CND(41) MIN(49) CND(42) MIN(50) CND(43) MIN(51) CND(44) MIN(48) CND(45) MIN(49) CND(46) MIN(50) CND(47) MIN(51) CND(40) MIN(48) CND(41) MIN(49) CND(42) MIN(50) CND(43) MIN(51) CND(44) MIN(48) CND(45) MIN(49) CND(46) MIN(50) CND(47) MIN(51), CL)
+
+struct Case { const char *name; void (*fn)(float *); };
+
+int main(int argc, char **argv) {
+    int wps = argc > 1 ? atoi(argv[1]) : 2;           // waves per SIMD
+    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const int blocks = cus * wps;                     // 256 threads = 4 waves = one wave per SIMD per block
+    float *out; hipMalloc(&out, 4);
+    Case cases[] = {
+        {"v_fma_f32", k_fma_f32}, {"v_mul_f32", k_mul_f32}, {"v_add_f32", k_add_f32}, {"v_min_f32", k_min_f32}, {"v_max3_f32", k_max3_f32},
+        {"v_mov_b32", k_mov_b32}, {"v_cndmask_b32", k_cndmask}, {"v_cndmask_b32 sgpr", k_cndmask_sgpr}, {"v_cmp_lt_f32 vcc", k_cmp_vcc}, {"v_cmp_lt_f32 sgpr", k_cmp_sgpr},
+        {"v_and_b32", k_and_b32}, {"v_lshl_add_u32", k_lshl_add}, {"v_bfe_u32", k_bfe}, {"v_mul_lo_u32", k_mul_lo_u32},
+        {"v_rcp_f32", k_rcp_f32}, {"v_sqrt_f32", k_sqrt_f32}, {"v_div_scale_f32", k_div_scale}, {"v_div_fmas_f32", k_div_fmas},
+        {"v_div_fixup_f32", k_div_fixup}, {"v_cvt_f64_f32", k_cvt_f64_f32}, {"v_cvt_f32_f64", k_cvt_f32_f64},
+        {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}, {"v_pk_mov_b32", k_pk_mov_b32},
+        {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_rcp_f64", k_rcp_f64},
+        {"v_mad_u64_u32", k_mad_u64_u32}, {"v_lshl_add_u64", k_lshl_add_u64}, {"ds_bpermute_b32", k_ds_bpermute},
+        {"v_readlane_b32", k_readlane}, {"16x(cmp vcc+cnd vcc)", k_cmp_cnd_vcc}, {"16x(cmp s+cnd s)", k_cmp_cnd_sgpr}, {"cnd e64 vcc", k_cnd_e64_vcc}, {"cmp; 32 cnd vcc", k_cnd_after_cmp}, {"vcc=exec; 32 cnd", k_cnd_exec_full}, {"vcc=0; 32 cnd", k_cnd_zero}, {"8x(min+3fma)", k_min_fma_mix}, {"fma dependent", k_fma_x32_dep}, {"8x(cmp+3cnd)", k_cmp_3cnd}, {"10x(cmp+2cnd)+2fma", k_cmp_2cnd}, {"16x(cnd,fma)", k_cnd_fma}, {"16x(cnd,min)", k_cnd_min}, {"v_mbcnt_lo", k_mbcnt}, {"s_and_b64", k_s_and},
+    };
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("waves/SIMD %d, %d CUs\n", wps, cus);
+    auto time_of = [&](void (*fn)(float *)) {
+        float best = 1e9f;
+        for (int r = 0; r < 3; ++r) {
+            hipEventRecord(e0); fn<<<blocks, 256>>>(out); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+        }
+        return best;
+    };
+    for (int w = 0; w < 20; ++w) k_fma_f32<<<blocks, 256>>>(out);     // clocks up
+    hipDeviceSynchronize();
+    for (auto &c : cases) {
+        float base = time_of(k_fma_f32);
+        float t = time_of(c.fn);
+        float base2 = time_of(k_fma_f32);
+        double rel = t / (0.5 * (base + base2)) * 4.0;
+        printf("%-20s %8.3f ms (fma %.3f/%.3f)  %6.2f cycles/wave-instr (v_fma_f32 := 4)\n", c.name, t, base, base2, rel);
+    }
+    return 0;
+}
