@@ -62,28 +62,14 @@ __device__ __forceinline__ bool slab_test(float4 lo, float4 hi, F3 ro, F3 rd, F3
     return tmax >= tmin && tmax > 0.0f && tmin < prev_min_t;
 }
 
-/* How a traversal reads the scene.  Two images of the same BVH:
- *
- * SceneViewGlobal — the uploaded node array as is (children adjacent, one visit = 64 contiguous bytes = half a
- *   cache line through L1/L2) and the (a, e1, e2) triangle records.
- *
- * SceneViewLds — the LDS-resident image of a small scene, built once at upload (rpt_hip.hip, build_lds_image).
- *   ds_read_b128 serves a wave in four groups of 16 lanes and banks by (addr/4) mod 64, i.e. 16 slots of 16 bytes.
- *   In the uploaded layout chunk j of child pair p sits at slot (4p + j) mod 16: for a given load instruction the
- *   16 lanes of a group can only ever land on 4 of the 16 slots, so incoherent rays serialise 3-4 deep and the
- *   LDS array, not the VALU, sets the pace (4 loads x 4 groups x conflicts > the ~110 VALU cycles of a visit).
- *   The image is therefore stored as four arrays indexed by pair — left.min | right.min | left.max | right.max —
- *   so that instruction j of pair p lands on slot (const_j + p) mod 16: all 16 slots in play.  Triangles likewise
- *   (a[] | e1[] | e2[]).  The .w lane of a min chunk carries the child's packed descriptor
- *   (triangle_count << 16 | first_triangle, or the pair index of an inner child), so entering or popping a node
- *   is one dword instead of two.  Pair p holds nodes 2p+1 and 2p+2 (the builder allocates children in pairs
- *   from node 1, bvh.rs:296-299); a node array that is not shaped like that simply is not given an LDS image. */
+/* How the generic loop reads the scene: the uploaded node array as is (children adjacent, one visit = 64
+ * contiguous bytes = half a cache line through L1/L2) and the (a, e1, e2) triangle records.  A finished lane
+ * carries count = 0x80000000 so that "at an inner node" / "at a leaf" are single compares on the register (a
+ * ballot of a compare is the compare itself; a ballot of a loop-carried bool costs two more VALU instructions). */
 struct SceneViewGlobal {
     const float4 *nodes, *tri_geom;
     typedef uint2 Cur;                                      /* x = triangle_count, y = left child / first triangle */
     __device__ __forceinline__ Cur root() const { return make_uint2(__float_as_uint(nodes[0].w), __float_as_uint(nodes[1].w)); }
-    /* a finished lane carries count = 0x80000000: both predicates are single compares on the register (a ballot
-     * of a compare is the compare itself; a ballot of a loop-carried bool costs two more VALU instructions) */
     __device__ __forceinline__ static bool is_inner(Cur c) { return c.x == 0u; }
     __device__ __forceinline__ static bool is_leaf(Cur c) { return (int32_t)c.x > 0; }
     __device__ __forceinline__ static Cur dead() { return make_uint2(0x80000000u, 0u); }
@@ -104,31 +90,38 @@ struct SceneViewGlobal {
     __device__ __forceinline__ F3 corner(uint32_t ti) const { return xyz4(tri_geom[3u * ti]); }
 };
 
+/* The LDS-resident image of a small scene, built once at upload (rpt_hip.hip, build_lds_image) and copied into
+ * LDS by every workgroup.  Measured on MI355X (tools/microbench/valu_rates.hip, SQ counters in profiles/): the
+ * traversal kernel is VALU-ISSUE bound — fma/mul/add issue in ~2 cycles per wave64 instruction, everything else
+ * (min/max, compares, selects, integer/address ops) in ~4 — so the image is laid out to delete instructions:
+ *
+ *   plane records   K_A[p] = (L.lo.k, R.lo.k, L.hi.k, R.hi.k),  K_B[p] = (L.hi.k, R.hi.k, L.lo.k, R.lo.k)
+ *                   for axis k = x, y, z and child pair p = nodes (2p+1, 2p+2).  A ray whose direction component is
+ *                   positive reads K_A, a negative one K_B (a per-ray base address), so the register quad is always
+ *                   (L.near, R.near, L.far, R.far): with lo <= hi and a finite non-zero divisor, RN((lo-o)/d) and
+ *                   RN((hi-o)/d) are ordered by the sign of d (RN subtraction and division are monotone), so the
+ *                   reference's six f32::min/max per box (intersection.rs:108-117) become one max3 and one min3,
+ *                   value for value.  Rays outside the exact-division guard keep the explicit min/max on K_A.
+ *   descriptors     D[p] = desc(L) | desc(R) << 16;  desc = pair index (< 0x4000) of an inner child,
+ *                   0x8000 | triangle_count << 9 | first_triangle for a leaf; 0x4000 marks a finished lane.
+ *                   The 16-bit stack holds descriptors, so a pop is one ds_read_u16 — no node lookup.
+ *   triangles       a[] | e1[] | e2[]  (16-byte records, one array each)
+ *
+ * Every load instruction of a visit addresses "array base + 16 * p": the 16 lanes that ds_read_b128 serves per
+ * LDS cycle spread over all 64 banks instead of the 4 bank groups an array-of-nodes layout allows.
+ * A node array that is not pair-shaped, has an empty/inverted box, or a leaf of 64+ triangles gets no image and
+ * is traversed from global memory by the generic loop. */
+#define LDS_DESC_DEAD 0x4000u
+#define LDS_DESC_LEAF 0x8000u
 struct SceneViewLds {
     const float4 *img;
-    uint32_t pairs, tris, root_word;
-    typedef uint32_t Cur;                                   /* count << 16 | first triangle; count == 0: pair index */
-    __device__ __forceinline__ Cur root() const { return root_word; }
-    __device__ __forceinline__ static bool is_inner(Cur c) { return c < 0x10000u; }
-    __device__ __forceinline__ static bool is_leaf(Cur c) { return (int32_t)c > 0xffff; }
-    __device__ __forceinline__ static Cur dead() { return 0x80000000u; }
-    __device__ __forceinline__ static uint32_t leaf_count(Cur c) { return c >> 16; }
-    __device__ __forceinline__ static uint32_t leaf_first(Cur c) { return c & 0xffffu; }
-    __device__ __forceinline__ void children(Cur c, float4 &lmin, float4 &lmax, float4 &rmin, float4 &rmax) const {
-        const float4 *ch = img + c;
-        lmin = ch[0]; rmin = ch[pairs]; lmax = ch[2u * pairs]; rmax = ch[3u * pairs];
-    }
-    __device__ __forceinline__ static Cur enter(bool right, float4 lmin, float4, float4 rmin, float4) {
-        return __float_as_uint(right ? rmin.w : lmin.w);
-    }
-    /* stack entries index the two min arrays directly: left of pair p = p, right = pairs + p */
-    __device__ __forceinline__ uint32_t far_entry(Cur c, bool far_is_left) const { return far_is_left ? c : c + pairs; }
-    __device__ __forceinline__ Cur from_entry(uint32_t e) const { return __float_as_uint(img[e].w); }
+    uint32_t pairs, tris, root_desc;
+    __device__ __forceinline__ const float4 *tri_base() const { return img + 6u * pairs + ((pairs + 3u) >> 2); }
     __device__ __forceinline__ void edges(uint32_t ti, F3 &e1, F3 &e2) const {
-        const float4 *t = img + 4u * pairs + ti;
+        const float4 *t = tri_base() + ti;
         e1 = xyz4(t[tris]); e2 = xyz4(t[2u * tris]);
     }
-    __device__ __forceinline__ F3 corner(uint32_t ti) const { return xyz4(img[4u * pairs + ti]); }
+    __device__ __forceinline__ F3 corner(uint32_t ti) const { return xyz4(tri_base()[ti]); }
 };
 
 /* intersection.rs:9-54 with edge1/edge2 precomputed at upload; the corner is fetched only by lanes that get
@@ -239,12 +232,119 @@ __device__ __forceinline__ HitRecord traverse_one(const View &view, uint32_t fas
     return traverse_loop<STACK, ANY_HIT, false>(view, ro, rd, rd, max_t, stack);
 }
 
+/* The same walk over the LDS image (SceneViewLds).  SIGNED = the ray passed the exact-division guard: plane
+ * records are read through the per-ray sign-selected bases and near/far need no min/max. */
+template <bool SIGNED>
+__device__ __forceinline__ bool slab_pair_lds(float n_x, float n_y, float n_z, float f_x, float f_y, float f_z, F3 ro, F3 rd, F3 ird,
+                                              float prev_min_t, float &tmin_out) {
+    float tmin, tmax;
+    if (SIGNED) {
+        float a = rptm::div_by_rcp(n_x - ro.x, rd.x, ird.x), b = rptm::div_by_rcp(n_y - ro.y, rd.y, ird.y), c = rptm::div_by_rcp(n_z - ro.z, rd.z, ird.z);
+        float d = rptm::div_by_rcp(f_x - ro.x, rd.x, ird.x), e = rptm::div_by_rcp(f_y - ro.y, rd.y, ird.y), f = rptm::div_by_rcp(f_z - ro.z, rd.z, ird.z);
+        tmin = __builtin_fmaxf(__builtin_fmaxf(a, b), c);       /* no NaN on this path: plain max3 / min3 */
+        tmax = __builtin_fminf(__builtin_fminf(d, e), f);
+    } else {
+        float tx1 = (n_x - ro.x) / rd.x, tx2 = (f_x - ro.x) / rd.x;
+        float ty1 = (n_y - ro.y) / rd.y, ty2 = (f_y - ro.y) / rd.y;
+        float tz1 = (n_z - ro.z) / rd.z, tz2 = (f_z - ro.z) / rd.z;
+        tmin = rptm::fminr(tx1, tx2);
+        tmax = rptm::fmaxr(tx1, tx2);
+        tmin = rptm::fmaxr(tmin, rptm::fminr(ty1, ty2));
+        tmax = rptm::fminr(tmax, rptm::fmaxr(ty1, ty2));
+        tmin = rptm::fmaxr(tmin, rptm::fminr(tz1, tz2));
+        tmax = rptm::fminr(tmax, rptm::fmaxr(tz1, tz2));
+    }
+    tmin_out = tmin;
+    return tmax >= tmin && tmax > 0.0f && tmin < prev_min_t;
+}
+
+/* leaf batching threshold of the LDS loop: its inner step is ~25 % cheaper than the generic one, so waiting for
+ * more leaf lanes pays (traverse 28.4 ms at K = 8, 26.8-27.3 ms for K = 16..32, 29.0 ms at 48) */
+#ifndef RPT_LEAF_K_LDS
+#define RPT_LEAF_K_LDS 16
+#endif
+template <int STACK, bool ANY_HIT, bool SIGNED>
+__device__ __forceinline__ HitRecord traverse_loop_lds(const SceneViewLds &view, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack) {
+    HitRecord res;
+    res.t = 1000000.0f;
+    res.tri = HIT_MISS;
+    int sp = 0;
+    const uint32_t P = view.pairs;
+    /* per-ray plane-record bases (float4 units): x | y | z, A or B variant by the sign of the direction */
+    const float4 *px = view.img + ((SIGNED && rd.x < 0.0f) ? P : 0u);
+    const float4 *py = view.img + 2u * P + ((SIGNED && rd.y < 0.0f) ? P : 0u);
+    const float4 *pz = view.img + 4u * P + ((SIGNED && rd.z < 0.0f) ? P : 0u);
+    const uint32_t *descs = reinterpret_cast<const uint32_t *>(view.img + 6u * P);
+    uint32_t cur = view.root_desc;
+    for (;;) {
+        const bool at_inner = cur < LDS_DESC_DEAD;
+        const bool at_leaf = cur >= LDS_DESC_LEAF;
+        const unsigned long long inner_m = rpt_ballot(at_inner), leaf_m = rpt_ballot(at_leaf);
+        if ((inner_m | leaf_m) == 0ull) break;
+        if (at_inner) {
+            const float4 X = px[cur], Y = py[cur], Z = pz[cur];     /* (L.near, R.near, L.far, R.far) per axis */
+            const uint32_t d = descs[cur];
+            float tl, tr;
+            const bool hit_l = slab_pair_lds<SIGNED>(X.x, Y.x, Z.x, X.z, Y.z, Z.z, ro, rd, ird, res.t, tl);
+            const bool hit_r = slab_pair_lds<SIGNED>(X.y, Y.y, Z.y, X.w, Y.w, Z.w, ro, rd, ird, res.t, tr);
+            const bool swap = hit_r && (!hit_l || tl > tr);     /* strict: ties keep left first */
+            asm volatile("" ::"v"(d));     /* keep the descriptor load up with the plane loads: sunk into the hit branch it
+                                               puts an LDS round trip on every step's critical path */
+            if (hit_l || hit_r) {
+                const uint32_t nf = __builtin_amdgcn_alignbit(d, d, swap ? 16u : 0u);    /* near | far << 16 */
+                if (hit_l && hit_r && sp < STACK) {
+                    stack[sp * RPT_WAVE] = (uint16_t)(nf >> 16);
+                    sp += 1;
+                }
+                cur = nf & 0xffffu;
+            } else if (sp == 0) {
+                cur = LDS_DESC_DEAD;
+            } else {
+                sp -= 1;
+                cur = stack[sp * RPT_WAVE];
+            }
+        }
+        if (at_leaf && ((uint32_t)__popcll(leaf_m) >= (uint32_t)RPT_LEAF_K_LDS || inner_m == 0ull)) {
+            bool accepted = false;
+            const uint32_t count = (cur >> 9) & 63u, first = cur & 511u;
+            for (uint32_t i = 0; i < count; ++i) {
+                uint32_t ti = first + i;
+                float t = 0.0f;
+                bool bf = false;
+                if (moller_trumbore_view(view, ti, ro, rd, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
+                    res.t = rptm::fminr(res.t, t);
+                    res.tri = ti | (bf ? 0x80000000u : 0u);
+                    if (ANY_HIT) { accepted = true; break; }
+                }
+            }
+            if ((ANY_HIT && accepted) || sp == 0) {
+                cur = LDS_DESC_DEAD;
+            } else {
+                sp -= 1;
+                cur = stack[sp * RPT_WAVE];
+            }
+        }
+    }
+    return res;
+}
+
+template <int STACK, bool ANY_HIT>
+__device__ __forceinline__ HitRecord traverse_one(const SceneViewLds &view, uint32_t fastdiv_ok, F3 ro, F3 rd, float max_t, uint16_t *stack) {
+    bool fast = fastdiv_ok != 0u && rptm::fastdiv_divisor_ok(rd.x) && rptm::fastdiv_divisor_ok(rd.y) && rptm::fastdiv_divisor_ok(rd.z) &&
+                rptm::fastdiv_operand_ok(ro.x) && rptm::fastdiv_operand_ok(ro.y) && rptm::fastdiv_operand_ok(ro.z);
+    if (fast) {
+        F3 ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        return traverse_loop_lds<STACK, ANY_HIT, true>(view, ro, rd, ird, max_t, stack);
+    }
+    return traverse_loop_lds<STACK, ANY_HIT, false>(view, ro, rd, rd, max_t, stack);
+}
+
 /* Small scenes live in LDS: when nodes + triangle geometry fit in RPT_LDS_SCENE_BYTES
  * every workgroup copies the upload-time LDS image in once and traverses out of LDS
  * (ds_read_b128, ~64-cycle latency, no pressure on the CU's single vector-memory address
  * unit — the measured limiter once the divisions were gone: ~380 divergent 16-byte
  * wave-loads per wave through one TA per CU).  Larger scenes read through L1/L2. */
-#define RPT_LDS_SCENE_BYTES 24576
+#define RPT_LDS_SCENE_BYTES 32768
 extern __shared__ __attribute__((aligned(16))) float4 rpt_lds_dyn[];   /* sized at launch to the scene (LDS variants only) */
 template <bool LDS_SCENE> struct SceneViewOf { typedef SceneViewGlobal type; };
 template <> struct SceneViewOf<true> { typedef SceneViewLds type; };

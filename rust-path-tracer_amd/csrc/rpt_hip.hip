@@ -243,18 +243,20 @@ int alloc_state(rpt_ctx *c) {
     return RPT_OK;
 }
 
-/* The LDS-resident traversal image of a small scene (k_traverse.h, SceneViewLds):
- *   [left.min | desc] x P, [right.min | desc] x P, [left.max] x P, [right.max] x P, a[] , e1[], e2[]
- * with pair p = nodes (2p+1, 2p+2) and desc = triangle_count << 16 | first_triangle for a leaf child, the child's own
- * pair index for an inner child.  Returns false when the node array is not pair-shaped (children of every inner
- * node at an odd index l and l+1, all nodes reachable slots used): such a scene traverses from global memory. */
+/* The LDS-resident traversal image of a small scene (layout and rationale: k_traverse.h, SceneViewLds):
+ *   float4 K_A[P], K_B[P] for K = x, y, z   (L.lo, R.lo, L.hi, R.hi) and (L.hi, R.hi, L.lo, R.lo)
+ *   u32    D[P] (padded to 16 bytes)        desc(L) | desc(R) << 16
+ *   float4 a[T], e1[T], e2[T]
+ * with pair p = nodes (2p+1, 2p+2).  Returns false when the node array cannot be represented (not pair-shaped,
+ * a box with lo > hi or a NaN bound, a leaf of 64+ triangles, 512+ triangles): such a scene is traversed from
+ * global memory by the generic loop. */
 bool build_lds_image(const rpt_bvh_node *nodes, size_t nn, const std::vector<float4> &geom, size_t nt,
                      std::vector<float4> &image, uint32_t &pairs, uint32_t &root) {
-    if (nn == 0 || (nn & 1u) == 0u || nt >= 65536 || nn >= 65536) return false;
+    if (nn == 0 || (nn & 1u) == 0u || nt > 512 || nn >= 2 * (size_t)LDS_DESC_DEAD) return false;
     auto desc = [&](const rpt_bvh_node &n, uint32_t &out) {
         if (n.triangle_count != 0u) {
-            if (n.triangle_count >= 32768u || n.left_or_first >= 65536u) return false;   /* bit 31 of a descriptor = finished lane */
-            out = (n.triangle_count << 16) | n.left_or_first;
+            if (n.triangle_count >= 64u || n.left_or_first >= 512u || (size_t)n.left_or_first + n.triangle_count > nt) return false;
+            out = LDS_DESC_LEAF | (n.triangle_count << 9) | n.left_or_first;
             return true;
         }
         uint32_t l = n.left_or_first;
@@ -263,26 +265,33 @@ bool build_lds_image(const rpt_bvh_node *nodes, size_t nn, const std::vector<flo
         return true;
     };
     if (!desc(nodes[0], root)) return false;
-    const size_t P = (nn - 1) / 2;
+    for (size_t i = 0; i < nn; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!(nodes[i].aabb_min[k] <= nodes[i].aabb_max[k])) return false;
+    const size_t P = (nn - 1) / 2, desc_vecs = (P + 3) / 4;
     pairs = (uint32_t)P;
-    image.assign(4 * P + 3 * nt, make_float4(0, 0, 0, 0));
+    image.assign(6 * P + desc_vecs + 3 * nt, make_float4(0, 0, 0, 0));
+    uint32_t *descs = reinterpret_cast<uint32_t *>(image.data() + 6 * P);
     for (size_t p = 0; p < P; ++p) {
         const rpt_bvh_node &L = nodes[2 * p + 1], &R = nodes[2 * p + 2];
         uint32_t dl, dr;
         if (!desc(L, dl) || !desc(R, dr)) return false;
-        float fl, fr;
-        memcpy(&fl, &dl, 4); memcpy(&fr, &dr, 4);
-        image[p] = make_float4(L.aabb_min[0], L.aabb_min[1], L.aabb_min[2], fl);
-        image[P + p] = make_float4(R.aabb_min[0], R.aabb_min[1], R.aabb_min[2], fr);
-        image[2 * P + p] = make_float4(L.aabb_max[0], L.aabb_max[1], L.aabb_max[2], 0.0f);
-        image[3 * P + p] = make_float4(R.aabb_max[0], R.aabb_max[1], R.aabb_max[2], 0.0f);
+        descs[p] = dl | (dr << 16);
+        for (int k = 0; k < 3; ++k) {
+            image[(2 * k) * P + p] = make_float4(L.aabb_min[k], R.aabb_min[k], L.aabb_max[k], R.aabb_max[k]);
+            image[(2 * k + 1) * P + p] = make_float4(L.aabb_max[k], R.aabb_max[k], L.aabb_min[k], R.aabb_min[k]);
+        }
     }
     for (size_t t = 0; t < nt; ++t)
-        for (int j = 0; j < 3; ++j) image[4 * P + (size_t)j * nt + t] = geom[3 * t + j];
+        for (int j = 0; j < 3; ++j) image[6 * P + desc_vecs + (size_t)j * nt + t] = geom[3 * t + j];
     return true;
 }
 
-constexpr int LDS_THREADS = 512;     /* workgroup size of the LDS-resident-scene traversal variants */
+#ifndef RPT_LDS_THREADS
+#define RPT_LDS_THREADS 1024
+#endif
+constexpr int LDS_THREADS = RPT_LDS_THREADS;     /* workgroup size of the LDS-resident-scene traversal variants: 2 x (32 KB of
+                                                    16-bit stacks + up to 32 KB of scene = the 64 KB a workgroup may hold) per CU = 32 waves */
 
 template <int STACK, int NEE, bool TEXTURED>
 void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
@@ -290,8 +299,8 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     auto mark = [&]() {
         if (ev) (void)hipEventRecord((*ev)[ev_at++], s);
     };
-    const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
+    const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
     if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else
@@ -366,6 +375,7 @@ int rpt_create(int device_id, rpt_ctx **out) {
     }
     const char *env = getenv("RPT_STAGE_TIMING");
     c->stage_timing = env && env[0] == '1';
+    if (const char *e3 = getenv("RPT_SAMPLES_IN_FLIGHT")) c->samples_in_flight_request = std::min(32, std::max(0, atoi(e3)));
     *out = c;
     return RPT_OK;
 }
@@ -481,10 +491,10 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     s.n_nodes = (uint32_t)nn;
     s.n_triangles = (uint32_t)nt;
     s.lds_scene = 0u; s.lds_image = nullptr; s.lds_pairs = s.lds_vecs = s.lds_root = 0u;
-    if (nn * 32 + nt * 48 <= RPT_LDS_SCENE_BYTES && depth <= 15) {
+    if (nn * 50 + nt * 48 <= RPT_LDS_SCENE_BYTES && depth <= 15) {
         std::vector<float4> image;
         uint32_t pairs = 0, root = 0;
-        if (build_lds_image(nodes, nn, geom, nt, image, pairs, root)) {
+        if (build_lds_image(nodes, nn, geom, nt, image, pairs, root) && image.size() * sizeof(float4) <= RPT_LDS_SCENE_BYTES) {
             HIP_TRY(c, c->lds_image.alloc(std::max<size_t>(1, image.size())));
             if (!image.empty())
                 HIP_TRY(c, hipMemcpy(c->lds_image.p, image.data(), image.size() * sizeof(float4), hipMemcpyHostToDevice));
@@ -539,12 +549,17 @@ int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
         release_state(c);
         build_pixel_order(cfg->width, cfg->height, c->rank, c->world, c->pixel_xy_host);
         c->n_pixels = (uint32_t)c->pixel_xy_host.size();
-        /* samples of one pixel in flight: enough slots to fill 256 CUs even when this rank owns few tiles */
+        /* Samples of one pixel in flight.  The GPU holds 8 192 waves = 0.5 M paths at once and ray costs inside a
+         * launch vary widely, so a launch of only 1-2 x that ends in a long half-empty tail (measured 4.3 of 8 waves
+         * per SIMD resident on average with 1 M slots); up to 16 M slots (~3 GB of path state at 200 B/slot, nothing
+         * on a 288 GB part) make the tail a small fraction and quarter the number of launches per batch:
+         * DarkCornell 1024^2 4.84 -> 6.33 Grays/s for S = 1 -> 16.  The image does not depend on S. */
         uint32_t S = 1;
         if (c->samples_in_flight_request > 0) {
             while (S < (uint32_t)c->samples_in_flight_request && S < 32u) S <<= 1;
         } else {
-            while (S < 16u && (uint64_t)c->n_pixels * S < 786432ull) S <<= 1;
+            if (c->n_pixels < (3u << 20))       /* measured: at 4 M pixels (PBRTest 2048^2) S > 1 only costs (-10 %) */
+                while (S < 16u && (uint64_t)c->n_pixels * S * 2u <= (16ull << 20)) S <<= 1;
         }
         c->group_shift = 0;
         while ((1u << c->group_shift) < S) c->group_shift += 1;
