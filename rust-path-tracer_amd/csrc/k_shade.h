@@ -155,6 +155,7 @@ template <int NEE, bool TEXTURED>
 __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
                                                      DevStats *stats) {
     __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
+    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
     bool to_sky = false;
     bool emit_shadow = false;

@@ -125,11 +125,14 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
     const uint32_t n = q.count[Q_SKY];
     const uint32_t alive = q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE];
+    const uint32_t drained = q.count[Q_DRAINED];
     if (i == 0u) {
-        uint32_t busy = alive | q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE] | (n != 0u ? 1u : 0u);
+        uint32_t busy = drained ? 0u : (alive | q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE] | (n != 0u ? 1u : 0u));
+        if (busy == 0u && drained == 0u) q.count[Q_DRAINED] = 1u;
         __hip_atomic_store(&q.host_ring[iteration & q.ring_mask], ((unsigned long long)(iteration + 1u) << 32) | busy,
                            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (drained != 0u) return;                                 /* surplus launch (grid-uniform) */
     if (n < q.sky_threshold && alive != 0u) return;          /* not worth a pass yet (same test as k_traverse_nearest) */
     if (i == 0u && n) atomicAdd(&stats->sky_evals, (unsigned long long)n);
     if (cfg.c.has_skybox == 0u && n <= q.sky_wide_limit) {

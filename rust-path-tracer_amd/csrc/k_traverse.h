@@ -372,6 +372,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     typedef typename StackElem<LDS_SCENE>::type StackT;
     __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
+    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     const uint32_t slot = blockIdx.x * THREADS + threadIdx.x;
     if (slot == 0u) {
         /* Per-iteration bookkeeping that needs no kernel of its own.  The shadow queue was consumed by the
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
     typedef typename StackElem<LDS_SCENE>::type StackT;
     __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
+    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     uint32_t n = q.count[Q_SHADOW];
     if (i == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);

@@ -54,7 +54,7 @@ template <typename T> struct DevBuf {
     }
 };
 
-constexpr int LAG = 6;           /* iterations the host may run ahead of the queue-size report it inspects */
+constexpr int LAG = 6;           /* most iterations the host may run ahead of the progress report it inspects (small launches) */
 constexpr int RING = 16;         /* power of two, > LAG */
 
 }  // namespace
@@ -628,6 +628,9 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
 
     uint64_t it = 0;
     bool drained = c->cfg.c.max_bounces == 0u;
+    /* Run-ahead: it only has to cover the enqueue latency (tens of microseconds).  Launches over millions of slots
+     * last far longer than that, and every surplus iteration still dispatches its (instantly returning) workgroups. */
+    const int lag = c->n_slots >= (4u << 20) ? 2 : (c->n_slots >= (1u << 20) ? 3 : LAG);
     /* worst case: every sample needs max_bounces iterations, one after another */
     /* safety net against a stuck pipeline (a bug), far above what deferral of sky work can cost */
     const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces + 2u) * 16u + 4096u;
@@ -643,9 +646,9 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
             default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at); break;
         }
         it += 1;
-        if (it >= (uint64_t)LAG) {
+        if (it >= (uint64_t)lag) {
             /* the sky kernel of iteration j published (j + 1) << 32 | "work remains after iteration j" */
-            uint64_t j = it - LAG;
+            uint64_t j = it - lag;
             volatile unsigned long long *slot = &c->host_ring[j & (RING - 1)];
             unsigned long long v;
             uint64_t spins = 0;

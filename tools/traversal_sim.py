@@ -111,7 +111,7 @@ def main():
         report("if-if (one step per iter)", [sim_if_if(*wv) for wv in waves], n_rays)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold", "sort")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold", "sort", "regroup")):
     main()
 
 
@@ -299,3 +299,73 @@ def main_sort():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sort":
     main_sort()
+
+
+def sim_regroup(ev, ln, valid, group, budgets, leaf_k, cost_inner, cost_leaf, cost_regroup):
+    """Workgroup-level regrouping: the `group` rays of a workgroup start one per lane; after budgets[0] loop trips every
+    wave stops, the unfinished rays are re-dealt densely to lanes (state handed over), and the new waves run
+    budgets[1] more trips, ...; the last budget repeats.  budgets = [10**9] is the plain deferred-leaf loop."""
+    total = 0.0
+    n = len(ln)
+    for base in range(0, n, group):
+        rays = [(i, 0) for i in range(base, min(base + group, n)) if valid[i] and ln[i] > 0]
+        phase = 0
+        while rays:
+            budget = budgets[min(phase, len(budgets) - 1)]
+            nxt = []
+            for w0 in range(0, len(rays), 64):
+                lanes = [list(r) for r in rays[w0:w0 + 64]]
+                trips = 0
+                while trips < budget:
+                    live = [l for l in lanes if l[1] < ln[l[0]]]
+                    if not live:
+                        break
+                    inner = [l for l in live if ev[l[0], l[1]] == 0]
+                    leaf = [l for l in live if ev[l[0], l[1]] == 1]
+                    if inner:
+                        total += cost_inner
+                        for l in inner: l[1] += 1
+                    if leaf and (len(leaf) >= leaf_k or not inner):
+                        total += cost_leaf
+                        for l in leaf: l[1] += 1
+                    trips += 1
+                left = [tuple(l) for l in lanes if l[1] < ln[l[0]]]
+                if left:
+                    total += cost_regroup
+                nxt += left
+            rays = nxt
+            phase += 1
+    return total
+
+
+def main_regroup():
+    scene = sys.argv[2] if len(sys.argv) > 2 else "DarkCornell"
+    W = H = 128
+    orc = Oracle()
+    w = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    sc = orc.scene(w)
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    order = hip.tile_order(W, H, 0, 1)
+    px = (order >> 16).astype(np.int64) * W + (order & 0xFFFF).astype(np.int64)
+    CI, CL, CR = 214.0, 200.0, 150.0       # SIMD cycles per inner step / leaf step / hand-over (per wave)
+    for bounce in (0, 2):
+        rays = np.zeros((W * H, 6), np.float32)
+        valid = np.zeros(W * H, np.uint8)
+        orc.lib.oracle_dump_rays(C.byref(cfg), C.byref(sc), seeds.ctypes.data_as(C.c_void_p), C.c_uint32(bounce),
+                                 rays.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+        rays, valid = rays[px], valid[px]
+        ev, ln = events_for(orc, sc, np.ascontiguousarray(rays[:, :3]), np.ascontiguousarray(rays[:, 3:]))
+        ln = np.where(valid == 1, ln, 0)
+        sub = slice(0, 8192)
+        evs, lns, vs = ev[sub], ln[sub], valid[sub]
+        n_rays = int(vs.sum())
+        print(f"{scene} bounce {bounce}: visits/ray mean {lns[vs==1].mean():.1f} p50 {np.percentile(lns[vs==1],50):.0f} p90 {np.percentile(lns[vs==1],90):.0f} max {lns.max()}")
+        for name, budgets in [("no regroup", [10**9]), ("16,8..", [16, 8]), ("24,8..", [24, 8]), ("24,12..", [24, 12]), ("32,8..", [32, 8]),
+                              ("32,16..", [32, 16]), ("20,10,10,20..", [20, 10, 10, 20]), ("40,..", [40, 16]), ("12,12..", [12]), ("8,8..", [8])]:
+            c = sim_regroup(evs, lns, vs, 1024, budgets, 16, CI, CL, CR)
+            print(f"  budgets {name:16s}: cycles/ray {c/n_rays:7.1f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "regroup":
+    main_regroup()
