@@ -136,25 +136,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        r.render(args.spp_per_step)
-        if world_size > 1:
+    def finish_gather():
+        """Complete the gather of the previous batch; rank 0 un-tiles it into the full image."""
+        recv = gatherer.end()
+        if rank == 0 and recv is not None:
+            if staged is not None:
+                staged.copy_(recv)
+                recv = staged
             torch.cuda.current_stream().synchronize()
-            recv = gatherer.gather(local_block)                      # the single collective per sample batch
-            if rank == 0:
-                if staged is not None:
-                    staged.copy_(recv)
-                    recv = staged
-                torch.cuda.current_stream().synchronize()
-                r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)
+            r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)
+
+    def step():
+        r.render(args.spp_per_step)                                  # returns when the batch is accumulated
+        if world_size > 1:
+            finish_gather()                                          # batch k-1 travelled while batch k rendered
+            gatherer.begin(local_block)                              # the single collective per sample batch
+            torch.cuda.current_stream().synchronize()                # staging copy done: accumulators are free again
 
     for _ in range(args.warmup):
         step()
+    if world_size > 1:
+        finish_gather()
     barrier()
     s0 = r.stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if world_size > 1:
+        finish_gather()                                              # the last batch's image is complete inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     s1 = r.stats()

@@ -287,6 +287,10 @@ bool build_lds_image(const rpt_bvh_node *nodes, size_t nn, const std::vector<flo
     return true;
 }
 
+#ifndef RPT_GLOBAL_THREADS
+#define RPT_GLOBAL_THREADS 64      /* one wave: no scene staging to share, and a finished wave frees its stack at once (PBRTest traverse -5 %) */
+#endif
+constexpr int GLOBAL_THREADS = RPT_GLOBAL_THREADS;   /* workgroup size of the global-memory traversal variants */
 #ifndef RPT_LDS_THREADS
 #define RPT_LDS_THREADS 1024
 #endif
@@ -304,7 +308,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else
-        k_traverse_nearest<STACK, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, iteration);
+        k_traverse_nearest<STACK, false, GLOBAL_THREADS><<<(c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
     mark();
     k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
@@ -312,7 +316,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else
-            k_traverse_shadow<STACK, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+            k_traverse_shadow<STACK, false, GLOBAL_THREADS><<<(c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
     }
     mark();
     k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
@@ -630,7 +634,7 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     bool drained = c->cfg.c.max_bounces == 0u;
     /* Run-ahead: it only has to cover the enqueue latency (tens of microseconds).  Launches over millions of slots
      * last far longer than that, and every surplus iteration still dispatches its (instantly returning) workgroups. */
-    const int lag = c->n_slots >= (4u << 20) ? 2 : (c->n_slots >= (1u << 20) ? 3 : LAG);
+    const int lag = c->n_slots >= (512u << 10) ? 2 : (c->n_slots >= (128u << 10) ? 3 : LAG);
     /* worst case: every sample needs max_bounces iterations, one after another */
     /* safety net against a stuck pipeline (a bug), far above what deferral of sky work can cost */
     const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces + 2u) * 16u + 4096u;

@@ -50,13 +50,28 @@ class Gatherer:
         self.recv = torch.zeros((self.world, self.stride, 4), dtype=torch.float32, device=device) if self.rank == 0 else None
         self.recv_list = [self.recv[r] for r in range(self.world)] if self.rank == 0 else None
 
+        self._work = None
+
     def gather(self, local_block):
         """local_block: (n_local, 4) tensor aliasing the renderer's accumulator block. Returns recv on rank 0."""
+        self.begin(local_block)
+        return self.end()
+
+    def begin(self, local_block):
+        """Start the gather of this batch and return at once: the block is first copied into a torch-owned staging
+        buffer (the collective never sees memory it did not allocate; 2 MiB per rank at 1024^2; also the move to the
+        host for the gloo tests), so the renderer may go on accumulating the next batch while the blocks travel."""
+        assert self._work is None, "previous gather not finished (call end())"
         n = self.sizes[self.rank]
-        # always stage through a torch-owned buffer: the collective then never sees memory it did not allocate
-        # (2 MiB per rank at 1024^2 — noise next to a sample batch); also moves to the host for the gloo tests
         self.send[:n].copy_(local_block)
-        dist.gather(self.send, gather_list=self.recv_list, dst=0, group=self.group)
+        self._work = dist.gather(self.send, gather_list=self.recv_list, dst=0, group=self.group, async_op=True)
+
+    def end(self):
+        """Wait for the gather started by begin(); returns recv on rank 0 (None elsewhere, or when nothing is pending)."""
+        if self._work is None:
+            return None
+        self._work.wait()
+        self._work = None
         return self.recv
 
 

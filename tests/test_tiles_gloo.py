@@ -37,13 +37,20 @@ def _worker(rank, world_size, port, image_path, out_path):
     blocks = tiles.gather_blocks(local, W, H)
     g = tiles.Gatherer(W, H, "cpu")
     recv = g.gather(local)                       # the pre-allocated form bench.py uses
+    # the overlapped form: begin() snapshots the block, the "renderer" keeps accumulating, end() delivers the snapshot
+    g.begin(local)
+    local += 1000.0                              # next batch lands in the accumulators while the blocks travel
+    recv2 = g.end()
+    assert g.end() is None                       # nothing pending any more
     if rank == 0:
         out = tiles.untile_host([b.numpy() for b in blocks], W, H, world_size)
         out2 = tiles.untile_host([recv[r_, : g.sizes[r_]].numpy() for r_ in range(world_size)], W, H, world_size)
         assert np.array_equal(out.view(np.uint32), out2.view(np.uint32))
+        out3 = tiles.untile_host([recv2[r_, : g.sizes[r_]].numpy() for r_ in range(world_size)], W, H, world_size)
+        assert np.array_equal(out.view(np.uint32), out3.view(np.uint32))
         np.save(out_path, out)
     else:
-        assert blocks is None and recv is None
+        assert blocks is None and recv is None and recv2 is None
     dist.barrier()
     dist.destroy_process_group()
 
