@@ -167,6 +167,16 @@ void rpt_destroy(rpt_ctx *ctx);
 const char *rpt_last_error(rpt_ctx *ctx);
 int rpt_abi_version(void);
 
+/* --- scene preparation on the device ---------------------- */
+/* BVHBuilder::new(vertices, indices).sah_samples(n).build()  (reference src/bvh.rs:59-324, the call at
+ * src/asset.rs:196) on the GPU: reorders `triangles` in place and writes the node pool exactly as the sequential
+ * builder does (same nodes, same order, same bits; tests/test_gpu_bvh_build.py).  Host pointers, no context needed;
+ * vertices are Vec4 (xyzw) as in bvh.rs:52; nodes_capacity >= 2 * n_triangles - 1; sah_samples <= 128.
+ * device_ms_out (nullable) receives the device time of the build proper.  Errors: rpt_last_error(NULL). */
+int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertices, rpt_triangle *triangles,
+                      size_t n_triangles, uint32_t sah_samples, rpt_bvh_node *nodes_out, size_t nodes_capacity,
+                      size_t *n_nodes_out, double *device_ms_out);
+
 /* --- test hooks (not part of the reference boundary) --------------------- */
 /* Evaluate one shared-math function on the DEVICE over n floats so tests can
  * check bit-equality with the host build of the same header. op: 0 sin, 1 cos,

@@ -74,6 +74,12 @@ void rpt_world_free(rpt_world *world);
 int rpt_bvh_build(const float *vertices_xyzw, size_t n_vertices, rpt_triangle *triangles, size_t n_triangles,
                   uint32_t sah_samples, rpt_bvh_node *nodes_out, size_t nodes_capacity, size_t *n_nodes_out);
 
+/* Which builder rpt_world_load / rpt_world_from_buffers use for the BVH (src/asset.rs:196): 0 = the sequential host
+ * restatement (default), 1 = rpt_bvh_build_gpu of librpt_hip.so (hip_library_path NULL = next to this library) on
+ * device_id.  Both give the same node pool and triangle order bit for bit; a failing device build is an error, never
+ * a silent fall-back. */
+int rpt_host_set_bvh_builder(int use_gpu, const char *hip_library_path, int device_id);
+
 /* compute_emissive_mask + build_light_pick_table (src/light_pick.rs:13-122).
  * table_out needs capacity >= max(1, n_triangles). */
 int rpt_light_table_build(const float *vertices_xyzw, size_t n_vertices, const rpt_triangle *triangles,

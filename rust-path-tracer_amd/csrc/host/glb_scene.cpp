@@ -366,10 +366,10 @@ bool walk_node(const Glb &g, int node_index, const M4 &trs, Gather &out, int dep
 
 }  // namespace
 
-void finish_world(World &w, std::vector<Vec4f> &vertices, std::vector<Vec4f> &normals, std::vector<Vec4f> &tangents,
+bool finish_world(World &w, std::vector<Vec4f> &vertices, std::vector<Vec4f> &normals, std::vector<Vec4f> &tangents,
                   std::vector<float> &uvs) {
     /* asset.rs:196 BVH (reorders indices), :201-202 light table, :206-215 packing */
-    bvh_build(vertices.data(), w.indices.data(), w.indices.size(), 128, w.nodes);
+    if (!build_world_bvh(vertices.data(), vertices.size(), w.indices, w.nodes)) return false;
     w.max_depth = bvh_max_depth(w.nodes);
     w.light_pick = build_light_pick_table(vertices.data(), w.indices.data(), w.indices.size(), w.materials.data(), &w.n_emissive);
     w.per_vertex.resize(vertices.size());
@@ -381,6 +381,7 @@ void finish_world(World &w, std::vector<Vec4f> &vertices, std::vector<Vec4f> &no
         if (2 * i + 1 < uvs.size()) { pv.uv0[0] = uvs[2 * i]; pv.uv0[1] = uvs[2 * i + 1]; }
         w.per_vertex[i] = pv;
     }
+    return true;
 }
 
 bool load_glb(const char *path, World &out) {
@@ -458,8 +459,7 @@ bool load_glb(const char *path, World &out) {
         if (t.material >= out.materials.size()) { set_error("material index out of range"); return false; }
 
     out.indices = ga.indices;
-    finish_world(out, ga.vertices, ga.normals, ga.tangents, ga.uvs);
-    return true;
+    return finish_world(out, ga.vertices, ga.normals, ga.tangents, ga.uvs);
 }
 
 }  // namespace rpth

@@ -90,7 +90,7 @@ int rpt_world_from_buffers(const float *vertices_xyz, const float *normals_xyz, 
         w->w.indices[i] = t;
     }
     w->w.materials.assign(materials, materials + n_materials);
-    finish_world(w->w, vertices, normals, tangents, uv);
+    if (!finish_world(w->w, vertices, normals, tangents, uv)) { delete w; return RPT_EHIP; }
     *out = w;
     return 0;
 }
@@ -205,6 +205,65 @@ rpt_tracing_state *rpt_setup_trace(uint32_t width, uint32_t height, uint32_t sam
 }
 
 }  // extern "C"
+
+/* ------------------------------------------------ BVH builder choice ---- */
+namespace {
+typedef int (*bvh_build_gpu_fn)(int, const float *, size_t, rpt_triangle *, size_t, uint32_t, rpt_bvh_node *, size_t, size_t *, double *);
+typedef const char *(*last_error_fn)(void *);
+std::mutex g_builder_lock;
+bvh_build_gpu_fn g_gpu_builder = nullptr;
+last_error_fn g_gpu_last_error = nullptr;
+void *g_gpu_builder_lib = nullptr;
+int g_gpu_builder_device = 0;
+std::string hip_library_default_path() {
+    Dl_info info;
+    std::string p = "librpt_hip.so";
+    if (dladdr((void *)&hip_library_default_path, &info) && info.dli_fname) {
+        std::string self(info.dli_fname);
+        size_t s = self.find_last_of('/');
+        if (s != std::string::npos) p = self.substr(0, s) + "/librpt_hip.so";
+    }
+    return p;
+}
+}  // namespace
+
+namespace rpth {
+bool build_world_bvh(const Vec4f *vertices, size_t n_vertices, std::vector<rpt_triangle> &triangles, std::vector<rpt_bvh_node> &nodes) {
+    bvh_build_gpu_fn gpu;
+    int device;
+    { std::lock_guard<std::mutex> g(g_builder_lock); gpu = g_gpu_builder; device = g_gpu_builder_device; }
+    if (!gpu || triangles.empty()) {
+        bvh_build(vertices, triangles.data(), triangles.size(), 128, nodes);
+        return true;
+    }
+    nodes.assign(triangles.size() * 2 - 1, rpt_bvh_node{});
+    size_t n = 0;
+    int rc = gpu(device, reinterpret_cast<const float *>(vertices), n_vertices, triangles.data(), triangles.size(), 128, nodes.data(),
+                 nodes.size(), &n, nullptr);
+    if (rc) {
+        set_error(std::string("GPU BVH build failed: ") + (g_gpu_last_error ? g_gpu_last_error(nullptr) : "?"));
+        return false;                                    /* no silent fall-back to the host builder */
+    }
+    nodes.resize(n);
+    return true;
+}
+}  // namespace rpth
+
+extern "C" int rpt_host_set_bvh_builder(int use_gpu, const char *hip_library_path, int device_id) {
+    std::lock_guard<std::mutex> g(g_builder_lock);
+    if (!use_gpu) { g_gpu_builder = nullptr; return 0; }
+    if (!g_gpu_builder_lib) {
+        std::string p = hip_library_path ? std::string(hip_library_path) : hip_library_default_path();
+        g_gpu_builder_lib = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!g_gpu_builder_lib) { set_error(std::string("dlopen failed: ") + dlerror()); return RPT_HOST_EDLOPEN; }
+    }
+    auto fn = reinterpret_cast<bvh_build_gpu_fn>(dlsym(g_gpu_builder_lib, "rpt_bvh_build_gpu"));
+    g_gpu_last_error = reinterpret_cast<last_error_fn>(dlsym(g_gpu_builder_lib, "rpt_last_error"));
+    if (!fn) { set_error("librpt_hip.so has no rpt_bvh_build_gpu"); return RPT_HOST_EDLOPEN; }
+    g_gpu_builder = fn;
+    g_gpu_builder_device = device_id;
+    return 0;
+}
 
 /* ------------------------------------------------------- trace_gpu ------ */
 namespace {

@@ -40,8 +40,12 @@ struct World {
 };
 
 /* shared tail of World::from_path (src/asset.rs:194-223) */
-void finish_world(World &w, std::vector<Vec4f> &vertices, std::vector<Vec4f> &normals, std::vector<Vec4f> &tangents,
+bool finish_world(World &w, std::vector<Vec4f> &vertices, std::vector<Vec4f> &normals, std::vector<Vec4f> &tangents,
                   std::vector<float> &uvs);
+
+/* BVH builder used by finish_world: the sequential restatement (default) or the device build of librpt_hip.so
+ * (rpt_host_set_bvh_builder).  Both produce the same node pool and triangle order. */
+bool build_world_bvh(const Vec4f *vertices, size_t n_vertices, std::vector<rpt_triangle> &triangles, std::vector<rpt_bvh_node> &nodes);
 
 bool load_glb(const char *path, World &out);
 

@@ -1,0 +1,390 @@
+/*
+ * k_bvh_build.h — the reference's binned-SAH BVH build (src/bvh.rs:59-324) on the GPU, level by level, producing
+ * the SAME node pool and the SAME triangle order as the sequential builder, bit for bit.
+ *
+ * What makes that possible:
+ *   - A node's split depends only on the triangles in its range and on their ORDER (the order decides the sign of a
+ *     zero bound and the next partition), never on when the node is processed.  So the explicit-stack, depth-first
+ *     build of bvh.rs:257-324 can run breadth-first — one workgroup per node, all nodes of a level in one launch —
+ *     and the nodes are renumbered afterwards to the order in which the reference would have split them
+ *     (children get the next two indices at split time, left subtree first: bvh.rs:296-320).
+ *   - f32::min / f32::max folds (bvh.rs:85-103, 9-33) are order-independent except for the sign of a zero result:
+ *     `a < b ? a : b` keeps the LATER operand on a tie, and -0 == +0.  Every reduction here therefore runs on 64-bit
+ *     keys  ord(value) << 32 | tie-break(sequence position) | sign-of-zero  so that the winner is the element the
+ *     sequential fold would have kept.
+ *   - The in-place two-pointer partition (bvh.rs:281-292) is a data-dependent walk, but its result has a closed
+ *     form: with nl = #(centroid < split), left-side elements already in [first, first+nl) stay; the i-th "hole"
+ *     (right-side element in that prefix, ascending) is filled by the i-th left-side element of the suffix taken in
+ *     DESCENDING order; right-side elements land at last - r where r is their discovery rank: hole i is discovered
+ *     after i earlier holes and after every suffix right-side element above the (i-1)-th suffix left-side element; a
+ *     suffix right-side element q after min(m+1, H) holes (m = suffix left-side elements above q, H = #holes) and
+ *     after the suffix right-side elements above it — except in the tail below the lowest suffix left-side element,
+ *     where the element AT first+nl is met first.  (Checked against the sequential loop on 200 000 random inputs
+ *     before it was written down here; tests/test_gpu_bvh_build.py compares whole builds.)
+ *
+ * One workgroup walks its node's range with a stride loop, so the top of a large tree is slow per node (the root of
+ * a 1 M-triangle scene: ~4 000 trips per pass) and the bottom is wide; that is still two orders of magnitude
+ * faster than the sequential host build and keeps one code path.
+ */
+#ifndef RPT_K_BVH_BUILD_H
+#define RPT_K_BVH_BUILD_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BVB_THREADS 256
+#define BVB_MAX_BINS 128
+#define BVB_NONE 0xffffffffu
+
+struct BvbNode {
+    float mn[3];
+    uint32_t first;
+    float mx[3];
+    uint32_t count;
+    uint32_t left;        /* build-order id of the left child (right = left + 1), BVB_NONE for a leaf */
+    uint32_t pad[3];
+};
+
+struct BvbArgs {
+    const float4 *verts;
+    const uint4 *tris;          /* original order */
+    float4 *centroid;           /* per original triangle */
+    uint32_t *order;            /* position -> original triangle */
+    uint32_t *order_tmp, *tmp_a, *tmp_b;
+    BvbNode *nodes;
+    uint32_t *node_count;
+    uint32_t n_tris, bins;
+};
+
+/* monotone float -> u32 with both zeros on the same code; the sign of a zero travels separately */
+__device__ __forceinline__ uint32_t bvb_ord(float v, uint32_t &neg_zero) {
+    uint32_t u = __float_as_uint(v);
+    neg_zero = u == 0x80000000u ? 1u : 0u;
+    if (neg_zero) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float bvb_unord(uint32_t o, uint32_t neg_zero) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    if (u == 0u && neg_zero) u = 0x80000000u;
+    return __uint_as_float(u);
+}
+/* keys: a sequential `cur = (cur < x) ? cur : x` keeps the later operand on ties */
+__device__ __forceinline__ unsigned long long bvb_min_key(float v, uint32_t seq) {
+    uint32_t nz;
+    uint32_t o = bvb_ord(v, nz);
+    return ((unsigned long long)o << 32) | (unsigned long long)(((0x7fffffffu - seq) << 1) | nz);
+}
+__device__ __forceinline__ unsigned long long bvb_max_key(float v, uint32_t seq) {
+    uint32_t nz;
+    uint32_t o = bvb_ord(v, nz);
+    return ((unsigned long long)o << 32) | (unsigned long long)((seq << 1) | nz);
+}
+__device__ __forceinline__ float bvb_key_value(unsigned long long k) { return bvb_unord((uint32_t)(k >> 32), (uint32_t)k & 1u); }
+
+#define BVB_MIN_IDENT 0xffffffffffffffffull
+#define BVB_MAX_IDENT 0ull
+
+__global__ __launch_bounds__(BVB_THREADS) void k_bvb_init(BvbArgs a) {
+    uint32_t i = blockIdx.x * BVB_THREADS + threadIdx.x;
+    if (i >= a.n_tris) return;
+    uint4 t = a.tris[i];
+    float4 v0 = a.verts[t.x], v1 = a.verts[t.y], v2 = a.verts[t.z];
+    /* (v0 + v1 + v2) / 3.0 (bvh.rs:66-69) */
+    a.centroid[i] = make_float4(((v0.x + v1.x) + v2.x) / 3.0f, ((v0.y + v1.y) + v2.y) / 3.0f, ((v0.z + v1.z) + v2.z) / 3.0f, 0.0f);
+    a.order[i] = i;
+}
+
+struct BvbBox {
+    float mn[3], mx[3];
+};
+__device__ __forceinline__ float bvb_min(float a, float b) { return (a < b || b != b) ? a : b; }
+__device__ __forceinline__ float bvb_max(float a, float b) { return (a > b || b != b) ? a : b; }
+__device__ __forceinline__ float bvb_area(const BvbBox &b) {
+    float ex = b.mx[0] - b.mn[0], ey = b.mx[1] - b.mn[1], ez = b.mx[2] - b.mn[2];
+    return ex * ey + ey * ez + ez * ex;
+}
+
+/* exclusive prefix of a per-thread 0/1 flag over the workgroup (+ running base), in thread order; every thread calls */
+__device__ __forceinline__ uint32_t bvb_block_rank(bool flag, uint32_t *wave_tot, uint32_t &block_total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+    uint32_t within = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    __syncthreads();                       /* wave_tot free again */
+    if (lane == 0u) wave_tot[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0u, total = 0u;
+    for (uint32_t w = 0; w < BVB_THREADS / 64u; ++w) {
+        uint32_t n = wave_tot[w];
+        before += w < wave ? n : 0u;
+        total += n;
+    }
+    block_total = total;
+    return before + within;
+}
+
+__global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t level_begin) {
+    __shared__ unsigned long long s_key[3][BVB_MAX_BINS][6];      /* [axis][bin]: min x,y,z  max x,y,z */
+    __shared__ uint32_t s_cnt[3][BVB_MAX_BINS];
+    __shared__ float s_la[3][BVB_MAX_BINS], s_ra[3][BVB_MAX_BINS];
+    __shared__ uint32_t s_lc[3][BVB_MAX_BINS], s_rc[3][BVB_MAX_BINS];
+    __shared__ unsigned long long s_red[6];
+    __shared__ uint32_t s_cb[6];                                  /* centroid bounds: ord(min) x3, ord(max) x3 */
+    __shared__ float s_best_cost[3];
+    __shared__ uint32_t s_best_i[3];
+    __shared__ uint32_t s_wave_tot[BVB_THREADS / 64];
+    __shared__ uint32_t s_misc[4];
+    __shared__ float s_split;
+    __shared__ int s_axis;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t node_id = level_begin + blockIdx.x;
+    BvbNode &node = a.nodes[node_id];
+    const uint32_t first = node.first, count = node.count, S = a.bins;
+    const uint32_t last = first + count - 1u;
+
+    /* ---- update_node_aabb (bvh.rs:85-103), sequential tie-breaking reproduced by the keys */
+    if (tid < 6u) s_red[tid] = tid < 3u ? BVB_MIN_IDENT : BVB_MAX_IDENT;
+    if (tid < 3u) { s_cb[tid] = 0xffffffffu; s_cb[3u + tid] = 0u; }
+    __syncthreads();
+    {
+        unsigned long long kmin[3] = {BVB_MIN_IDENT, BVB_MIN_IDENT, BVB_MIN_IDENT}, kmax[3] = {BVB_MAX_IDENT, BVB_MAX_IDENT, BVB_MAX_IDENT};
+        uint32_t cmin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, cmax[3] = {0u, 0u, 0u};
+        for (uint32_t i = tid; i < count; i += BVB_THREADS) {
+            const uint32_t tri = a.order[first + i];
+            const uint4 t = a.tris[tri];
+            const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t seq = i * 3u + k;
+                const float c[3] = {v[k].x, v[k].y, v[k].z};
+                for (int j = 0; j < 3; ++j) {
+                    unsigned long long lo = bvb_min_key(c[j], seq), hi = bvb_max_key(c[j], seq);
+                    kmin[j] = lo < kmin[j] ? lo : kmin[j];
+                    kmax[j] = hi > kmax[j] ? hi : kmax[j];
+                }
+            }
+            const float4 ce = a.centroid[tri];
+            const float cc[3] = {ce.x, ce.y, ce.z};
+            for (int j = 0; j < 3; ++j) {
+                uint32_t nz;
+                uint32_t o = bvb_ord(cc[j], nz);
+                cmin[j] = o < cmin[j] ? o : cmin[j];
+                cmax[j] = o > cmax[j] ? o : cmax[j];
+            }
+        }
+        for (int j = 0; j < 3; ++j) {
+            atomicMin(&s_red[j], kmin[j]);
+            atomicMax(&s_red[3 + j], kmax[j]);
+            atomicMin(&s_cb[j], cmin[j]);
+            atomicMax(&s_cb[3 + j], cmax[j]);
+        }
+    }
+    __syncthreads();
+    if (tid < 3u) {
+        node.mn[tid] = bvb_key_value(s_red[tid]);
+        node.mx[tid] = bvb_key_value(s_red[3u + tid]);
+    }
+    float bmin[3], bmax[3];
+    for (int j = 0; j < 3; ++j) { bmin[j] = bvb_unord(s_cb[j], 0u); bmax[j] = bvb_unord(s_cb[3 + j], 0u); }
+    const float nmn[3] = {bvb_key_value(s_red[0]), bvb_key_value(s_red[1]), bvb_key_value(s_red[2])};
+    const float nmx[3] = {bvb_key_value(s_red[3]), bvb_key_value(s_red[4]), bvb_key_value(s_red[5])};
+
+    /* ---- find_best_split_segmented (bvh.rs:178-255): all three axes binned in one pass */
+    for (uint32_t k = tid; k < 3u * BVB_MAX_BINS; k += BVB_THREADS) {
+        const uint32_t ax = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
+        for (int j = 0; j < 6; ++j) s_key[ax][b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
+        s_cnt[ax][b] = 0u;
+    }
+    __syncthreads();
+    float scale[3];
+    bool axis_on[3];
+    for (int j = 0; j < 3; ++j) {
+        axis_on[j] = !(bmin[j] == bmax[j]);
+        scale[j] = (float)S / (bmax[j] - bmin[j]);
+    }
+    for (uint32_t i = tid; i < count; i += BVB_THREADS) {
+        const uint32_t tri = a.order[first + i];
+        const uint4 t = a.tris[tri];
+        const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
+        const float4 ce = a.centroid[tri];
+        const float cc[3] = {ce.x, ce.y, ce.z};
+        for (int ax = 0; ax < 3; ++ax) {
+            if (!axis_on[ax]) continue;
+            const float x = (cc[ax] - bmin[ax]) * scale[ax];
+            uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;      /* `as usize` then min(S-1) */
+            if (si > S - 1u) si = S - 1u;
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t seq = i * 3u + k;
+                const float c[3] = {v[k].x, v[k].y, v[k].z};
+                for (int j = 0; j < 3; ++j) {
+                    atomicMin(&s_key[ax][si][j], bvb_min_key(c[j], seq));
+                    atomicMax(&s_key[ax][si][3 + j], bvb_max_key(c[j], seq));
+                }
+            }
+            atomicAdd(&s_cnt[ax][si], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 3u) {
+        const uint32_t ax = tid;
+        float best_cost = __builtin_inff();
+        uint32_t best_i = 0u;
+        if (axis_on[ax]) {
+            BvbBox lb, rb;
+            for (int j = 0; j < 3; ++j) { lb.mn[j] = rb.mn[j] = __builtin_inff(); lb.mx[j] = rb.mx[j] = -__builtin_inff(); }
+            uint32_t lsum = 0u, rsum = 0u;
+            for (uint32_t i = 0; i + 1u < S; ++i) {
+                lsum += s_cnt[ax][i];
+                s_lc[ax][i] = lsum;
+                if (s_cnt[ax][i] != 0u && bvb_key_value(s_key[ax][i][0]) != __builtin_inff()) {     /* encapsulate_node skips an empty box */
+                    for (int j = 0; j < 3; ++j) {
+                        lb.mn[j] = bvb_min(lb.mn[j], bvb_key_value(s_key[ax][i][j]));
+                        lb.mx[j] = bvb_max(lb.mx[j], bvb_key_value(s_key[ax][i][3 + j]));
+                    }
+                }
+                s_la[ax][i] = bvb_area(lb);
+                const uint32_t r = S - 1u - i;
+                rsum += s_cnt[ax][r];
+                s_rc[ax][S - 2u - i] = rsum;
+                if (s_cnt[ax][r] != 0u && bvb_key_value(s_key[ax][r][0]) != __builtin_inff()) {
+                    for (int j = 0; j < 3; ++j) {
+                        rb.mn[j] = bvb_min(rb.mn[j], bvb_key_value(s_key[ax][r][j]));
+                        rb.mx[j] = bvb_max(rb.mx[j], bvb_key_value(s_key[ax][r][3 + j]));
+                    }
+                }
+                s_ra[ax][S - 2u - i] = bvb_area(rb);
+            }
+            for (uint32_t i = 0; i + 1u < S; ++i) {
+                const float cost = (float)s_lc[ax][i] * s_la[ax][i] + (float)s_rc[ax][i] * s_ra[ax][i];
+                if (cost < best_cost) { best_cost = cost; best_i = i; }
+            }
+        }
+        s_best_cost[ax] = best_cost;
+        s_best_i[ax] = best_i;
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        int axis = 0;
+        float split = 0.0f, cost = __builtin_inff();
+        for (int ax = 0; ax < 3; ++ax) {
+            if (s_best_cost[ax] < cost) {
+                cost = s_best_cost[ax];
+                axis = ax;
+                const float scale2 = (bmax[ax] - bmin[ax]) / (float)S;
+                split = bmin[ax] + scale2 * (float)(s_best_i[ax] + 1u);
+            }
+        }
+        BvbBox nb;
+        for (int j = 0; j < 3; ++j) { nb.mn[j] = nmn[j]; nb.mx[j] = nmx[j]; }
+        const float parent_cost = bvb_area(nb) * (float)count;
+        s_axis = parent_cost <= cost ? -1 : axis;                 /* bvh.rs:272-277 */
+        s_split = split;
+    }
+    __syncthreads();
+    const int axis = s_axis;
+    if (axis < 0) {
+        if (tid == 0u) node.left = BVB_NONE;
+        return;
+    }
+    const float split = s_split;
+
+    /* ---- the partition (bvh.rs:281-292) in closed form (file header) */
+    auto is_left = [&](uint32_t pos) {
+        const float4 ce = a.centroid[a.order[pos]];
+        const float c = axis == 0 ? ce.x : (axis == 1 ? ce.y : ce.z);
+        return c < split;
+    };
+    uint32_t nl;
+    {
+        uint32_t mine = 0u;
+        for (uint32_t i = tid; i < count; i += BVB_THREADS) mine += is_left(first + i) ? 1u : 0u;
+        if (tid == 0u) s_misc[0] = 0u;
+        __syncthreads();
+        atomicAdd(&s_misc[0], mine);
+        __syncthreads();
+        nl = s_misc[0];
+    }
+    const uint32_t back_n = count - nl;                 /* suffix positions first+nl .. last */
+    /* pass B1: suffix, descending — rb_at_L[m] = right-side elements above the m-th left-side element */
+    uint32_t H = 0u;
+    {
+        uint32_t run_l = 0u, run_r = 0u;
+        for (uint32_t base = 0; base < back_n; base += BVB_THREADS) {
+            const uint32_t i = base + tid;
+            const bool valid = i < back_n;
+            const uint32_t q = last - i;
+            const bool L = valid && is_left(q);
+            const bool R = valid && !L;
+            uint32_t tot_l, tot_r;
+            const uint32_t m = run_l + bvb_block_rank(L, s_wave_tot, tot_l);
+            const uint32_t rb = run_r + bvb_block_rank(R, s_wave_tot, tot_r);
+            if (L) a.tmp_b[first + m] = rb;
+            run_l += tot_l;
+            run_r += tot_r;
+        }
+        H = run_l;
+    }
+    __syncthreads();
+    __threadfence_block();
+    const uint32_t base_rb = H >= 1u ? a.tmp_b[first + H - 1u] : 0u;
+    /* pass F: prefix, ascending */
+    {
+        uint32_t run = 0u;
+        for (uint32_t base = 0; base < nl; base += BVB_THREADS) {
+            const uint32_t i = base + tid;
+            const bool valid = i < nl;
+            const uint32_t p = first + i;
+            const bool L = valid && is_left(p);
+            const bool R = valid && !L;
+            uint32_t tot;
+            const uint32_t hole = run + bvb_block_rank(R, s_wave_tot, tot);
+            if (L) a.order_tmp[p] = a.order[p];
+            if (R) {
+                const uint32_t rank = hole + (hole >= 1u ? a.tmp_b[first + hole - 1u] : 0u);
+                a.order_tmp[last - rank] = a.order[p];
+                a.tmp_a[first + hole] = p;
+            }
+            run += tot;
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    /* pass B2: suffix again, now every destination is known */
+    {
+        uint32_t run_l = 0u, run_r = 0u;
+        for (uint32_t base = 0; base < back_n; base += BVB_THREADS) {
+            const uint32_t i = base + tid;
+            const bool valid = i < back_n;
+            const uint32_t q = last - i;
+            const bool L = valid && is_left(q);
+            const bool R = valid && !L;
+            uint32_t tot_l, tot_r;
+            const uint32_t m = run_l + bvb_block_rank(L, s_wave_tot, tot_l);
+            const uint32_t rb = run_r + bvb_block_rank(R, s_wave_tot, tot_r);
+            if (L) a.order_tmp[a.tmp_a[first + m]] = a.order[q];
+            if (R) {
+                uint32_t rank;
+                if (m == H) rank = (q == first + nl) ? H + base_rb : H + rb + 1u;
+                else rank = (m + 1u) + rb;
+                a.order_tmp[last - rank] = a.order[q];
+            }
+            run_l += tot_l;
+            run_r += tot_r;
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (uint32_t i = tid; i < count; i += BVB_THREADS) a.order[first + i] = a.order_tmp[first + i];
+
+    if (tid == 0u) {
+        if (nl == 0u || nl == count) {
+            node.left = BVB_NONE;                               /* bvh.rs:294-296: stays a leaf, triangles already permuted */
+        } else {
+            const uint32_t id = atomicAdd(a.node_count, 2u);
+            node.left = id;
+            a.nodes[id].first = first;          a.nodes[id].count = nl;              a.nodes[id].left = BVB_NONE;
+            a.nodes[id + 1u].first = first + nl; a.nodes[id + 1u].count = count - nl; a.nodes[id + 1u].left = BVB_NONE;
+        }
+    }
+}
+
+#endif /* RPT_K_BVH_BUILD_H */

@@ -22,6 +22,7 @@
 #include "../../include/rpt/rpt.h"
 #include "k_common.h"
 #include "k_traverse.h"
+#include "k_bvh_build.h"
 #include "k_shade.h"
 #include "k_sky_generate.h"
 
@@ -944,6 +945,125 @@ int rpt_debug_trace_rays(rpt_ctx *c, int any_hit, size_t n, const float *origins
     d_o.release(); d_d.release(); d_m.release(); d_t.release(); d_tri.release(); d_fl.release();
     HIP_TRY(c, e);
     return RPT_OK;
+}
+
+/* BVHBuilder::new(vertices, indices).sah_samples(n).build() (src/bvh.rs:59-324) on the device: same node pool, same
+ * triangle order as the sequential build (k_bvh_build.h).  Host pointers in and out, like rpt_bvh_build of
+ * rpt_host.h; needs no context. */
+int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertices, rpt_triangle *triangles, size_t n_triangles,
+                      uint32_t sah_samples, rpt_bvh_node *nodes_out, size_t nodes_capacity, size_t *n_nodes_out, double *device_ms_out) {
+    if (!vertices_xyzw || !triangles || !nodes_out || !n_nodes_out || n_triangles == 0 || n_vertices == 0) {
+        g_create_error = "rpt_bvh_build_gpu: null or empty argument";
+        return RPT_EINVAL;
+    }
+    if (sah_samples < 2) sah_samples = 2;
+    if (sah_samples > BVB_MAX_BINS) { g_create_error = "rpt_bvh_build_gpu: at most 128 SAH bins"; return RPT_EINVAL; }
+    if (n_triangles >= (1u << 28)) { g_create_error = "rpt_bvh_build_gpu: too many triangles"; return RPT_EINVAL; }
+    if (nodes_capacity < 2 * n_triangles - 1) { g_create_error = "rpt_bvh_build_gpu: node buffer needs 2N-1 entries"; return RPT_EINVAL; }
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].v0 >= n_vertices || triangles[i].v1 >= n_vertices || triangles[i].v2 >= n_vertices) {
+            g_create_error = "rpt_bvh_build_gpu: vertex index out of range";
+            return RPT_ESCENE;
+        }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0) { g_create_error = "no HIP device"; return RPT_ENODEV; }
+    if (device_id < 0 || device_id >= n_dev) { g_create_error = "device id out of range"; return RPT_EINVAL; }
+#define BVB_TRY(x)                                                                                      \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess) {                                                                         \
+            g_create_error = std::string("rpt_bvh_build_gpu: ") + hipGetErrorString(e_);                \
+            goto fail;                                                                                  \
+        }                                                                                               \
+    } while (0)
+    DevBuf<float4> d_verts, d_centroid;
+    DevBuf<uint4> d_tris;
+    DevBuf<uint32_t> d_order, d_order_tmp, d_tmp_a, d_tmp_b, d_count;
+    DevBuf<BvbNode> d_nodes;
+    std::vector<BvbNode> bn;
+    std::vector<uint32_t> order;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const uint32_t nt = (uint32_t)n_triangles;
+    {
+        BVB_TRY(hipSetDevice(device_id));
+        BVB_TRY(d_verts.alloc(n_vertices));
+        BVB_TRY(d_tris.alloc(nt));
+        BVB_TRY(d_centroid.alloc(nt));
+        BVB_TRY(d_order.alloc(nt));
+        BVB_TRY(d_order_tmp.alloc(nt));
+        BVB_TRY(d_tmp_a.alloc(nt));
+        BVB_TRY(d_tmp_b.alloc(nt));
+        BVB_TRY(d_count.alloc(1));
+        BVB_TRY(d_nodes.alloc(2 * (size_t)nt - 1));
+        BVB_TRY(hipMemcpy(d_verts.p, vertices_xyzw, n_vertices * sizeof(float4), hipMemcpyHostToDevice));
+        BVB_TRY(hipMemcpy(d_tris.p, triangles, nt * sizeof(uint4), hipMemcpyHostToDevice));
+        BvbNode root{};
+        root.first = 0; root.count = nt; root.left = BVB_NONE;
+        BVB_TRY(hipMemcpy(d_nodes.p, &root, sizeof(root), hipMemcpyHostToDevice));
+        uint32_t one = 1;
+        BVB_TRY(hipMemcpy(d_count.p, &one, 4, hipMemcpyHostToDevice));
+        BVB_TRY(hipEventCreate(&ev0));
+        BVB_TRY(hipEventCreate(&ev1));
+        BvbArgs a{d_verts.p, d_tris.p, d_centroid.p, d_order.p, d_order_tmp.p, d_tmp_a.p, d_tmp_b.p, d_nodes.p, d_count.p, nt, sah_samples};
+        BVB_TRY(hipEventRecord(ev0, nullptr));
+        k_bvb_init<<<(nt + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(a);
+        uint32_t begin = 0, end = 1;
+        while (begin < end) {                               /* one launch per tree level */
+            k_bvb_level<<<end - begin, BVB_THREADS>>>(a, begin);
+            uint32_t total = 0;
+            BVB_TRY(hipMemcpy(&total, d_count.p, 4, hipMemcpyDeviceToHost));
+            begin = end;
+            end = total;
+        }
+        BVB_TRY(hipEventRecord(ev1, nullptr));
+        BVB_TRY(hipEventSynchronize(ev1));
+        float ms = 0.0f;
+        BVB_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        if (device_ms_out) *device_ms_out = ms;
+        bn.resize(end);
+        order.resize(nt);
+        BVB_TRY(hipMemcpy(bn.data(), d_nodes.p, (size_t)end * sizeof(BvbNode), hipMemcpyDeviceToHost));
+        BVB_TRY(hipMemcpy(order.data(), d_order.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
+    }
+    {
+        /* renumber to the order in which the reference splits nodes: children get the next two indices when their
+         * parent is popped from its stack, left subtree first (bvh.rs:296-320) */
+        size_t node_count = 1;
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 0u}};       /* (build-order id, output index) */
+        while (!stack.empty()) {
+            auto [b, o] = stack.back();
+            stack.pop_back();
+            const BvbNode &n = bn[b];
+            rpt_bvh_node &out = nodes_out[o];
+            for (int k = 0; k < 3; ++k) { out.aabb_min[k] = n.mn[k]; out.aabb_max[k] = n.mx[k]; }
+            if (n.left == BVB_NONE) {
+                out.triangle_count = n.count;
+                out.left_or_first = n.first;
+            } else {
+                out.triangle_count = 0;
+                out.left_or_first = (uint32_t)node_count;
+                stack.push_back({n.left + 1u, (uint32_t)node_count + 1u});
+                stack.push_back({n.left, (uint32_t)node_count});
+                node_count += 2;
+            }
+        }
+        *n_nodes_out = node_count;
+        std::vector<rpt_triangle> src(triangles, triangles + nt);
+        for (uint32_t i = 0; i < nt; ++i) triangles[i] = src[order[i]];
+    }
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
+    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release();
+    return RPT_OK;
+fail:
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
+    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release();
+    return RPT_EHIP;
+#undef BVB_TRY
 }
 
 }  // extern "C"

@@ -19,7 +19,7 @@ EXPORTS = [
     "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_set_samples_in_flight", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
     "rpt_render", "rpt_read_accum", "rpt_resolve", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
     "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
-    "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_trace_rays",
+    "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_trace_rays", "rpt_bvh_build_gpu",
 ]
 
 
@@ -59,6 +59,8 @@ def lib():
         L.rpt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.rpt_debug_math_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.rpt_debug_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 6
+        L.rpt_bvh_build_gpu.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -223,3 +225,20 @@ def debug_math_host(op, x, y=None):
     if rc != 0:
         raise RptError(rc, "rpt_debug_math_host")
     return out
+
+
+def bvh_build_gpu(vertices_xyzw, triangles, sah_samples=128, device=0):
+    """BVHBuilder::build on the GPU (rpt_bvh_build_gpu; reference src/bvh.rs:59-324).
+    vertices_xyzw: (n, 4) float32; triangles: TRIANGLE_DTYPE array (v0, v1, v2, material).
+    Returns (nodes, reordered triangles, device milliseconds)."""
+    from ._ffi import BVH_NODE_DTYPE, TRIANGLE_DTYPE
+    v = np.ascontiguousarray(vertices_xyzw, np.float32).reshape(-1, 4)
+    t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE).copy()
+    nodes = np.zeros(max(1, 2 * len(t) - 1), BVH_NODE_DTYPE)
+    n_nodes = C.c_size_t(0)
+    ms = C.c_double(0.0)
+    rc = lib().rpt_bvh_build_gpu(device, v.ctypes.data, len(v), t.ctypes.data, len(t), sah_samples, nodes.ctypes.data, len(nodes),
+                                 C.byref(n_nodes), C.byref(ms))
+    if rc != 0:
+        raise RptError(rc, lib().rpt_last_error(None).decode())
+    return nodes[: n_nodes.value].copy(), t, ms.value

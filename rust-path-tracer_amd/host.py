@@ -220,3 +220,23 @@ def trace_gpu(scene_path, skybox_path, state, device_id=0):
     """trace_gpu(scene_path, skybox_path, state) (reference: src/trace.rs:136-224) on librpt_hip.so."""
     _check(lib().rpt_trace_gpu(os.fsencode(scene_path), None if skybox_path is None else os.fsencode(skybox_path),
                                state._h, device_id, None))
+
+
+def bvh_build(vertices_xyzw, triangles, sah_samples=128):
+    """BVHBuilder::build on the host (rpt_bvh_build; reference src/bvh.rs:59-324): returns (nodes, reordered triangles)."""
+    v = np.ascontiguousarray(vertices_xyzw, np.float32).reshape(-1, 4)
+    t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE).copy()
+    nodes = np.zeros(max(1, 2 * len(t) - 1), BVH_NODE_DTYPE)
+    n_nodes = C.c_size_t(0)
+    L = lib()
+    L.rpt_bvh_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    _check(L.rpt_bvh_build(v.ctypes.data, len(v), t.ctypes.data, len(t), sah_samples, nodes.ctypes.data, len(nodes), C.byref(n_nodes)))
+    return nodes[: n_nodes.value].copy(), t
+
+
+def set_bvh_builder(use_gpu, hip_library_path=None, device=0):
+    """Choose the BVH builder behind World.from_path / from_buffers: the host restatement (default) or the device build
+    (rpt_bvh_build_gpu).  Same output either way."""
+    L = lib()
+    L.rpt_host_set_bvh_builder.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    _check(L.rpt_host_set_bvh_builder(1 if use_gpu else 0, os.fsencode(hip_library_path) if hip_library_path else None, device))

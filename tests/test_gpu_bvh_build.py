@@ -1,0 +1,107 @@
+"""the GPU BVH build (rpt_bvh_build_gpu, csrc/k_bvh_build.h) against the sequential host restatement of
+the reference builder (src/bvh.rs:59-324 -> csrc/host/bvh_build.cpp): node pool and reordered index buffer must be
+identical bit for bit — node order, leaf ranges, bounds including the sign of zero."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    return importlib.import_module("rust-path-tracer_amd"), importlib.import_module("rust-path-tracer_amd.hip"), \
+        importlib.import_module("rust-path-tracer_amd.host")
+
+
+def _original_soup(world):
+    """vertices (n,4) and a de-ordered triangle list from a loaded World (the build must not depend on input order,
+    but the test feeds both builders the same shuffled input)."""
+    v = np.ascontiguousarray(world.per_vertex["vertex"], np.float32).reshape(-1, 4)
+    t = world.indices.copy()
+    rng = np.random.default_rng(5)
+    return v, t[rng.permutation(len(t))]
+
+
+def _assert_same(a_nodes, a_tris, b_nodes, b_tris):
+    assert len(a_nodes) == len(b_nodes)
+    assert a_tris.tobytes() == b_tris.tobytes()
+    assert a_nodes.tobytes() == b_nodes.tobytes()
+
+
+@pytest.mark.parametrize("scene", ["DarkCornell", "VeachMIS", "FurnaceTest", "PBRTest"])
+def test_gpu_build_equals_host_build_on_shipped_scenes(scene):
+    rpt, hip, host = _mods()
+    v, t = _original_soup(rpt.World.from_path(rpt.fixture(scene + ".glb")))
+    hn, ht = host.bvh_build(v, t)
+    gn, gt, ms = hip.bvh_build_gpu(v, t)
+    _assert_same(gn, gt, hn, ht)
+
+
+@pytest.mark.parametrize("bins", [2, 3, 16, 128])
+def test_gpu_build_bin_counts_and_signed_zeros(bins):
+    """Random soup with many exactly-equal coordinates, +0/-0 vertices and degenerate (point) triangles: ties decide
+    zero signs of bounds and empty-side partitions reorder a leaf's triangles (bvh.rs:294-296)."""
+    rpt, hip, host = _mods()
+    rng = np.random.default_rng(bins)
+    n = 3000
+    grid = rng.integers(-3, 4, (n * 3, 3)).astype(np.float32) * 0.5
+    grid[rng.random(grid.shape) < 0.15] = -0.0
+    grid[rng.random(grid.shape) < 0.15] = 0.0
+    v = np.concatenate([grid, np.ones((len(grid), 1), np.float32)], 1)
+    from importlib import import_module
+    ffi = import_module("rust-path-tracer_amd._ffi")
+    t = np.zeros(n, ffi.TRIANGLE_DTYPE)
+    idx = np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
+    names = t.dtype.names
+    t[names[0]], t[names[1]], t[names[2]] = idx[:, 0], idx[:, 1], idx[:, 2]
+    t[names[3]] = rng.integers(0, 4, n)
+    hn, ht = host.bvh_build(v, t, bins)
+    gn, gt, _ = hip.bvh_build_gpu(v, t, bins)
+    _assert_same(gn, gt, hn, ht)
+
+
+def test_gpu_build_large_standin_and_timing():
+    """The BreakTime stand-in at 200 k triangles (deep tree, long thin overlapping primitives)."""
+    import time
+    rpt, hip, host = _mods()
+    from scenes import deep_bvh_scene
+    w = deep_bvh_scene(200_000)
+    v, t = _original_soup(w)
+    t0 = time.perf_counter(); hn, ht = host.bvh_build(v, t); t_host = time.perf_counter() - t0
+    t0 = time.perf_counter(); gn, gt, ms = hip.bvh_build_gpu(v, t); t_gpu = time.perf_counter() - t0
+    _assert_same(gn, gt, hn, ht)
+    print(f"\n200k-triangle build: host {t_host * 1e3:.0f} ms, GPU {t_gpu * 1e3:.0f} ms wall ({ms:.0f} ms device), {len(gn)} nodes")
+
+
+def test_gpu_build_argument_errors():
+    rpt, hip, host = _mods()
+    v = np.zeros((3, 4), np.float32)
+    ffi = importlib.import_module("rust-path-tracer_amd._ffi")
+    t = np.zeros(1, ffi.TRIANGLE_DTYPE)
+    t[t.dtype.names[2]] = 7                       # vertex index out of range
+    with pytest.raises(hip.RptError):
+        hip.bvh_build_gpu(v, t)
+    t[t.dtype.names[2]] = 2
+    with pytest.raises(hip.RptError):
+        hip.bvh_build_gpu(v, t, sah_samples=500)  # more bins than the device kernel holds
+    nodes, tris, _ = hip.bvh_build_gpu(v, t)      # one degenerate triangle: a single leaf
+    assert len(nodes) == 1 and int(nodes[0]["triangle_count"]) == 1
+
+
+def test_world_loader_with_gpu_builder_gives_the_same_world():
+    rpt, hip, host = _mods()
+    ref = rpt.World.from_path(rpt.fixture("PBRTest.glb"))
+    host.set_bvh_builder(True)
+    try:
+        got = rpt.World.from_path(rpt.fixture("PBRTest.glb"))
+    finally:
+        host.set_bvh_builder(False)
+    for name in ("nodes", "indices", "light_pick", "per_vertex", "materials"):
+        assert getattr(ref, name).tobytes() == getattr(got, name).tobytes(), name
