@@ -263,20 +263,35 @@ __device__ __forceinline__ bool slab_pair_lds(float n_x, float n_y, float n_z, f
 #ifndef RPT_LEAF_K_LDS
 #define RPT_LEAF_K_LDS 16
 #endif
-template <int STACK, bool ANY_HIT, bool SIGNED>
-__device__ __forceinline__ HitRecord traverse_loop_lds(const SceneViewLds &view, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack) {
+/* A walk over the LDS image that can be stopped after a number of loop trips and resumed (k_traverse_nearest_stream):
+ * everything a ray needs besides (ro, rd, 1/rd) is in here and in its stack column. */
+struct LdsWalk {
+    uint32_t cur;          /* descriptor of the node the ray stands on; LDS_DESC_DEAD when finished / no ray */
+    int sp;
     HitRecord res;
-    res.t = 1000000.0f;
-    res.tri = HIT_MISS;
-    int sp = 0;
+};
+__device__ __forceinline__ void lds_walk_begin(const SceneViewLds &view, LdsWalk &w) {
+    w.cur = view.root_desc;
+    w.sp = 0;
+    w.res.t = 1000000.0f;
+    w.res.tri = HIT_MISS;
+}
+
+/* At most `budget` trips of the deferred-leaf loop (see traverse_loop) for the lanes of this wave; returns early when
+ * no lane has anything left.  Per ray the visiting order and every comparison are the reference's. */
+template <int STACK, bool ANY_HIT, bool SIGNED>
+__device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &w, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack,
+                                             int budget) {
     const uint32_t P = view.pairs;
     /* per-ray plane-record bases (float4 units): x | y | z, A or B variant by the sign of the direction */
     const float4 *px = view.img + ((SIGNED && rd.x < 0.0f) ? P : 0u);
     const float4 *py = view.img + 2u * P + ((SIGNED && rd.y < 0.0f) ? P : 0u);
     const float4 *pz = view.img + 4u * P + ((SIGNED && rd.z < 0.0f) ? P : 0u);
     const uint32_t *descs = reinterpret_cast<const uint32_t *>(view.img + 6u * P);
-    uint32_t cur = view.root_desc;
-    for (;;) {
+    uint32_t cur = w.cur;
+    int sp = w.sp;
+    HitRecord res = w.res;
+    for (int trip = 0; trip < budget; ++trip) {
         const bool at_inner = cur < LDS_DESC_DEAD;
         const bool at_leaf = cur >= LDS_DESC_LEAF;
         const unsigned long long inner_m = rpt_ballot(at_inner), leaf_m = rpt_ballot(at_leaf);
@@ -288,8 +303,6 @@ __device__ __forceinline__ HitRecord traverse_loop_lds(const SceneViewLds &view,
             const bool hit_l = slab_pair_lds<SIGNED>(X.x, Y.x, Z.x, X.z, Y.z, Z.z, ro, rd, ird, res.t, tl);
             const bool hit_r = slab_pair_lds<SIGNED>(X.y, Y.y, Z.y, X.w, Y.w, Z.w, ro, rd, ird, res.t, tr);
             const bool swap = hit_r && (!hit_l || tl > tr);     /* strict: ties keep left first */
-            asm volatile("" ::"v"(d));     /* keep the descriptor load up with the plane loads: sunk into the hit branch it
-                                               puts an LDS round trip on every step's critical path */
             if (hit_l || hit_r) {
                 const uint32_t nf = __builtin_amdgcn_alignbit(d, d, swap ? 16u : 0u);    /* near | far << 16 */
                 if (hit_l && hit_r && sp < STACK) {
@@ -325,14 +338,27 @@ __device__ __forceinline__ HitRecord traverse_loop_lds(const SceneViewLds &view,
             }
         }
     }
-    return res;
+    w.cur = cur;
+    w.sp = sp;
+    w.res = res;
+}
+
+template <int STACK, bool ANY_HIT, bool SIGNED>
+__device__ __forceinline__ HitRecord traverse_loop_lds(const SceneViewLds &view, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack) {
+    LdsWalk w;
+    lds_walk_begin(view, w);
+    lds_walk_run<STACK, ANY_HIT, SIGNED>(view, w, ro, rd, ird, max_t, stack, 0x7fffffff);
+    return w.res;
+}
+
+__device__ __forceinline__ bool fastdiv_ray_ok(uint32_t fastdiv_ok, F3 ro, F3 rd) {
+    return fastdiv_ok != 0u && rptm::fastdiv_divisor_ok(rd.x) && rptm::fastdiv_divisor_ok(rd.y) && rptm::fastdiv_divisor_ok(rd.z) &&
+           rptm::fastdiv_operand_ok(ro.x) && rptm::fastdiv_operand_ok(ro.y) && rptm::fastdiv_operand_ok(ro.z);
 }
 
 template <int STACK, bool ANY_HIT>
 __device__ __forceinline__ HitRecord traverse_one(const SceneViewLds &view, uint32_t fastdiv_ok, F3 ro, F3 rd, float max_t, uint16_t *stack) {
-    bool fast = fastdiv_ok != 0u && rptm::fastdiv_divisor_ok(rd.x) && rptm::fastdiv_divisor_ok(rd.y) && rptm::fastdiv_divisor_ok(rd.z) &&
-                rptm::fastdiv_operand_ok(ro.x) && rptm::fastdiv_operand_ok(ro.y) && rptm::fastdiv_operand_ok(ro.z);
-    if (fast) {
+    if (fastdiv_ray_ok(fastdiv_ok, ro, rd)) {
         F3 ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
         return traverse_loop_lds<STACK, ANY_HIT, true>(view, ro, rd, ird, max_t, stack);
     }
@@ -407,6 +433,97 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     HitRecord h = traverse_one<STACK, false>(view, sc.fastdiv_ok, ro, rd, 0.0f, stack);
     float2 *out = reinterpret_cast<float2 *>(&st.ray_b[slot]);
     out[1] = make_float2(h.t, __uint_as_float(h.tri));
+}
+
+/* Extension rays of an LDS-resident scene, STREAMED: a wave owns RPT_STREAM_RAYS x 64 consecutive slots instead of 64.
+ * The traversal is VALU-issue bound and after the first bounce the rays of a wave need very different numbers of
+ * trips (DarkCornell bounce 2: median 25, p90 34, max 68 node visits), so a one-ray-per-lane wave spends most of its
+ * trips with a minority of lanes alive (lane utilisation 40 %).  Here, every RPT_STREAM_TRIPS trips the wave looks at
+ * its idle lanes; when at least RPT_STREAM_REFILL are idle they write their hit records and take the next slots of the
+ * wave's range.  The walk itself (lds_walk_run) is the same code with a trip budget: no per-lane bookkeeping inside
+ * the hot loop.  Per ray nothing changes — same tests in the same order — so hit records are the reference's bit for
+ * bit, and slots stay identity mapped (a slot's ray is traced by SOME lane of the wave that owns its range). */
+#ifndef RPT_STREAM_RAYS
+#define RPT_STREAM_RAYS 4
+#endif
+#ifndef RPT_STREAM_TRIPS
+#define RPT_STREAM_TRIPS 12
+#endif
+#ifndef RPT_STREAM_REFILL
+#define RPT_STREAM_REFILL 16
+#endif
+template <int STACK, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc, DevState st, DevQueues q, uint32_t iteration) {
+    constexpr uint32_t NW = THREADS / RPT_WAVE;
+    constexpr uint32_t SPAN = RPT_STREAM_RAYS * RPT_WAVE;      /* slots per wave */
+    __shared__ uint16_t lds_stack[NW][STACK][RPT_WAVE];
+    float4 *lds_scene = rpt_lds_dyn;
+    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        /* per-iteration bookkeeping, as in k_traverse_nearest */
+        const uint32_t prev = (iteration + 1u) & 1u;
+        q.count[Q_SHADOW] = 0u;
+        if (q.count[Q_SKY] >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q.count[Q_SKY] = 0u;
+        q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
+        q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
+    }
+    const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
+    const uint32_t span_begin = (blockIdx.x * NW + wave) * SPAN;
+    const uint32_t span_end = span_begin + SPAN < st.n_slots ? span_begin + SPAN : st.n_slots;
+    if (blockIdx.x * NW * SPAN >= st.n_slots) return;          /* block-uniform */
+    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);
+    if (span_begin >= span_end) return;
+    uint16_t *stack = &lds_stack[wave][0][lane];
+    F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
+    LdsWalk w;
+    lds_walk_begin(view, w);
+    w.cur = LDS_DESC_DEAD;
+    uint32_t slot = 0u;
+    bool have = false;                                         /* this lane holds a ray whose result is not written yet */
+    uint32_t next = span_begin;                                /* wave-uniform: first slot not handed out yet */
+    uint32_t traced = 0u;                                      /* wave-uniform */
+    for (;;) {
+        const unsigned long long idle_m = rpt_ballot(w.cur == LDS_DESC_DEAD);
+        if (next < span_end && (uint32_t)__popcll(idle_m) >= (uint32_t)RPT_STREAM_REFILL) {
+            bool took = false;
+            if (w.cur == LDS_DESC_DEAD) {
+                if (have) {
+                    reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(w.res.t, __uint_as_float(w.res.tri));
+                    have = false;
+                }
+                const uint32_t cand = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                if (cand < span_end) {
+                    const float4 rb = st.ray_b[cand];
+                    if (__float_as_uint(rb.w) == HIT_PENDING) {
+                        const float4 ra = st.ray_a[cand];
+                        ro = f3(ra.x, ra.y, ra.z); rd = f3(ra.w, rb.x, rb.y);
+                        slot = cand;
+                        took = true;
+                        if (fastdiv_ray_ok(sc.fastdiv_ok, ro, rd)) {
+                            ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                            lds_walk_begin(view, w);
+                            have = true;
+                        } else {
+                            /* outside the exact-division guard (a zero / denormal-small direction component): walked here, alone */
+                            HitRecord h = traverse_loop_lds<STACK, false, false>(view, ro, rd, rd, 0.0f, stack);
+                            reinterpret_cast<float2 *>(&st.ray_b[cand])[1] = make_float2(h.t, __uint_as_float(h.tri));
+                        }
+                    }
+                }
+            }
+            next += (uint32_t)__popcll(idle_m);
+            traced += (uint32_t)__popcll(rpt_ballot(took));
+            continue;                                          /* slots that were not pending leave lanes idle: look again */
+        }
+        if (idle_m == ~0ull) break;                            /* nothing in flight and nothing left to hand out */
+        lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, next < span_end ? RPT_STREAM_TRIPS : 0x7fffffff);
+    }
+    if (have) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(w.res.t, __uint_as_float(w.res.tri));
+    /* ray accounting + the alive flag, once per wave */
+    if (lane == 0u && traced != 0u) {
+        raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
+        atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)traced);
+    }
 }
 
 /* Shadow rays (kernels/src/light_pick.rs:141-148): any-hit over the compacted

@@ -111,7 +111,7 @@ def main():
         report("if-if (one step per iter)", [sim_if_if(*wv) for wv in waves], n_rays)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold", "sort", "regroup")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold", "sort", "regroup", "stream")):
     main()
 
 
@@ -369,3 +369,80 @@ def main_regroup():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "regroup":
     main_regroup()
+
+
+def sim_stream(ev, ln, valid, rays_per_lane, trips, refill_thresh, leaf_k, cost_inner, cost_leaf, cost_refill):
+    """k_traverse_nearest_stream as built: a wave owns rays_per_lane*64 consecutive slots; every `trips` loop trips, if at
+    least refill_thresh lanes are idle and slots remain, the idle lanes take the next slots (non-pending slots leave a lane
+    idle until the next look)."""
+    total = 0.0
+    n = len(ln)
+    span = rays_per_lane * 64
+    for base in range(0, n, span):
+        idx = list(range(base, min(base + span, n)))
+        nxt = 0
+        lane_ray = [-1] * 64
+        lane_pos = [0] * 64
+        while True:
+            idle = [l for l in range(64) if lane_ray[l] < 0]
+            if nxt < len(idx) and len(idle) >= refill_thresh:
+                for l in idle:
+                    if nxt < len(idx):
+                        i = idx[nxt]; nxt += 1
+                        if valid[i] and ln[i] > 0:
+                            lane_ray[l] = i; lane_pos[l] = 0
+                total += cost_refill
+                continue
+            if len(idle) == 64:
+                break
+            budget = trips if nxt < len(idx) else 10**9
+            t = 0
+            while t < budget:
+                live = [l for l in range(64) if lane_ray[l] >= 0]
+                if not live:
+                    break
+                inner = [l for l in live if ev[lane_ray[l], lane_pos[l]] == 0]
+                leaf = [l for l in live if ev[lane_ray[l], lane_pos[l]] == 1]
+                step = []
+                if inner:
+                    total += cost_inner; step += inner
+                if leaf and (len(leaf) >= leaf_k or not inner):
+                    total += cost_leaf; step += leaf
+                for l in step:
+                    lane_pos[l] += 1
+                    if lane_pos[l] >= ln[lane_ray[l]]: lane_ray[l] = -1
+                t += 1
+    return total
+
+
+def main_stream():
+    scene = sys.argv[2] if len(sys.argv) > 2 else "DarkCornell"
+    W = H = 128
+    orc = Oracle()
+    w = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    sc = orc.scene(w)
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    order = hip.tile_order(W, H, 0, 1)
+    px = (order >> 16).astype(np.int64) * W + (order & 0xFFFF).astype(np.int64)
+    CI, CL, CR = 214.0, 200.0, 300.0
+    for bounce in (0, 2):
+        rays = np.zeros((W * H, 6), np.float32)
+        valid = np.zeros(W * H, np.uint8)
+        orc.lib.oracle_dump_rays(C.byref(cfg), C.byref(sc), seeds.ctypes.data_as(C.c_void_p), C.c_uint32(bounce),
+                                 rays.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p))
+        rays, valid = rays[px], valid[px]
+        ev, ln = events_for(orc, sc, np.ascontiguousarray(rays[:, :3]), np.ascontiguousarray(rays[:, 3:]))
+        ln = np.where(valid == 1, ln, 0)
+        sub = slice(0, 8192)
+        evs, lns, vs = ev[sub], ln[sub], valid[sub]
+        n_rays = int(vs.sum())
+        print(f"{scene} bounce {bounce}")
+        for name, (r, t, f) in [("one ray per lane", (1, 10**9, 64)), ("R4 T12 F16", (4, 12, 16)), ("R8 T12 F16", (8, 12, 16)), ("R4 T4 F8", (4, 4, 8)),
+                                ("R4 T1 F1", (4, 1, 1)), ("R16 T4 F8", (16, 4, 8)), ("R128 T1 F1", (128, 1, 1))]:
+            c = sim_stream(evs, lns, vs, r, t, f, 16, CI, CL, CR)
+            print(f"  {name:18s}: cycles/ray {c/n_rays:7.1f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stream":
+    main_stream()
