@@ -435,16 +435,17 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     out[1] = make_float2(h.t, __uint_as_float(h.tri));
 }
 
-/* Extension rays of an LDS-resident scene, STREAMED: a wave owns RPT_STREAM_RAYS x 64 consecutive slots instead of 64.
+/* Extension rays of an LDS-resident scene, STREAMED: a workgroup owns up to RPT_STREAM_RAYS x THREADS consecutive slots
+ * and deals them to the idle lanes of its waves on demand.
  * The traversal is VALU-issue bound and after the first bounce the rays of a wave need very different numbers of
  * trips (DarkCornell bounce 2: median 25, p90 34, max 68 node visits), so a one-ray-per-lane wave spends most of its
  * trips with a minority of lanes alive (lane utilisation 40 %).  Here, every RPT_STREAM_TRIPS trips the wave looks at
- * its idle lanes; when at least RPT_STREAM_REFILL are idle they write their hit records and take the next slots of the
- * wave's range.  The walk itself (lds_walk_run) is the same code with a trip budget: no per-lane bookkeeping inside
+ * its idle lanes; when at least RPT_STREAM_REFILL are idle they write their hit records and take the next slots from the
+ * workgroup's pool (an LDS counter over the workgroup's RPT_STREAM_RAYS x THREADS consecutive slots).  The walk itself (lds_walk_run) is the same code with a trip budget: no per-lane bookkeeping inside
  * the hot loop.  Per ray nothing changes — same tests in the same order — so hit records are the reference's bit for
  * bit, and slots stay identity mapped (a slot's ray is traced by SOME lane of the wave that owns its range). */
 #ifndef RPT_STREAM_RAYS
-#define RPT_STREAM_RAYS 4
+#define RPT_STREAM_RAYS 8          /* most slots per lane of a workgroup (the host lowers it for small launches) */
 #endif
 #ifndef RPT_STREAM_TRIPS
 #define RPT_STREAM_TRIPS 12
@@ -453,10 +454,11 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
 #define RPT_STREAM_REFILL 16
 #endif
 template <int STACK, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc, DevState st, DevQueues q, uint32_t iteration) {
+__global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
+                                                                       uint32_t SPAN /* slots per workgroup, dealt to its waves on demand */) {
     constexpr uint32_t NW = THREADS / RPT_WAVE;
-    constexpr uint32_t SPAN = RPT_STREAM_RAYS * RPT_WAVE;      /* slots per wave */
     __shared__ uint16_t lds_stack[NW][STACK][RPT_WAVE];
+    __shared__ uint32_t pool_next;
     float4 *lds_scene = rpt_lds_dyn;
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     if (blockIdx.x == 0u && threadIdx.x == 0u) {
@@ -468,11 +470,11 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
         q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
     }
     const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
-    const uint32_t span_begin = (blockIdx.x * NW + wave) * SPAN;
+    const uint32_t span_begin = blockIdx.x * SPAN;
+    if (span_begin >= st.n_slots) return;                      /* block-uniform */
     const uint32_t span_end = span_begin + SPAN < st.n_slots ? span_begin + SPAN : st.n_slots;
-    if (blockIdx.x * NW * SPAN >= st.n_slots) return;          /* block-uniform */
-    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);
-    if (span_begin >= span_end) return;
+    if (threadIdx.x == 0u) pool_next = span_begin;
+    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);     /* (barrier inside: pool_next visible) */
     uint16_t *stack = &lds_stack[wave][0][lane];
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     LdsWalk w;
@@ -480,18 +482,23 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
     w.cur = LDS_DESC_DEAD;
     uint32_t slot = 0u;
     bool have = false;                                         /* this lane holds a ray whose result is not written yet */
-    uint32_t next = span_begin;                                /* wave-uniform: first slot not handed out yet */
+    bool pool_open = true;                                     /* wave-uniform: the workgroup's pool may still have slots */
     uint32_t traced = 0u;                                      /* wave-uniform */
     for (;;) {
         const unsigned long long idle_m = rpt_ballot(w.cur == LDS_DESC_DEAD);
-        if (next < span_end && (uint32_t)__popcll(idle_m) >= (uint32_t)RPT_STREAM_REFILL) {
+        const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+        if (pool_open && n_idle >= (uint32_t)RPT_STREAM_REFILL) {
+            uint32_t base = 0u;
+            if (lane == 0u) base = atomicAdd(&pool_next, n_idle);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            pool_open = base + n_idle < span_end;
             bool took = false;
             if (w.cur == LDS_DESC_DEAD) {
                 if (have) {
                     reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(w.res.t, __uint_as_float(w.res.tri));
                     have = false;
                 }
-                const uint32_t cand = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                const uint32_t cand = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
                 if (cand < span_end) {
                     const float4 rb = st.ray_b[cand];
                     if (__float_as_uint(rb.w) == HIT_PENDING) {
@@ -511,12 +518,11 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
                     }
                 }
             }
-            next += (uint32_t)__popcll(idle_m);
             traced += (uint32_t)__popcll(rpt_ballot(took));
             continue;                                          /* slots that were not pending leave lanes idle: look again */
         }
         if (idle_m == ~0ull) break;                            /* nothing in flight and nothing left to hand out */
-        lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, next < span_end ? RPT_STREAM_TRIPS : 0x7fffffff);
+        lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
     }
     if (have) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(w.res.t, __uint_as_float(w.res.tri));
     /* ray accounting + the alive flag, once per wave */

@@ -308,9 +308,13 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
     if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
-        constexpr uint32_t per_block = (LDS_THREADS / RPT_WAVE) * RPT_STREAM_RAYS * RPT_WAVE;
+        /* slots per workgroup: as many as keep >= 2048 workgroups in the launch (8 per CU: the dispatcher needs that
+         * many to balance), at most RPT_STREAM_RAYS per lane (measured best at 16 M slots: 6-8) */
+        uint32_t rays = c->n_slots / (2048u * LDS_THREADS);
+        rays = rays < 1u ? 1u : (rays > (uint32_t)RPT_STREAM_RAYS ? (uint32_t)RPT_STREAM_RAYS : rays);
+        const uint32_t per_block = rays * LDS_THREADS;
         k_traverse_nearest_stream<16, LDS_THREADS><<<(c->n_slots + per_block - 1) / per_block, LDS_THREADS, lds_bytes, s>>>(
-            c->scene, c->state, c->queues, iteration);
+            c->scene, c->state, c->queues, iteration, per_block);
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else
