@@ -299,6 +299,12 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                 const float w_spec = bsdf.specular_weight(view, normal);
                 F3 sdir;
                 const bool spec = !(r3 >= w_spec);
+                /* Both lobes turn one random number into an azimuth and take its sine and cosine (util.rs:27-28, 70), and
+                 * both normalise their final direction (util.rs:31, 84): in a wave that holds both kinds of lanes — nearly
+                 * every wave — the divergent branches would each issue those ~130 instructions.  They are issued once,
+                 * on the lane's own operand. */
+                float sin_p, cos_p;
+                rptm::sincosr(2.0f * RPT_PI_F * (spec ? r1 : r2), sin_p, cos_p);
                 if (!spec) {
                     /* create_cartesian(normal) (util.rs:34-40) */
                     F3 temp_vec = norm3(cross3(normal, f3(0.1f, 0.5f, 0.9f)));
@@ -306,30 +312,26 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                     F3 nb = norm3(cross3(normal, nt));             /* forward */
                     /* cosine_sample_hemisphere (util.rs:24-32) */
                     float theta = rptm::acosr(rptm::sqrtr(r1));
-                    float phi = 2.0f * RPT_PI_F * r2;
-                    float sin_t, cos_t, sin_p, cos_p;
+                    float sin_t, cos_t;
                     rptm::sincosr(theta, sin_t, cos_t);
-                    rptm::sincosr(phi, sin_p, cos_p);
                     F3 s = f3(sin_t * cos_p, cos_t, sin_t * sin_p);
-                    sdir = norm3(f3(s.x * nb.x + s.y * normal.x + s.z * nt.x,
-                                    s.x * nb.y + s.y * normal.y + s.z * nt.y,
-                                    s.x * nb.z + s.y * normal.z + s.z * nt.z));
+                    sdir = f3(s.x * nb.x + s.y * normal.x + s.z * nt.x,
+                              s.x * nb.y + s.y * normal.y + s.z * nt.y,
+                              s.x * nb.z + s.y * normal.z + s.z * nt.z);
                 } else {
                     /* reflect(-view, n) then sample_ggx (util.rs:42-44, 67-85) */
                     F3 inc = -view;
                     F3 refl = inc - normal * 2.0f * dot3(inc, normal);
                     float a = bsdf.roughness * bsdf.roughness;
-                    float phi = 2.0f * RPT_PI_F * r1;
                     float cos_theta = rptm::sqrtr((1.0f - r2) / (r2 * (a * a - 1.0f) + 1.0f));
                     float sin_theta = rptm::sqrtr(1.0f - cos_theta * cos_theta);
-                    float sin_p, cos_p;
-                    rptm::sincosr(phi, sin_p, cos_p);
                     F3 h = f3(cos_p * sin_theta, sin_p * sin_theta, cos_theta);
                     F3 up = rptm::absr(refl.z) < 0.999f ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
                     F3 tangent = norm3(cross3(up, refl));
                     F3 bitangent = cross3(refl, tangent);
-                    sdir = norm3(tangent * h.x + bitangent * h.y + refl * h.z);
+                    sdir = tangent * h.x + bitangent * h.y + refl * h.z;
                 }
+                sdir = norm3(sdir);
                 const float cos_theta = rptm::fmaxr(dot3(normal, sdir), RPT_EPS);
                 const F3 halfway = norm3(view + sdir);
                 const F3 ks = bsdf.ks_of(view, halfway);

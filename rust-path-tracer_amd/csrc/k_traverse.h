@@ -259,9 +259,10 @@ __device__ __forceinline__ bool slab_pair_lds(float n_x, float n_y, float n_z, f
 }
 
 /* leaf batching threshold of the LDS loop: its inner step is ~25 % cheaper than the generic one, so waiting for
- * more leaf lanes pays (traverse 28.4 ms at K = 8, 26.8-27.3 ms for K = 16..32, 29.0 ms at 48) */
+ * more leaf lanes pays (one ray per lane: traverse 28.4 ms at K = 8, 26.8-27.3 ms for K = 16..32, 29.0 ms at 48;
+ * streamed: 26.0 / 23.7 / 23.5 / 22.6 / 23.3 ms for K = 8 / 12 / 16 / 24 / 32) */
 #ifndef RPT_LEAF_K_LDS
-#define RPT_LEAF_K_LDS 16
+#define RPT_LEAF_K_LDS 24
 #endif
 /* A walk over the LDS image that can be stopped after a number of loop trips and resumed (k_traverse_nearest_stream):
  * everything a ray needs besides (ro, rd, 1/rd) is in here and in its stack column. */
