@@ -205,7 +205,11 @@ __device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 r
                 float t = 0.0f;
                 bool bf = false;
                 if (moller_trumbore_view(view, ti, ro, rd, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
-                    res.t = rptm::fminr(res.t, t);
+                    /* result.t = result.t.min(t) with t < result.t already established (intersection.rs:195-199).  Kept a
+                     * real branch: as two selects on vcc the update becomes back-to-back VOP2 v_cndmask, which gfx950 issues
+                     * at ~22 cycles each (tools/microbench/valu_rates.hip) */
+                    asm volatile("" ::: "memory");
+                    res.t = t;
                     res.tri = ti | (bf ? 0x80000000u : 0u);
                     if (ANY_HIT) { accepted = true; break; }
                 }
@@ -326,7 +330,11 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
                 float t = 0.0f;
                 bool bf = false;
                 if (moller_trumbore_view(view, ti, ro, rd, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
-                    res.t = rptm::fminr(res.t, t);
+                    /* result.t = result.t.min(t) with t < result.t already established (intersection.rs:195-199).  Kept a
+                     * real branch: as two selects on vcc the update becomes back-to-back VOP2 v_cndmask, which gfx950 issues
+                     * at ~22 cycles each (tools/microbench/valu_rates.hip) */
+                    asm volatile("" ::: "memory");
+                    res.t = t;
                     res.tri = ti | (bf ? 0x80000000u : 0u);
                     if (ANY_HIT) { accepted = true; break; }
                 }
