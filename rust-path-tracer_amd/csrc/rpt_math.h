@@ -42,6 +42,8 @@
 
 namespace rptm {
 
+#define RPT_COEF(name, NAME) const double c[NAME##_N] = NAME##_INIT
+
 /* ---- bit casts ---------------------------------------------------------- */
 RPT_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 RPT_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
@@ -49,6 +51,19 @@ RPT_HD uint64_t d2u(double f) { return __builtin_bit_cast(uint64_t, f); }
 RPT_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 
 RPT_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/* One Horner step p*t + c with a literal coefficient.  A 64-bit constant cannot be an inline operand; left to itself
+ * the compiler materialises it with two v_mov into the destination of a two-address v_fmac_f64 — in the sky stage
+ * those moves outnumbered the f64 arithmetic.  Asked for in an SGPR pair it costs two s_mov (scalar unit, off the
+ * VALU port) and the step is one v_fma_f64.  Same operation, same bits. */
+RPT_HD double horner(double p, double t, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(t), "s"(c));
+    return r;
+#else
+    return __builtin_fma(p, t, c);
+#endif
+}
 
 /* ---- IEEE float helpers with Rust semantics ------------------------------ */
 /* f32::min / f32::max: a NaN operand yields the other operand
@@ -147,20 +162,20 @@ RPT_HD double reduce_pio2(double x, int &q) {
 }
 
 RPT_HD double sin_poly(double r) {
-    const double c[RPT_SIN_C_N] = RPT_SIN_C_INIT;
+    RPT_COEF(k_sin_c, RPT_SIN_C);
     double t = r * r;
     double p = c[RPT_SIN_C_N - 1];
 RPT_UNROLL
-    for (int i = RPT_SIN_C_N - 2; i >= 1; --i) p = fmad(p, t, c[i]);
+    for (int i = RPT_SIN_C_N - 2; i >= 1; --i) p = horner(p, t, c[i]);
     /* sin r = r + r*t*p */
     return fmad(r * t, p, r);
 }
 RPT_HD double cos_poly(double r) {
-    const double c[RPT_COS_C_N] = RPT_COS_C_INIT;
+    RPT_COEF(k_cos_c, RPT_COS_C);
     double t = r * r;
     double p = c[RPT_COS_C_N - 1];
 RPT_UNROLL
-    for (int i = RPT_COS_C_N - 2; i >= 0; --i) p = fmad(p, t, c[i]);
+    for (int i = RPT_COS_C_N - 2; i >= 0; --i) p = horner(p, t, c[i]);
     return p;
 }
 
@@ -186,13 +201,13 @@ RPT_HD float cosr(float x) { float s, c; sincosr(x, s, c); return c; }
 
 /* exp of a double t, returned as double (t in [-700, 700]) */
 RPT_HD double exp_core(double t) {
-    const double c[RPT_EXP_C_N] = RPT_EXP_C_INIT;
+    RPT_COEF(k_exp_c, RPT_EXP_C);
     double kf = rint_magic(t * RPT_LOG2E);
     double r = fmad(-kf, RPT_LN2_HI, t);
     r = fmad(-kf, RPT_LN2_LO, r);
     double p = c[RPT_EXP_C_N - 1];
 RPT_UNROLL
-    for (int i = RPT_EXP_C_N - 2; i >= 0; --i) p = fmad(p, r, c[i]);
+    for (int i = RPT_EXP_C_N - 2; i >= 0; --i) p = horner(p, r, c[i]);
     int k = (int)kf;
     /* split the scale so that 2^k never leaves the normal double range */
     int k1 = k / 2, k2 = k - k1;
@@ -208,7 +223,7 @@ RPT_HD float expr(float x) {
 
 /* natural log of a positive finite double-representable float value */
 RPT_HD double log_core(double x) {
-    const double c[RPT_ATANH_C_N] = RPT_ATANH_C_INIT;
+    RPT_COEF(k_atanh_c, RPT_ATANH_C);
     uint64_t u = d2u(x);
     int e = (int)((u >> 52) & 0x7ff) - 1023;
     double m = u2d((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);   /* [1,2) */
@@ -217,7 +232,7 @@ RPT_HD double log_core(double x) {
     double t = f * f;
     double p = c[RPT_ATANH_C_N - 1];
 RPT_UNROLL
-    for (int i = RPT_ATANH_C_N - 2; i >= 1; --i) p = fmad(p, t, c[i]);
+    for (int i = RPT_ATANH_C_N - 2; i >= 1; --i) p = horner(p, t, c[i]);
     /* atanh f = f + f*t*p ; log m = 2 atanh f */
     double lm = 2.0 * fmad(f * t, p, f);
     double ed = (double)e;
@@ -259,10 +274,10 @@ RPT_HD float powr(float x, float y) {
 
 /* asin core: x * P(x^2), |x| <= 1/2 */
 RPT_HD double asin_poly(double x, double t) {
-    const double c[RPT_ASIN_C_N] = RPT_ASIN_C_INIT;
+    RPT_COEF(k_asin_c, RPT_ASIN_C);
     double p = c[RPT_ASIN_C_N - 1];
 RPT_UNROLL
-    for (int i = RPT_ASIN_C_N - 2; i >= 1; --i) p = fmad(p, t, c[i]);
+    for (int i = RPT_ASIN_C_N - 2; i >= 1; --i) p = horner(p, t, c[i]);
     return fmad(x * t, p, x * c[0]);
 }
 
@@ -308,7 +323,7 @@ RPT_HD float asinr(float xf) {
 
 /* atan of a in [0, 1] as double */
 RPT_HD double atan01(double a) {
-    const double c[RPT_ATAN_C_N] = RPT_ATAN_C_INIT;
+    RPT_COEF(k_atan_c, RPT_ATAN_C);
     double base = 0.0, base_lo = 0.0, x = a;
     if (a > RPT_TAN_PIO8) {
         x = (a - 1.0) * rcp_newton(a + 1.0);
@@ -318,7 +333,7 @@ RPT_HD double atan01(double a) {
     double t = x * x;
     double p = c[RPT_ATAN_C_N - 1];
 RPT_UNROLL
-    for (int i = RPT_ATAN_C_N - 2; i >= 1; --i) p = fmad(p, t, c[i]);
+    for (int i = RPT_ATAN_C_N - 2; i >= 1; --i) p = horner(p, t, c[i]);
     double at = fmad(x * t, p, x * c[0]);
     return (base + at) + base_lo;
 }
