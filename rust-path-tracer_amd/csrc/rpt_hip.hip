@@ -308,9 +308,11 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
     if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
-        /* slots per workgroup: as many as keep >= 2048 workgroups in the launch (8 per CU: the dispatcher needs that
-         * many to balance), at most RPT_STREAM_RAYS per lane (measured best at 16 M slots: 6-8) */
-        uint32_t rays = c->n_slots / (2048u * LDS_THREADS);
+        /* slots per workgroup: as many as keep >= 1024 workgroups in the launch (the dispatcher needs a few per CU to
+         * balance), at most RPT_STREAM_RAYS per lane (measured best at 16 M slots: 6-8) */
+        uint32_t min_blocks = 1024u;     /* measured at 2 M slots (1/8 of DarkCornell 1024^2): 5.5 / 6.2 / 6.2 / 5.6 Grays/s for 2048 / 1024 / 512 / 256 */
+        if (const char *e = getenv("RPT_STREAM_MIN_BLOCKS")) min_blocks = (uint32_t)std::max(1, atoi(e));
+        uint32_t rays = c->n_slots / (min_blocks * LDS_THREADS);
         rays = rays < 1u ? 1u : (rays > (uint32_t)RPT_STREAM_RAYS ? (uint32_t)RPT_STREAM_RAYS : rays);
         const uint32_t per_block = rays * LDS_THREADS;
         k_traverse_nearest_stream<16, LDS_THREADS><<<(c->n_slots + per_block - 1) / per_block, LDS_THREADS, lds_bytes, s>>>(
@@ -645,6 +647,13 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     bool drained = c->cfg.c.max_bounces == 0u;
     /* Run-ahead: it only has to cover the enqueue latency (tens of microseconds).  Launches over millions of slots
      * last far longer than that, and every surplus iteration still dispatches its (instantly returning) workgroups. */
+    /* When no slot gets a second sample in this call (n_samples <= slots per pixel) nothing is regenerated: every path
+     * ends within max_bounces iterations (lib.rs:62), its misses and shadow rays inside the iteration that produced
+     * them (with several slots per pixel a path ended by a side stage is accumulated by the NEXT shade pass: one more
+     * iteration) — so exactly that many iterations are enqueued and no progress report is awaited (saves the run-ahead's
+     * surplus launches, 4 % of a 1.3 ms batch on 1/8 of an image). */
+    const uint64_t known_iterations =
+        (n_samples <= (1u << c->group_shift) && c->queues.sky_threshold <= 1u) ? (uint64_t)c->cfg.c.max_bounces + (c->group_shift ? 1u : 0u) : 0u;
     const int lag = c->n_slots >= (512u << 10) ? 2 : (c->n_slots >= (128u << 10) ? 3 : LAG);
     /* worst case: every sample needs max_bounces iterations, one after another */
     /* safety net against a stuck pipeline (a bug), far above what deferral of sky work can cost */
@@ -661,7 +670,8 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
             default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at); break;
         }
         it += 1;
-        if (it >= (uint64_t)lag) {
+        if (it == known_iterations) break;                      /* (no report needed: nothing can be left) */
+        if (known_iterations == 0 && it >= (uint64_t)lag) {
             /* the sky kernel of iteration j published (j + 1) << 32 | "work remains after iteration j" */
             uint64_t j = it - lag;
             volatile unsigned long long *slot = &c->host_ring[j & (RING - 1)];
@@ -682,6 +692,11 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
+    if (known_iterations != 0 && c->group_shift != 0 && it == known_iterations) {
+        /* the extra completion iteration must have found nothing left to do: cross-check of the bound above */
+        const unsigned long long v = c->host_ring[(it - 1) & (RING - 1)];
+        if ((v >> 32) != (it & 0xffffffffull) || (uint32_t)v != 0u) { c->error = "wavefront not drained after max_bounces + 1 iterations (internal error)"; return RPT_EHIP; }
+    }
     const bool nee = c->cfg.nee_mode != RPT_NEE_NONE;
     c->stats.iterations += it;
     c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += it;

@@ -1,0 +1,14 @@
+import importlib, sys, time, os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+rpt = importlib.import_module('rust-path-tracer_amd'); hip = importlib.import_module('rust-path-tracer_amd.hip')
+w = rpt.World.from_path(rpt.fixture('DarkCornell.glb'))
+cfg = rpt.default_config(1024, 1024); seeds = rpt.blue_noise_seeds(1024, 1024)
+for world in (int(a) for a in sys.argv[1:]):
+    r = hip.Renderer(0, rank=0, world_size=world); r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+    r.render(16)
+    s0 = r.stats(); t = time.perf_counter(); 
+    for _ in range(8): r.render(16)
+    dt = time.perf_counter() - t; s1 = r.stats()
+    rays = s1['extension_rays'] - s0['extension_rays']
+    print(f'world {world}: {rays/dt/1e6:.0f} Mrays/s per GPU ; ms/step {dt/8*1e3:.3f}')
+    r.close()
