@@ -136,34 +136,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Everything of a step is ordered ON THE DEVICE, on the library's own stream (wrapped for torch): batch k is
+    # enqueued (rpt_render_async: no host wait when the iteration count is known), the previous gather is awaited
+    # stream-side, its image un-tiled, this batch's accumulators copied into the staging buffer and handed to the
+    # collective — the host never blocks inside the timed loop, so launch gaps and Python time hide behind kernels.
+    lib_stream = torch.cuda.ExternalStream(r.stream_ptr(), device=device) if world_size > 1 else None
+
     def finish_gather():
         """Complete the gather of the previous batch; rank 0 un-tiles it into the full image."""
-        recv = gatherer.end()
+        recv = gatherer.end()                                        # (stream-level wait under lib_stream)
         if rank == 0 and recv is not None:
             if staged is not None:
                 staged.copy_(recv)
                 recv = staged
-            torch.cuda.current_stream().synchronize()
-            r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)
+            r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)     # enqueued on the same stream
 
     def step():
-        r.render(args.spp_per_step)                                  # returns when the batch is accumulated
+        r.render_async(args.spp_per_step)
         if world_size > 1:
-            finish_gather()                                          # batch k-1 travelled while batch k rendered
-            gatherer.begin(local_block)                              # the single collective per sample batch
-            torch.cuda.current_stream().synchronize()                # staging copy done: accumulators are free again
+            with torch.cuda.stream(lib_stream):
+                finish_gather()                                      # batch k-1 travelled while batch k rendered
+                gatherer.begin(local_block)                          # the single collective per sample batch
+
+    def drain():
+        if world_size > 1:
+            with torch.cuda.stream(lib_stream):
+                finish_gather()
+        r.wait()
 
     for _ in range(args.warmup):
         step()
-    if world_size > 1:
-        finish_gather()
+    drain()
     barrier()
     s0 = r.stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world_size > 1:
-        finish_gather()                                              # the last batch's image is complete inside the timed region
+    drain()                                                          # the last batch's image is complete inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     s1 = r.stats()

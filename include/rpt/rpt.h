@@ -123,6 +123,16 @@ int rpt_reset(rpt_ctx *ctx, const rpt_rng_state *rng_seed,
  * (kernels/src/lib.rs:225-226) in sample order. Synchronous on return. */
 int rpt_render(rpt_ctx *ctx, uint32_t n_samples);
 
+/* rpt_render that returns as soon as the batch is enqueued — possible when its iteration count is known up front,
+ * i.e. when no slot gets a second sample in this call (n_samples <= slots per pixel, the usual batch); otherwise it
+ * behaves exactly like rpt_render.  Results are read through the same entry points (each synchronises by itself).
+ * rpt_wait blocks until everything enqueued so far has completed.  rpt_stream hands out the HIP stream
+ * (hipStream_t) the library works on, so that a caller can order its own copies / collectives after a batch without
+ * a host round trip (bench.py wraps it as a torch ExternalStream for the per-batch gather). */
+int rpt_render_async(rpt_ctx *ctx, uint32_t n_samples);
+int rpt_wait(rpt_ctx *ctx);
+int rpt_stream(rpt_ctx *ctx, void **hip_stream_out);
+
 /* Replaces output_buffer.read_blocking (src/trace.rs:198).  Writes the SUM
  * (not the mean) as width*height float4 (r, g, b, sample count) in row-major,
  * y-down order.  Pixels of tiles owned by other ranks are written as zeros. */

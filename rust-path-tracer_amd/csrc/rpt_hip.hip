@@ -108,6 +108,11 @@ struct rpt_ctx {
     rpt_stats stats{};
     bool stage_timing = false;
     std::vector<hipEvent_t> timing_events;
+    /* batches enqueued by rpt_render_async whose stage timing has not been read back yet */
+    struct TimingBatch { std::vector<hipEvent_t> ev; uint64_t iterations; };
+    std::vector<TimingBatch> timing_pending;
+    std::vector<hipEvent_t> timing_pool;
+    bool async_pending = false;
 };
 
 namespace {
@@ -407,6 +412,8 @@ void rpt_destroy(rpt_ctx *c) {
     c->indices.release(); c->light_pick.release(); c->atlas.release(); c->skybox.release();
     c->dev_stats.release();
     for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
+    for (auto &b : c->timing_pending) for (hipEvent_t e : b.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->timing_pool) (void)hipEventDestroy(e);
     if (c->host_ring) (void)hipHostFree(c->host_ring);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -621,23 +628,76 @@ int rpt_reset(rpt_ctx *c, const rpt_rng_state *seed, const float *accum_init, ui
     return RPT_OK;
 }
 
-int rpt_render(rpt_ctx *c, uint32_t n_samples) {
+/* rpt_wait: completes everything rpt_render_async enqueued (and folds its stage timing into the statistics). */
+int rpt_wait(rpt_ctx *c) {
+    if (!c) return RPT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    const int stage_of[EVENTS_PER_ITER] = {RPT_STAGE_TRAVERSE, RPT_STAGE_SHADE, RPT_STAGE_SHADOW, RPT_STAGE_SKY};
+    for (auto &b : c->timing_pending) {
+        size_t at = 1;
+        for (uint64_t k = 0; k < b.iterations; ++k)
+            for (int e = 0; e < EVENTS_PER_ITER; ++e) {
+                float ms;
+                if (hipEventElapsedTime(&ms, b.ev[at - 1], b.ev[at]) == hipSuccess) c->stats.kernel_ms[stage_of[e]] += ms;
+                at += 1;
+            }
+        c->timing_pool.insert(c->timing_pool.end(), b.ev.begin(), b.ev.end());
+    }
+    c->timing_pending.clear();
+    c->async_pending = false;
+    return RPT_OK;
+}
+
+int rpt_stream(rpt_ctx *c, void **stream_out) {
+    if (!c || !stream_out) return RPT_EINVAL;
+    *stream_out = reinterpret_cast<void *>(c->stream);
+    return RPT_OK;
+}
+
+static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     if (!c) return RPT_EINVAL;
     if (!c->has_scene || !c->has_config || !c->has_state) { c->error = "scene, config and reset must precede rpt_render"; return RPT_EINVAL; }
     if (n_samples == 0 || c->n_slots == 0) { c->samples += n_samples; return RPT_OK; }
     if ((uint64_t)n_samples + (1u << c->group_shift) >= 0x100000000ull) { c->error = "n_samples too large"; return RPT_EINVAL; }
+    /* When no slot gets a second sample in this call (n_samples <= slots per pixel) nothing is regenerated: every path
+     * ends within max_bounces iterations (lib.rs:62), its misses and shadow rays inside the iteration that produced
+     * them (with several slots per pixel a path ended by a side stage is accumulated by the NEXT shade pass: one more
+     * iteration) — so exactly that many iterations are enqueued and no progress report is awaited (saves the run-ahead's
+     * surplus launches, 4 % of a 1.3 ms batch on 1/8 of an image). */
+    const uint64_t known_iterations =
+        (n_samples <= (1u << c->group_shift) && c->queues.sky_threshold <= 1u) ? (uint64_t)c->cfg.c.max_bounces + (c->group_shift ? 1u : 0u) : 0u;
     HIP_TRY(c, hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
     const uint32_t blocks = (c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK;
+    /* asynchronous only when the iteration count is known up front: nothing has to be polled */
+    const bool async = allow_async && known_iterations != 0;
+    if (!async && c->async_pending) {                     /* the progress ring is about to be reused by the host */
+        int rc = rpt_wait(c);
+        if (rc) return rc;
+    }
 
     HIP_TRY(c, hipMemsetAsync(c->queues.count, 0, Q_COUNT * sizeof(uint32_t), s));
-    for (int k = 0; k < RING; ++k) __atomic_store_n(&c->host_ring[k], 0ull, __ATOMIC_RELAXED);
+    if (!async) for (int k = 0; k < RING; ++k) __atomic_store_n(&c->host_ring[k], 0ull, __ATOMIC_RELAXED);
     k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples);
     c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
 
-    std::vector<hipEvent_t> *ev = c->stage_timing ? &c->timing_events : nullptr;
+    std::vector<hipEvent_t> async_events;
+    std::vector<hipEvent_t> *ev = c->stage_timing ? (async ? &async_events : &c->timing_events) : nullptr;
     size_t ev_at = 0;
+    if (ev && async) {
+        /* this batch's own events, from the pool: they are read back by rpt_wait */
+        const size_t need = 1 + (size_t)known_iterations * EVENTS_PER_ITER;
+        while (c->timing_pool.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(c, hipEventCreate(&e));
+            c->timing_pool.push_back(e);
+        }
+        async_events.assign(c->timing_pool.end() - (long)need, c->timing_pool.end());
+        c->timing_pool.resize(c->timing_pool.size() - need);
+    }
     if (ev) {
         if (ev->empty()) { ev->resize(1); HIP_TRY(c, hipEventCreate(&(*ev)[0])); }
         HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s));
@@ -647,13 +707,6 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     bool drained = c->cfg.c.max_bounces == 0u;
     /* Run-ahead: it only has to cover the enqueue latency (tens of microseconds).  Launches over millions of slots
      * last far longer than that, and every surplus iteration still dispatches its (instantly returning) workgroups. */
-    /* When no slot gets a second sample in this call (n_samples <= slots per pixel) nothing is regenerated: every path
-     * ends within max_bounces iterations (lib.rs:62), its misses and shadow rays inside the iteration that produced
-     * them (with several slots per pixel a path ended by a side stage is accumulated by the NEXT shade pass: one more
-     * iteration) — so exactly that many iterations are enqueued and no progress report is awaited (saves the run-ahead's
-     * surplus launches, 4 % of a 1.3 ms batch on 1/8 of an image). */
-    const uint64_t known_iterations =
-        (n_samples <= (1u << c->group_shift) && c->queues.sky_threshold <= 1u) ? (uint64_t)c->cfg.c.max_bounces + (c->group_shift ? 1u : 0u) : 0u;
     const int lag = c->n_slots >= (512u << 10) ? 2 : (c->n_slots >= (128u << 10) ? 3 : LAG);
     /* worst case: every sample needs max_bounces iterations, one after another */
     /* safety net against a stuck pipeline (a bug), far above what deferral of sky work can cost */
@@ -690,6 +743,19 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
         }
         if (it > it_limit) { c->error = "wavefront did not drain (internal error)"; return RPT_EHIP; }
     }
+    if (async) {
+        c->async_pending = true;
+        c->stats.iterations += it;
+        c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += it;
+        c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
+        c->stats.kernel_launches[RPT_STAGE_SHADOW] += c->cfg.nee_mode != RPT_NEE_NONE ? it : 0;
+        c->stats.kernel_launches[RPT_STAGE_SKY] += it;
+        if (ev) c->timing_pending.push_back(rpt_ctx::TimingBatch{async_events, it});
+        c->samples += n_samples;
+        c->stats.samples += (uint64_t)c->n_pixels * n_samples;
+        c->stats.render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return RPT_OK;
+    }
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
     if (known_iterations != 0 && c->group_shift != 0 && it == known_iterations) {
@@ -720,6 +786,13 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) {
     c->stats.render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RPT_OK;
 }
+
+int rpt_render(rpt_ctx *c, uint32_t n_samples) { return render_impl(c, n_samples, false); }
+
+/* Like rpt_render, but returns as soon as the batch is enqueued when its iteration count is known up front (no slot
+ * gets a second sample: n_samples <= slots per pixel); otherwise identical to rpt_render.  Every entry point that
+ * reads results synchronises by itself; rpt_wait does so explicitly. */
+int rpt_render_async(rpt_ctx *c, uint32_t n_samples) { return render_impl(c, n_samples, true); }
 
 int rpt_read_accum(rpt_ctx *c, float *out, uint32_t *out_samples) {
     if (!c || !out) return RPT_EINVAL;
@@ -855,8 +928,7 @@ int rpt_resolve(rpt_ctx *c, uint32_t tonemap_op, float *out_rgb) {
 
 int rpt_get_stats(rpt_ctx *c, rpt_stats *out) {
     if (!c || !out) return RPT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc = rpt_wait(c); if (rc) return rc; }
     DevStats ds;
     HIP_TRY(c, hipMemcpy(&ds, c->dev_stats.p, sizeof(ds), hipMemcpyDeviceToHost));
     std::vector<unsigned long long> shards(RPT_STAT_SHARDS * RPT_STAT_STRIDE, 0ull);

@@ -17,7 +17,7 @@ _lib = None
 
 EXPORTS = [
     "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_set_samples_in_flight", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
-    "rpt_render", "rpt_read_accum", "rpt_resolve", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
+    "rpt_render", "rpt_render_async", "rpt_wait", "rpt_stream", "rpt_read_accum", "rpt_resolve", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
     "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
     "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_trace_rays", "rpt_bvh_build_gpu",
 ]
@@ -46,6 +46,9 @@ def lib():
         L.rpt_set_config.argtypes = [C.c_void_p, C.POINTER(TracingConfig)]
         L.rpt_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.rpt_render.argtypes = [C.c_void_p, C.c_uint32]
+        L.rpt_render_async.argtypes = [C.c_void_p, C.c_uint32]
+        L.rpt_wait.argtypes = [C.c_void_p]
+        L.rpt_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.rpt_read_accum.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.rpt_read_rng.argtypes = [C.c_void_p, C.c_void_p]
         L.rpt_resolve.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
@@ -135,6 +138,20 @@ class Renderer:
     # -- rpt_render <-> the enqueue/poll loop (reference: src/trace.rs:182-194)
     def render(self, n_samples):
         self._check(lib().rpt_render(self._h, n_samples))
+
+    def render_async(self, n_samples):
+        """rpt_render_async: returns once the batch is enqueued when its iteration count is known (n_samples <= slots per
+        pixel), else behaves like render()."""
+        self._check(lib().rpt_render_async(self._h, n_samples))
+
+    def wait(self):
+        self._check(lib().rpt_wait(self._h))
+
+    def stream_ptr(self):
+        """The hipStream_t the library enqueues on (wrap with torch.cuda.ExternalStream to order work after a batch)."""
+        p = C.c_void_p()
+        self._check(lib().rpt_stream(self._h, C.byref(p)))
+        return p.value
 
     # -- rpt_read_accum <-> output_buffer.read_blocking (reference: src/trace.rs:198)
     def read_accum(self):

@@ -325,6 +325,33 @@ def test_render_in_batches_equals_one_batch(renderer, rpt, world):
     assert s == 6 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def test_render_async_equals_render(rpt, hipmod, world):
+    """rpt_render_async enqueues batches back to back without a host wait when the iteration count is known
+    (n_samples <= slots per pixel) and falls back to the synchronous loop otherwise; accumulators, rng and ray counts
+    must not depend on which entry point was used."""
+    W, H = 96, 64
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+    out = {}
+    for mode in ("sync", "async"):
+        r = hipmod.Renderer(0)
+        r.upload_scene(world("DarkCornell"))
+        r.set_config(cfg)
+        r.reset(seeds)
+        for n in (4, 16, 3, 40, 1):                  # 40 > slots per pixel: exercises the fall-back inside the async call
+            (r.render if mode == "sync" else r.render_async)(n)
+        if mode == "async":
+            r.wait()
+        acc, ns = r.read_accum()
+        st = r.stats()
+        out[mode] = (acc.copy(), ns, r.read_rng().copy(), st["extension_rays"], st["shadow_rays"])
+        r.close()
+    assert out["sync"][1] == out["async"][1] == 64
+    assert np.array_equal(out["sync"][0].view(np.uint32), out["async"][0].view(np.uint32))
+    assert np.array_equal(out["sync"][2], out["async"][2])
+    assert out["sync"][3:5] == out["async"][3:5]
+
+
 def test_resume_from_mean_times_samples(renderer, oracle, rpt, world):
     """accum_init = mean * samples (reference: src/trace.rs:163-164)."""
     w = world("FurnaceTest")

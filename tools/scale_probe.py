@@ -10,7 +10,8 @@ for world in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
     r = hip.Renderer(0, rank=0, world_size=world); r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
     r.render(16)
     s0 = r.stats(); t = time.perf_counter(); 
-    for _ in range(8): r.render(16)
+    for _ in range(8): r.render_async(16)
+    r.wait()
     dt = time.perf_counter() - t; s1 = r.stats()
     rays = s1['extension_rays'] - s0['extension_rays']
     print(f'world {world}: {rays/dt/1e6:.0f} Mrays/s per GPU ; ms/step {dt/8*1e3:.3f}')
