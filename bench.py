@@ -79,7 +79,10 @@ def main():
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="testing aid for --dist-backend gloo")
     args = ap.parse_args()
 
-    os.environ.setdefault("RPT_STAGE_TIMING", "1")   # HIP events between stage kernels on the render stream
+    # HIP events on the render stream: after every stage kernel at N = 1 (per-stage breakdown), only around the
+    # traversal kernel (the dominant one, which the roofline needs) at N > 1, where a 16-kernel batch lasts ~1.3 ms
+    # and 20 event records per batch cost 7 % of it
+    os.environ.setdefault("RPT_STAGE_TIMING", "1" if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else "2")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch

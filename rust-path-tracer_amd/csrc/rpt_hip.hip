@@ -107,6 +107,7 @@ struct rpt_ctx {
     /* stats */
     rpt_stats stats{};
     bool stage_timing = false;
+    int timing_level = 0;           /* RPT_STAGE_TIMING: 1 = an event after every stage kernel, 2 = only around the traversal kernel */
     std::vector<hipEvent_t> timing_events;
     /* batches enqueued by rpt_render_async whose stage timing has not been read back yet */
     struct TimingBatch { std::vector<hipEvent_t> ev; uint64_t iterations; };
@@ -307,9 +308,11 @@ constexpr int LDS_THREADS = RPT_LDS_THREADS;     /* workgroup size of the LDS-re
 template <int STACK, int NEE, bool TEXTURED>
 void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
     hipStream_t s = c->stream;
-    auto mark = [&]() {
-        if (ev) (void)hipEventRecord((*ev)[ev_at++], s);
+    const bool only_traverse = c->timing_level == 2;
+    auto mark = [&](bool traverse_edge = false) {
+        if (ev && (!only_traverse || traverse_edge)) (void)hipEventRecord((*ev)[ev_at++], s);
     };
+    if (only_traverse) mark(true);
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
     if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
@@ -326,7 +329,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else
         k_traverse_nearest<STACK, false, GLOBAL_THREADS><<<(c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
-    mark();
+    mark(true);
     k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
     if (NEE != RPT_NEE_NONE) {
@@ -359,7 +362,27 @@ void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std
     }
 }
 
-constexpr int EVENTS_PER_ITER = 4;   /* after traverse, shade, shadow, sky */
+constexpr int EVENTS_PER_ITER = 4;   /* timing level 1: after traverse, shade, shadow, sky (+ one leading event per call);
+                                        level 2: before and after the traversal kernel only */
+
+static size_t timing_events_needed(const rpt_ctx *c, uint64_t iterations) {
+    return c->timing_level == 2 ? (size_t)iterations * 2 : 1 + (size_t)iterations * EVENTS_PER_ITER;
+}
+static void timing_accumulate(rpt_ctx *c, const std::vector<hipEvent_t> &ev, uint64_t iterations) {
+    float ms;
+    if (c->timing_level == 2) {
+        for (uint64_t k = 0; k < iterations; ++k)
+            if (hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) == hipSuccess) c->stats.kernel_ms[RPT_STAGE_TRAVERSE] += ms;
+        return;
+    }
+    const int stage_of[EVENTS_PER_ITER] = {RPT_STAGE_TRAVERSE, RPT_STAGE_SHADE, RPT_STAGE_SHADOW, RPT_STAGE_SKY};
+    size_t at = 1;
+    for (uint64_t k = 0; k < iterations; ++k)
+        for (int e = 0; e < EVENTS_PER_ITER; ++e) {
+            if (hipEventElapsedTime(&ms, ev[at - 1], ev[at]) == hipSuccess) c->stats.kernel_ms[stage_of[e]] += ms;
+            at += 1;
+        }
+}
 
 }  // namespace
 
@@ -395,7 +418,9 @@ int rpt_create(int device_id, rpt_ctx **out) {
         return RPT_ENOMEM;
     }
     const char *env = getenv("RPT_STAGE_TIMING");
-    c->stage_timing = env && env[0] == '1';
+    c->timing_level = env ? atoi(env) : 0;
+    if (c->timing_level < 0 || c->timing_level > 2) c->timing_level = 0;
+    c->stage_timing = c->timing_level != 0;
     if (const char *e2 = getenv("RPT_LDS_STREAM")) c->lds_stream = e2[0] != '0';
     if (const char *e3 = getenv("RPT_SAMPLES_IN_FLIGHT")) c->samples_in_flight_request = std::min(32, std::max(0, atoi(e3)));
     *out = c;
@@ -634,15 +659,8 @@ int rpt_wait(rpt_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    const int stage_of[EVENTS_PER_ITER] = {RPT_STAGE_TRAVERSE, RPT_STAGE_SHADE, RPT_STAGE_SHADOW, RPT_STAGE_SKY};
     for (auto &b : c->timing_pending) {
-        size_t at = 1;
-        for (uint64_t k = 0; k < b.iterations; ++k)
-            for (int e = 0; e < EVENTS_PER_ITER; ++e) {
-                float ms;
-                if (hipEventElapsedTime(&ms, b.ev[at - 1], b.ev[at]) == hipSuccess) c->stats.kernel_ms[stage_of[e]] += ms;
-                at += 1;
-            }
+        timing_accumulate(c, b.ev, b.iterations);
         c->timing_pool.insert(c->timing_pool.end(), b.ev.begin(), b.ev.end());
     }
     c->timing_pending.clear();
@@ -689,7 +707,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     size_t ev_at = 0;
     if (ev && async) {
         /* this batch's own events, from the pool: they are read back by rpt_wait */
-        const size_t need = 1 + (size_t)known_iterations * EVENTS_PER_ITER;
+        const size_t need = timing_events_needed(c, known_iterations);
         while (c->timing_pool.size() < need) {
             hipEvent_t e;
             HIP_TRY(c, hipEventCreate(&e));
@@ -698,7 +716,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         async_events.assign(c->timing_pool.end() - (long)need, c->timing_pool.end());
         c->timing_pool.resize(c->timing_pool.size() - need);
     }
-    if (ev) {
+    if (ev && c->timing_level == 1) {
         if (ev->empty()) { ev->resize(1); HIP_TRY(c, hipEventCreate(&(*ev)[0])); }
         HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s));
     }
@@ -769,18 +787,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
     c->stats.kernel_launches[RPT_STAGE_SHADOW] += nee ? it : 0;
     c->stats.kernel_launches[RPT_STAGE_SKY] += it;
-    if (ev) {
-        /* one start event, then per iteration: traverse, shade, shadow, sky */
-        size_t at = 1;
-        const int stage_of[EVENTS_PER_ITER] = {RPT_STAGE_TRAVERSE, RPT_STAGE_SHADE, RPT_STAGE_SHADOW, RPT_STAGE_SKY};
-        for (uint64_t k = 0; k < it; ++k) {
-            for (int e = 0; e < EVENTS_PER_ITER; ++e) {
-                float ms;
-                if (hipEventElapsedTime(&ms, (*ev)[at - 1], (*ev)[at]) == hipSuccess) c->stats.kernel_ms[stage_of[e]] += ms;
-                at += 1;
-            }
-        }
-    }
+    if (ev) timing_accumulate(c, *ev, it);
     c->samples += n_samples;
     c->stats.samples += (uint64_t)c->n_pixels * n_samples;
     c->stats.render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
