@@ -183,10 +183,12 @@ def test_full_size_baseline_config_properties(hipmod, oracle, rpt, world):
         r.render(n)
     b, _ = r.read_accum()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    rect = (480, 470, 544, 534)
-    ref, _, _ = oracle.trace_cpu(cfg, oracle.scene(world("DarkCornell")), seeds, spp, rect=rect)
-    x0, y0, x1, y1 = rect
-    assert np.array_equal(a[y0:y1, x0:x1].view(np.uint32), ref[y0:y1, x0:x1].view(np.uint32))
+    # windows in the middle, at two corners and across a 64-pixel tile seam: 16 M slots are in flight here, so this is
+    # the streamed traversal with lane refill (k_traverse_nearest_stream) checked against the oracle at full size
+    for rect in ((480, 470, 544, 534), (0, 0, 48, 40), (976, 992, 1024, 1024), (40, 600, 90, 650)):
+        ref, _, _ = oracle.trace_cpu(cfg, oracle.scene(world("DarkCornell")), seeds, spp, rect=rect)
+        x0, y0, x1, y1 = rect
+        assert np.array_equal(a[y0:y1, x0:x1].view(np.uint32), ref[y0:y1, x0:x1].view(np.uint32)), rect
     r.close()
 
 
