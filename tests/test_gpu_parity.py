@@ -192,6 +192,28 @@ def test_full_size_baseline_config_properties(hipmod, oracle, rpt, world):
     r.close()
 
 
+@pytest.mark.parametrize("scene,W,H,nee,spp", [("VeachMIS", 1920, 1080, 1, 3), ("PBRTest", 2048, 2048, 0, 2)])
+def test_full_size_other_baseline_configs_windows(hipmod, oracle, rpt, world, scene, W, H, nee, spp):
+    """BASELINE configs [2] and [3] at their full resolutions (few samples): windows of the full-size image equal the
+    oracle's render of those windows bit for bit, and the ray counts obey their bounds."""
+    cfg = rpt.default_config(W, H, nee=nee)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    r.upload_scene(world(scene))
+    r.set_config(cfg)
+    r.reset(seeds)
+    r.render(spp)
+    a, s = r.read_accum()
+    st = r.stats()
+    assert s == spp and np.all(a[..., 3] == spp) and np.isfinite(a).all()
+    assert W * H * spp <= st["extension_rays"] <= W * H * spp * cfg.max_bounces
+    for rect in ((W // 2 - 24, H // 2 - 20, W // 2 + 24, H // 2 + 20), (0, H - 32, 40, H), (W - 40, 0, W, 36)):
+        ref, _, _ = oracle.trace_cpu(cfg, oracle.scene(world(scene)), seeds, spp, rect=rect)
+        x0, y0, x1, y1 = rect
+        assert np.array_equal(a[y0:y1, x0:x1].view(np.uint32), ref[y0:y1, x0:x1].view(np.uint32)), rect
+    r.close()
+
+
 @pytest.mark.parametrize("scene,nee,spp", [("DarkCornell", 0, 7), ("VeachMIS", 1, 5), ("PBRTest", 2, 3)])
 def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp):
     """Any number of samples of a pixel in flight gives the sequential sample-order sum, bit for bit
