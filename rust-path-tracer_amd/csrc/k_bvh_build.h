@@ -22,9 +22,9 @@
  *     where the element AT first+nl is met first.  (Checked against the sequential loop on 200 000 random inputs
  *     before it was written down here; tests/test_gpu_bvh_build.py compares whole builds.)
  *
- * One workgroup walks its node's range with a stride loop, so the top of a large tree is slow per node (the root of
- * a 1 M-triangle scene: ~4 000 trips per pass) and the bottom is wide; that is still two orders of magnitude
- * faster than the sequential host build and keeps one code path.
+ * One workgroup walks its node's range with a stride loop (1024 threads for the few huge nodes at the top, 256 below),
+ * so the top of a large tree is slow per node (the root of a 1 M-triangle scene: ~1 000 trips per pass) and the bottom
+ * is wide; that is still an order of magnitude faster than the sequential host build and keeps one code path.
  */
 #ifndef RPT_K_BVH_BUILD_H
 #define RPT_K_BVH_BUILD_H
@@ -105,6 +105,7 @@ __device__ __forceinline__ float bvb_area(const BvbBox &b) {
 }
 
 /* exclusive prefix of a per-thread 0/1 flag over the workgroup (+ running base), in thread order; every thread calls */
+template <int THREADS>
 __device__ __forceinline__ uint32_t bvb_block_rank(bool flag, uint32_t *wave_tot, uint32_t &block_total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
@@ -113,7 +114,7 @@ __device__ __forceinline__ uint32_t bvb_block_rank(bool flag, uint32_t *wave_tot
     if (lane == 0u) wave_tot[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     uint32_t before = 0u, total = 0u;
-    for (uint32_t w = 0; w < BVB_THREADS / 64u; ++w) {
+    for (uint32_t w = 0; w < (uint32_t)THREADS / 64u; ++w) {
         uint32_t n = wave_tot[w];
         before += w < wave ? n : 0u;
         total += n;
@@ -122,7 +123,9 @@ __device__ __forceinline__ uint32_t bvb_block_rank(bool flag, uint32_t *wave_tot
     return before + within;
 }
 
-__global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t level_begin) {
+/* THREADS = 1024 for the few huge nodes at the top of the tree (a workgroup walks its node's whole range), 256 below */
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level_begin) {
     __shared__ unsigned long long s_key[3][BVB_MAX_BINS][6];      /* [axis][bin]: min x,y,z  max x,y,z */
     __shared__ uint32_t s_cnt[3][BVB_MAX_BINS];
     __shared__ float s_la[3][BVB_MAX_BINS], s_ra[3][BVB_MAX_BINS];
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
     __shared__ uint32_t s_cb[6];                                  /* centroid bounds: ord(min) x3, ord(max) x3 */
     __shared__ float s_best_cost[3];
     __shared__ uint32_t s_best_i[3];
-    __shared__ uint32_t s_wave_tot[BVB_THREADS / 64];
+    __shared__ uint32_t s_wave_tot[THREADS / 64];
     __shared__ uint32_t s_misc[4];
     __shared__ float s_split;
     __shared__ int s_axis;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
     {
         unsigned long long kmin[3] = {BVB_MIN_IDENT, BVB_MIN_IDENT, BVB_MIN_IDENT}, kmax[3] = {BVB_MAX_IDENT, BVB_MAX_IDENT, BVB_MAX_IDENT};
         uint32_t cmin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, cmax[3] = {0u, 0u, 0u};
-        for (uint32_t i = tid; i < count; i += BVB_THREADS) {
+        for (uint32_t i = tid; i < count; i += THREADS) {
             const uint32_t tri = a.order[first + i];
             const uint4 t = a.tris[tri];
             const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
     const float nmx[3] = {bvb_key_value(s_red[3]), bvb_key_value(s_red[4]), bvb_key_value(s_red[5])};
 
     /* ---- find_best_split_segmented (bvh.rs:178-255): all three axes binned in one pass */
-    for (uint32_t k = tid; k < 3u * BVB_MAX_BINS; k += BVB_THREADS) {
+    for (uint32_t k = tid; k < 3u * BVB_MAX_BINS; k += THREADS) {
         const uint32_t ax = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
         for (int j = 0; j < 6; ++j) s_key[ax][b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
         s_cnt[ax][b] = 0u;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
         axis_on[j] = !(bmin[j] == bmax[j]);
         scale[j] = (float)S / (bmax[j] - bmin[j]);
     }
-    for (uint32_t i = tid; i < count; i += BVB_THREADS) {
+    for (uint32_t i = tid; i < count; i += THREADS) {
         const uint32_t tri = a.order[first + i];
         const uint4 t = a.tris[tri];
         const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
     uint32_t nl;
     {
         uint32_t mine = 0u;
-        for (uint32_t i = tid; i < count; i += BVB_THREADS) mine += is_left(first + i) ? 1u : 0u;
+        for (uint32_t i = tid; i < count; i += THREADS) mine += is_left(first + i) ? 1u : 0u;
         if (tid == 0u) s_misc[0] = 0u;
         __syncthreads();
         atomicAdd(&s_misc[0], mine);
@@ -308,15 +311,15 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
     uint32_t H = 0u;
     {
         uint32_t run_l = 0u, run_r = 0u;
-        for (uint32_t base = 0; base < back_n; base += BVB_THREADS) {
+        for (uint32_t base = 0; base < back_n; base += THREADS) {
             const uint32_t i = base + tid;
             const bool valid = i < back_n;
             const uint32_t q = last - i;
             const bool L = valid && is_left(q);
             const bool R = valid && !L;
             uint32_t tot_l, tot_r;
-            const uint32_t m = run_l + bvb_block_rank(L, s_wave_tot, tot_l);
-            const uint32_t rb = run_r + bvb_block_rank(R, s_wave_tot, tot_r);
+            const uint32_t m = run_l + bvb_block_rank<THREADS>(L, s_wave_tot, tot_l);
+            const uint32_t rb = run_r + bvb_block_rank<THREADS>(R, s_wave_tot, tot_r);
             if (L) a.tmp_b[first + m] = rb;
             run_l += tot_l;
             run_r += tot_r;
@@ -329,14 +332,14 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
     /* pass F: prefix, ascending */
     {
         uint32_t run = 0u;
-        for (uint32_t base = 0; base < nl; base += BVB_THREADS) {
+        for (uint32_t base = 0; base < nl; base += THREADS) {
             const uint32_t i = base + tid;
             const bool valid = i < nl;
             const uint32_t p = first + i;
             const bool L = valid && is_left(p);
             const bool R = valid && !L;
             uint32_t tot;
-            const uint32_t hole = run + bvb_block_rank(R, s_wave_tot, tot);
+            const uint32_t hole = run + bvb_block_rank<THREADS>(R, s_wave_tot, tot);
             if (L) a.order_tmp[p] = a.order[p];
             if (R) {
                 const uint32_t rank = hole + (hole >= 1u ? a.tmp_b[first + hole - 1u] : 0u);
@@ -351,15 +354,15 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
     /* pass B2: suffix again, now every destination is known */
     {
         uint32_t run_l = 0u, run_r = 0u;
-        for (uint32_t base = 0; base < back_n; base += BVB_THREADS) {
+        for (uint32_t base = 0; base < back_n; base += THREADS) {
             const uint32_t i = base + tid;
             const bool valid = i < back_n;
             const uint32_t q = last - i;
             const bool L = valid && is_left(q);
             const bool R = valid && !L;
             uint32_t tot_l, tot_r;
-            const uint32_t m = run_l + bvb_block_rank(L, s_wave_tot, tot_l);
-            const uint32_t rb = run_r + bvb_block_rank(R, s_wave_tot, tot_r);
+            const uint32_t m = run_l + bvb_block_rank<THREADS>(L, s_wave_tot, tot_l);
+            const uint32_t rb = run_r + bvb_block_rank<THREADS>(R, s_wave_tot, tot_r);
             if (L) a.order_tmp[a.tmp_a[first + m]] = a.order[q];
             if (R) {
                 uint32_t rank;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_level(BvbArgs a, uint32_t l
     }
     __syncthreads();
     __threadfence_block();
-    for (uint32_t i = tid; i < count; i += BVB_THREADS) a.order[first + i] = a.order_tmp[first + i];
+    for (uint32_t i = tid; i < count; i += THREADS) a.order[first + i] = a.order_tmp[first + i];
 
     if (tid == 0u) {
         if (nl == 0u || nl == count) {

@@ -1114,7 +1114,8 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         k_bvb_init<<<(nt + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(a);
         uint32_t begin = 0, end = 1;
         while (begin < end) {                               /* one launch per tree level */
-            k_bvb_level<<<end - begin, BVB_THREADS>>>(a, begin);
+            if (end - begin < 64u) k_bvb_level<1024><<<end - begin, 1024>>>(a, begin);      /* top of the tree: few, huge nodes */
+            else k_bvb_level<BVB_THREADS><<<end - begin, BVB_THREADS>>>(a, begin);
             uint32_t total = 0;
             BVB_TRY(hipMemcpy(&total, d_count.p, 4, hipMemcpyDeviceToHost));
             begin = end;
