@@ -84,7 +84,7 @@ struct DevScene {
     const rpt_light_pick_entry *light_pick;
     uint32_t n_light_pick;
     uint32_t n_nodes, n_triangles;
-    uint32_t lds_scene;            /* nodes + tri_geom fit in RPT_LDS_SCENE_BYTES: traverse out of LDS */
+    uint32_t lds_scene;            /* the traversal image fits in RPT_LDS_SCENE_BYTES: traverse out of LDS */
     const float4 *lds_image;       /* LDS-resident traversal image (k_traverse.h SceneViewLds), lds_vecs float4 */
     uint32_t lds_pairs, lds_vecs, lds_root;
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */

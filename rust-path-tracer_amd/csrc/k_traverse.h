@@ -374,7 +374,7 @@ __device__ __forceinline__ HitRecord traverse_one(const SceneViewLds &view, uint
     return traverse_loop_lds<STACK, ANY_HIT, false>(view, ro, rd, rd, max_t, stack);
 }
 
-/* Small scenes live in LDS: when nodes + triangle geometry fit in RPT_LDS_SCENE_BYTES
+/* Small scenes live in LDS: when the traversal image (SceneViewLds) fits in RPT_LDS_SCENE_BYTES
  * every workgroup copies the upload-time LDS image in once and traverses out of LDS
  * (ds_read_b128, ~64-cycle latency, no pressure on the CU's single vector-memory address
  * unit — the measured limiter once the divisions were gone: ~380 divergent 16-byte
@@ -402,8 +402,8 @@ __device__ __forceinline__ typename SceneViewOf<LDS_SCENE>::type stage_scene(con
  * stores the same value), which the shade stage reports to the host. */
 template <int STACK, bool LDS_SCENE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevState st, DevQueues q, uint32_t iteration) {
-    /* an LDS-resident scene has < 768 nodes: 16-bit stack entries halve the stack (36 KB per 512-thread
-     * workgroup with the scene -> 4 workgroups = 32 waves per CU instead of 24) */
+    /* LDS-resident scenes walk 16-bit descriptors: 16-bit stack entries (32 KB per 1024-thread workgroup, which with a
+     * <= 32 KB scene image is the 64 KB a workgroup may hold: 2 workgroups = 32 waves per CU) */
     typedef typename StackElem<LDS_SCENE>::type StackT;
     __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
@@ -548,8 +548,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
  * in place (its slot becomes HIT_PENDING again). */
 template <int STACK, bool LDS_SCENE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats) {
-    /* an LDS-resident scene has < 768 nodes: 16-bit stack entries halve the stack (36 KB per 512-thread
-     * workgroup with the scene -> 4 workgroups = 32 waves per CU instead of 24) */
+    /* LDS-resident scenes walk 16-bit descriptors: 16-bit stack entries (32 KB per 1024-thread workgroup, which with a
+     * <= 32 KB scene image is the 64 KB a workgroup may hold: 2 workgroups = 32 waves per CU) */
     typedef typename StackElem<LDS_SCENE>::type StackT;
     __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
@@ -589,8 +589,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
 template <int STACK, bool ANY_HIT, bool LDS_SCENE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_trace_debug(DevScene sc, uint32_t n, const float *origins, const float *dirs,
                                                          const float *max_t, float *out_t, uint32_t *out_tri, uint32_t *out_flags) {
-    /* an LDS-resident scene has < 768 nodes: 16-bit stack entries halve the stack (36 KB per 512-thread
-     * workgroup with the scene -> 4 workgroups = 32 waves per CU instead of 24) */
+    /* LDS-resident scenes walk 16-bit descriptors: 16-bit stack entries (32 KB per 1024-thread workgroup, which with a
+     * <= 32 KB scene image is the 64 KB a workgroup may hold: 2 workgroups = 32 waves per CU) */
     typedef typename StackElem<LDS_SCENE>::type StackT;
     __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
