@@ -28,8 +28,8 @@
 #include "k_path.h"
 #include "rpt_fastdiv.h"
 
-template <bool LDS_SCENE> struct StackElem { typedef uint32_t type; };
-template <> struct StackElem<true> { typedef uint16_t type; };
+template <bool SMALL> struct StackElem { typedef uint32_t type; };      /* node indices on the stack */
+template <> struct StackElem<true> { typedef uint16_t type; };          /* < 65 536 nodes (and every LDS-resident scene) */
 
 struct HitRecord {
     float t;
@@ -400,11 +400,11 @@ __device__ __forceinline__ typename SceneViewOf<LDS_SCENE>::type stage_scene(con
  * pending (HIT_PENDING) and writes the hit record into ray_b.zw.  A wave that
  * found work raises this iteration's alive flag (plain store, every writer
  * stores the same value), which the shade stage reports to the host. */
-template <int STACK, bool LDS_SCENE, int THREADS>
+template <int STACK, bool LDS_SCENE, int THREADS, bool SMALL = false>
 __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevState st, DevQueues q, uint32_t iteration) {
     /* LDS-resident scenes walk 16-bit descriptors: 16-bit stack entries (32 KB per 1024-thread workgroup, which with a
      * <= 32 KB scene image is the 64 KB a workgroup may hold: 2 workgroups = 32 waves per CU) */
-    typedef typename StackElem<LDS_SCENE>::type StackT;
+    typedef typename StackElem<LDS_SCENE || SMALL>::type StackT;
     __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
@@ -546,11 +546,11 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
  * path's radiance (lib.rs:164).  A path that ended at this bounce (bit 31 of
  * the tag) is finished here: accumulated and, if samples remain, regenerated
  * in place (its slot becomes HIT_PENDING again). */
-template <int STACK, bool LDS_SCENE, int THREADS>
+template <int STACK, bool LDS_SCENE, int THREADS, bool SMALL = false>
 __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats) {
     /* LDS-resident scenes walk 16-bit descriptors: 16-bit stack entries (32 KB per 1024-thread workgroup, which with a
      * <= 32 KB scene image is the 64 KB a workgroup may hold: 2 workgroups = 32 waves per CU) */
-    typedef typename StackElem<LDS_SCENE>::type StackT;
+    typedef typename StackElem<LDS_SCENE || SMALL>::type StackT;
     __shared__ StackT lds_stack[THREADS / RPT_WAVE][STACK][RPT_WAVE];
     float4 *lds_scene = rpt_lds_dyn;
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */

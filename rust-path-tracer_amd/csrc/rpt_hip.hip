@@ -328,7 +328,11 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else
-        k_traverse_nearest<STACK, false, GLOBAL_THREADS><<<(c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
+    {
+        const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
+        if (c->scene.n_nodes < 65536u) k_traverse_nearest<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
+        else k_traverse_nearest<STACK, false, GLOBAL_THREADS><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
+    }
     mark(true);
     k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
@@ -336,7 +340,11 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         if (STACK == 16 && c->scene.lds_scene)     /* (streaming the shadow queue was measured slower: 36.8 vs 32.7 ms) */
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else
-            k_traverse_shadow<STACK, false, GLOBAL_THREADS><<<(c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+        {
+            const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
+            if (c->scene.n_nodes < 65536u) k_traverse_shadow<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+            else k_traverse_shadow<STACK, false, GLOBAL_THREADS><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
+        }
     }
     mark();
     k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
