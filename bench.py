@@ -6,9 +6,10 @@ TracingConfig (nee = 0, min/max bounces 3/4 — the reference's own bench settin
 benches/benchmark.rs:17-19), blue-noise seeds.  A "step" is one sample batch:
 `rpt_render(spp_per_step)` over every pixel of this rank's tiles, followed (N > 1)
 by the ONE gather of per-rank tile-major accumulator blocks to rank 0 and the
-root's un-tile.  Default 16 steps x 16 spp = the full 256 spp of the config.
+root's un-tile.  A batch is 32 samples — the reference's default `sync_rate` (src/trace.rs:75), the number of
+samples its GPU loop renders between two read-backs; default 8 steps x 32 spp = the full 256 spp of the config.
 
-  python bench.py --gpus 1 --steps 16 --warmup 1
+  python bench.py --gpus 1 --steps 8 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -68,10 +69,10 @@ def usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="darkcornell", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=32, help="samples per batch (reference default sync_rate = 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],

@@ -83,7 +83,9 @@ struct rpt_ctx {
     DevConfig cfg{};
     uint32_t n_slots = 0;       /* n_pixels << group_shift */
     uint32_t n_pixels = 0;      /* pixels of this rank's tiles */
-    uint32_t group_shift = 0;   /* log2 of the samples of one pixel kept in flight */
+    uint32_t group_shift = 0;   /* log2 of the samples of one pixel kept in flight (of the current / last rpt_render call) */
+    uint32_t max_group_shift = 0, max_slots = 0;   /* what the state arrays are sized for */
+    uint32_t sky_wide_cfg = 32768;
     int samples_in_flight_request = 0;   /* 0 = automatic */
     std::vector<uint32_t> pixel_xy_host;
     DevBuf<uint32_t> pixel_xy;
@@ -218,7 +220,7 @@ void release_state(rpt_ctx *c) {
 }
 
 int alloc_state(rpt_ctx *c) {
-    size_t n = c->n_slots, np = c->n_pixels;
+    size_t n = c->max_slots, np = c->n_pixels;
     HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n));
     HIP_TRY(c, c->thr_rad.alloc(n)); HIP_TRY(c, c->rad_misc.alloc(n));
     HIP_TRY(c, c->mis0.alloc(n)); HIP_TRY(c, c->mis1.alloc(n)); HIP_TRY(c, c->mis2.alloc(n)); HIP_TRY(c, c->mis3.alloc(n));
@@ -243,8 +245,9 @@ int alloc_state(rpt_ctx *c) {
     /* 1 = shade misses in the iteration that found them.  Letting them pile up (threshold ~ n/64) removes most
      * of the near-empty sky launches on closed scenes, but the parked pixels finish later and lengthen the tail:
      * measured DarkCornell 3650 Mrays/s deferred vs 3928 eager — so eager is the default. */
-    q.sky_wide_limit = (uint32_t)std::min<size_t>(n / 16, 32768);
-    if (const char *env = getenv("RPT_SKY_WIDE_LIMIT")) q.sky_wide_limit = (uint32_t)std::min<size_t>(n / 16, (size_t)std::max(0, atoi(env)));
+    c->sky_wide_cfg = 32768u;
+    if (const char *env = getenv("RPT_SKY_WIDE_LIMIT")) c->sky_wide_cfg = (uint32_t)std::max(0, atoi(env));
+    q.sky_wide_limit = (uint32_t)std::min<size_t>(n / 16, c->sky_wide_cfg);     /* re-clamped per call to that call's slot count */
     q.sky_threshold = 1u;
     if (const char *env = getenv("RPT_SKY_THRESHOLD")) q.sky_threshold = (uint32_t)std::max(1, atoi(env));
     c->has_state = true;
@@ -611,16 +614,23 @@ int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
          * per SIMD resident on average with 1 M slots); up to 16 M slots (~3 GB of path state at 200 B/slot, nothing
          * on a 288 GB part) make the tail a small fraction and quarter the number of launches per batch:
          * DarkCornell 1024^2 4.84 -> 6.33 Grays/s for S = 1 -> 16.  The image does not depend on S. */
+        /* This is the MOST a call may use (the arrays are sized for it); each rpt_render call keeps
+         * min(this, next power of two >= its n_samples) slots per pixel busy — slots without a sample would only be
+         * scanned (16 spp on 32 slots per pixel: 6.0 instead of 8.2 Grays/s).  Up to 32 slots per pixel and 32 M
+         * slots: with the reference's default batch of 32 samples (sync_rate, src/trace.rs:75) a rank that owns 1/8
+         * of a 1024^2 image then has 4 M paths in flight (7.2 instead of 6.6 Grays/s per GPU). */
         uint32_t S = 1;
         if (c->samples_in_flight_request > 0) {
             while (S < (uint32_t)c->samples_in_flight_request && S < 32u) S <<= 1;
         } else {
             if (c->n_pixels < (3u << 20))       /* measured: at 4 M pixels (PBRTest 2048^2) S > 1 only costs (-10 %) */
-                while (S < 16u && (uint64_t)c->n_pixels * S * 2u <= (16ull << 20)) S <<= 1;
+                while (S < 32u && (uint64_t)c->n_pixels * S * 2u <= (32ull << 20)) S <<= 1;
         }
-        c->group_shift = 0;
-        while ((1u << c->group_shift) < S) c->group_shift += 1;
-        c->n_slots = c->n_pixels << c->group_shift;
+        c->max_group_shift = 0;
+        while ((1u << c->max_group_shift) < S) c->max_group_shift += 1;
+        c->max_slots = c->n_pixels << c->max_group_shift;
+        c->group_shift = c->max_group_shift;
+        c->n_slots = c->max_slots;
         int rc = alloc_state(c);
         if (rc) return rc;
         /* fresh accumulators; seeds must come from rpt_reset */
@@ -685,8 +695,17 @@ int rpt_stream(rpt_ctx *c, void **stream_out) {
 static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     if (!c) return RPT_EINVAL;
     if (!c->has_scene || !c->has_config || !c->has_state) { c->error = "scene, config and reset must precede rpt_render"; return RPT_EINVAL; }
-    if (n_samples == 0 || c->n_slots == 0) { c->samples += n_samples; return RPT_OK; }
-    if ((uint64_t)n_samples + (1u << c->group_shift) >= 0x100000000ull) { c->error = "n_samples too large"; return RPT_EINVAL; }
+    if (n_samples == 0 || c->n_pixels == 0) { c->samples += n_samples; return RPT_OK; }
+    if ((uint64_t)n_samples + (1u << c->max_group_shift) >= 0x100000000ull) { c->error = "n_samples too large"; return RPT_EINVAL; }
+    {   /* slots per pixel of THIS call: no more than it has samples for */
+        uint32_t shift = 0;
+        while (shift < c->max_group_shift && (1u << shift) < n_samples) shift += 1;
+        c->group_shift = shift;
+        c->n_slots = c->n_pixels << shift;
+        c->state.group_shift = shift;
+        c->state.n_slots = c->n_slots;
+        c->queues.sky_wide_limit = std::min(c->n_slots / 16u, c->sky_wide_cfg);   /* the wide sky pass spends 16 threads of the grid per miss */
+    }
     /* When no slot gets a second sample in this call (n_samples <= slots per pixel) nothing is regenerated: every path
      * ends within max_bounces iterations (lib.rs:62), its misses and shadow rays inside the iteration that produced
      * them (with several slots per pixel a path ended by a side stage is accumulated by the NEXT shade pass: one more
