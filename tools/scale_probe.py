@@ -8,9 +8,9 @@ w = rpt.World.from_path(rpt.fixture('DarkCornell.glb'))
 cfg = rpt.default_config(1024, 1024); seeds = rpt.blue_noise_seeds(1024, 1024)
 for world in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
     r = hip.Renderer(0, rank=0, world_size=world); r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
-    r.render(16)
+    r.render(32)
     s0 = r.stats(); t = time.perf_counter(); 
-    for _ in range(8): r.render_async(16)
+    for _ in range(8): r.render_async(32)
     r.wait()
     dt = time.perf_counter() - t; s1 = r.stats()
     rays = s1['extension_rays'] - s0['extension_rays']
