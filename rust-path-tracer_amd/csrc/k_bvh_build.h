@@ -22,9 +22,9 @@
  *     where the element AT first+nl is met first.  (Checked against the sequential loop on 200 000 random inputs
  *     before it was written down here; tests/test_gpu_bvh_build.py compares whole builds.)
  *
- * One workgroup walks its node's range with a stride loop (1024 threads for the few huge nodes at the top, 256 below),
- * so the top of a large tree is slow per node (the root of a 1 M-triangle scene: ~1 000 trips per pass) and the bottom
- * is wide; that is still an order of magnitude faster than the sequential host build and keeps one code path.
+ * One workgroup walks its node's range with a stride loop (k_bvb_level); nodes of 65 536+ triangles — the top of a
+ * large tree, where a level is only as fast as its largest node — are split by a team of 64 workgroups (k_bvb_team,
+ * end of this file).
  */
 #ifndef RPT_K_BVH_BUILD_H
 #define RPT_K_BVH_BUILD_H
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
     const uint32_t tid = threadIdx.x;
     const uint32_t node_id = level_begin + blockIdx.x;
     BvbNode &node = a.nodes[node_id];
+    if (node.pad[0] != 0u) return;                 /* already split at this level by a team (k_bvb_team) */
     const uint32_t first = node.first, count = node.count, S = a.bins;
     const uint32_t last = first + count - 1u;
 
@@ -384,8 +385,380 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
         } else {
             const uint32_t id = atomicAdd(a.node_count, 2u);
             node.left = id;
-            a.nodes[id].first = first;          a.nodes[id].count = nl;              a.nodes[id].left = BVB_NONE;
-            a.nodes[id + 1u].first = first + nl; a.nodes[id + 1u].count = count - nl; a.nodes[id + 1u].left = BVB_NONE;
+            a.nodes[id].first = first;          a.nodes[id].count = nl;              a.nodes[id].left = BVB_NONE;   a.nodes[id].pad[0] = 0u;
+            a.nodes[id + 1u].first = first + nl; a.nodes[id + 1u].count = count - nl; a.nodes[id + 1u].left = BVB_NONE; a.nodes[id + 1u].pad[0] = 0u;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The few HUGE nodes at the top of a large tree: a TEAM of BVB_TEAM workgroups per node instead of one.
+ * Same arithmetic, same keys, same closed-form partition — the passes are cut into contiguous chunks of the node's
+ * range, partial results meet in global memory (64-bit atomic min/max on the same keys, per-chunk left counts), and
+ * the workgroups of a team meet at a counter barrier between passes (all of them are resident: the host launches at
+ * most BVB_MAX_TEAMS teams).  With L(p) = number of left-side elements at positions < p (chunk prefix + local rank)
+ * every quantity of the closed form is local:  hole rank of p = (p - first) - L(p);  for a suffix position q:
+ * m(q) = nl - L(q+1) left-side elements above it, rb(q) = (last - q) - m(q) right-side elements above it.
+ * Measured on the 1 M-triangle stand-in: the levels that hold a 0.5-1 M-triangle node took 7-15 ms each with one
+ * workgroup per node. */
+#define BVB_TEAM 64
+#define BVB_TEAM_THREADS 256
+#define BVB_MAX_TEAMS 16          /* x 64 workgroups of ~26 KB LDS: all resident at once (the barrier needs that) */
+#define BVB_TEAM_MIN_COUNT 65536u
+
+struct BvbTeamScratch {
+    unsigned long long red[6];
+    unsigned long long key[3][BVB_MAX_BINS][6];
+    uint32_t cb[6];
+    uint32_t cnt[3][BVB_MAX_BINS];
+    uint32_t chunk_l[BVB_TEAM], chunk_lf[BVB_TEAM];
+    uint32_t barrier;
+    int axis;
+    float split;
+    uint32_t node_id;
+};
+
+__global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team_init(BvbTeamScratch *scratch, const uint32_t *team_nodes) {
+    BvbTeamScratch &t = scratch[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 6u) { t.red[tid] = tid < 3u ? BVB_MIN_IDENT : BVB_MAX_IDENT; t.cb[tid] = tid < 3u ? 0xffffffffu : 0u; }
+    for (uint32_t k = tid; k < 3u * BVB_MAX_BINS; k += BVB_TEAM_THREADS) {
+        const uint32_t ax = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
+        for (int j = 0; j < 6; ++j) t.key[ax][b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
+        t.cnt[ax][b] = 0u;
+    }
+    if (tid < BVB_TEAM) { t.chunk_l[tid] = 0u; t.chunk_lf[tid] = 0u; }
+    if (tid == 0u) { t.barrier = 0u; t.axis = -1; t.split = 0.0f; t.node_id = team_nodes[blockIdx.x]; }
+}
+
+/* all BVB_TEAM workgroups of a team arrive; `phase` counts the barriers passed so far */
+__device__ __forceinline__ void bvb_team_sync(uint32_t *counter, uint32_t &phase) {
+    __syncthreads();
+    phase += 1u;
+    if (threadIdx.x == 0u) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < phase * BVB_TEAM) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTeamScratch *scratch) {
+    constexpr int THREADS = BVB_TEAM_THREADS;
+    __shared__ unsigned long long s_key[3][BVB_MAX_BINS][6];
+    __shared__ uint32_t s_cnt[3][BVB_MAX_BINS];
+    __shared__ float s_la[3][BVB_MAX_BINS], s_ra[3][BVB_MAX_BINS];
+    __shared__ uint32_t s_lc[3][BVB_MAX_BINS], s_rc[3][BVB_MAX_BINS];
+    __shared__ unsigned long long s_red[6];
+    __shared__ uint32_t s_cb[6];
+    __shared__ float s_best_cost[3];
+    __shared__ uint32_t s_best_i[3];
+    __shared__ uint32_t s_wave_tot[THREADS / 64];
+    __shared__ uint32_t s_misc[4];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t team = blockIdx.x / BVB_TEAM, member = blockIdx.x % BVB_TEAM;
+    BvbTeamScratch &T = scratch[team];
+    BvbNode &node = a.nodes[T.node_id];
+    const uint32_t first = node.first, count = node.count, S = a.bins;
+    const uint32_t last = first + count - 1u;
+    const uint32_t chunk = (count + BVB_TEAM - 1u) / BVB_TEAM;
+    const uint32_t c_begin = first + member * chunk < first + count ? first + member * chunk : first + count;
+    const uint32_t c_end = c_begin + chunk < first + count ? c_begin + chunk : first + count;      /* positions [c_begin, c_end) */
+    uint32_t phase = 0u;
+
+    /* ---- pass 1: update_node_aabb keys + centroid bounds over the chunk */
+    if (tid < 6u) { s_red[tid] = tid < 3u ? BVB_MIN_IDENT : BVB_MAX_IDENT; s_cb[tid] = tid < 3u ? 0xffffffffu : 0u; }
+    __syncthreads();
+    {
+        unsigned long long kmin[3] = {BVB_MIN_IDENT, BVB_MIN_IDENT, BVB_MIN_IDENT}, kmax[3] = {BVB_MAX_IDENT, BVB_MAX_IDENT, BVB_MAX_IDENT};
+        uint32_t cmin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, cmax[3] = {0u, 0u, 0u};
+        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) {
+            const uint32_t i = pos - first;
+            const uint32_t tri = a.order[pos];
+            const uint4 t = a.tris[tri];
+            const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t seq = i * 3u + k;
+                const float c[3] = {v[k].x, v[k].y, v[k].z};
+                for (int j = 0; j < 3; ++j) {
+                    unsigned long long lo = bvb_min_key(c[j], seq), hi = bvb_max_key(c[j], seq);
+                    kmin[j] = lo < kmin[j] ? lo : kmin[j];
+                    kmax[j] = hi > kmax[j] ? hi : kmax[j];
+                }
+            }
+            const float4 ce = a.centroid[tri];
+            const float cc[3] = {ce.x, ce.y, ce.z};
+            for (int j = 0; j < 3; ++j) {
+                uint32_t nz;
+                uint32_t o = bvb_ord(cc[j], nz);
+                cmin[j] = o < cmin[j] ? o : cmin[j];
+                cmax[j] = o > cmax[j] ? o : cmax[j];
+            }
+        }
+        for (int j = 0; j < 3; ++j) {
+            atomicMin(&s_red[j], kmin[j]);
+            atomicMax(&s_red[3 + j], kmax[j]);
+            atomicMin(&s_cb[j], cmin[j]);
+            atomicMax(&s_cb[3 + j], cmax[j]);
+        }
+    }
+    __syncthreads();
+    if (tid < 3u) {
+        atomicMin(&T.red[tid], s_red[tid]);
+        atomicMax(&T.red[3u + tid], s_red[3u + tid]);
+        atomicMin(&T.cb[tid], s_cb[tid]);
+        atomicMax(&T.cb[3u + tid], s_cb[3u + tid]);
+    }
+    bvb_team_sync(&T.barrier, phase);
+    float bmin[3], bmax[3], nmn[3], nmx[3];
+    for (int j = 0; j < 3; ++j) {
+        bmin[j] = bvb_unord(__hip_atomic_load(&T.cb[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0u);
+        bmax[j] = bvb_unord(__hip_atomic_load(&T.cb[3 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0u);
+        nmn[j] = bvb_key_value(__hip_atomic_load(&T.red[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        nmx[j] = bvb_key_value(__hip_atomic_load(&T.red[3 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (member == 0u && tid < 3u) { node.mn[tid] = nmn[tid]; node.mx[tid] = nmx[tid]; }
+
+    /* ---- pass 2: bins of the chunk in LDS, merged into the team's bins */
+    for (uint32_t k = tid; k < 3u * BVB_MAX_BINS; k += THREADS) {
+        const uint32_t ax = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
+        for (int j = 0; j < 6; ++j) s_key[ax][b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
+        s_cnt[ax][b] = 0u;
+    }
+    __syncthreads();
+    float scale[3];
+    bool axis_on[3];
+    for (int j = 0; j < 3; ++j) {
+        axis_on[j] = !(bmin[j] == bmax[j]);
+        scale[j] = (float)S / (bmax[j] - bmin[j]);
+    }
+    for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) {
+        const uint32_t i = pos - first;
+        const uint32_t tri = a.order[pos];
+        const uint4 t = a.tris[tri];
+        const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
+        const float4 ce = a.centroid[tri];
+        const float cc[3] = {ce.x, ce.y, ce.z};
+        for (int ax = 0; ax < 3; ++ax) {
+            if (!axis_on[ax]) continue;
+            const float x = (cc[ax] - bmin[ax]) * scale[ax];
+            uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;
+            if (si > S - 1u) si = S - 1u;
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t seq = i * 3u + k;
+                const float c[3] = {v[k].x, v[k].y, v[k].z};
+                for (int j = 0; j < 3; ++j) {
+                    atomicMin(&s_key[ax][si][j], bvb_min_key(c[j], seq));
+                    atomicMax(&s_key[ax][si][3 + j], bvb_max_key(c[j], seq));
+                }
+            }
+            atomicAdd(&s_cnt[ax][si], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < 3u * BVB_MAX_BINS; k += THREADS) {
+        const uint32_t ax = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
+        const uint32_t n = s_cnt[ax][b];
+        if (n != 0u) {
+            atomicAdd(&T.cnt[ax][b], n);
+            for (int j = 0; j < 3; ++j) {
+                atomicMin(&T.key[ax][b][j], s_key[ax][b][j]);
+                atomicMax(&T.key[ax][b][3 + j], s_key[ax][b][3 + j]);
+            }
+        }
+    }
+    bvb_team_sync(&T.barrier, phase);
+
+    /* ---- pass 3: member 0 evaluates the splits exactly as the single-workgroup kernel does */
+    if (member == 0u) {
+        for (uint32_t k = tid; k < 3u * BVB_MAX_BINS; k += THREADS) {
+            const uint32_t ax = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
+            for (int j = 0; j < 6; ++j) s_key[ax][b][j] = __hip_atomic_load(&T.key[ax][b][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_cnt[ax][b] = __hip_atomic_load(&T.cnt[ax][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid < 3u) {
+            const uint32_t ax = tid;
+            float best_cost = __builtin_inff();
+            uint32_t best_i = 0u;
+            if (axis_on[ax]) {
+                BvbBox lb, rb;
+                for (int j = 0; j < 3; ++j) { lb.mn[j] = rb.mn[j] = __builtin_inff(); lb.mx[j] = rb.mx[j] = -__builtin_inff(); }
+                uint32_t lsum = 0u, rsum = 0u;
+                for (uint32_t i = 0; i + 1u < S; ++i) {
+                    lsum += s_cnt[ax][i];
+                    s_lc[ax][i] = lsum;
+                    if (s_cnt[ax][i] != 0u && bvb_key_value(s_key[ax][i][0]) != __builtin_inff()) {
+                        for (int j = 0; j < 3; ++j) {
+                            lb.mn[j] = bvb_min(lb.mn[j], bvb_key_value(s_key[ax][i][j]));
+                            lb.mx[j] = bvb_max(lb.mx[j], bvb_key_value(s_key[ax][i][3 + j]));
+                        }
+                    }
+                    s_la[ax][i] = bvb_area(lb);
+                    const uint32_t r = S - 1u - i;
+                    rsum += s_cnt[ax][r];
+                    s_rc[ax][S - 2u - i] = rsum;
+                    if (s_cnt[ax][r] != 0u && bvb_key_value(s_key[ax][r][0]) != __builtin_inff()) {
+                        for (int j = 0; j < 3; ++j) {
+                            rb.mn[j] = bvb_min(rb.mn[j], bvb_key_value(s_key[ax][r][j]));
+                            rb.mx[j] = bvb_max(rb.mx[j], bvb_key_value(s_key[ax][r][3 + j]));
+                        }
+                    }
+                    s_ra[ax][S - 2u - i] = bvb_area(rb);
+                }
+                for (uint32_t i = 0; i + 1u < S; ++i) {
+                    const float cost = (float)s_lc[ax][i] * s_la[ax][i] + (float)s_rc[ax][i] * s_ra[ax][i];
+                    if (cost < best_cost) { best_cost = cost; best_i = i; }
+                }
+            }
+            s_best_cost[ax] = best_cost;
+            s_best_i[ax] = best_i;
+        }
+        __syncthreads();
+        if (tid == 0u) {
+            int axis = 0;
+            float split = 0.0f, cost = __builtin_inff();
+            for (int ax = 0; ax < 3; ++ax) {
+                if (s_best_cost[ax] < cost) {
+                    cost = s_best_cost[ax];
+                    axis = ax;
+                    const float scale2 = (bmax[ax] - bmin[ax]) / (float)S;
+                    split = bmin[ax] + scale2 * (float)(s_best_i[ax] + 1u);
+                }
+            }
+            BvbBox nb;
+            for (int j = 0; j < 3; ++j) { nb.mn[j] = nmn[j]; nb.mx[j] = nmx[j]; }
+            const float parent_cost = bvb_area(nb) * (float)count;
+            T.axis = parent_cost <= cost ? -1 : axis;
+            T.split = split;
+        }
+    }
+    bvb_team_sync(&T.barrier, phase);
+    const int axis = T.axis;
+    if (axis < 0) {
+        if (member == 0u && tid == 0u) { node.left = BVB_NONE; node.pad[0] = 1u; }
+        return;                                                   /* team-uniform */
+    }
+    const float split = T.split;
+    auto is_left = [&](uint32_t pos) {
+        const float4 ce = a.centroid[a.order[pos]];
+        const float c = axis == 0 ? ce.x : (axis == 1 ? ce.y : ce.z);
+        return c < split;
+    };
+
+    /* ---- pass 4: left counts per chunk -> nl and this chunk's prefix */
+    {
+        uint32_t mine = 0u;
+        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) mine += is_left(pos) ? 1u : 0u;
+        if (tid == 0u) s_misc[0] = 0u;
+        __syncthreads();
+        atomicAdd(&s_misc[0], mine);
+        __syncthreads();
+        if (tid == 0u) T.chunk_l[member] = s_misc[0];
+    }
+    bvb_team_sync(&T.barrier, phase);
+    uint32_t nl = 0u, pref_l = 0u;
+    for (uint32_t b = 0; b < BVB_TEAM; ++b) {
+        const uint32_t n = __hip_atomic_load(&T.chunk_l[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pref_l += b < member ? n : 0u;
+        nl += n;
+    }
+    const uint32_t split_pos = first + nl;                       /* prefix = [first, split_pos), suffix = [split_pos, last] */
+    /* ---- pass 5: left-side elements inside the prefix -> H (holes) */
+    {
+        uint32_t mine = 0u;
+        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) mine += (pos < split_pos && is_left(pos)) ? 1u : 0u;
+        __syncthreads();
+        if (tid == 0u) s_misc[0] = 0u;
+        __syncthreads();
+        atomicAdd(&s_misc[0], mine);
+        __syncthreads();
+        if (tid == 0u) T.chunk_lf[member] = s_misc[0];
+    }
+    bvb_team_sync(&T.barrier, phase);
+    uint32_t l_in_prefix = 0u;
+    for (uint32_t b = 0; b < BVB_TEAM; ++b) l_in_prefix += __hip_atomic_load(&T.chunk_lf[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t H = nl - l_in_prefix;
+
+    /* ---- pass 6 (B1): rb_at_L for the suffix left-side elements of this chunk */
+    {
+        uint32_t run = pref_l;                                    /* left-side elements before the current tile */
+        for (uint32_t base = c_begin; base < c_end; base += THREADS) {
+            const uint32_t q = base + tid;
+            const bool valid = q < c_end;
+            const bool L = valid && is_left(q);
+            uint32_t tot;
+            const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
+            if (L && q >= split_pos) {
+                const uint32_t m = nl - (l_before + 1u);
+                a.tmp_b[first + m] = (last - q) - m;
+            }
+            run += tot;
+        }
+    }
+    bvb_team_sync(&T.barrier, phase);
+    const uint32_t base_rb = H >= 1u ? __hip_atomic_load(&a.tmp_b[first + H - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    /* ---- pass 7 (F): the prefix */
+    {
+        uint32_t run = pref_l;
+        for (uint32_t base = c_begin; base < c_end; base += THREADS) {
+            const uint32_t p = base + tid;
+            const bool valid = p < c_end;
+            const bool L = valid && is_left(p);
+            uint32_t tot;
+            const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
+            if (valid && p < split_pos) {
+                if (L) {
+                    a.order_tmp[p] = a.order[p];
+                } else {
+                    const uint32_t hole = (p - first) - l_before;
+                    const uint32_t rank = hole + (hole >= 1u ? __hip_atomic_load(&a.tmp_b[first + hole - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
+                    a.order_tmp[last - rank] = a.order[p];
+                    a.tmp_a[first + hole] = p;
+                }
+            }
+            run += tot;
+        }
+    }
+    bvb_team_sync(&T.barrier, phase);
+    /* ---- pass 8 (B2): the suffix */
+    {
+        uint32_t run = pref_l;
+        for (uint32_t base = c_begin; base < c_end; base += THREADS) {
+            const uint32_t q = base + tid;
+            const bool valid = q < c_end;
+            const bool L = valid && is_left(q);
+            uint32_t tot;
+            const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
+            if (valid && q >= split_pos) {
+                if (L) {
+                    const uint32_t m = nl - (l_before + 1u);
+                    a.order_tmp[__hip_atomic_load(&a.tmp_a[first + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = a.order[q];
+                } else {
+                    const uint32_t m = nl - l_before;
+                    const uint32_t rb = (last - q) - m;
+                    uint32_t rank;
+                    if (m == H) rank = (q == split_pos) ? H + base_rb : H + rb + 1u;
+                    else rank = (m + 1u) + rb;
+                    a.order_tmp[last - rank] = a.order[q];
+                }
+            }
+            run += tot;
+        }
+    }
+    bvb_team_sync(&T.barrier, phase);
+    for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS)
+        a.order[pos] = __hip_atomic_load(&a.order_tmp[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (member == 0u && tid == 0u) {
+        node.pad[0] = 1u;
+        if (nl == 0u || nl == count) {
+            node.left = BVB_NONE;
+        } else {
+            const uint32_t id = atomicAdd(a.node_count, 2u);
+            node.left = id;
+            a.nodes[id].first = first;          a.nodes[id].count = nl;              a.nodes[id].left = BVB_NONE;   a.nodes[id].pad[0] = 0u;
+            a.nodes[id + 1u].first = first + nl; a.nodes[id + 1u].count = count - nl; a.nodes[id + 1u].left = BVB_NONE; a.nodes[id + 1u].pad[0] = 0u;
         }
     }
 }

@@ -1112,6 +1112,12 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     DevBuf<uint4> d_tris;
     DevBuf<uint32_t> d_order, d_order_tmp, d_tmp_a, d_tmp_b, d_count;
     DevBuf<BvbNode> d_nodes;
+    DevBuf<BvbTeamScratch> d_scratch;
+    DevBuf<uint32_t> d_team_nodes;
+    const char *no_teams = getenv("RPT_BVH_NO_TEAMS");
+    const bool use_teams = !(no_teams && no_teams[0] == '1');
+    uint32_t team_min = BVB_TEAM_MIN_COUNT;           /* RPT_BVH_TEAM_MIN: test aid, lets small nodes take the team path */
+    if (const char *e = getenv("RPT_BVH_TEAM_MIN")) team_min = (uint32_t)std::max(2, atoi(e));
     std::vector<BvbNode> bn;
     std::vector<uint32_t> order;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1127,6 +1133,8 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BVB_TRY(d_tmp_b.alloc(nt));
         BVB_TRY(d_count.alloc(1));
         BVB_TRY(d_nodes.alloc(2 * (size_t)nt - 1));
+        BVB_TRY(d_scratch.alloc(BVB_MAX_TEAMS));
+        BVB_TRY(d_team_nodes.alloc(BVB_MAX_TEAMS));
         BVB_TRY(hipMemcpy(d_verts.p, vertices_xyzw, n_vertices * sizeof(float4), hipMemcpyHostToDevice));
         BVB_TRY(hipMemcpy(d_tris.p, triangles, nt * sizeof(uint4), hipMemcpyHostToDevice));
         BvbNode root{};
@@ -1140,8 +1148,23 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BVB_TRY(hipEventRecord(ev0, nullptr));
         k_bvb_init<<<(nt + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(a);
         uint32_t begin = 0, end = 1;
+        std::vector<BvbNode> level_nodes;
+        std::vector<uint32_t> team_nodes;
         while (begin < end) {                               /* one launch per tree level */
-            if (end - begin < 64u) k_bvb_level<1024><<<end - begin, 1024>>>(a, begin);      /* top of the tree: few, huge nodes */
+            /* the huge nodes of this level (if any) are split by teams of workgroups first */
+            if (use_teams && end - begin <= 4096u) {
+                level_nodes.resize(end - begin);
+                BVB_TRY(hipMemcpy(level_nodes.data(), d_nodes.p + begin, (size_t)(end - begin) * sizeof(BvbNode), hipMemcpyDeviceToHost));
+                team_nodes.clear();
+                for (uint32_t k = 0; k < end - begin && team_nodes.size() < BVB_MAX_TEAMS; ++k)
+                    if (level_nodes[k].count >= team_min) team_nodes.push_back(begin + k);
+                if (!team_nodes.empty()) {
+                    BVB_TRY(hipMemcpy(d_team_nodes.p, team_nodes.data(), team_nodes.size() * 4, hipMemcpyHostToDevice));
+                    k_bvb_team_init<<<(unsigned)team_nodes.size(), BVB_TEAM_THREADS>>>(d_scratch.p, d_team_nodes.p);
+                    k_bvb_team<<<(unsigned)team_nodes.size() * BVB_TEAM, BVB_TEAM_THREADS>>>(a, d_scratch.p);
+                }
+            }
+            if (end - begin < 64u) k_bvb_level<1024><<<end - begin, 1024>>>(a, begin);      /* top of the tree: few, big nodes */
             else k_bvb_level<BVB_THREADS><<<end - begin, BVB_THREADS>>>(a, begin);
             uint32_t total = 0;
             BVB_TRY(hipMemcpy(&total, d_count.p, 4, hipMemcpyDeviceToHost));
@@ -1187,13 +1210,13 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
-    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release();
+    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_nodes.release();
     return RPT_OK;
 fail:
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
-    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release();
+    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_nodes.release();
     return RPT_EHIP;
 #undef BVB_TRY
 }
