@@ -66,6 +66,7 @@ struct rpt_ctx {
     std::string error;
     uint32_t rank = 0, world = 1;
     bool lds_stream = true;
+    uint32_t stream_min_blocks = 1024;   /* measured at 2 M slots (1/8 of DarkCornell 1024^2): 5.5 / 6.2 / 6.2 / 5.6 Grays/s for 2048 / 1024 / 512 / 256 */
 
     /* scene */
     bool has_scene = false;
@@ -321,9 +322,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
         /* slots per workgroup: as many as keep >= 1024 workgroups in the launch (the dispatcher needs a few per CU to
          * balance), at most RPT_STREAM_RAYS per lane (measured best at 16 M slots: 6-8) */
-        uint32_t min_blocks = 1024u;     /* measured at 2 M slots (1/8 of DarkCornell 1024^2): 5.5 / 6.2 / 6.2 / 5.6 Grays/s for 2048 / 1024 / 512 / 256 */
-        if (const char *e = getenv("RPT_STREAM_MIN_BLOCKS")) min_blocks = (uint32_t)std::max(1, atoi(e));
-        uint32_t rays = c->n_slots / (min_blocks * LDS_THREADS);
+        uint32_t rays = c->n_slots / (c->stream_min_blocks * LDS_THREADS);
         rays = rays < 1u ? 1u : (rays > (uint32_t)RPT_STREAM_RAYS ? (uint32_t)RPT_STREAM_RAYS : rays);
         const uint32_t per_block = rays * LDS_THREADS;
         k_traverse_nearest_stream<16, LDS_THREADS><<<(c->n_slots + per_block - 1) / per_block, LDS_THREADS, lds_bytes, s>>>(
@@ -433,6 +432,7 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (c->timing_level < 0 || c->timing_level > 2) c->timing_level = 0;
     c->stage_timing = c->timing_level != 0;
     if (const char *e2 = getenv("RPT_LDS_STREAM")) c->lds_stream = e2[0] != '0';
+    if (const char *e5 = getenv("RPT_STREAM_MIN_BLOCKS")) c->stream_min_blocks = (uint32_t)std::max(1, atoi(e5));
     if (const char *e3 = getenv("RPT_SAMPLES_IN_FLIGHT")) c->samples_in_flight_request = std::min(32, std::max(0, atoi(e3)));
     *out = c;
     return RPT_OK;
