@@ -465,6 +465,33 @@ def test_host_dispatch_trace_gpu_furnace(rpt):
         state.close()
 
 
+@pytest.mark.parametrize("knob", ["RPT_LDS_STREAM=0", "RPT_NO_LDS_SCENE=1", "RPT_NO_FASTDIV=1", "RPT_SKY_THRESHOLD=4096",
+                                  "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MIN_BLOCKS=4", "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2"])
+def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world, knob):
+    """README: every tuning knob leaves the image bit-identical (they select kernels / schedules, never arithmetic)."""
+    W, H, spp = 160, 96, 6
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+
+    def render():
+        r = hipmod.Renderer(0)
+        r.upload_scene(world("DarkCornell"))
+        r.set_config(cfg)
+        r.reset(seeds)
+        r.render(spp)
+        acc, _ = r.read_accum()
+        st = r.stats()
+        r.close()
+        return acc, (st["extension_rays"], st["shadow_rays"], st["sky_evals"])
+
+    base = render()
+    name, value = knob.split("=")
+    monkeypatch.setenv(name, value)
+    got = render()
+    assert got[1] == base[1]
+    assert np.array_equal(got[0].view(np.uint32), base[0].view(np.uint32))
+
+
 def test_error_behaviour(hipmod, rpt, world):
     r = hipmod.Renderer(0)
     with pytest.raises(hipmod.RptError):           # render before scene/config
