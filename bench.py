@@ -9,7 +9,7 @@ by the ONE gather of per-rank tile-major accumulator blocks to rank 0 and the
 root's un-tile.  A batch is 32 samples — the reference's default `sync_rate` (src/trace.rs:75), the number of
 samples its GPU loop renders between two read-backs; default 8 steps x 32 spp = the full 256 spp of the config.
 
-  python bench.py --gpus 1 --steps 8 --warmup 1
+  python bench.py --gpus 1 --steps 8 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -70,7 +70,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3, help="untimed batches first (clocks ramp up over the first ~50 ms)")
     ap.add_argument("--workload", default="darkcornell", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=32, help="samples per batch (reference default sync_rate = 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
