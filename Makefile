@@ -12,7 +12,7 @@ CXX      ?= g++
 
 HOST_SRCS := $(CSRC)/host/host_api.cpp $(CSRC)/host/glb_scene.cpp $(CSRC)/host/bvh_build.cpp \
              $(CSRC)/host/light_table.cpp $(CSRC)/host/bluenoise.cpp $(CSRC)/host/image_io.cpp
-HIP_SRCS  := $(CSRC)/rpt_hip.hip
+HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_comm.hip
 HIP_DEPS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hip) $(wildcard include/rpt/*.h)
 
 CXXFLAGS_COMMON := -std=c++20 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unknown-pragmas
@@ -41,7 +41,7 @@ oracle/liboracle_libm.so: oracle/rpt_oracle.cpp $(CSRC)/rpt_math.h $(CSRC)/rpt_m
 
 $(LIBDIR)/librpt_hip.so: $(HIP_DEPS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -ldl
 
 clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so

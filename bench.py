@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo (host-staged gather) only exists to exercise the N>1 logic on a box with one GPU")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="testing aid for --dist-backend gloo")
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
+                    help="rccl: the per-batch gather runs inside librpt_hip.so (C ABI, RCCL); torch: tiles.Gatherer over torch.distributed")
+    ap.add_argument("--with-gather", action="store_true", help="N = 1 only: still run the per-batch gather (a 1-rank communicator), to exercise that path")
+    ap.add_argument("--no-readback", action="store_true", help="skip the extra render -> read_accum loop (reference loop shape, src/trace.rs:182-204)")
     args = ap.parse_args()
 
     # HIP events on the render stream: after every stage kernel at N = 1 (per-stage breakdown), only around the
@@ -132,12 +136,8 @@ def main():
     for _ in range(2):
         r.render(args.spp_per_step)
     r.reset(seeds)
-    local_block = tiles.device_block_as_tensor(r, device)
-    image = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
+    image = None
     comm_device = device if args.dist_backend == "nccl" else "cpu"
-    gatherer = tiles.Gatherer(W, H, comm_device) if world_size > 1 else None
-    staged = torch.zeros((world_size, gatherer.stride, 4), dtype=torch.float32, device=device) \
-        if (world_size > 1 and rank == 0 and comm_device == "cpu") else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,30 +145,68 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Everything of a step is ordered ON THE DEVICE, on the library's own stream (wrapped for torch): batch k is
-    # enqueued (rpt_render_async: no host wait when the iteration count is known), the previous gather is awaited
-    # stream-side, its image un-tiled, this batch's accumulators copied into the staging buffer and handed to the
-    # collective — the host never blocks inside the timed loop, so launch gaps and Python time hide behind kernels.
-    lib_stream = torch.cuda.ExternalStream(r.stream_ptr(), device=device) if world_size > 1 else None
+    # The single collective per sample batch.  Default: inside the library, behind the C ABI (rpt_comm_init = RCCL
+    # ncclCommInitRank, rpt_gather_async = grouped ncclSend/ncclRecv to rank 0 on the library's second HIP stream,
+    # root un-tile with a map built once): stream-ordered after the batch, nothing on the host per step, batch k+1
+    # renders while the blocks of batch k travel.  torch.distributed only carries the 128-byte unique id, the barrier
+    # and the final statistics.  --gather torch keeps the round-1 path (tiles.Gatherer over torch.distributed); it is
+    # also what the bench falls back to — loudly, recorded in the JSON — if RCCL cannot be initialised from the library.
+    gather_impl = None
+    if world_size > 1 or args.with_gather:
+        want = args.gather if args.dist_backend == "nccl" else "torch"
+        if want == "rccl":
+            try:
+                ids = [hip.comm_unique_id() if rank == 0 else None]
+                if world_size > 1:
+                    dist.broadcast_object_list(ids, src=0, device=torch.device(comm_device))
+                r.comm_init(ids[0], rank, world_size)
+                gather_impl = "rccl-c-abi"
+            except Exception as e:                                   # noqa: BLE001 — recorded, never silent
+                gather_note = f"{type(e).__name__}: {e}"
+                ok = torch.tensor([0.0], device=comm_device)
+            else:
+                gather_note = None
+                ok = torch.tensor([1.0], device=comm_device)
+            if world_size > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok[0]) < 1.0:
+                gather_impl = "torch.distributed (fallback: " + (gather_note or "another rank failed rpt_comm_init") + ")"
+                if rank == 0:
+                    print("bench: RCCL inside the library failed, falling back to torch.distributed gather: " + str(gather_note), file=sys.stderr)
+        else:
+            gather_impl = "torch.distributed"
+    use_lib_gather = gather_impl == "rccl-c-abi"
+    gatherer = lib_stream = local_block = staged = None
+    if gather_impl and not use_lib_gather:
+        local_block = tiles.device_block_as_tensor(r, device)
+        image = torch.zeros((H, W, 4), dtype=torch.float32, device=device) if rank == 0 else None
+        gatherer = tiles.Gatherer(W, H, comm_device)
+        staged = torch.zeros((world_size, gatherer.stride, 4), dtype=torch.float32, device=device) \
+            if (rank == 0 and comm_device == "cpu") else None
+        lib_stream = torch.cuda.ExternalStream(r.stream_ptr(), device=device)
 
     def finish_gather():
-        """Complete the gather of the previous batch; rank 0 un-tiles it into the full image."""
+        """(torch path) complete the gather of the previous batch; rank 0 un-tiles it into the full image."""
         recv = gatherer.end()                                        # (stream-level wait under lib_stream)
         if rank == 0 and recv is not None:
             if staged is not None:
                 staged.copy_(recv)
                 recv = staged
-            r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)     # enqueued on the same stream
+            r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)     # launch only, on the same stream
 
     def step():
         r.render_async(args.spp_per_step)
-        if world_size > 1:
+        if use_lib_gather:
+            r.gather_async()                                         # stream-ordered; returns at once
+        elif gatherer is not None:
             with torch.cuda.stream(lib_stream):
                 finish_gather()                                      # batch k-1 travelled while batch k rendered
-                gatherer.begin(local_block)                          # the single collective per sample batch
+                gatherer.begin(local_block)
 
     def drain():
-        if world_size > 1:
+        if use_lib_gather:
+            r.gather_wait()
+        elif gatherer is not None:
             with torch.cuda.stream(lib_stream):
                 finish_gather()
         r.wait()
@@ -188,6 +226,27 @@ def main():
 
     def delta(key):
         return s1[key] - s0[key]
+
+    # The reference's own loop shape (src/trace.rs:182-204): render sync_rate samples, read the accumulators back to
+    # the host, repeat.  Timed separately — it is not `value` (inputs and outputs of `value` stay in HBM) — so that the
+    # PCIe-inclusive rate is a measurement too.  One device-side un-tile + one DMA into pinned memory per read-back.
+    readback = None
+    if world_size == 1 and not args.no_readback:
+        host_image = np.empty((H, W, 4), np.float32)
+        r.reset(seeds)
+        r.render(args.spp_per_step)
+        r.read_accum(host_image)
+        sa = r.stats()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            r.render(args.spp_per_step)
+            r.read_accum(host_image)
+        tb = time.perf_counter() - ta
+        sb = r.stats()
+        rb_rays = (sb["extension_rays"] - sa["extension_rays"]) + (sb["shadow_rays"] - sa["shadow_rays"])
+        readback = {"loop": "rpt_render(spp_per_step) -> rpt_read_accum (host buffer), as src/trace.rs:182-204",
+                    "ms_per_step": round(tb / args.steps * 1e3, 4), "value": round(rb_rays / tb / 1e6, 3), "unit": "Mrays/s",
+                    "all_samples_arrived": bool((host_image[..., 3] == float(args.spp_per_step * (args.steps + 1))).all())}
 
     local = torch.tensor([elapsed, float(delta("extension_rays")), float(delta("shadow_rays")), float(delta("samples")),
                           float(delta("sky_evals"))], dtype=torch.float64, device=comm_device if world_size > 1 else device)
@@ -225,18 +284,27 @@ def main():
             units = delta("extension_rays") / max(klaunch[dominant], 1)
             bytes_per_unit = 128
         achieved = bytes_per_unit * units / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes kept under profiles/ (tools/profile_workload.sh).
+        # PMC counters cannot be collected from inside this process, so the figure is only reported when it was measured
+        # on exactly these kernel sources (tools/source_fingerprint.py); otherwise null, never a stale number.
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(tpath):
             try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from source_fingerprint import fingerprint
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("workload") == args.workload and tj.get("kernel") == dominant:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                fp = fingerprint()
+                if tj.get("workload") == args.workload and tj.get("source_fingerprint") == fp and dominant in tj.get("stages", {}):
+                    traffic = tj["stages"][dominant]["hbm_bytes_per_launch"]
+                    traffic_source = f"profiles/traffic_{args.workload}.json@{fp}"
+                else:
+                    traffic_source = f"profiles/traffic_{args.workload}.json is from other kernel sources ({tj.get('source_fingerprint')} != {fp}): not reported"
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[dominant]),
                     "units_per_launch": round(units, 1), "algorithmic_bytes_per_unit": bytes_per_unit,
                     "stage_ms": {k: round(v, 3) for k, v in kms.items()}}
@@ -272,7 +340,8 @@ def main():
                  if not scene.startswith("procedural:") else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
         "config": {"workload": f"{scene}.glb {W}x{H}, {args.steps}x{args.spp_per_step} spp (config total {total_spp}), "
                                f"nee={cfg.nee}, bounces {cfg.min_bounces}/{cfg.max_bounces}",
-                   "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU"},
+                   "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU",
+                   "gather": gather_impl},
         "samples_per_s": round(n_samples / elapsed_max, 1),
         "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
                  "per_sample": round(rays / max(n_samples, 1), 4)},
@@ -281,6 +350,7 @@ def main():
                               "frac": round(pipeline_gbs / HBM_PEAK_GBS, 6),
                               "formula": "128*N_ext + 96*N_shadow + 128*N_mis + 40*samples (SURVEY.md 8d)"},
         "cpu_baseline": cpu,
+        "readback": readback,
     }
     print(json.dumps(out))
     if world_size > 1:

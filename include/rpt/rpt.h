@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RPT_ABI_VERSION 1
+#define RPT_ABI_VERSION 2
 
 enum {
     RPT_OK = 0,
@@ -135,8 +135,13 @@ int rpt_stream(rpt_ctx *ctx, void **hip_stream_out);
 
 /* Replaces output_buffer.read_blocking (src/trace.rs:198).  Writes the SUM
  * (not the mean) as width*height float4 (r, g, b, sample count) in row-major,
- * y-down order.  Pixels of tiles owned by other ranks are written as zeros. */
+ * y-down order.  Pixels of tiles owned by other ranks are written as zeros.
+ * The tile-major block is un-tiled on the device and leaves it as one DMA into
+ * pinned memory owned by the context; rpt_map_accum hands out that buffer itself
+ * (valid until the next rpt_read_accum / rpt_map_accum / rpt_set_config on the
+ * context), rpt_read_accum copies it into the caller's. */
 int rpt_read_accum(rpt_ctx *ctx, float *out_rgba, uint32_t *out_samples);
+int rpt_map_accum(rpt_ctx *ctx, const float **out_rgba, uint32_t *out_samples);
 
 /* Post-accumulation step on the device: mean = sum / samples
  * (src/trace.rs:199-204) then tonemap operator 0..6 exactly as the display shader
@@ -162,14 +167,64 @@ int rpt_read_rng(rpt_ctx *ctx, rpt_rng_state *out);
 int rpt_tile_order(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size,
                    uint32_t *out_xy, size_t capacity, size_t *n);
 int rpt_local_pixels(rpt_ctx *ctx, uint64_t *n_pixels);
+/* No synchronisation: order your work after the batch on rpt_stream().  The pointer is invalidated by
+ * rpt_set_config (resize), rpt_set_partition and rpt_set_samples_in_flight. */
 int rpt_local_block_device_ptr(rpt_ctx *ctx, void **dev_ptr);
 /* Pixel count of any rank's block for the current config (for gather sizes). */
 int rpt_rank_pixels(rpt_ctx *ctx, uint32_t rank, uint64_t *n_pixels);
-/* Root side: scatter the `world_size` gathered tile-major blocks (device memory)
- * into a row-major width*height float4 image in device memory.  Block r starts at
- * element r * block_stride_pixels (a gather into equal-sized padded slots), or the
- * blocks are tightly concatenated when block_stride_pixels == 0. */
+/* For callers that run their own collective: scatter the `world_size` gathered tile-major blocks (device memory)
+ * into a row-major width*height float4 image in device memory, on the context's stream — launch only (the destination
+ * map is rebuilt when the configuration changes, never per batch); synchronise with rpt_wait.  Block r starts at
+ * element r * block_stride_pixels (a gather into equal-sized padded slots), or the blocks are tightly concatenated
+ * when block_stride_pixels == 0. */
 int rpt_untile(rpt_ctx *ctx, const void *dev_gathered_blocks, uint64_t block_stride_pixels, void *dev_out_image);
+
+/* The gather itself, inside the library: RCCL (ncclSend / ncclRecv, grouped) over xGMI, on a second HIP stream.
+ *   one process per GPU:  rank 0 calls rpt_comm_unique_id and hands the 128 bytes to every rank by any means (file,
+ *                         socket, torch.distributed); every rank calls rpt_comm_init (= ncclCommInitRank on the
+ *                         context's device + rpt_set_partition(rank, world_size)).
+ *   after a batch:        rpt_gather_async — stream-ordered after everything enqueued so far (rpt_render_async
+ *                         included): the accumulators are snapshotted, the blocks travel to rank 0 and are un-tiled
+ *                         there while the next batch renders.  Collective: every rank must call it, in the same order.
+ *                         Nothing is allocated, copied from the host or synchronised per call.
+ *   rank 0:               rpt_read_gathered (host, W*H float4, the whole image) or rpt_gathered_device_ptr;
+ *                         rpt_gather_wait blocks until the last gather has completed. */
+#define RPT_COMM_ID_BYTES 128
+int rpt_comm_unique_id(uint8_t *id_out /* RPT_COMM_ID_BYTES */);
+int rpt_comm_init(rpt_ctx *ctx, const uint8_t *unique_id, uint32_t rank, uint32_t world_size);
+int rpt_comm_world(rpt_ctx *ctx, uint32_t *rank_out, uint32_t *world_size_out);   /* as RCCL reports it (ncclCommCount) */
+int rpt_gather_async(rpt_ctx *ctx);
+int rpt_gather_wait(rpt_ctx *ctx);
+int rpt_read_gathered(rpt_ctx *ctx, float *out_rgba, uint32_t *out_samples);
+int rpt_gathered_device_ptr(rpt_ctx *ctx, void **dev_ptr);
+
+/* ONE process driving every GPU of the node — the shape the reference's single render thread (src/trace.rs:136-224,
+ * src/app.rs:157-164) can call: the same entry points as above, fanned out over n_devices contexts created with
+ * ncclCommInitAll; the caller sees one W x H image.  rpt_multi_render = one batch on every GPU + the batch's single
+ * gather, returns once enqueued; rpt_multi_read_accum waits and returns the whole image from rank 0.
+ * RPT_MULTI_ALLOW_SHARED_DEVICE: test aid for boxes with one GPU — a device may be listed several times; ranks then
+ * exchange their blocks by stream-ordered device copies instead of RCCL (which refuses two ranks on one device). */
+typedef struct rpt_multi rpt_multi;
+#define RPT_MULTI_ALLOW_SHARED_DEVICE 1u
+int rpt_multi_create(const int *device_ids, int n_devices, uint32_t flags, rpt_multi **out);
+int rpt_multi_size(rpt_multi *m);
+rpt_ctx *rpt_multi_ctx(rpt_multi *m, int rank);        /* e.g. for rpt_set_samples_in_flight / rpt_get_stats per GPU */
+int rpt_multi_upload_scene(rpt_multi *m,
+                           const rpt_per_vertex_data *per_vertex, size_t n_vertices,
+                           const rpt_triangle *indices, size_t n_triangles,
+                           const rpt_bvh_node *nodes, size_t n_nodes,
+                           const rpt_material_data *materials, size_t n_materials,
+                           const rpt_light_pick_entry *light_pick, size_t n_light_pick,
+                           const uint8_t *atlas_rgba8, uint32_t atlas_w, uint32_t atlas_h,
+                           const float *skybox_rgba32f, uint32_t sky_w, uint32_t sky_h);
+int rpt_multi_set_config(rpt_multi *m, const rpt_tracing_config *config);
+int rpt_multi_reset(rpt_multi *m, const rpt_rng_state *rng_seed, const float *accum_init_rgba, uint32_t samples_init);
+int rpt_multi_render(rpt_multi *m, uint32_t n_samples);
+int rpt_multi_wait(rpt_multi *m);
+int rpt_multi_read_accum(rpt_multi *m, float *out_rgba, uint32_t *out_samples);
+int rpt_multi_get_stats(rpt_multi *m, rpt_stats *out);      /* counters summed, times = max over GPUs */
+void rpt_multi_destroy(rpt_multi *m);
+const char *rpt_multi_last_error(rpt_multi *m);
 
 int rpt_get_stats(rpt_ctx *ctx, rpt_stats *out);
 void rpt_destroy(rpt_ctx *ctx);

@@ -96,7 +96,10 @@ struct DevScene {
 /* ---- per-slot path state (SoA of float4 records) -------------------------- */
 struct DevState {
     float4 *ray_a;        /* (ox, oy, oz, dx) */
-    float4 *ray_b;        /* (dy, dz, hit_t, hit_tri bits: bit31 backface, 0xffffffff miss) */
+    float2 *ray_b;        /* (dy, dz) */
+    float2 *hit;          /* (hit_t, stage / hit word: triangle | backface << 31, or one of the HIT_* states below).  Its own dense
+                             array: the traversal stage writes exactly these 8 bytes per ray, as full 512-byte wave stores
+                             (as the upper half of a 16-byte ray record they were strided partial-sector writes: WRITE_SIZE 2.4 x) */
     float4 *thr_rad;      /* (thr.r, thr.g, thr.b, rad.r) */
     float4 *rad_misc;     /* (rad.g, rad.b, flags bits, todo bits) */
     float4 *mis0;         /* (light_area, ln.x, ln.y, ln.z)            nee == MIS only */
@@ -151,6 +154,7 @@ struct DevQueues {
 
 struct DevStats {
     unsigned long long extension_rays, shadow_rays, sky_evals, light_index_clamped, samples;
+    unsigned long long undrained;   /* slots a render call found (or left) with a sample still in flight: must stay 0 (k_generate_first, k_check_drained) */
 };
 
 /* per-render constants derived from TracingConfig on the host */

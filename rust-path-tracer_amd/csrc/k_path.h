@@ -37,7 +37,8 @@ __device__ __forceinline__ void start_path(const DevState &st, const DevConfig &
     F3 ro, rd;
     camera_ray(cfg, pxy & 0xffffu, pxy >> 16, n + offset, ro, rd);
     st.ray_a[slot] = make_float4(ro.x, ro.y, ro.z, rd.x);
-    st.ray_b[slot] = make_float4(rd.y, rd.z, 0.0f, __uint_as_float(HIT_PENDING));
+    st.ray_b[slot] = make_float2(rd.y, rd.z);
+    st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PENDING));
     st.thr_rad[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     st.rad_misc[slot] = make_float4(0.0f, 0.0f, __uint_as_float(MAKE_FLAGS(0u, 0u, 2u)), __uint_as_float(todo_after));
 }
@@ -55,12 +56,12 @@ __device__ __forceinline__ void finish_in_side_stage(const DevState &st, const D
         rs.x += 1u;
         st.rng[slot] = rs;
         uint32_t todo = __float_as_uint(rm.w);
-        if (todo == 0u) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+        if (todo == 0u) st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
         else start_path(st, cfg, slot, rs.x, rs.y, todo - 1u);
     } else {
         st.thr_rad[slot] = make_float4(tr.x, tr.y, tr.z, radiance.x);
         st.rad_misc[slot] = make_float4(radiance.y, radiance.z, rm.z, rm.w);
-        reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_DONE));
+        st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_DONE));
     }
 }
 
@@ -87,7 +88,7 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
             st.rng[slot] = rs1;
             uint32_t todo = __float_as_uint(rm.w);
             if (todo == 0u) {
-                reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+                st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
             } else {
                 start_path(st, cfg, slot, rs1.x, rs1.y, todo - 1u);
                 started = true;
@@ -131,12 +132,12 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
     if (!done) return;
     if (complete) {
         uint32_t todo = __float_as_uint(rm.w);
-        if (todo == 0u) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+        if (todo == 0u) st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
         else start_path(st, cfg, slot, new_n + (lane - g0), offset, todo - 1u);
     } else if (fresh) {
         st.thr_rad[slot] = make_float4(tr.x, tr.y, tr.z, radiance.x);
         st.rad_misc[slot] = make_float4(radiance.y, radiance.z, rm.z, rm.w);
-        reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_DONE));
+        st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_DONE));
     }
 }
 

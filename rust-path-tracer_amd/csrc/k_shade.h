@@ -160,9 +160,9 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     bool to_sky = false;
     bool emit_shadow = false;
     float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-    float4 rb = make_float4(0, 0, 0, __uint_as_float(HIT_PARKED));
-    if (slot < st.n_slots) rb = st.ray_b[slot];
-    const uint32_t hit_tri = __float_as_uint(rb.w);
+    float2 hw = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+    if (slot < st.n_slots) hw = st.hit[slot];
+    const uint32_t hit_tri = __float_as_uint(hw.y);
     const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;            /* traversed in this iteration */
     /* generation bookkeeping (k_path.h: complete_generations) */
     bool g_done = false, g_fresh = false;
@@ -178,11 +178,12 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
 
     if (active) {
         const float4 ra = st.ray_a[slot];
+        const float2 rb = st.ray_b[slot];
         const F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
-        const float hit_t = rb.z;
+        const float hit_t = hw.x;
         if (hit_tri == HIT_MISS) {
             to_sky = true;                           /* lib.rs:66-79: shaded by k_sky, which also ends the path */
-            reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+            st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
         } else {
             float4 tr = st.thr_rad[slot];
             float4 rm = st.rad_misc[slot];
@@ -447,11 +448,12 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                 st.rad_misc[slot] = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
                 if (!done) {
                     st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
-                    st.ray_b[slot] = make_float4(new_d.y, new_d.z, 0.0f, __uint_as_float(HIT_PENDING));
+                    st.ray_b[slot] = make_float2(new_d.y, new_d.z);
+                    st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PENDING));
                     sh_d.w = __uint_as_float(slot);
                 } else {
                     /* the shadow stage adds the NEE term and then finishes the path */
-                    reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+                    st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
                     sh_d.w = __uint_as_float(slot | 0x80000000u);
                 }
             }

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
         if (m < n) {
             const uint32_t slot = q.sky[m];
             const uint32_t lane = __lane_id(), g0 = lane & ~15u, j = lane & 15u;
-            float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+            float4 ra = st.ray_a[slot];
+            float2 rb = st.ray_b[slot];
             F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
             F3 sky = sky_scatter_wide(cfg.c.sun_direction, ro, rd, j, g0);
             if (j == 0u) {
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
     }
     if (i < n) {
         uint32_t slot = q.sky[i];
-        float4 ra = st.ray_a[slot], rb = st.ray_b[slot];
+        float4 ra = st.ray_a[slot];
+        float2 rb = st.ray_b[slot];
         F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
         float4 tr = st.thr_rad[slot], rm = st.rad_misc[slot];
         F3 throughput = f3(tr.x, tr.y, tr.z), radiance = f3(tr.w, rm.x, rm.y);
@@ -176,9 +178,13 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
 
 /* Start of an rpt_render call: slot k of every pixel begins sample k; it will take samples k, k+S, ... of
  * the n_samples this call owes the pixel. */
-__global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQueues q, DevConfig cfg, uint32_t n_samples) {
+__global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQueues q, DevConfig cfg, uint32_t n_samples, DevStats *stats) {
     uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
     if (slot >= st.n_slots) return;
+    /* Every slot must have been left idle by the previous render call: an asynchronous batch enqueues a fixed number of
+     * iterations (max_bounces, + 1 with several slots per pixel) without ever looking at a progress report, so this is
+     * where a wrong bound would show — a sample still in flight here would be overwritten and lost. */
+    if (__float_as_uint(st.hit[slot].y) != HIT_IDLE) atomicAdd(&stats->undrained, 1ull);
     const uint32_t S = 1u << st.group_shift, k = slot & (S - 1u), pix = slot >> st.group_shift;
     uint2 rs = st.rng[pix];
     if (cfg.c.max_bounces == 0u) {
@@ -190,22 +196,25 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQu
             rs.x += n_samples;
             st.rng[pix] = rs;
         }
-        reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+        st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
         return;
     }
     uint32_t count = n_samples > k ? (n_samples - k + S - 1u) / S : 0u;
-    if (count == 0u) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+    if (count == 0u) st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
     else start_path(st, cfg, slot, rs.x + k, rs.y, count - 1u);
 }
 
-/* root-side un-tiling of gathered per-rank blocks into a row-major image */
-__global__ __launch_bounds__(RPT_BLOCK) void k_untile(const float4 *blocks, const uint32_t *pixel_xy_all, uint32_t n_total,
-                                                      uint32_t width, float4 *image) {
+/* all slots idle (state after allocation: nothing in flight) */
+__global__ __launch_bounds__(RPT_BLOCK) void k_fill_idle(float2 *hit, uint32_t n) {
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    if (i >= n_total) return;
-    uint32_t pxy = pixel_xy_all[i];
-    if (pxy == 0xffffffffu) return;          /* padding between strided blocks */
-    image[(size_t)(pxy >> 16) * width + (pxy & 0xffffu)] = blocks[i];
+    if (i < n) hit[i] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+}
+/* counts the slots of the last render call that are not idle (rpt_wait: must be 0 once the stream has drained) */
+__global__ __launch_bounds__(RPT_BLOCK) void k_check_drained(const float2 *hit, uint32_t n, DevStats *stats) {
+    uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    const bool busy = i < n && __float_as_uint(hit[i].y) != HIT_IDLE;
+    const unsigned long long m = rpt_ballot(busy);
+    if (m != 0ull && __lane_id() == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(&stats->undrained, (unsigned long long)__popcll(m));
 }
 
 /* ---- post-accumulation step --------------------------------------------------------

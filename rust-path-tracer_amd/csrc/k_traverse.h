@@ -162,15 +162,32 @@ __device__ __forceinline__ bool moller_trumbore_view(const View &view, uint32_t 
 #ifndef RPT_LEAF_K
 #define RPT_LEAF_K 8
 #endif
-template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackT>
-__device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 rd, F3 ird, float max_t, StackT *stack) {
-    typedef typename View::Cur Cur;
+/* Everything a ray needs besides (ro, rd, 1/rd) and its stack column: the walk can be stopped after a number of loop
+ * trips and resumed (the streamed kernels hand finished lanes new rays in between). */
+template <typename View> struct Walk {
+    typename View::Cur cur;    /* node the ray stands on; View::dead() when finished / no ray */
+    int sp;
     HitRecord res;
-    res.t = 1000000.0f;
-    res.tri = HIT_MISS;
-    int sp = 0;
-    Cur cur = view.root();
-    for (;;) {
+};
+template <typename View>
+__device__ __forceinline__ void walk_begin(const View &view, Walk<View> &w) {
+    w.cur = view.root();
+    w.sp = 0;
+    w.res.t = 1000000.0f;
+    w.res.tri = HIT_MISS;
+}
+template <typename View>
+__device__ __forceinline__ bool walk_dead(const Walk<View> &w) { return !View::is_inner(w.cur) && !View::is_leaf(w.cur); }
+
+/* At most `budget` trips of the deferred-leaf loop for the lanes of this wave; returns early when no lane has anything
+ * left.  Per ray the visiting order and every comparison are the reference's. */
+template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackT>
+__device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro, F3 rd, F3 ird, float max_t, StackT *stack, int budget) {
+    typedef typename View::Cur Cur;
+    HitRecord res = w.res;
+    int sp = w.sp;
+    Cur cur = w.cur;
+    for (int trip = 0; trip < budget; ++trip) {
         const bool at_inner = View::is_inner(cur);
         const bool at_leaf = View::is_leaf(cur);
         const unsigned long long inner_m = rpt_ballot(at_inner), leaf_m = rpt_ballot(at_leaf);
@@ -222,7 +239,17 @@ __device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 r
             }
         }
     }
-    return res;
+    w.cur = cur;
+    w.sp = sp;
+    w.res = res;
+}
+
+template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackT>
+__device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 rd, F3 ird, float max_t, StackT *stack) {
+    Walk<View> w;
+    walk_begin(view, w);
+    walk_run<STACK, ANY_HIT, FAST>(view, w, ro, rd, ird, max_t, stack, 0x7fffffff);
+    return w.res;
 }
 
 template <int STACK, bool ANY_HIT, typename View, typename StackT>
@@ -397,7 +424,7 @@ __device__ __forceinline__ typename SceneViewOf<LDS_SCENE>::type stage_scene(con
 }
 
 /* Extension rays.  Thread i owns slot i; it traces the slot's ray if one is
- * pending (HIT_PENDING) and writes the hit record into ray_b.zw.  A wave that
+ * pending (HIT_PENDING) and writes the hit record into hit[slot].  A wave that
  * found work raises this iteration's alive flag (plain store, every writer
  * stores the same value), which the shade stage reports to the host. */
 template <int STACK, bool LDS_SCENE, int THREADS, bool SMALL = false>
@@ -420,12 +447,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
         q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
         q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
     }
-    float4 rb = make_float4(0, 0, 0, 0);
     bool pending = false;
-    if (slot < st.n_slots) {
-        rb = st.ray_b[slot];
-        pending = __float_as_uint(rb.w) == HIT_PENDING;
-    }
+    if (slot < st.n_slots) pending = __float_as_uint(st.hit[slot].y) == HIT_PENDING;
     if (LDS_SCENE && !__syncthreads_or(pending)) return;      /* block-uniform: nothing to trace here */
     const auto view = stage_scene<LDS_SCENE, THREADS>(sc, lds_scene);
     unsigned long long active = rpt_ballot(pending);
@@ -437,11 +460,11 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     }
     if (!pending) return;
     float4 ra = st.ray_a[slot];
+    float2 rb = st.ray_b[slot];
     F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
     StackT *stack = &lds_stack[threadIdx.x / RPT_WAVE][0][threadIdx.x % RPT_WAVE];
     HitRecord h = traverse_one<STACK, false>(view, sc.fastdiv_ok, ro, rd, 0.0f, stack);
-    float2 *out = reinterpret_cast<float2 *>(&st.ray_b[slot]);
-    out[1] = make_float2(h.t, __uint_as_float(h.tri));
+    st.hit[slot] = make_float2(h.t, __uint_as_float(h.tri));
 }
 
 /* Extension rays of an LDS-resident scene, STREAMED: a workgroup owns up to RPT_STREAM_RAYS x THREADS consecutive slots
@@ -504,14 +527,14 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
             bool took = false;
             if (w.cur == LDS_DESC_DEAD) {
                 if (have) {
-                    reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(w.res.t, __uint_as_float(w.res.tri));
+                    st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
                     have = false;
                 }
                 const uint32_t cand = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
                 if (cand < span_end) {
-                    const float4 rb = st.ray_b[cand];
-                    if (__float_as_uint(rb.w) == HIT_PENDING) {
+                    if (__float_as_uint(st.hit[cand].y) == HIT_PENDING) {
                         const float4 ra = st.ray_a[cand];
+                        const float2 rb = st.ray_b[cand];
                         ro = f3(ra.x, ra.y, ra.z); rd = f3(ra.w, rb.x, rb.y);
                         slot = cand;
                         took = true;
@@ -522,7 +545,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
                         } else {
                             /* outside the exact-division guard (a zero / denormal-small direction component): walked here, alone */
                             HitRecord h = traverse_loop_lds<STACK, false, false>(view, ro, rd, rd, 0.0f, stack);
-                            reinterpret_cast<float2 *>(&st.ray_b[cand])[1] = make_float2(h.t, __uint_as_float(h.tri));
+                            st.hit[cand] = make_float2(h.t, __uint_as_float(h.tri));
                         }
                     }
                 }
@@ -533,7 +556,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
         if (idle_m == ~0ull) break;                            /* nothing in flight and nothing left to hand out */
         lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
     }
-    if (have) reinterpret_cast<float2 *>(&st.ray_b[slot])[1] = make_float2(w.res.t, __uint_as_float(w.res.tri));
+    if (have) st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
     /* ray accounting + the alive flag, once per wave */
     if (lane == 0u && traced != 0u) {
         raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
@@ -582,6 +605,194 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
             st.thr_rad[slot] = tr;
             st.rad_misc[slot] = rm;
         }
+    }
+}
+
+/* ---- streamed walks through GLOBAL memory (scenes too large for LDS) ----------------------------------------
+ * Measured on MI355X (profiles/r02base_*): with one ray per lane the global-memory walk runs at 26 % (VeachMIS nearest),
+ * 29 % (PBRTest) and 22 % (VeachMIS shadow) lane utilisation while two thirds of its wave cycles wait on L1/L2 — an
+ * open scene leaves most slots of a wave without a pending ray after the first bounce (their paths ended in the sky),
+ * and any-hit walks end after anything between one and a hundred node visits.  One-wave workgroups make the remedy
+ * cheap: a wave owns SPAN consecutive slots (queue entries), and
+ *   - (nearest) first compacts the pending ones into a wave-local LDS list — ballot + mbcnt, no atomic, the pool
+ *     counter is a scalar register;
+ *   - walks with a trip budget and, when RPT_GSTREAM_REFILL lanes are idle, lets them write their results and take
+ *     the next rays of the list.
+ * Per ray nothing changes (same tests, same order); slots stay identity mapped. */
+#ifndef RPT_GSTREAM_RAYS
+#define RPT_GSTREAM_RAYS 8         /* most slots per lane of a wave (the host lowers it for small launches) */
+#endif
+#ifndef RPT_GSTREAM_TRIPS
+#define RPT_GSTREAM_TRIPS 8
+#endif
+#ifndef RPT_GSTREAM_REFILL
+#define RPT_GSTREAM_REFILL 16
+#endif
+template <int STACK, bool SMALL>
+__global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
+                                                                       uint32_t SPAN /* slots per wave, <= 64 * RPT_GSTREAM_RAYS */) {
+    typedef typename StackElem<SMALL>::type StackT;
+    __shared__ StackT lds_stack[STACK][RPT_WAVE];
+    __shared__ uint16_t pend[RPT_WAVE * RPT_GSTREAM_RAYS];
+    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x == 0u && lane == 0u) {
+        /* per-iteration bookkeeping, as in k_traverse_nearest */
+        const uint32_t prev = (iteration + 1u) & 1u;
+        q.count[Q_SHADOW] = 0u;
+        if (q.count[Q_SKY] >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q.count[Q_SKY] = 0u;
+        q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
+        q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
+    }
+    const uint32_t span_begin = blockIdx.x * SPAN;
+    if (span_begin >= st.n_slots) return;
+    const uint32_t span_end = span_begin + SPAN < st.n_slots ? span_begin + SPAN : st.n_slots;
+    /* the pending slots of the span, in slot order */
+    uint32_t count = 0u;                                       /* wave-uniform */
+    for (uint32_t base = span_begin; base < span_end; base += RPT_WAVE) {
+        const uint32_t s = base + lane;
+        const bool p = s < span_end && __float_as_uint(st.hit[s].y) == HIT_PENDING;
+        const unsigned long long m = rpt_ballot(p);
+        if (p) pend[count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(s - span_begin);
+        count += (uint32_t)__popcll(m);
+    }
+    if (count == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0u) {
+        raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
+        atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)count);
+    }
+    const SceneViewGlobal view{sc.nodes, sc.tri_geom};
+    StackT *stack = &lds_stack[0][lane];
+    F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
+    Walk<SceneViewGlobal> w;
+    walk_begin(view, w);
+    w.cur = SceneViewGlobal::dead();
+    uint32_t slot = 0u, next = 0u;                             /* next: wave-uniform position in the list */
+    bool have = false;                                         /* this lane holds a ray whose result is not written yet */
+    for (;;) {
+        const unsigned long long idle_m = rpt_ballot(walk_dead(w));
+        const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+        const bool more = next < count;                        /* wave-uniform */
+        if ((more && n_idle >= (uint32_t)RPT_GSTREAM_REFILL) || idle_m == ~0ull) {
+            if (walk_dead(w)) {
+                if (have) {
+                    st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
+                    have = false;
+                }
+                const uint32_t at = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                if (at < count) {
+                    slot = span_begin + pend[at];
+                    const float4 ra = st.ray_a[slot];
+                    const float2 rb = st.ray_b[slot];
+                    ro = f3(ra.x, ra.y, ra.z); rd = f3(ra.w, rb.x, rb.y);
+                    have = true;
+                    if (fastdiv_ray_ok(sc.fastdiv_ok, ro, rd)) {
+                        ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        walk_begin(view, w);
+                    } else {
+                        /* outside the exact-division guard (a zero / denormal-small direction component): walked here, alone;
+                         * the lane stays idle and writes the result at its next refill */
+                        w.res = traverse_loop<STACK, false, false>(view, ro, rd, rd, 0.0f, stack);
+                    }
+                }
+            }
+            if (!more) break;                                  /* everything handed out, walked and written */
+            next += n_idle;
+            continue;
+        }
+        walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, more ? RPT_GSTREAM_TRIPS : 0x7fffffff);
+    }
+}
+
+/* what k_traverse_shadow does with the result of one shadow ray (light_pick.rs:148 + lib.rs:164) */
+__device__ __forceinline__ void shadow_resolve(const DevState &st, const DevQueues &q, const DevConfig &cfg, uint32_t entry, uint32_t tag,
+                                               bool visible) {
+    const uint32_t slot = tag & 0x7fffffffu;
+    const bool finish = (tag >> 31) != 0u;
+    if (visible || finish) {
+        float4 tr = st.thr_rad[slot];
+        float4 rm = st.rad_misc[slot];
+        F3 radiance = f3(tr.w, rm.x, rm.y);
+        if (visible) {
+            float4 c = q.sh_c[entry];
+            radiance = radiance + mask_nan3(f3(c.x, c.y, c.z));
+        }
+        if (finish) {
+            finish_in_side_stage(st, cfg, slot, radiance, tr, rm);
+        } else {
+            tr.w = radiance.x; rm.x = radiance.y; rm.y = radiance.z;
+            st.thr_rad[slot] = tr;
+            st.rad_misc[slot] = rm;
+        }
+    }
+}
+
+/* Shadow rays, streamed: the queue is dense already; a wave owns SPAN consecutive entries and refills lanes whose
+ * any-hit walk has ended (found an occluder after two visits, or crossed the whole scene without one).  Lanes only note
+ * "occluded" per entry in LDS while walking; the NEE terms are added afterwards in one dense pass over the span (all
+ * lanes busy, and the registers of the walk are dead by then: 61 instead of 91 VGPRs). */
+template <int STACK, bool SMALL>
+__global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
+                                                                      uint32_t SPAN) {
+    typedef typename StackElem<SMALL>::type StackT;
+    __shared__ StackT lds_stack[STACK][RPT_WAVE];
+    __shared__ uint8_t occluded[RPT_WAVE * RPT_GSTREAM_RAYS];
+    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = q.count[Q_SHADOW];
+    if (blockIdx.x == 0u && lane == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
+    const uint32_t begin = blockIdx.x * SPAN;
+    if (begin >= n) return;
+    const uint32_t end = begin + SPAN < n ? begin + SPAN : n;
+    {
+        const SceneViewGlobal view{sc.nodes, sc.tri_geom};
+        StackT *stack = &lds_stack[0][lane];
+        F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
+        float max_t = 0.0f;
+        Walk<SceneViewGlobal> w;
+        walk_begin(view, w);
+        w.cur = SceneViewGlobal::dead();
+        uint32_t entry = 0u, next = begin;                     /* next: wave-uniform */
+        bool have = false;
+        for (;;) {
+            const unsigned long long idle_m = rpt_ballot(walk_dead(w));
+            const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+            const bool more = next < end;                      /* wave-uniform */
+            if ((more && n_idle >= (uint32_t)RPT_GSTREAM_REFILL) || idle_m == ~0ull) {
+                if (walk_dead(w)) {
+                    if (have) {
+                        occluded[entry - begin] = w.res.tri == HIT_MISS ? (uint8_t)0 : (uint8_t)1;
+                        have = false;
+                    }
+                    const uint32_t at = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                    if (at < end) {
+                        const float4 o = q.sh_o[at], d = q.sh_d[at];
+                        ro = f3(o.x, o.y, o.z); rd = f3(d.x, d.y, d.z);
+                        max_t = o.w;
+                        entry = at;
+                        have = true;
+                        if (fastdiv_ray_ok(sc.fastdiv_ok, ro, rd)) {
+                            ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                            walk_begin(view, w);
+                        } else {
+                            w.res = traverse_loop<STACK, true, false>(view, ro, rd, rd, max_t, stack);   /* alone; noted at the next refill */
+                        }
+                    }
+                }
+                if (!more) break;
+                next += n_idle;
+                continue;
+            }
+            walk_run<STACK, true, true>(view, w, ro, rd, ird, max_t, stack, more ? RPT_GSTREAM_TRIPS : 0x7fffffff);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = begin; base < end; base += RPT_WAVE) {
+        const uint32_t e = base + lane;
+        if (e < end) shadow_resolve(st, q, cfg, e, __float_as_uint(q.sh_d[e].w), occluded[e - begin] == 0u);
     }
 }
 

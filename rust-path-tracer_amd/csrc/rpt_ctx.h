@@ -1,0 +1,124 @@
+/*
+ * rpt_ctx.h — the context object behind the C ABI of include/rpt/rpt.h, shared by the translation units of
+ * librpt_hip.so (rpt_hip.hip: upload + wavefront scheduling; rpt_comm.hip: multi-GPU gather over RCCL, read-back).
+ */
+#ifndef RPT_CTX_H
+#define RPT_CTX_H
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rpt/rpt.h"
+#include "k_common.h"
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+            return RPT_EHIP;                                                                       \
+        }                                                                                          \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (!count) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+constexpr int RPT_RING_LAG = 6;   /* most iterations the host may run ahead of the progress report it inspects (small launches) */
+constexpr int RPT_RING = 16;      /* power of two, > RPT_RING_LAG */
+
+struct rpt_comm;                  /* rpt_comm.hip: RCCL communicator + gather buffers of one context */
+
+struct rpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    uint32_t rank = 0, world = 1;
+    bool lds_stream = true;
+    bool gstream = true;                 /* scenes walked from global memory: streamed kernels (k_traverse_*_gstream) */
+    uint32_t gstream_min_waves = 32768;
+    uint32_t stream_min_blocks = 1024;   /* measured at 2 M slots (1/8 of DarkCornell 1024^2): 5.5 / 6.2 / 6.2 / 5.6 Grays/s for 2048 / 1024 / 512 / 256 */
+
+    /* scene */
+    bool has_scene = false;
+    DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials, lds_image;
+    DevBuf<uint4> indices;
+    DevBuf<rpt_light_pick_entry> light_pick;
+    DevBuf<uchar4> atlas;
+    DevBuf<float4> skybox;
+    DevScene scene{};
+    uint32_t bvh_depth = 0;
+    int stack_cap = 16;
+
+    /* config + partition */
+    bool has_config = false;
+    DevConfig cfg{};
+    uint32_t n_slots = 0;       /* n_pixels << group_shift */
+    uint32_t n_pixels = 0;      /* pixels of this rank's tiles */
+    uint32_t group_shift = 0;   /* log2 of the samples of one pixel kept in flight (of the current / last rpt_render call) */
+    uint32_t max_group_shift = 0, max_slots = 0;   /* what the state arrays are sized for */
+    uint32_t sky_wide_cfg = 32768;
+    int samples_in_flight_request = 0;   /* 0 = automatic */
+    std::vector<uint32_t> pixel_xy_host;
+    DevBuf<uint32_t> pixel_xy;
+
+    /* state */
+    bool has_state = false;
+    DevBuf<float2> ray_b, hit;
+    DevBuf<float4> ray_a, thr_rad, rad_misc, mis0, mis1, mis2, mis3, accum;
+    DevBuf<uint2> rng;
+    DevBuf<uint32_t> q_sky, q_count;
+    DevBuf<unsigned long long> ray_shards;
+    DevBuf<float4> sh_o, sh_d, sh_c;
+    DevBuf<DevStats> dev_stats;
+    DevState state{};
+    DevQueues queues{};
+    uint32_t samples = 0;
+
+    /* scheduling: the traversal kernel reports each iteration's queue size into mapped pinned memory */
+    unsigned long long *host_ring = nullptr;       /* host view, RING entries */
+    unsigned long long *host_ring_dev = nullptr;   /* device view of the same memory */
+
+    /* stats */
+    rpt_stats stats{};
+    bool stage_timing = false;
+    int timing_level = 0;           /* RPT_STAGE_TIMING: 1 = an event after every stage kernel, 2 = only around the traversal kernel */
+    std::vector<hipEvent_t> timing_events;
+    /* batches enqueued by rpt_render_async whose stage timing has not been read back yet */
+    struct TimingBatch { std::vector<hipEvent_t> ev; uint64_t iterations; };
+    std::vector<TimingBatch> timing_pending;
+    std::vector<hipEvent_t> timing_pool;
+    bool async_pending = false;
+
+    /* read-back and multi-GPU gather (rpt_comm.hip) */
+    rpt_comm *comm = nullptr;
+    DevBuf<float4> image;                 /* row-major W x H accumulator image (device), built by k_untile */
+    float *host_image = nullptr;          /* pinned twin of it: rpt_read_accum is one DMA */
+    size_t host_image_floats = 0;
+    DevBuf<uint32_t> untile_map;          /* rpt_untile: destination map, rebuilt only when (W, H, world, stride) changes */
+    uint64_t untile_key = 0;
+    uint32_t untile_n = 0;
+};
+
+/* rank-local slot order (rpt_hip.hip) */
+void rpt_build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, std::vector<uint32_t> &out);
+/* rpt_comm.hip: called by rpt_hip.hip when the context / its state goes away */
+void rpt_comm_release(rpt_ctx *c);
+void rpt_image_release(rpt_ctx *c);
+std::string &rpt_create_error();
+
+#endif /* RPT_CTX_H */

@@ -19,8 +19,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/rpt/rpt.h"
-#include "k_common.h"
+#include "rpt_ctx.h"
 #include "k_traverse.h"
 #include "k_bvh_build.h"
 #include "k_shade.h"
@@ -28,96 +27,13 @@
 
 namespace {
 
-thread_local std::string g_create_error;
-
-#define HIP_TRY(ctx, expr)                                                                         \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) {                                                                    \
-            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
-            return RPT_EHIP;                                                                       \
-        }                                                                                          \
-    } while (0)
-
-template <typename T> struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    hipError_t alloc(size_t count) {
-        release();
-        n = count;
-        if (!count) return hipSuccess;
-        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-};
-
-constexpr int LAG = 6;           /* most iterations the host may run ahead of the progress report it inspects (small launches) */
-constexpr int RING = 16;         /* power of two, > LAG */
+constexpr int LAG = RPT_RING_LAG;
+constexpr int RING = RPT_RING;
 
 }  // namespace
 
-struct rpt_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string error;
-    uint32_t rank = 0, world = 1;
-    bool lds_stream = true;
-    uint32_t stream_min_blocks = 1024;   /* measured at 2 M slots (1/8 of DarkCornell 1024^2): 5.5 / 6.2 / 6.2 / 5.6 Grays/s for 2048 / 1024 / 512 / 256 */
-
-    /* scene */
-    bool has_scene = false;
-    DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials, lds_image;
-    DevBuf<uint4> indices;
-    DevBuf<rpt_light_pick_entry> light_pick;
-    DevBuf<uchar4> atlas;
-    DevBuf<float4> skybox;
-    DevScene scene{};
-    uint32_t bvh_depth = 0;
-    int stack_cap = 16;
-
-    /* config + partition */
-    bool has_config = false;
-    DevConfig cfg{};
-    uint32_t n_slots = 0;       /* n_pixels << group_shift */
-    uint32_t n_pixels = 0;      /* pixels of this rank's tiles */
-    uint32_t group_shift = 0;   /* log2 of the samples of one pixel kept in flight (of the current / last rpt_render call) */
-    uint32_t max_group_shift = 0, max_slots = 0;   /* what the state arrays are sized for */
-    uint32_t sky_wide_cfg = 32768;
-    int samples_in_flight_request = 0;   /* 0 = automatic */
-    std::vector<uint32_t> pixel_xy_host;
-    DevBuf<uint32_t> pixel_xy;
-
-    /* state */
-    bool has_state = false;
-    DevBuf<float4> ray_a, ray_b, thr_rad, rad_misc, mis0, mis1, mis2, mis3, accum;
-    DevBuf<uint2> rng;
-    DevBuf<uint32_t> q_sky, q_count;
-    DevBuf<unsigned long long> ray_shards;
-    DevBuf<float4> sh_o, sh_d, sh_c;
-    DevBuf<DevStats> dev_stats;
-    DevState state{};
-    DevQueues queues{};
-    uint32_t samples = 0;
-
-    /* scheduling: the traversal kernel reports each iteration's queue size into mapped pinned memory */
-    unsigned long long *host_ring = nullptr;       /* host view, RING entries */
-    unsigned long long *host_ring_dev = nullptr;   /* device view of the same memory */
-
-    /* stats */
-    rpt_stats stats{};
-    bool stage_timing = false;
-    int timing_level = 0;           /* RPT_STAGE_TIMING: 1 = an event after every stage kernel, 2 = only around the traversal kernel */
-    std::vector<hipEvent_t> timing_events;
-    /* batches enqueued by rpt_render_async whose stage timing has not been read back yet */
-    struct TimingBatch { std::vector<hipEvent_t> ev; uint64_t iterations; };
-    std::vector<TimingBatch> timing_pending;
-    std::vector<hipEvent_t> timing_pool;
-    bool async_pending = false;
-};
+thread_local std::string g_create_error;
+std::string &rpt_create_error() { return g_create_error; }
 
 namespace {
 
@@ -140,6 +56,10 @@ void build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, st
                     }
     }
 }
+
+}  // namespace
+void rpt_build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, std::vector<uint32_t> &out) { build_pixel_order(W, H, rank, world, out); }
+namespace {
 
 int validate_scene(rpt_ctx *ctx, const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt,
                    const rpt_bvh_node *nodes, size_t nn, const rpt_material_data *mats, size_t nm,
@@ -211,18 +131,19 @@ void mat3_mul_host(const float *a, const float *b, float *out) {   /* Mat3 * Mat
 }
 
 void release_state(rpt_ctx *c) {
-    c->ray_a.release(); c->ray_b.release(); c->thr_rad.release(); c->rad_misc.release();
+    c->ray_a.release(); c->ray_b.release(); c->hit.release(); c->thr_rad.release(); c->rad_misc.release();
     c->mis0.release(); c->mis1.release(); c->mis2.release(); c->mis3.release();
     c->accum.release(); c->rng.release();
     c->q_sky.release(); c->q_count.release(); c->ray_shards.release();
     c->sh_o.release(); c->sh_d.release(); c->sh_c.release();
     c->pixel_xy.release();
+    rpt_image_release(c);
     c->has_state = false;
 }
 
 int alloc_state(rpt_ctx *c) {
     size_t n = c->max_slots, np = c->n_pixels;
-    HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n));
+    HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n)); HIP_TRY(c, c->hit.alloc(n));
     HIP_TRY(c, c->thr_rad.alloc(n)); HIP_TRY(c, c->rad_misc.alloc(n));
     HIP_TRY(c, c->mis0.alloc(n)); HIP_TRY(c, c->mis1.alloc(n)); HIP_TRY(c, c->mis2.alloc(n)); HIP_TRY(c, c->mis3.alloc(n));
     HIP_TRY(c, c->accum.alloc(np)); HIP_TRY(c, c->rng.alloc(np));
@@ -234,8 +155,9 @@ int alloc_state(rpt_ctx *c) {
     HIP_TRY(c, c->pixel_xy.alloc(np));
     if (np) HIP_TRY(c, hipMemcpy(c->pixel_xy.p, c->pixel_xy_host.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemset(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t)));
+    if (n) k_fill_idle<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, c->stream>>>(c->hit.p, (uint32_t)n);   /* nothing in flight */
     DevState &s = c->state;
-    s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.thr_rad = c->thr_rad.p; s.rad_misc = c->rad_misc.p;
+    s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.hit = c->hit.p; s.thr_rad = c->thr_rad.p; s.rad_misc = c->rad_misc.p;
     s.mis0 = c->mis0.p; s.mis1 = c->mis1.p; s.mis2 = c->mis2.p; s.mis3 = c->mis3.p;
     s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = (uint32_t)n;
     s.n_pixels = (uint32_t)np; s.group_shift = c->group_shift;
@@ -319,6 +241,10 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     if (only_traverse) mark(true);
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
+    /* streamed global-memory walks: slots per wave — as many as keep >= gstream_min_waves waves in the launch, at most RPT_GSTREAM_RAYS per lane */
+    uint32_t grays = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
+    grays = grays < 1u ? 1u : (grays > (uint32_t)RPT_GSTREAM_RAYS ? (uint32_t)RPT_GSTREAM_RAYS : grays);
+    const uint32_t gspan = grays * RPT_WAVE, gblocks = (c->n_slots + gspan - 1) / gspan;
     if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
         /* slots per workgroup: as many as keep >= 1024 workgroups in the launch (the dispatcher needs a few per CU to
          * balance), at most RPT_STREAM_RAYS per lane (measured best at 16 M slots: 6-8) */
@@ -329,8 +255,10 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             c->scene, c->state, c->queues, iteration, per_block);
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
-    else
-    {
+    else if (c->gstream) {
+        if (c->scene.n_nodes < 65536u) k_traverse_nearest_gstream<STACK, true><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
+        else k_traverse_nearest_gstream<STACK, false><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
+    } else {
         const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
         if (c->scene.n_nodes < 65536u) k_traverse_nearest<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
         else k_traverse_nearest<STACK, false, GLOBAL_THREADS><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
@@ -341,8 +269,10 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     if (NEE != RPT_NEE_NONE) {
         if (STACK == 16 && c->scene.lds_scene)     /* (streaming the shadow queue was measured slower: 36.8 vs 32.7 ms) */
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
-        else
-        {
+        else if (c->gstream) {
+            if (c->scene.n_nodes < 65536u) k_traverse_shadow_gstream<STACK, true><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+            else k_traverse_shadow_gstream<STACK, false><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+        } else {
             const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
             if (c->scene.n_nodes < 65536u) k_traverse_shadow<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
             else k_traverse_shadow<STACK, false, GLOBAL_THREADS><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
@@ -432,6 +362,8 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (c->timing_level < 0 || c->timing_level > 2) c->timing_level = 0;
     c->stage_timing = c->timing_level != 0;
     if (const char *e2 = getenv("RPT_LDS_STREAM")) c->lds_stream = e2[0] != '0';
+    if (const char *e6 = getenv("RPT_GSTREAM")) c->gstream = e6[0] != '0';
+    if (const char *e7 = getenv("RPT_GSTREAM_MIN_WAVES")) c->gstream_min_waves = (uint32_t)std::max(1, atoi(e7));
     if (const char *e5 = getenv("RPT_STREAM_MIN_BLOCKS")) c->stream_min_blocks = (uint32_t)std::max(1, atoi(e5));
     if (const char *e3 = getenv("RPT_SAMPLES_IN_FLIGHT")) c->samples_in_flight_request = std::min(32, std::max(0, atoi(e3)));
     *out = c;
@@ -442,6 +374,7 @@ void rpt_destroy(rpt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    rpt_comm_release(c);
     release_state(c);
     c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
@@ -458,6 +391,7 @@ void rpt_destroy(rpt_ctx *c) {
 int rpt_set_partition(rpt_ctx *c, uint32_t rank, uint32_t world_size) {
     if (!c) return RPT_EINVAL;
     if (world_size == 0 || rank >= world_size) { c->error = "rank must be < world_size"; return RPT_EINVAL; }
+    if (c->rank == rank && c->world == world_size) return RPT_OK;      /* nothing changes: keep the state */
     c->rank = rank;
     c->world = world_size;
     if (c->has_config) {   /* re-derive the slot order for the new partition */
@@ -675,8 +609,21 @@ int rpt_reset(rpt_ctx *c, const rpt_rng_state *seed, const float *accum_init, ui
 int rpt_wait(rpt_ctx *c) {
     if (!c) return RPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->async_pending && c->has_state && c->n_slots)    /* the last asynchronous batch must have left every slot idle */
+        k_check_drained<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, c->stream>>>(c->hit.p, c->n_slots, c->dev_stats.p);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    if (c->async_pending) {
+        /* An asynchronous batch runs a fixed number of iterations and never inspects a progress report.  Every batch
+         * checks that its predecessor left all slots idle (k_generate_first), the last one is checked just above. */
+        unsigned long long undrained = 0ull;
+        HIP_TRY(c, hipMemcpy(&undrained, &c->dev_stats.p->undrained, sizeof(undrained), hipMemcpyDeviceToHost));
+        if (undrained != 0ull) {
+            c->async_pending = false;
+            c->error = "asynchronous batch not drained: " + std::to_string(undrained) + " samples were still in flight after its iterations (internal error)";
+            return RPT_EHIP;
+        }
+    }
     for (auto &b : c->timing_pending) {
         timing_accumulate(c, b.ev, b.iterations);
         c->timing_pool.insert(c->timing_pool.end(), b.ev.begin(), b.ev.end());
@@ -726,7 +673,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
 
     HIP_TRY(c, hipMemsetAsync(c->queues.count, 0, Q_COUNT * sizeof(uint32_t), s));
     if (!async) for (int k = 0; k < RING; ++k) __atomic_store_n(&c->host_ring[k], 0ull, __ATOMIC_RELAXED);
-    k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples);
+    k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples, c->dev_stats.p);
     c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
 
     std::vector<hipEvent_t> async_events;
@@ -750,6 +697,10 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
 
     uint64_t it = 0;
     bool drained = c->cfg.c.max_bounces == 0u;
+    /* RPT_TEST_SHORT_BATCH=1 (test aid): enqueue one iteration too few in an asynchronous batch, to prove that the
+     * completion checks of rpt_wait / k_generate_first notice */
+    uint64_t short_batch = 0;
+    if (async && known_iterations > 1) { const char *e = getenv("RPT_TEST_SHORT_BATCH"); if (e && e[0] == '1') short_batch = 1; }
     /* Run-ahead: it only has to cover the enqueue latency (tens of microseconds).  Launches over millions of slots
      * last far longer than that, and every surplus iteration still dispatches its (instantly returning) workgroups. */
     const int lag = c->n_slots >= (512u << 10) ? 2 : (c->n_slots >= (128u << 10) ? 3 : LAG);
@@ -768,7 +719,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
             default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at); break;
         }
         it += 1;
-        if (it == known_iterations) break;                      /* (no report needed: nothing can be left) */
+        if (it == known_iterations - short_batch) break;        /* (no report needed: nothing can be left) */
         if (known_iterations == 0 && it >= (uint64_t)lag) {
             /* the sky kernel of iteration j published (j + 1) << 32 | "work remains after iteration j" */
             uint64_t j = it - lag;
@@ -828,24 +779,6 @@ int rpt_render(rpt_ctx *c, uint32_t n_samples) { return render_impl(c, n_samples
  * reads results synchronises by itself; rpt_wait does so explicitly. */
 int rpt_render_async(rpt_ctx *c, uint32_t n_samples) { return render_impl(c, n_samples, true); }
 
-int rpt_read_accum(rpt_ctx *c, float *out, uint32_t *out_samples) {
-    if (!c || !out) return RPT_EINVAL;
-    if (!c->has_state) { c->error = "nothing to read: no config"; return RPT_EINVAL; }
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint32_t W = c->cfg.c.width, H = c->cfg.c.height;
-    std::vector<float4> acc(c->n_pixels);
-    if (c->n_pixels) HIP_TRY(c, hipMemcpy(acc.data(), c->accum.p, c->n_pixels * sizeof(float4), hipMemcpyDeviceToHost));
-    memset(out, 0, (size_t)W * H * 4 * sizeof(float));
-    for (size_t s = 0; s < c->n_pixels; ++s) {
-        uint32_t pxy = c->pixel_xy_host[s];
-        size_t i = (size_t)(pxy >> 16) * W + (pxy & 0xffffu);
-        out[4 * i] = acc[s].x; out[4 * i + 1] = acc[s].y; out[4 * i + 2] = acc[s].z; out[4 * i + 3] = acc[s].w;
-    }
-    if (out_samples) *out_samples = c->samples;
-    return RPT_OK;
-}
-
 int rpt_read_rng(rpt_ctx *c, rpt_rng_state *out) {
     if (!c || !out) return RPT_EINVAL;
     if (!c->has_state) { c->error = "nothing to read: no config"; return RPT_EINVAL; }
@@ -881,14 +814,6 @@ int rpt_set_samples_in_flight(rpt_ctx *c, int s) {
     return RPT_OK;
 }
 
-int rpt_local_block_device_ptr(rpt_ctx *c, void **p) {
-    if (!c || !p) return RPT_EINVAL;
-    if (!c->has_state) { c->error = "no config"; return RPT_EINVAL; }
-    (void)hipStreamSynchronize(c->stream);
-    *p = c->accum.p;
-    return RPT_OK;
-}
-
 int rpt_rank_pixels(rpt_ctx *c, uint32_t rank, uint64_t *n) {
     if (!c || !n) return RPT_EINVAL;
     if (!c->has_config || rank >= c->world) { c->error = "no config / bad rank"; return RPT_EINVAL; }
@@ -908,34 +833,6 @@ int rpt_tile_order(uint32_t width, uint32_t height, uint32_t rank, uint32_t worl
         if (capacity < order.size()) return RPT_EINVAL;
         memcpy(out_xy, order.data(), order.size() * sizeof(uint32_t));
     }
-    return RPT_OK;
-}
-
-int rpt_untile(rpt_ctx *c, const void *dev_blocks, uint64_t block_stride_pixels, void *dev_out_image) {
-    if (!c || !dev_blocks || !dev_out_image) return RPT_EINVAL;
-    if (!c->has_config) { c->error = "no config"; return RPT_EINVAL; }
-    HIP_TRY(c, hipSetDevice(c->device));
-    /* map[i] = destination pixel of element i of the gathered buffer (0xffffffff = padding) */
-    std::vector<uint32_t> all, order;
-    for (uint32_t r = 0; r < c->world; ++r) {
-        build_pixel_order(c->cfg.c.width, c->cfg.c.height, r, c->world, order);
-        if (block_stride_pixels) {
-            if (order.size() > block_stride_pixels) { c->error = "block stride smaller than a rank's block"; return RPT_EINVAL; }
-            all.resize((size_t)r * block_stride_pixels, 0xffffffffu);
-        }
-        all.insert(all.end(), order.begin(), order.end());
-    }
-    DevBuf<uint32_t> map;
-    HIP_TRY(c, map.alloc(all.size()));
-    hipError_t e = hipMemcpy(map.p, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        uint32_t n = (uint32_t)all.size();
-        k_untile<<<(n + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, c->stream>>>(reinterpret_cast<const float4 *>(dev_blocks), map.p, n,
-                                                                             c->cfg.c.width, reinterpret_cast<float4 *>(dev_out_image));
-        e = hipStreamSynchronize(c->stream);
-    }
-    map.release();
-    HIP_TRY(c, e);
     return RPT_OK;
 }
 
@@ -974,6 +871,7 @@ int rpt_get_stats(rpt_ctx *c, rpt_stats *out) {
     c->stats.sky_evals = ds.sky_evals;
     c->stats.light_index_clamped = ds.light_index_clamped;
     *out = c->stats;
+    if (ds.undrained != 0ull) { c->error = "a render call found samples still in flight (internal error)"; return RPT_EHIP; }
     return RPT_OK;
 }
 

@@ -20,7 +20,13 @@ EXPORTS = [
     "rpt_render", "rpt_render_async", "rpt_wait", "rpt_stream", "rpt_read_accum", "rpt_resolve", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
     "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
     "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_trace_rays", "rpt_bvh_build_gpu",
+    "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
+    "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
+    "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
+    "rpt_multi_last_error",
 ]
+COMM_ID_BYTES = 128
+MULTI_ALLOW_SHARED_DEVICE = 1
 
 
 def lib_path():
@@ -64,6 +70,29 @@ def lib():
         L.rpt_debug_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 6
         L.rpt_bvh_build_gpu.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
+        L.rpt_map_accum.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32)]
+        L.rpt_comm_unique_id.argtypes = [C.c_void_p]
+        L.rpt_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rpt_comm_world.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.rpt_gather_async.argtypes = [C.c_void_p]
+        L.rpt_gather_wait.argtypes = [C.c_void_p]
+        L.rpt_read_gathered.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rpt_gathered_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rpt_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.rpt_multi_size.argtypes = [C.c_void_p]
+        L.rpt_multi_ctx.argtypes = [C.c_void_p, C.c_int]
+        L.rpt_multi_ctx.restype = C.c_void_p
+        L.rpt_multi_upload_scene.argtypes = [C.c_void_p] + [C.c_void_p, C.c_size_t] * 5 + [C.c_void_p, C.c_uint32, C.c_uint32] * 2
+        L.rpt_multi_set_config.argtypes = [C.c_void_p, C.POINTER(TracingConfig)]
+        L.rpt_multi_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.rpt_multi_render.argtypes = [C.c_void_p, C.c_uint32]
+        L.rpt_multi_wait.argtypes = [C.c_void_p]
+        L.rpt_multi_read_accum.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rpt_multi_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.rpt_multi_destroy.argtypes = [C.c_void_p]
+        L.rpt_multi_destroy.restype = None
+        L.rpt_multi_last_error.argtypes = [C.c_void_p]
+        L.rpt_multi_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -154,11 +183,22 @@ class Renderer:
         return p.value
 
     # -- rpt_read_accum <-> output_buffer.read_blocking (reference: src/trace.rs:198)
-    def read_accum(self):
-        out = np.zeros((self.config.height, self.config.width, 4), np.float32)
+    def read_accum(self, out=None):
+        if out is None:
+            out = np.zeros((self.config.height, self.config.width, 4), np.float32)
+        assert out.dtype == np.float32 and out.size == self.config.height * self.config.width * 4 and out.flags["C_CONTIGUOUS"]
         samples = C.c_uint32()
         self._check(lib().rpt_read_accum(self._h, ptr(out), C.byref(samples)))
         return out, samples.value
+
+    def map_accum(self):
+        """rpt_map_accum: the library's own pinned read-back buffer as an (H, W, 4) array — no copy; valid until the
+        next read_accum / map_accum / set_config on this renderer."""
+        p = C.POINTER(C.c_float)()
+        samples = C.c_uint32()
+        self._check(lib().rpt_map_accum(self._h, C.byref(p), C.byref(samples)))
+        h, w = self.config.height, self.config.width
+        return np.ctypeslib.as_array(p, shape=(h, w, 4)), samples.value
 
     def resolve(self, tonemap_op=0):
         """mean radiance (+ display tonemap 0..6, reference: src/resources/render.wgsl:131-153) as (H, W, 3) float32."""
@@ -199,6 +239,31 @@ class Renderer:
     def untile(self, dev_blocks_ptr, dev_out_ptr, block_stride_pixels=0):
         self._check(lib().rpt_untile(self._h, C.c_void_p(dev_blocks_ptr), block_stride_pixels, C.c_void_p(dev_out_ptr)))
 
+    # -- the gather inside the library (RCCL): rpt_comm_init / rpt_gather_async / rpt_read_gathered
+    def comm_init(self, unique_id, rank, world_size):
+        """ncclCommInitRank on this renderer's device + rpt_set_partition(rank, world_size); unique_id = the 128 bytes
+        rank 0 got from comm_unique_id(), handed to every rank by any means."""
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(lib().rpt_comm_init(self._h, buf, rank, world_size))
+        self.rank, self.world_size = rank, world_size
+
+    def comm_world(self):
+        r, w = C.c_uint32(), C.c_uint32()
+        self._check(lib().rpt_comm_world(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def gather_async(self):
+        self._check(lib().rpt_gather_async(self._h))
+
+    def gather_wait(self):
+        self._check(lib().rpt_gather_wait(self._h))
+
+    def read_gathered(self):
+        out = np.zeros((self.config.height, self.config.width, 4), np.float32)
+        samples = C.c_uint32()
+        self._check(lib().rpt_read_gathered(self._h, ptr(out), C.byref(samples)))
+        return out, samples.value
+
     # -- test hooks
     def debug_math(self, op, x, y=None):
         x = np.ascontiguousarray(x, np.float32)
@@ -218,6 +283,89 @@ class Renderer:
         self._check(lib().rpt_debug_trace_rays(self._h, int(bool(any_hit)), n, ptr(origins), ptr(dirs), ptr(max_t),
                                                ptr(t), ptr(tri), ptr(flags)))
         return t, tri, flags
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI (rank 0 calls it; the 128 bytes go to every rank)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib().rpt_comm_unique_id(buf)
+    if rc != 0:
+        raise RptError(rc, lib().rpt_last_error(None).decode())
+    return bytes(buf)
+
+
+class MultiRenderer:
+    """rpt_multi_*: ONE process driving several GPUs (ncclCommInitAll) — the entry points a single render thread like
+    the reference's (src/trace.rs:136-224) calls; the caller sees one W x H image."""
+
+    def __init__(self, device_ids, allow_shared_device=False):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        rc = lib().rpt_multi_create(ids, len(device_ids), MULTI_ALLOW_SHARED_DEVICE if allow_shared_device else 0, C.byref(self._h))
+        if rc != 0:
+            raise RptError(rc, lib().rpt_multi_last_error(None).decode())
+        self.config = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RptError(rc, lib().rpt_multi_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rpt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return lib().rpt_multi_size(self._h)
+
+    def upload_scene(self, world, skybox_f32=None):
+        atlas = getattr(world, "atlas", None)
+        aw = ah = sw = sh = 0
+        if atlas is not None:
+            atlas = np.ascontiguousarray(atlas, np.uint8)
+            ah, aw = atlas.shape[:2]
+        if skybox_f32 is not None:
+            skybox_f32 = np.ascontiguousarray(skybox_f32, np.float32)
+            sh, sw = skybox_f32.shape[:2]
+        self._check(lib().rpt_multi_upload_scene(
+            self._h, ptr(world.per_vertex), len(world.per_vertex), ptr(world.indices), len(world.indices),
+            ptr(world.nodes), len(world.nodes), ptr(world.materials), len(world.materials),
+            ptr(world.light_pick), len(world.light_pick), ptr(atlas), aw, ah, ptr(skybox_f32), sw, sh))
+
+    def set_config(self, config):
+        self._check(lib().rpt_multi_set_config(self._h, C.byref(config)))
+        self.config = config.copy()
+
+    def reset(self, rng_seed, accum_init=None, samples_init=0):
+        rng_seed = np.ascontiguousarray(rng_seed, RNG_DTYPE)
+        if accum_init is not None:
+            accum_init = np.ascontiguousarray(accum_init, np.float32)
+        self._check(lib().rpt_multi_reset(self._h, ptr(rng_seed), ptr(accum_init), samples_init))
+
+    def render(self, n_samples):
+        self._check(lib().rpt_multi_render(self._h, n_samples))
+
+    def wait(self):
+        self._check(lib().rpt_multi_wait(self._h))
+
+    def read_accum(self, out=None):
+        if out is None:
+            out = np.zeros((self.config.height, self.config.width, 4), np.float32)
+        assert out.dtype == np.float32 and out.size == self.config.height * self.config.width * 4 and out.flags["C_CONTIGUOUS"]
+        samples = C.c_uint32()
+        self._check(lib().rpt_multi_read_accum(self._h, ptr(out), C.byref(samples)))
+        return out, samples.value
+
+    def stats(self):
+        s = Stats()
+        self._check(lib().rpt_multi_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k in ("samples", "extension_rays", "shadow_rays", "sky_evals", "light_index_clamped", "iterations")}
 
 
 def tile_order(width, height, rank, world_size):

@@ -1,0 +1,164 @@
+"""GPU tests of what follows a sample batch behind the C ABI: read-back (device un-tile + one DMA), the per-batch
+gather inside the library (RCCL), the one-process multi-GPU driver (rpt_multi_*), the drained check of
+asynchronous batches, and BASELINE config 5's resolution (4096 x 4096) on the 1 M-triangle stand-in.
+
+A box with one GPU can only hold a 1-rank RCCL communicator (RCCL refuses two ranks on a device), so the N-rank logic
+— staging, strides, un-tile map, overlap with the next batch — is exercised with rpt_multi's shared-device transport
+(stream-ordered device copies in place of ncclSend/ncclRecv; everything else is the code the 8-GPU run executes).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _single_image(hipmod, rpt, w, cfg, seeds, batches):
+    r = hipmod.Renderer(0)
+    r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+    for n in batches:
+        r.render(n)
+    img, s = r.read_accum()
+    st = r.stats()
+    r.close()
+    return img.copy(), s, st
+
+
+def test_map_accum_is_the_read_accum_image(renderer, rpt, world):
+    w = world("DarkCornell")
+    W, H = 200, 136                                    # ragged: partial tiles on both edges
+    cfg = rpt.default_config(W, H, nee=1)
+    renderer.upload_scene(w); renderer.set_config(cfg); renderer.reset(rpt.blue_noise_seeds(W, H))
+    renderer.render(3)
+    a, s = renderer.read_accum()
+    m, s2 = renderer.map_accum()
+    assert s == s2 == 3 and np.all(a[..., 3] == 3)
+    assert np.array_equal(a.view(np.uint32), np.asarray(m).view(np.uint32))
+    out = np.full((H, W, 4), np.nan, np.float32)       # caller-provided buffer is fully overwritten
+    renderer.read_accum(out)
+    assert np.array_equal(a.view(np.uint32), out.view(np.uint32))
+
+
+def test_rccl_gather_one_rank_through_the_c_abi(hipmod, rpt, world):
+    """rpt_comm_unique_id -> rpt_comm_init (ncclCommInitRank) -> rpt_render_async + rpt_gather_async per batch ->
+    rpt_read_gathered: the gathered image is the accumulator image, and RCCL itself reports the communicator size."""
+    w = world("DarkCornell")
+    W, H = 136, 72
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    ref, _, _ = _single_image(hipmod, rpt, w, cfg, seeds, (4, 4, 4))
+    r = hipmod.Renderer(0)
+    r.comm_init(hipmod.comm_unique_id(), 0, 1)
+    assert r.comm_world() == (0, 1)
+    r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+    for _ in range(3):
+        r.render_async(4)
+        r.gather_async()
+    r.gather_wait()
+    img, s = r.read_gathered()
+    assert s == 12 and np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    own, _ = r.read_accum()
+    assert np.array_equal(own.view(np.uint32), ref.view(np.uint32))
+    r.close()
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_multi_driver_image_is_independent_of_the_rank_count(hipmod, rpt, world, ranks):
+    """rpt_multi_*: several ranks (here sharing the one GPU), each rendering its round-robin tiles, one gather per batch
+    overlapped with the next batch: image, sample count and ray counts equal the single-context render bit for bit."""
+    w = world("DarkCornell")
+    W, H = 200, 136
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+    ref, s_ref, st_ref = _single_image(hipmod, rpt, w, cfg, seeds, (4, 4, 2))
+    m = hipmod.MultiRenderer([0] * ranks, allow_shared_device=True)
+    assert m.size() == ranks
+    m.upload_scene(w); m.set_config(cfg); m.reset(seeds)
+    for n in (4, 4, 2):
+        m.render(n)                                    # returns once enqueued; the gather of batch k overlaps batch k + 1
+    img, s = m.read_accum()
+    st = m.stats()
+    assert s == s_ref == 10
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert st["extension_rays"] == st_ref["extension_rays"] and st["shadow_rays"] == st_ref["shadow_rays"]
+    assert st["samples"] == W * H * 10
+    # a second image on the same driver (flush path: reset + render), and reading before any render
+    m.reset(seeds)
+    z, s0 = m.read_accum()
+    assert s0 == 0 and not z.any()
+    m.render(10)
+    img2, _ = m.read_accum()
+    assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32))
+    m.close()
+
+
+def test_multi_driver_with_rccl_on_the_devices_present(hipmod, rpt, world):
+    """ncclCommInitAll over every GPU of the box (one here, eight on the scaling node): same image as one context."""
+    import torch
+    n = torch.cuda.device_count()
+    w = world("FurnaceTest")
+    W, H = 128, 128
+    cfg = rpt.default_config(W, H, nee=2)
+    seeds = rpt.blue_noise_seeds(W, H)
+    ref, _, _ = _single_image(hipmod, rpt, w, cfg, seeds, (8,))
+    m = hipmod.MultiRenderer(list(range(n)))
+    m.upload_scene(w); m.set_config(cfg); m.reset(seeds)
+    m.render(8)
+    img, s = m.read_accum()
+    assert s == 8 and np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    m.close()
+    with pytest.raises(hipmod.RptError):
+        hipmod.MultiRenderer([0, 0])                   # a device twice needs the explicit test-aid flag
+
+
+def test_async_batches_are_checked_for_completion(monkeypatch, hipmod, rpt, world):
+    """An asynchronous batch enqueues a fixed number of iterations and never looks at a progress report.  rpt_wait (and
+    every next batch) verifies that all samples finished; RPT_TEST_SHORT_BATCH=1 enqueues one iteration too few and
+    must be caught — by rpt_wait for the last batch, by the following batch for an earlier one."""
+    w = world("DarkCornell")
+    W, H = 96, 64
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+    for _ in range(3):
+        r.render_async(8)
+    r.wait()                                           # complete batches pass
+    assert r.read_accum()[1] == 24
+    r.close()
+    monkeypatch.setenv("RPT_TEST_SHORT_BATCH", "1")
+    for batches in (1, 2):
+        r = hipmod.Renderer(0)
+        r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+        for _ in range(batches):
+            r.render_async(8)
+        with pytest.raises(hipmod.RptError, match="in flight"):
+            r.wait()
+        r.close()
+
+
+def test_baseline_config5_resolution_on_the_stand_in(hipmod, oracle, rpt):
+    """BASELINE config 5: 4096 x 4096 with NEE + MIS on the deep-BVH scene.  BreakTime.glb is absent from the reference
+    mount; the labelled stand-in is the procedural 1 M-triangle scene (tests/scenes.py).  16.8 M pixels in one launch:
+    every pixel sampled exactly spp times, ray accounting within its bounds, and three windows (centre, a corner, across
+    a tile seam) equal to the oracle's render of those windows bit for bit."""
+    from scenes import deep_bvh_scene
+    w = deep_bvh_scene(1_000_000)
+    W = H = 4096
+    spp = 2
+    cfg = rpt.default_config(W, H, nee=1, cam_position=(0.0, 2.5, -0.5, 0.0))
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+    r.render(spp)
+    a, s = r.map_accum()
+    st = r.stats()
+    assert s == spp and np.all(a[..., 3] == spp) and np.isfinite(a).all()
+    assert st["samples"] == W * H * spp
+    assert W * H * spp <= st["extension_rays"] <= W * H * spp * cfg.max_bounces
+    assert 0 < st["shadow_rays"] <= st["extension_rays"]
+    osc = oracle.scene(w)
+    for rect in ((2040, 2030, 2072, 2054), (4064, 4072, 4096, 4096), (1000, 3060, 1040, 3080)):
+        ref, _, _ = oracle.trace_cpu(cfg, osc, seeds, spp, rect=rect)
+        x0, y0, x1, y1 = rect
+        assert np.array_equal(np.asarray(a[y0:y1, x0:x1]).view(np.uint32), ref[y0:y1, x0:x1].view(np.uint32)), rect
+    r.close()

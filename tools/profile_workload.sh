@@ -1,0 +1,41 @@
+#!/bin/bash
+# Judged evidence of ONE bench workload on the GPU box, into gpurun_out/profile/:
+#   ${TAG}_${WL}_bench.json          the bench line (python3 bench.py --workload WL ...)
+#   ${TAG}_${WL}_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (--no-cpu-baseline)
+#   ${TAG}_${WL}_pmc_{FETCH_SIZE,WRITE_SIZE}.txt   per-kernel per-launch averages, one --pmc pass each (--kernel-trace only)
+#   ${TAG}_${WL}_pmc_sq.txt, _pmc_cache.txt        SQ issue / lane utilisation, TCP / TCC hit passes
+#   traffic_${WL}.json               HBM bytes per launch per stage + source fingerprint (bench.py reads profiles/traffic_*.json)
+# usage: tools/profile_workload.sh TAG WORKLOAD [bench args, e.g. --steps 4]     env: SKIP_PMC=1 keeps only bench + stats
+set -u
+TAG=$1; WL=$2; shift 2
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/profile
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="$ROOT/bench.py --workload $WL"
+python3 $B "$@" 2>"$OUT/${TAG}_${WL}_bench.err" | tail -1 > "$OUT/${TAG}_${WL}_bench.json"
+rm -rf /tmp/prof_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $B --no-cpu-baseline "$@" > "$OUT/${TAG}_${WL}_stats_run.log" 2>&1
+cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_${WL}_kernel_stats.csv"
+if [ "${SKIP_PMC:-0}" != "1" ]; then
+  pass() {   # name, counters...
+    local name=$1; shift
+    rm -rf /tmp/prof_p
+    rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/prof_p -- python3 $B --steps 2 --warmup 0 --no-cpu-baseline > "$OUT/${TAG}_${WL}_pmc_${name}.log" 2>&1
+    local f; f=$(find /tmp/prof_p -name '*counter_collection.csv' | head -1)
+    if [ -n "$f" ]; then
+      cp "$f" "/tmp/${name}.csv"
+      { echo "# rocprofv3 --pmc $* --kernel-trace -- python3 bench.py --workload $WL --steps 2 --warmup 0 --no-cpu-baseline ; per-launch averages"; python3 "$ROOT/tools/pmc_summary.py" "$f"; } > "$OUT/${TAG}_${WL}_pmc_${name}.txt"
+      rm -f "$OUT/${TAG}_${WL}_pmc_${name}.log"
+    fi
+  }
+  pass FETCH_SIZE FETCH_SIZE
+  pass WRITE_SIZE WRITE_SIZE
+  python3 "$ROOT/tools/traffic_from_pmc.py" /tmp/FETCH_SIZE.csv /tmp/WRITE_SIZE.csv "$WL" "$OUT/traffic_${WL}.json" \
+    "profiles/${TAG}_${WL}_pmc_FETCH_SIZE.txt, profiles/${TAG}_${WL}_pmc_WRITE_SIZE.txt (separate --pmc passes, bench.py --workload $WL --steps 2 --warmup 0 --no-cpu-baseline)" > /dev/null
+  pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
+  pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES
+  pass cache TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
+fi
+head -8 "$OUT/${TAG}_${WL}_kernel_stats.csv" | cut -c1-200
+cat "$OUT/${TAG}_${WL}_bench.json" | cut -c1-600
