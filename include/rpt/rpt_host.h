@@ -50,6 +50,16 @@ typedef struct rpt_world rpt_world;
  * Returns RPT_HOST_ELOAD when the file cannot be imported (the reference
  * returns None and trace_gpu silently returns, trace.rs:141-143). */
 int rpt_world_load(const char *path, rpt_world **out);
+/* rpt_world_load with options.  RPT_LOAD_EMISSIVE_STRENGTH: honour KHR_materials_emissive_strength
+ * (emissive = factor * strength) instead of the reference's fixed x15 (src/asset.rs:163-166) for materials that carry
+ * the extension — NOT the reference's behaviour, hence opt-in. */
+#define RPT_LOAD_EMISSIVE_STRENGTH 1u
+int rpt_world_load_ex(const char *path, uint32_t flags, rpt_world **out);
+/* load_dynamic_image + dynamic_image_to_cpu_buffer (src/asset.rs:238-273): a skybox file (.png, Radiance .hdr) as the
+ * reference's CPU path sees it — quantised to 8 bits per channel, alpha 1 — as width*height float RGBA, the layout
+ * rpt_upload_scene takes.  Caller frees with rpt_host_free. */
+int rpt_skybox_load(const char *path, float **rgba_out, uint32_t *width, uint32_t *height);
+void rpt_host_free(void *p);
 /* Build a World from caller-supplied geometry (already in the reference's
  * post-swap space): runs the same BVH + light-table + packing steps.  Used for
  * procedural scenes. normals/uvs may be NULL (zero-filled like asset.rs:209-212). */

@@ -8,4 +8,4 @@ Only what the hot path needs lives here:
 The CPU oracle is NOT part of this package (see oracle/, test infrastructure only).
 """
 from . import _ffi  # noqa: F401
-from .host import World, TracingState, blue_noise_seeds, default_config, fixture, setup_trace, trace_gpu  # noqa: F401
+from .host import World, TracingState, blue_noise_seeds, default_config, fixture, load_skybox, setup_trace, trace_gpu  # noqa: F401

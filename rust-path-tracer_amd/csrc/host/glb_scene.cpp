@@ -228,10 +228,19 @@ bool read_accessor(const Glb &g, int index, int want_components, std::vector<dou
     int view_idx = (int)a.number_or("bufferView", -1);
     if (view_idx < 0 || (size_t)view_idx >= views->arr.size()) return false;
     const JValue &bv = *views->arr[view_idx];
-    size_t offset = (size_t)bv.number_or("byteOffset", 0) + (size_t)a.number_or("byteOffset", 0);
-    size_t stride = (size_t)bv.number_or("byteStride", 0);
+    /* every number comes from the file: convert and bound it before it sizes or addresses anything (a crafted count
+     * must not reach resize(), offset + i * stride must not wrap) */
+    auto to_size = [](double v, size_t &dst) {
+        if (!(v >= 0.0) || v > 4.0e15 || v != std::floor(v)) return false;
+        dst = (size_t)v;
+        return true;
+    };
+    size_t view_off = 0, acc_off = 0, stride = 0;
+    if (!to_size(bv.number_or("byteOffset", 0), view_off) || !to_size(a.number_or("byteOffset", 0), acc_off) ||
+        !to_size(bv.number_or("byteStride", 0), stride) || !to_size(a.number_or("count", 0), count))
+        return false;
+    const size_t offset = view_off + acc_off;
     int ctype = (int)a.number_or("componentType", 0);
-    count = (size_t)a.number_or("count", 0);
     const JValue *type = a.get("type");
     if (!type) return false;
     int comps = type->str == "SCALAR" ? 1 : type->str == "VEC2" ? 2 : type->str == "VEC3" ? 3 : type->str == "VEC4" ? 4 : 0;
@@ -240,6 +249,9 @@ bool read_accessor(const Glb &g, int index, int want_components, std::vector<dou
     if (!csize) return false;
     if (!stride) stride = csize * comps;
     bool normalized = a.get("normalized") && a.get("normalized")->b;
+    const size_t elem = csize * (size_t)comps, bin = g.bin.size();
+    if (stride > (1u << 20) || offset > bin) return false;
+    if (count != 0 && (elem > bin - offset || (count - 1) > (bin - offset - elem) / stride)) return false;   /* last element ends inside the chunk */
     out.resize(count * comps);
     for (size_t i = 0; i < count; ++i)
         for (int c = 0; c < comps; ++c) {
@@ -263,6 +275,7 @@ bool read_accessor(const Glb &g, int index, int want_components, std::vector<dou
 struct Gather {
     std::vector<Vec4f> vertices, normals, tangents;
     std::vector<float> uvs;   /* 2 per vertex */
+    bool any_tangent_missing = false;
     std::vector<rpt_triangle> indices;
     bool used_default_material = false;
     uint32_t default_material_index = 0;
@@ -308,6 +321,9 @@ bool walk_node(const Glb &g, int node_index, const M4 &trs, Gather &out, int dep
                 if (!read_accessor(g, (int)attrs->number_or("POSITION", -1), 3, pos, n_pos)) return false;
                 bool has_nor = read_accessor(g, (int)attrs->number_or("NORMAL", -1), 3, nor, n_nor);
                 bool has_uv = read_accessor(g, (int)attrs->number_or("TEXCOORD_0", -1), 2, uv, n_uv);
+                std::vector<double> tan;
+                size_t n_tan = 0;
+                bool has_tan = read_accessor(g, (int)attrs->number_or("TANGENT", -1), 4, tan, n_tan) && n_tan == n_pos;
                 int idx_acc = (int)prim.number_or("indices", -1);
                 if (idx_acc >= 0) {
                     if (!read_accessor(g, idx_acc, 1, idx, n_idx)) return false;
@@ -334,6 +350,9 @@ bool walk_node(const Glb &g, int node_index, const M4 &trs, Gather &out, int dep
                         w[r] = ((new_trs.m[0][r] * v[0] + new_trs.m[1][r] * v[1]) + new_trs.m[2][r] * v[2]) + new_trs.m[3][r];
                     out.vertices.push_back(Vec4f{w[0], w[2], w[1], 1.0f});
                 }
+                for (size_t k = 0; k < n_idx; ++k)       /* an index must name a vertex of THIS primitive (the reference would panic on it) */
+                    if (!(idx[k] >= 0.0) || !(idx[k] < (double)n_pos)) return false;
+                if (out.vertices.size() + n_pos > 0xfffffff0ull) return false;
                 for (size_t f = 0; f + 2 < n_idx; f += 3) {
                     uint32_t i0 = (uint32_t)idx[f], i1 = (uint32_t)idx[f + 1], i2 = (uint32_t)idx[f + 2];
                     out.indices.push_back(rpt_triangle{triangle_offset + i0, triangle_offset + i2, triangle_offset + i1, material});
@@ -347,6 +366,22 @@ bool walk_node(const Glb &g, int node_index, const M4 &trs, Gather &out, int dep
                         float inv = 1.0f / std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
                         out.normals.push_back(Vec4f{r[0] * inv, r[2] * inv, r[1] * inv, 0.0f});
                     }
+                }
+                /* tangents (asset.rs:111-114): the glTF importer hands a file's TANGENT attribute through (CalcTangentSpace
+                 * leaves meshes that have tangents alone); without one assimp derives them from positions and uvs — see
+                 * derive_tangents below */
+                out.tangents.resize(triangle_offset, Vec4f{0, 0, 0, 0});
+                if (has_tan) {
+                    for (size_t i = 0; i < n_tan; ++i) {
+                        float t[3] = {(float)tan[4 * i] / node_scale[0], (float)tan[4 * i + 1] / node_scale[1], (float)tan[4 * i + 2] / node_scale[2]};
+                        float r[3];
+                        quat_rotate(node_quat, t, r);
+                        float inv = 1.0f / std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+                        out.tangents.push_back(Vec4f{r[0] * inv, r[2] * inv, r[1] * inv, 0.0f});
+                    }
+                } else {
+                    out.any_tangent_missing = true;
+                    out.tangents.resize(out.vertices.size(), Vec4f{0, 0, 0, 0});
                 }
                 if (has_uv) {
                     for (size_t i = 0; i < n_uv; ++i) {
@@ -384,7 +419,66 @@ bool finish_world(World &w, std::vector<Vec4f> &vertices, std::vector<Vec4f> &no
     return true;
 }
 
-bool load_glb(const char *path, World &out) {
+namespace {
+
+/* Vertices without a TANGENT attribute: per-triangle tangent from the uv gradient (the construction assimp's
+ * CalcTangentsProcess starts from: T = (dv2 * e1 - dv1 * e2) / (du1 * dv2 - du2 * dv1)), accumulated per vertex,
+ * made orthogonal to the normal and normalised.  assimp additionally merges across its own vertex joins, which cannot
+ * be reproduced without it: parity for normal-mapped materials is defined at the buffer boundary (TANGENT in the file,
+ * or buffers handed over directly). */
+void derive_tangents(const std::vector<Vec4f> &v, const std::vector<Vec4f> &n, const std::vector<float> &uv,
+                     const std::vector<rpt_triangle> &tris, std::vector<Vec4f> &tangents) {
+    std::vector<Vec4f> acc(v.size(), Vec4f{0, 0, 0, 0});
+    for (const rpt_triangle &t : tris) {
+        const uint32_t i0 = t.v0, i1 = t.v1, i2 = t.v2;
+        if (2 * (size_t)std::max(i0, std::max(i1, i2)) + 1 >= uv.size()) continue;
+        float e1[3] = {v[i1].x - v[i0].x, v[i1].y - v[i0].y, v[i1].z - v[i0].z};
+        float e2[3] = {v[i2].x - v[i0].x, v[i2].y - v[i0].y, v[i2].z - v[i0].z};
+        float du1 = uv[2 * i1] - uv[2 * i0], dv1 = uv[2 * i1 + 1] - uv[2 * i0 + 1];
+        float du2 = uv[2 * i2] - uv[2 * i0], dv2 = uv[2 * i2 + 1] - uv[2 * i0 + 1];
+        float det = du1 * dv2 - du2 * dv1;
+        if (det == 0.0f) continue;
+        float r = 1.0f / det;
+        float tx = (dv2 * e1[0] - dv1 * e2[0]) * r, ty = (dv2 * e1[1] - dv1 * e2[1]) * r, tz = (dv2 * e1[2] - dv1 * e2[2]) * r;
+        for (uint32_t i : {i0, i1, i2}) { acc[i].x += tx; acc[i].y += ty; acc[i].z += tz; }
+    }
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (i < tangents.size() && (tangents[i].x != 0.0f || tangents[i].y != 0.0f || tangents[i].z != 0.0f)) continue;   /* from the file */
+        float t[3] = {acc[i].x, acc[i].y, acc[i].z};
+        if (i < n.size()) {
+            float d = t[0] * n[i].x + t[1] * n[i].y + t[2] * n[i].z;
+            t[0] -= d * n[i].x; t[1] -= d * n[i].y; t[2] -= d * n[i].z;
+        }
+        float len = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        if (tangents.size() <= i) tangents.resize(i + 1, Vec4f{0, 0, 0, 0});
+        tangents[i] = len > 0.0f ? Vec4f{t[0] / len, t[1] / len, t[2] / len, 0.0f} : Vec4f{0, 0, 0, 0};
+    }
+}
+
+/* images[textures[index].source] of the GLB, decoded (asset.rs:27-44).  index < 0: no texture. */
+bool load_gltf_texture(const Glb &g, const JValue *texinfo, Image8 &img, bool &present) {
+    present = false;
+    if (!texinfo) return true;
+    int ti = (int)texinfo->number_or("index", -1);
+    const JValue *textures = g.arr("textures"), *images = g.arr("images"), *views = g.arr("bufferViews");
+    if (ti < 0 || !textures || (size_t)ti >= textures->arr.size()) return true;
+    int src = (int)textures->arr[ti]->number_or("source", -1);
+    if (src < 0 || !images || (size_t)src >= images->arr.size()) return true;
+    const JValue &im = *images->arr[src];
+    int bv = (int)im.number_or("bufferView", -1);
+    if (bv < 0 || !views || (size_t)bv >= views->arr.size()) { set_error("GLB image without an embedded bufferView (external uri) is not supported"); return false; }
+    double off = views->arr[bv]->number_or("byteOffset", 0), len = views->arr[bv]->number_or("byteLength", 0);
+    if (!(off >= 0) || !(len >= 8) || off + len > (double)g.bin.size()) { set_error("GLB image bufferView out of range"); return false; }
+    const uint8_t *p = g.bin.data() + (size_t)off;
+    if (p[0] == 0xff && p[1] == 0xd8) { set_error("GLB image is a JPEG: only PNG textures are decoded"); return false; }
+    if (!decode_png(p, (size_t)len, img)) return false;
+    present = true;
+    return true;
+}
+
+}  // namespace
+
+bool load_glb(const char *path, World &out, uint32_t flags) {
     FILE *f = fopen(path, "rb");
     if (!f) { set_error(std::string("cannot open ") + path); return false; }
     std::vector<uint8_t> data;
@@ -435,10 +529,13 @@ bool load_glb(const char *path, World &out) {
 
     /* materials (asset.rs:135-175) */
     out.materials.assign(n_file_materials + (ga.used_default_material ? 1 : 0), rpt_material_data{});
+    std::vector<Image8> textures;          /* in the reference's push order: per material albedo, metallic, roughness, normals */
     for (size_t i = 0; i < out.materials.size(); ++i) {
         rpt_material_data &m = out.materials[i];
         float base[4] = {1, 1, 1, 1}, emissive[3] = {0, 0, 0};
         float metallic = 1.0f, roughness = 1.0f;
+        float strength = 1.0f;
+        bool has_strength = false;
         if (i < n_file_materials) {
             const JValue &jm = *materials->arr[i];
             if (const JValue *pbr = jm.get("pbrMetallicRoughness")) {
@@ -449,15 +546,49 @@ bool load_glb(const char *path, World &out) {
             }
             if (const JValue *e = jm.get("emissiveFactor"); e && e->arr.size() == 3)
                 for (int k = 0; k < 3; ++k) emissive[k] = (float)e->arr[k]->num;
+            if (flags & RPT_LOAD_EMISSIVE_STRENGTH)
+                if (const JValue *ext = jm.get("extensions"))
+                    if (const JValue *es = ext->get("KHR_materials_emissive_strength")) {
+                        strength = (float)es->number_or("emissiveStrength", 1.0);
+                        has_strength = true;
+                    }
+            /* textures (asset.rs:140-160).  assimp's glTF2 importer exposes metallicRoughnessTexture under BOTH
+             * aiTextureType_METALNESS and aiTextureType_DIFFUSE_ROUGHNESS, so the reference atlases it twice. */
+            const JValue *pbr = jm.get("pbrMetallicRoughness");
+            Image8 img;
+            bool present = false;
+            if (!load_gltf_texture(g, pbr ? pbr->get("baseColorTexture") : nullptr, img, present)) return false;
+            if (present) { albedo_gamma_to_linear(img); textures.push_back(img); m.has_albedo_texture = 1; }
+            if (!load_gltf_texture(g, pbr ? pbr->get("metallicRoughnessTexture") : nullptr, img, present)) return false;
+            if (present) { textures.push_back(img); m.has_metallic_texture = 1; textures.push_back(img); m.has_roughness_texture = 1; }
+            if (!load_gltf_texture(g, jm.get("normalTexture"), img, present)) return false;
+            if (present) { textures.push_back(img); m.has_normal_texture = 1; }
         }
         for (int k = 0; k < 4; ++k) m.albedo[k] = base[k];
-        m.emissive[0] = emissive[0] * 15.0f; m.emissive[1] = emissive[1] * 15.0f;
-        m.emissive[2] = emissive[2] * 15.0f; m.emissive[3] = 1.0f * 15.0f;
+        /* asset.rs:163-166: "Multiply by 15 since assimp 5.2.5 doesn't support emissive strength" — the reference's
+         * behaviour and the default here; RPT_LOAD_EMISSIVE_STRENGTH honours KHR_materials_emissive_strength instead */
+        const float gain = has_strength ? strength : 15.0f;
+        m.emissive[0] = emissive[0] * gain; m.emissive[1] = emissive[1] * gain;
+        m.emissive[2] = emissive[2] * gain; m.emissive[3] = 1.0f * gain;
         for (int k = 0; k < 4; ++k) { m.metallic[k] = metallic; m.roughness[k] = roughness; }
     }
     for (const rpt_triangle &t : ga.indices)
         if (t.material >= out.materials.size()) { set_error("material index out of range"); return false; }
 
+    if (!textures.empty()) {
+        /* atlas.rs:26-90 + asset.rs:174-187: pack, then hand the uvst out in push order */
+        std::vector<std::array<float, 4>> sts;
+        out.atlas_w = out.atlas_h = 4096;
+        pack_textures(textures, out.atlas_w, out.atlas_h, out.atlas, sts);
+        size_t at = 0;
+        for (rpt_material_data &m : out.materials) {
+            if (m.has_albedo_texture) memcpy(m.albedo, sts[at++].data(), 16);
+            if (m.has_metallic_texture) memcpy(m.metallic, sts[at++].data(), 16);
+            if (m.has_roughness_texture) memcpy(m.roughness, sts[at++].data(), 16);
+            if (m.has_normal_texture) memcpy(m.normals, sts[at++].data(), 16);
+        }
+        if (ga.any_tangent_missing) derive_tangents(ga.vertices, ga.normals, ga.uvs, ga.indices, ga.tangents);
+    }
     out.indices = ga.indices;
     return finish_world(out, ga.vertices, ga.normals, ga.tangents, ga.uvs);
 }

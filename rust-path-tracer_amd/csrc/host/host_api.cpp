@@ -10,7 +10,10 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <mutex>
 
 #include "../../../include/rpt/rpt.h"
@@ -55,10 +58,42 @@ void rpt_tracing_config_default(rpt_tracing_config *c) {
 }
 
 /* ------------------------------------------------------------- World ---- */
-int rpt_world_load(const char *path, rpt_world **out) {
+int rpt_world_load(const char *path, rpt_world **out) { return rpt_world_load_ex(path, 0u, out); }
+
+void rpt_host_free(void *p) { free(p); }
+
+int rpt_skybox_load(const char *path, float **rgba_out, uint32_t *width, uint32_t *height) {
+    if (!path || !rgba_out || !width || !height) { set_error("null argument"); return RPT_EINVAL; }
+    try {
+        std::vector<float> rgba;
+        if (!load_skybox_file(path, rgba, *width, *height)) return RPT_HOST_ELOAD;
+        float *p = (float *)malloc(rgba.size() * sizeof(float));
+        if (!p) { set_error("out of memory"); return RPT_ENOMEM; }
+        memcpy(p, rgba.data(), rgba.size() * sizeof(float));
+        *rgba_out = p;
+    } catch (const std::exception &e) {
+        set_error(std::string("skybox load failed: ") + e.what());
+        return RPT_HOST_ELOAD;
+    }
+    return 0;
+}
+
+int rpt_world_load_ex(const char *path, uint32_t flags, rpt_world **out) {
     if (!path || !out) { set_error("null argument"); return RPT_EINVAL; }
-    auto *w = new rpt_world();
-    if (!load_glb(path, w->w)) { delete w; return RPT_HOST_ELOAD; }
+    /* nothing may unwind across the C ABI: a hostile file can still ask for more memory than there is */
+    rpt_world *w = nullptr;
+    try {
+        w = new rpt_world();
+        if (!load_glb(path, w->w, flags)) { delete w; return RPT_HOST_ELOAD; }
+    } catch (const std::bad_alloc &) {
+        delete w;
+        set_error("out of memory while loading the scene");
+        return RPT_ENOMEM;
+    } catch (const std::exception &e) {
+        delete w;
+        set_error(std::string("scene load failed: ") + e.what());
+        return RPT_HOST_ELOAD;
+    }
     *out = w;
     return 0;
 }
@@ -310,7 +345,11 @@ extern "C" {
 int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_state *state, int device_id,
                   const char *hip_library_path) {
     if (!scene_path || !state) { set_error("null argument"); return RPT_EINVAL; }
-    if (skybox_path) { set_error("image skyboxes are passed through rpt_upload_scene; file loading is out of scope"); return RPT_EINVAL; }
+    /* skybox_path.and_then(load_dynamic_image) ... unwrap_or_else(fallback) (trace.rs:144): a file that cannot be
+     * read falls back to the 2x2 magenta image, as the reference does */
+    std::vector<float> skybox;
+    uint32_t sky_w = 0, sky_h = 0;
+    if (skybox_path && !load_skybox_file(skybox_path, skybox, sky_w, sky_h)) { skybox.clear(); sky_w = sky_h = 0; }
 
     rpt_world *world = nullptr;
     int rc = rpt_world_load(scene_path, &world);
@@ -363,7 +402,8 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
     rpt_world_view v;
     rpt_world_view_get(world, &v);
     if ((rc = api.upload_scene(ctx, v.per_vertex, v.n_vertices, v.indices, v.n_triangles, v.nodes, v.n_nodes, v.materials,
-                               v.n_materials, v.light_pick, v.n_light_pick, v.atlas_rgba8, v.atlas_w, v.atlas_h, nullptr, 0, 0)))
+                               v.n_materials, v.light_pick, v.n_light_pick, v.atlas_rgba8, v.atlas_w, v.atlas_h,
+                               skybox.empty() ? nullptr : skybox.data(), sky_w, sky_h)))
         return fail(rc);
     if ((rc = api.set_config(ctx, &config))) return fail(rc);
     if ((rc = api.reset(ctx, seeds(), accum_init.data(), samples_init))) return fail(rc);
@@ -400,6 +440,15 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
             state->dirty.store(false, std::memory_order_relaxed);
             state->samples.store(0, std::memory_order_relaxed);
             { std::lock_guard<std::mutex> g(state->lock); config = state->config; }
+            if (config.width != W || config.height != H) {
+                /* every buffer of this call (seeds, read-back image, the state's framebuffer) is sized for the
+                 * resolution the call started with, as in the reference (trace.rs:146-148): a resize needs a new call */
+                set_error("resolution changed while rendering: stop and call rpt_trace_gpu again");
+                api.destroy(ctx);
+                rpt_world_free(world);
+                dlclose(api.handle);
+                return RPT_EINVAL;
+            }
             if ((rc = api.set_config(ctx, &config))) return fail(rc);
             if ((rc = api.reset(ctx, seeds(), nullptr, 0))) return fail(rc);
         }

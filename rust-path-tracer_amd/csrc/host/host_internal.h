@@ -2,6 +2,7 @@
 #ifndef RPT_HOST_INTERNAL_H
 #define RPT_HOST_INTERNAL_H
 
+#include <array>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -23,6 +24,16 @@ uint32_t bvh_max_depth(const std::vector<rpt_bvh_node> &nodes);
 std::vector<rpt_light_pick_entry> build_light_pick_table(const Vec4f *vertices, const rpt_triangle *triangles,
                                                          size_t n_triangles, const rpt_material_data *materials,
                                                          uint32_t *n_emissive);
+
+/* textures.cpp: decoders, the texture atlas (src/atlas.rs), the skybox as the CPU path sees it (src/asset.rs:238-273) */
+struct Image8 { uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; };
+bool read_file(const char *path, std::vector<uint8_t> &data);
+bool decode_png(const uint8_t *data, size_t size, Image8 &out);
+void albedo_gamma_to_linear(Image8 &img);
+void resize_lanczos3(const Image8 &src, uint32_t dw, uint32_t dh, Image8 &dst);
+void pack_textures(const std::vector<Image8> &textures, uint32_t atlas_w, uint32_t atlas_h, std::vector<uint8_t> &atlas,
+                   std::vector<std::array<float, 4>> &sts);
+bool load_skybox_file(const char *path, std::vector<float> &rgba, uint32_t &w, uint32_t &h);
 
 /* bluenoise.png -> 8-bit tile */
 bool load_blue_noise(const char *path, std::vector<uint8_t> &tile, uint32_t &w, uint32_t &h);
@@ -47,7 +58,8 @@ bool finish_world(World &w, std::vector<Vec4f> &vertices, std::vector<Vec4f> &no
  * (rpt_host_set_bvh_builder).  Both produce the same node pool and triangle order. */
 bool build_world_bvh(const Vec4f *vertices, size_t n_vertices, std::vector<rpt_triangle> &triangles, std::vector<rpt_bvh_node> &nodes);
 
-bool load_glb(const char *path, World &out);
+/* flags: RPT_LOAD_* of rpt_host.h */
+bool load_glb(const char *path, World &out, uint32_t flags = 0);
 
 }  // namespace rpth
 

@@ -67,6 +67,7 @@ __device__ __forceinline__ bool slab_test(float4 lo, float4 hi, F3 ro, F3 rd, F3
  * carries count = 0x80000000 so that "at an inner node" / "at a leaf" are single compares on the register (a
  * ballot of a compare is the compare itself; a ballot of a loop-carried bool costs two more VALU instructions). */
 struct SceneViewGlobal {
+    static constexpr bool kCoopLeaves = true;               /* leaves may hold dozens of triangles: see walk_run */
     const float4 *nodes, *tri_geom;
     typedef uint2 Cur;                                      /* x = triangle_count, y = left child / first triangle */
     __device__ __forceinline__ Cur root() const { return make_uint2(__float_as_uint(nodes[0].w), __float_as_uint(nodes[1].w)); }
@@ -114,6 +115,7 @@ struct SceneViewGlobal {
 #define LDS_DESC_DEAD 0x4000u
 #define LDS_DESC_LEAF 0x8000u
 struct SceneViewLds {
+    static constexpr bool kCoopLeaves = false;
     const float4 *img;
     uint32_t pairs, tris, root_desc;
     __device__ __forceinline__ const float4 *tri_base() const { return img + 6u * pairs + ((pairs + 3u) >> 2); }
@@ -162,6 +164,12 @@ __device__ __forceinline__ bool moller_trumbore_view(const View &view, uint32_t 
 #ifndef RPT_LEAF_K
 #define RPT_LEAF_K 8
 #endif
+#ifndef RPT_COOP_LEAF_MIN
+#define RPT_COOP_LEAF_MIN 6        /* leaves with more triangles than this are tested by the whole wave (global-memory scenes) */
+#endif
+__device__ __forceinline__ float rpt_readlane(float v, int lane) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane)); }
+__device__ __forceinline__ uint32_t rpt_readlane_u(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+
 /* Everything a ray needs besides (ro, rd, 1/rd) and its stack column: the walk can be stopped after a number of loop
  * trips and resumed (the streamed kernels hand finished lanes new rays in between). */
 template <typename View> struct Walk {
@@ -213,29 +221,84 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
                 cur = view.from_entry(stack[sp * RPT_WAVE]);
             }
         }
-        if (at_leaf && ((uint32_t)__popcll(leaf_m) >= (uint32_t)RPT_LEAF_K || inner_m == 0ull)) {
-            /* leaf triangles in index order (:186-205) */
-            bool accepted = false;
+        if ((uint32_t)__popcll(leaf_m) >= (uint32_t)RPT_LEAF_K || inner_m == 0ull) {       /* (wave-uniform) */
+            bool accepted = false, coop_done = false;
             const uint32_t count = View::leaf_count(cur), first = View::leaf_first(cur);
-            for (uint32_t i = 0; i < count; ++i) {
-                uint32_t ti = first + i;
-                float t = 0.0f;
-                bool bf = false;
-                if (moller_trumbore_view(view, ti, ro, rd, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
-                    /* result.t = result.t.min(t) with t < result.t already established (intersection.rs:195-199).  Kept a
-                     * real branch: as two selects on vcc the update becomes back-to-back VOP2 v_cndmask, which gfx950 issues
-                     * at ~22 cycles each (tools/microbench/valu_rates.hip) */
-                    asm volatile("" ::: "memory");
-                    res.t = t;
-                    res.tri = ti | (bf ? 0x80000000u : 0u);
-                    if (ANY_HIT) { accepted = true; break; }
+            if constexpr (View::kCoopLeaves) {
+                /* FAT leaves, wave-cooperatively.  The reference's builder stops splitting where the SAH says so, and on
+                 * clustered geometry that leaves up to 64 triangles in a leaf (the 1 M-triangle stand-in: 140 triangle
+                 * tests per ray).  One lane looping over 64 triangles while the other 63 wait ran that scene at 7 % lane
+                 * utilisation (profiles/r02base_deepbvh_pmc_sq.txt).  Instead the owner's ray is broadcast (readlane:
+                 * it lives in scalar registers) and every lane tests ONE triangle of the leaf.  The sequential loop
+                 * accepts t_i < running best in index order, i.e. ends with the smallest t and, among equal t, the lowest
+                 * index (any-hit: the lowest index that passes) — which is what the scalar scan below selects. */
+                const bool fat = at_leaf && count > (uint32_t)RPT_COOP_LEAF_MIN;
+                unsigned long long fat_m = rpt_ballot(fat);
+                if (fat_m != 0ull) {
+                    const unsigned long long exec_m = rpt_ballot(true);
+                    const uint32_t n_act = (uint32_t)__popcll(exec_m);
+                    const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(exec_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)exec_m, 0u));
+                    coop_done = fat;
+                    do {
+                        const int L = __ffsll((long long)fat_m) - 1;
+                        fat_m &= fat_m - 1ull;
+                        const F3 bo = f3(rpt_readlane(ro.x, L), rpt_readlane(ro.y, L), rpt_readlane(ro.z, L));
+                        const F3 bd = f3(rpt_readlane(rd.x, L), rpt_readlane(rd.y, L), rpt_readlane(rd.z, L));
+                        const uint32_t b_count = rpt_readlane_u(count, L), b_first = rpt_readlane_u(first, L);
+                        const float b_max = ANY_HIT ? rpt_readlane(max_t, L) : 0.0f;
+                        uint32_t best_bits = __float_as_uint(rpt_readlane(res.t, L));      /* positive floats order like their bits */
+                        uint32_t best_tri = HIT_MISS;
+                        for (uint32_t base = 0; base < b_count; base += n_act) {
+                            const uint32_t ti = b_first + base + my_rank;
+                            float t = 0.0f;
+                            bool bf = false;
+                            const bool acc = base + my_rank < b_count && moller_trumbore_view(view, ti, bo, bd, t, bf) && t > 0.001f &&
+                                             __float_as_uint(t) < best_bits && (!ANY_HIT || t <= b_max);
+                            unsigned long long am = rpt_ballot(acc);
+                            while (am != 0ull) {                                          /* scalar scan, lowest triangle first */
+                                const int l = __ffsll((long long)am) - 1;
+                                am &= am - 1ull;
+                                const uint32_t tb = __float_as_uint(rpt_readlane(t, l));
+                                if (tb < best_bits) {
+                                    best_bits = tb;
+                                    best_tri = rpt_readlane_u(ti, l) | (rpt_readlane_u(bf ? 1u : 0u, l) << 31);
+                                    if (ANY_HIT) break;
+                                }
+                            }
+                            if (ANY_HIT && best_tri != HIT_MISS) break;
+                        }
+                        if ((int)__lane_id() == L && best_tri != HIT_MISS) {
+                            res.t = __uint_as_float(best_bits);
+                            res.tri = best_tri;
+                            accepted = true;
+                        }
+                    } while (fat_m != 0ull);
                 }
             }
-            if ((ANY_HIT && accepted) || sp == 0) {
-                cur = View::dead();
-            } else {
-                sp -= 1;
-                cur = view.from_entry(stack[sp * RPT_WAVE]);
+            if (at_leaf && !coop_done) {
+                /* leaf triangles in index order (:186-205) */
+                for (uint32_t i = 0; i < count; ++i) {
+                    uint32_t ti = first + i;
+                    float t = 0.0f;
+                    bool bf = false;
+                    if (moller_trumbore_view(view, ti, ro, rd, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
+                        /* result.t = result.t.min(t) with t < result.t already established (intersection.rs:195-199).  Kept a
+                         * real branch: as two selects on vcc the update becomes back-to-back VOP2 v_cndmask, which gfx950 issues
+                         * at ~22 cycles each (tools/microbench/valu_rates.hip) */
+                        asm volatile("" ::: "memory");
+                        res.t = t;
+                        res.tri = ti | (bf ? 0x80000000u : 0u);
+                        if (ANY_HIT) { accepted = true; break; }
+                    }
+                }
+            }
+            if (at_leaf) {
+                if ((ANY_HIT && accepted) || sp == 0) {
+                    cur = View::dead();
+                } else {
+                    sp -= 1;
+                    cur = view.from_entry(stack[sp * RPT_WAVE]);
+                }
             }
         }
     }
@@ -295,6 +358,10 @@ __device__ __forceinline__ bool slab_pair_lds(float n_x, float n_y, float n_z, f
 #ifndef RPT_LEAF_K_LDS
 #define RPT_LEAF_K_LDS 24
 #endif
+#ifndef RPT_LEAF_GREEDY_PCT
+#define RPT_LEAF_GREEDY_PCT 100    /* 0: the threshold rule above; > 0: one body per trip, see lds_walk_run (measured, streamed DarkCornell:
+                                      traverse 82.6 / 80.0 / 81.4 / 82.8 ms per 8 batches for 0 / 100 / 130 / 170) */
+#endif
 /* A walk over the LDS image that can be stopped after a number of loop trips and resumed (k_traverse_nearest_stream):
  * everything a ray needs besides (ro, rd, 1/rd) is in here and in its stack column. */
 struct LdsWalk {
@@ -328,7 +395,14 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
         const bool at_leaf = cur >= LDS_DESC_LEAF;
         const unsigned long long inner_m = rpt_ballot(at_inner), leaf_m = rpt_ballot(at_leaf);
         if ((inner_m | leaf_m) == 0ull) break;
+#if RPT_LEAF_GREEDY_PCT
+        /* ONE body per trip, the one with more lanes ready for it (a leaf step counts RPT_LEAF_GREEDY_PCT % of an inner one):
+         * lanes on a leaf no longer sit out a fixed quota of inner steps, and no body is issued for a handful of lanes */
+        const bool do_leaf = (uint32_t)__popcll(leaf_m) * 100u > (uint32_t)__popcll(inner_m) * (uint32_t)RPT_LEAF_GREEDY_PCT;
+        if (at_inner && !do_leaf) {
+#else
         if (at_inner) {
+#endif
             const float4 X = px[cur], Y = py[cur], Z = pz[cur];     /* (L.near, R.near, L.far, R.far) per axis */
             const uint32_t d = descs[cur];
             float tl, tr;
@@ -349,7 +423,11 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
                 cur = stack[sp * RPT_WAVE];
             }
         }
+#if RPT_LEAF_GREEDY_PCT
+        if (at_leaf && do_leaf) {
+#else
         if (at_leaf && ((uint32_t)__popcll(leaf_m) >= (uint32_t)RPT_LEAF_K_LDS || inner_m == 0ull)) {
+#endif
             bool accepted = false;
             const uint32_t count = (cur >> 9) & 63u, first = cur & 511u;
             for (uint32_t i = 0; i < count; ++i) {
@@ -480,33 +558,76 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
 #define RPT_STREAM_RAYS 8          /* most slots per lane of a workgroup (the host lowers it for small launches) */
 #endif
 #ifndef RPT_STREAM_TRIPS
-#define RPT_STREAM_TRIPS 12
+#define RPT_STREAM_TRIPS 8
 #endif
 #ifndef RPT_STREAM_REFILL
-#define RPT_STREAM_REFILL 16
+#define RPT_STREAM_REFILL 12
 #endif
+/* The workgroup's pool is one 64-bit LDS word (next slot | end slot << 32): a wave takes slots with ONE 64-bit ds_add that
+ * returns a consistent (next, end) pair.  When the span is used up the wave that notices fetches the next span of SPAN
+ * slots from the launch-wide counter (one global atomic per SPAN slots) — PERSISTENT workgroups: the grid holds as many
+ * workgroups as the GPU keeps resident, and none of them drains before the whole launch runs out of slots.  (Round 1
+ * gave every workgroup one fixed span: each of the 4 096 workgroups then ended in its own tail of ever emptier waves —
+ * the replay, tools/traversal_sim.py, puts 17 % of the issue slots there — and the launch in a tail of late workgroups.
+ * Stealing 512-slot chunks per WAVE from one global counter was measured slower: 65 k atomics per launch on one address.) */
+struct WgPool {
+    unsigned long long word;     /* lo = next slot, hi = end of the span; hi == 0: the launch has no slots left */
+    uint32_t lock;
+};
+/* one lane: take up to `want` slots.  Returns the first slot and how many were obtained (0: none right now);
+ * *finished is set once the launch-wide pool is empty. */
+__device__ __forceinline__ uint32_t wg_pool_take(WgPool *pool, uint32_t *global_next, uint32_t n_slots, uint32_t SPAN, uint32_t want,
+                                                 uint32_t &got, bool &finished) {
+    got = 0u;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const unsigned long long v = atomicAdd(&pool->word, (unsigned long long)want);
+        const uint32_t next = (uint32_t)v, end = (uint32_t)(v >> 32);
+        if (next < end) {
+            got = end - next < want ? end - next : want;
+            return next;
+        }
+        if (end == 0u) { finished = true; return 0u; }
+        if (atomicCAS(&pool->lock, 0u, 1u) != 0u) return 0u;            /* another wave is fetching the next span: look again later */
+        const unsigned long long now = atomicAdd(&pool->word, 0ull);
+        if ((uint32_t)now >= (uint32_t)(now >> 32) && (uint32_t)(now >> 32) != 0u) {
+            const uint32_t g = atomicAdd(global_next, SPAN);
+            const unsigned long long fresh = g < n_slots ? ((unsigned long long)(g + SPAN < n_slots ? g + SPAN : n_slots) << 32) | g
+                                                         : 0x00000000f0000000ull;
+            atomicExch(&pool->word, fresh);
+        }
+        __threadfence_block();
+        atomicExch(&pool->lock, 0u);
+    }
+    return 0u;
+}
+
 template <int STACK, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
-                                                                       uint32_t SPAN /* slots per workgroup, dealt to its waves on demand */) {
+                                                                       uint32_t SPAN /* slots a workgroup fetches at a time */) {
     constexpr uint32_t NW = THREADS / RPT_WAVE;
     __shared__ uint16_t lds_stack[NW][STACK][RPT_WAVE];
-    __shared__ uint32_t pool_next;
+    __shared__ WgPool pool;
     float4 *lds_scene = rpt_lds_dyn;
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
+    uint32_t *global_next = &q.count[Q_POOL0 + (iteration & 1u) * Q_LINE];
     if (blockIdx.x == 0u && threadIdx.x == 0u) {
-        /* per-iteration bookkeeping, as in k_traverse_nearest */
+        /* per-iteration bookkeeping, as in k_traverse_nearest (+ the other parity's slot counter, unused in this launch) */
         const uint32_t prev = (iteration + 1u) & 1u;
         q.count[Q_SHADOW] = 0u;
         if (q.count[Q_SKY] >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q.count[Q_SKY] = 0u;
         q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
         q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
+        q.count[Q_POOL0 + prev * Q_LINE] = 0u;
     }
     const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
-    const uint32_t span_begin = blockIdx.x * SPAN;
-    if (span_begin >= st.n_slots) return;                      /* block-uniform */
-    const uint32_t span_end = span_begin + SPAN < st.n_slots ? span_begin + SPAN : st.n_slots;
-    if (threadIdx.x == 0u) pool_next = span_begin;
-    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);     /* (barrier inside: pool_next visible) */
+    if (threadIdx.x == 0u) {
+        const uint32_t g = atomicAdd(global_next, SPAN);
+        pool.word = g < st.n_slots ? ((unsigned long long)(g + SPAN < st.n_slots ? g + SPAN : st.n_slots) << 32) | g : 0x00000000f0000000ull;
+        pool.lock = 0u;
+    }
+    __syncthreads();
+    if ((uint32_t)(pool.word >> 32) == 0u) return;             /* block-uniform: a late workgroup, nothing left */
+    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);
     uint16_t *stack = &lds_stack[wave][0][lane];
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     LdsWalk w;
@@ -514,24 +635,27 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
     w.cur = LDS_DESC_DEAD;
     uint32_t slot = 0u;
     bool have = false;                                         /* this lane holds a ray whose result is not written yet */
-    bool pool_open = true;                                     /* wave-uniform: the workgroup's pool may still have slots */
+    bool pool_open = true;                                     /* wave-uniform: the launch may still have slots */
     uint32_t traced = 0u;                                      /* wave-uniform */
     for (;;) {
         const unsigned long long idle_m = rpt_ballot(w.cur == LDS_DESC_DEAD);
         const uint32_t n_idle = (uint32_t)__popcll(idle_m);
         if (pool_open && n_idle >= (uint32_t)RPT_STREAM_REFILL) {
-            uint32_t base = 0u;
-            if (lane == 0u) base = atomicAdd(&pool_next, n_idle);
+            uint32_t base = 0u, got = 0u;
+            bool finished = false;
+            if (lane == 0u) base = wg_pool_take(&pool, global_next, st.n_slots, SPAN, n_idle, got, finished);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            pool_open = base + n_idle < span_end;
+            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            pool_open = __builtin_amdgcn_readfirstlane((int)finished) == 0;
             bool took = false;
             if (w.cur == LDS_DESC_DEAD) {
                 if (have) {
                     st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
                     have = false;
                 }
-                const uint32_t cand = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                if (cand < span_end) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                if (rank < got) {
+                    const uint32_t cand = base + rank;
                     if (__float_as_uint(st.hit[cand].y) == HIT_PENDING) {
                         const float4 ra = st.ray_a[cand];
                         const float2 rb = st.ray_b[cand];
@@ -551,9 +675,13 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
                 }
             }
             traced += (uint32_t)__popcll(rpt_ballot(took));
-            continue;                                          /* slots that were not pending leave lanes idle: look again */
+            if (got != 0u || !pool_open) continue;             /* slots that were not pending leave lanes idle: look again */
+            if (idle_m == ~0ull) { __builtin_amdgcn_s_sleep(8); continue; }   /* another wave is fetching the next span */
         }
-        if (idle_m == ~0ull) break;                            /* nothing in flight and nothing left to hand out */
+        if (idle_m == ~0ull) {
+            if (!pool_open) break;                             /* nothing in flight and nothing left to hand out */
+            continue;
+        }
         lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
     }
     if (have) st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));

@@ -51,7 +51,8 @@ struct rpt_ctx {
     bool lds_stream = true;
     bool gstream = true;                 /* scenes walked from global memory: streamed kernels (k_traverse_*_gstream) */
     uint32_t gstream_min_waves = 32768;
-    uint32_t stream_min_blocks = 1024;   /* measured at 2 M slots (1/8 of DarkCornell 1024^2): 5.5 / 6.2 / 6.2 / 5.6 Grays/s for 2048 / 1024 / 512 / 256 */
+    uint32_t stream_max_blocks = 512;    /* persistent workgroups of the streamed LDS traversal: 2 per CU (each holds 32 KB of stacks + the scene image) */
+    uint32_t stream_span = 0;            /* slots a workgroup fetches at a time; 0 = automatic */
 
     /* scene */
     bool has_scene = false;

@@ -39,6 +39,10 @@ def lib():
         L.rpt_tracing_state_set_sync_rate.argtypes = [C.c_void_p, C.c_uint32]
         L.rpt_trace_gpu.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_char_p]
         L.rpt_world_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.rpt_world_load_ex.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.rpt_skybox_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.rpt_host_free.argtypes = [C.c_void_p]
+        L.rpt_host_free.restype = None
         L.rpt_world_view_get.argtypes = [C.c_void_p, C.POINTER(WorldView)]
         L.rpt_world_free.argtypes = [C.c_void_p]
         L.rpt_world_save.argtypes = [C.c_void_p, C.c_char_p]
@@ -111,9 +115,11 @@ class World:
         return w
 
     @classmethod
-    def from_path(cls, path):
+    def from_path(cls, path, emissive_strength=False):
+        """World::from_path (reference: src/asset.rs:55-224).  emissive_strength=True honours
+        KHR_materials_emissive_strength instead of the reference's fixed x15 (opt-in: not the reference's behaviour)."""
         h = C.c_void_p()
-        _check(lib().rpt_world_load(os.fsencode(path), C.byref(h)))
+        _check(lib().rpt_world_load_ex(os.fsencode(path), C.c_uint32(1 if emissive_strength else 0), C.byref(h)))
         return cls._from_handle(h)
 
     @classmethod
@@ -161,6 +167,18 @@ def write_png(path, rgb, srgb=True):
     """8-bit PNG of a resolved (H, W, 3) float frame, sRGB-encoded like the reference's saved renders."""
     rgb = np.ascontiguousarray(rgb, np.float32)
     _check(lib().rpt_write_png(os.fsencode(path), ptr(rgb), C.c_uint32(rgb.shape[1]), C.c_uint32(rgb.shape[0]), int(bool(srgb))))
+
+
+def load_skybox(path):
+    """load_dynamic_image + dynamic_image_to_cpu_buffer (reference: src/asset.rs:238-273): the skybox file as the CPU
+    path sees it — 8 bits per channel, alpha 1 — as an (H, W, 4) float32 array for Renderer.upload_scene(skybox_f32=...)."""
+    p = C.POINTER(C.c_float)()
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib().rpt_skybox_load(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)))
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().rpt_host_free(p)
 
 
 def blue_noise_tile(png_path=None):

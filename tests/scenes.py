@@ -125,3 +125,86 @@ def deep_bvh_scene(n_triangles=200_000, seed=1):
     m["metallic"][:, :] = np.array([0.8, 0.0, 0.3, 0.0, 0.0], np.float32)[:, None]
     m["emissive"][4] = [18.0, 17.0, 15.0, 15.0]
     return rpt.World.from_buffers(verts, normals.astype(np.float32), None, tris, m)
+
+
+def write_glb(path, positions, indices, *, normals=None, uvs=None, materials=None, images=None, textures=None, accessor_patch=None,
+              node_extra=None):
+    """Minimal glTF 2.0 binary writer for tests: one mesh, one primitive, optional embedded PNG images.
+    positions (n, 3) float32, indices (m,) uint32.  `accessor_patch(accessors, views)` may corrupt the JSON on purpose."""
+    import json
+    import struct
+    import numpy as np
+    blob = bytearray()
+    views, accessors = [], []
+
+    def add(data, target=None):
+        while len(blob) % 4:
+            blob.append(0)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)})
+        blob.extend(data)
+        return len(views) - 1
+
+    positions = np.ascontiguousarray(positions, np.float32)
+    indices = np.ascontiguousarray(indices, np.uint32)
+    attrs = {}
+    accessors.append({"bufferView": add(positions.tobytes()), "componentType": 5126, "count": len(positions), "type": "VEC3"})
+    attrs["POSITION"] = 0
+    if normals is not None:
+        accessors.append({"bufferView": add(np.ascontiguousarray(normals, np.float32).tobytes()), "componentType": 5126,
+                          "count": len(normals), "type": "VEC3"})
+        attrs["NORMAL"] = len(accessors) - 1
+    if uvs is not None:
+        accessors.append({"bufferView": add(np.ascontiguousarray(uvs, np.float32).tobytes()), "componentType": 5126,
+                          "count": len(uvs), "type": "VEC2"})
+        attrs["TEXCOORD_0"] = len(accessors) - 1
+    accessors.append({"bufferView": add(indices.tobytes()), "componentType": 5125, "count": len(indices), "type": "SCALAR"})
+    prim = {"attributes": attrs, "indices": len(accessors) - 1}
+    if materials:
+        prim["material"] = 0
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [dict({"mesh": 0}, **(node_extra or {}))],
+           "meshes": [{"primitives": [prim]}], "accessors": accessors, "bufferViews": views}
+    if materials:
+        doc["materials"] = materials
+    if images:
+        doc["images"] = [{"bufferView": add(png), "mimeType": "image/png"} for png in images]
+        doc["textures"] = textures if textures is not None else [{"source": i} for i in range(len(images))]
+    if accessor_patch:
+        accessor_patch(accessors, views)
+    doc["buffers"] = [{"byteLength": len(blob)}]
+    js = json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    while len(blob) % 4:
+        blob.append(0)
+    total = 12 + 8 + len(js) + 8 + len(blob)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<III", 0x46546C67, 2, total))
+        f.write(struct.pack("<II", len(js), 0x4E4F534A) + js)
+        f.write(struct.pack("<II", len(blob), 0x004E4942) + bytes(blob))
+    return path
+
+
+def png_bytes(rgb):
+    """Encode an (H, W, 3|4) uint8 array as a PNG (filter 0, zlib level 1) — test input for the loader's decoder."""
+    import struct
+    import zlib
+    import numpy as np
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, c = rgb.shape
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), rgb.reshape(h, w * c)], axis=1).tobytes()
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw, 1)) + chunk(b"IEND", b""))
+
+
+def pack_rects(n_textures, atlas=4096):
+    """src/atlas.rs:26-71 restated: the leaf rectangle (x, y, w, h) of every texture, in texture order."""
+    from collections import deque
+    q = deque([(0, 0, atlas, atlas)])
+    while len(q) <= n_textures:
+        x, y, w, h = q.popleft()
+        hw, hh = w // 2, h // 2
+        q.extend([(x, y, hw, hh), (x + hw, y, hw, hh), (x, y + hh, hw, hh), (x + hw, y + hh, hw, hh)])
+    leafs = sorted(q, key=lambda r: -r[2])          # stable, by width descending
+    return leafs[:n_textures]

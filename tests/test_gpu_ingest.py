@@ -1,0 +1,67 @@
+"""GPU parity on scenes that come out of the loader's texture / skybox paths: a GLB with embedded
+base-colour, metallic-roughness and normal textures -> atlas -> k_shade<.., TEXTURED>, and a skybox FILE through the host
+dispatch mirror (rpt_trace_gpu(scene, skybox_path, ..) = trace_gpu, src/trace.rs:136-224) — both against the oracle."""
+import numpy as np
+import pytest
+
+from scenes import png_bytes, write_glb
+
+pytestmark = pytest.mark.gpu
+
+
+def _textured_glb(tmp_path):
+    y, x = np.mgrid[0:64, 0:64]
+    albedo = np.stack([(x * 4) % 256, (y * 4) % 256, ((x + y) * 2) % 256], -1).astype(np.uint8)
+    mr = np.stack([(x * 3 + 40) % 256, (y * 2 + 90) % 256, np.full_like(x, 30)], -1).astype(np.uint8)
+    nrm = np.stack([128 + 40 * np.sin(x / 5.0), 128 + 40 * np.cos(y / 7.0), np.full(x.shape, 230.0)], -1).astype(np.uint8)
+    pos = np.array([[-3, 0, 6], [3, 0, 6], [3, 0, -2], [-3, 0, -2],          # glTF y-up floor ...
+                    [-3, 0, 6], [3, 0, 6], [3, 4, 6], [-3, 4, 6]], np.float32)  # ... and a back wall
+    nor = np.array([[0, 1, 0]] * 4 + [[0, 0, -1]] * 4, np.float32)
+    uv = np.array([[0, 0], [2.5, 0], [2.5, 3], [0, 3], [0, 0], [1, 0], [1, 1], [0, 1]], np.float32)   # the floor wraps
+    idx = np.array([0, 1, 2, 0, 2, 3, 4, 6, 5, 4, 7, 6], np.uint32)
+    mats = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1}},
+             "normalTexture": {"index": 2}}]
+    return write_glb(str(tmp_path / "textured.glb"), pos, idx, normals=nor, uvs=uv, materials=mats,
+                     images=[png_bytes(albedo), png_bytes(mr), png_bytes(nrm)])
+
+
+def test_textured_glb_through_the_loader_matches_the_oracle(renderer, oracle, rpt, tmp_path):
+    w = rpt.World.from_path(_textured_glb(tmp_path))
+    assert w.atlas is not None and w.materials[0]["has_normal_texture"] == 1
+    W, H, spp = 144, 96, 4
+    cfg = rpt.default_config(W, H, cam_position=(0.0, 1.5, -4.0, 0.0))
+    seeds = rpt.blue_noise_seeds(W, H)
+    renderer.upload_scene(w)
+    renderer.set_config(cfg)
+    renderer.reset(seeds)
+    renderer.render(spp)
+    acc, _ = renderer.read_accum()
+    ref, _, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    g = renderer.stats()
+    assert st.error_flags == 0 and g["extension_rays"] == st.extension_rays and g["sky_evals"] == st.sky_evals
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    assert ref[..., :3].std() > 0.02
+
+
+def test_host_dispatch_with_a_skybox_file(oracle, rpt, world, tmp_path):
+    """trace_gpu(scene_path, Some(skybox_path), state): the file is loaded as the reference's CPU path loads it (8-bit
+    quantised, asset.rs:266-273) and used by the image-skybox branch (lib.rs:70-78); the framebuffer (mean) equals the
+    oracle's on the same buffers bit for bit.  A skybox that cannot be read falls back to the 2x2 magenta image."""
+    y, x = np.mgrid[0:32, 0:64]
+    sky = np.stack([(x * 4) % 256, (y * 8) % 256, ((x * y) // 4) % 256], -1).astype(np.uint8)
+    sky_path = tmp_path / "sky.png"
+    sky_path.write_bytes(png_bytes(sky))
+    W, H, spp = 96, 64, 8
+    for path in (str(sky_path), str(tmp_path / "missing.png")):
+        state = rpt.setup_trace(W, H, spp)
+        state.config.has_skybox = 1
+        state.set_sync_rate(spp)
+        rpt.trace_gpu(rpt.fixture("PBRTest.glb"), path, state)
+        frame = state.framebuffer()
+        cfg = rpt.default_config(W, H, has_skybox=1)
+        skybox = rpt.load_skybox(path) if path == str(sky_path) else None
+        ref, _, _ = oracle.trace_cpu(cfg, oracle.scene(world("PBRTest"), skybox_f32=skybox), rpt.blue_noise_seeds(W, H), spp)
+        want = ref[..., :3] / np.float32(spp)
+        assert state.samples == spp
+        assert np.array_equal(frame.view(np.uint32), want.view(np.uint32))
+        state.close()

@@ -99,3 +99,40 @@ def test_png_writer_srgb(rpt, tmp_path):
     assert list(px[2, 2, :3]) == [0, 127, 0]            # NaN -> 0 ; 0.214 -> ~0.5
     rpt.host.write_png(path, img, srgb=False)
     assert list(np.array(Image.open(path))[0, 0, :3]) == [0, 128, 255]
+
+
+def _quad():
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    idx = np.array([0, 1, 2, 0, 2, 3], np.uint32)
+    return pos, idx
+
+
+def test_crafted_glb_is_rejected_without_reading_out_of_bounds(rpt, tmp_path):
+    """A .glb is untrusted input: vertex indices beyond the primitive, accessor counts / offsets / strides that point
+    outside the binary chunk or wrap around must be reported as load errors (the Rust reference panics safely)."""
+    from scenes import write_glb
+    pos, idx = _quad()
+    ok = rpt.World.from_path(write_glb(str(tmp_path / "ok.glb"), pos, idx))
+    assert len(ok.indices) == 2 and len(ok.per_vertex) == 4
+
+    bad_idx = idx.copy()
+    bad_idx[4] = 4                                        # one past the last vertex
+    with pytest.raises(rpt.host.HostError):
+        rpt.World.from_path(write_glb(str(tmp_path / "idx.glb"), pos, bad_idx))
+    bad_idx[4] = 0xFFFFFFF0
+    with pytest.raises(rpt.host.HostError):
+        rpt.World.from_path(write_glb(str(tmp_path / "idx2.glb"), pos, bad_idx))
+
+    def huge_count(acc, views):
+        acc[0]["count"] = 1 << 40                         # would be a 24 TB resize
+    def negative_count(acc, views):
+        acc[-1]["count"] = -3
+    def offset_past_end(acc, views):
+        acc[0]["byteOffset"] = 1 << 50
+    def wrapping_stride(acc, views):
+        views[0]["byteStride"] = 1 << 62
+    def fractional(acc, views):
+        acc[-1]["count"] = 4.5
+    for k, patch in enumerate((huge_count, negative_count, offset_past_end, wrapping_stride, fractional)):
+        with pytest.raises(rpt.host.HostError):
+            rpt.World.from_path(write_glb(str(tmp_path / f"acc{k}.glb"), pos, idx, accessor_patch=patch))

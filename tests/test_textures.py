@@ -1,0 +1,147 @@
+"""Scene-ingestion fidelity, CPU only: embedded glTF textures -> the reference's texture atlas
+(src/atlas.rs:26-90, src/asset.rs:135-192), KHR_materials_emissive_strength (opt-in), skybox files as the CPU path sees
+them (src/asset.rs:238-273)."""
+import struct
+
+import numpy as np
+import pytest
+
+from scenes import pack_rects, png_bytes, write_glb
+
+
+def _quad_with_uv():
+    pos = np.array([[-1, 0, 0], [1, 0, 0], [1, 2, 0], [-1, 2, 0]], np.float32)
+    nor = np.tile(np.array([[0, 0, -1]], np.float32), (4, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    return pos, np.array([0, 1, 2, 0, 2, 3], np.uint32), nor, uv
+
+
+def _pattern(n, seed, channels=3):
+    """A cheap-to-compress but position-dependent image."""
+    y, x = np.mgrid[0:n, 0:n]
+    img = np.stack([(x * 7 + y * 3 + seed * 11) % 256, (x // 3 + 2 * y + seed) % 256, (x ^ y) % 256], -1).astype(np.uint8)
+    return img if channels == 3 else np.concatenate([img, np.full((n, n, 1), 200, np.uint8)], -1)
+
+
+def test_atlas_layout_matches_the_reference_packer(rpt, tmp_path):
+    """One material with base colour (2048^2), metallic-roughness (64^2) and normal (1024^2) textures = 4 atlas entries
+    (assimp lists the metallic-roughness image under two texture types, so the reference atlases it twice): rectangles,
+    uvst (with the reference's y / atlas_WIDTH), vertical flip, gamma -> linear of the albedo only, flags."""
+    pos, idx, nor, uv = _quad_with_uv()
+    albedo, mr, normal = _pattern(2048, 1), _pattern(64, 2), _pattern(1024, 3, channels=4)
+    mats = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1},
+                                      "baseColorFactor": [0.5, 0.6, 0.7, 1.0]}, "normalTexture": {"index": 2}}]
+    path = write_glb(str(tmp_path / "tex.glb"), pos, idx, normals=nor, uvs=uv, materials=mats,
+                     images=[png_bytes(albedo), png_bytes(mr), png_bytes(normal)])
+    w = rpt.World.from_path(path)
+    m = w.materials[0]
+    assert (m["has_albedo_texture"], m["has_metallic_texture"], m["has_roughness_texture"], m["has_normal_texture"]) == (1, 1, 1, 1)
+    assert w.atlas is not None and w.atlas.shape == (4096, 4096, 4)
+    rects = pack_rects(4)
+    assert [r[2] for r in rects] == [2048, 2048, 2048, 1024]
+    for field, (x, y, rw, rh) in zip(("albedo", "metallic", "roughness", "normals"), rects):
+        want = np.array([x / 4096, y / 4096, rw / 4096, rh / 4096], np.float32)
+        assert np.array_equal(m[field], want), field
+    # albedo: exact copy (texture size == leaf size), gamma -> linear with truncation, alpha 255, rows flipped
+    lut = np.array([int(np.float32(np.float32(v / np.float32(255.0)) ** np.float32(2.2)) * np.float32(255.0)) for v in range(256)], np.uint8)
+    x, y, rw, rh = rects[0]
+    got = w.atlas[y:y + rh, x:x + rw]
+    want = lut[albedo][::-1]
+    close = np.abs(got[..., :3].astype(int) - want.astype(int))
+    assert close.max() <= 1 and (close != 0).mean() < 1e-3      # powf of this libm vs the correctly rounded one: the odd boundary value
+    assert np.all(got[..., 3] == 255)
+    # normal map: exact copy into its 1024^2 leaf, alpha kept (to_rgba8), flipped
+    x, y, rw, rh = rects[3]
+    assert np.array_equal(w.atlas[y:y + rh, x:x + rw], normal[::-1])
+    # metallic-roughness: the same image in two leaves, upscaled 64 -> 2048 (Lanczos3): identical copies, in range, smooth
+    (x1, y1, s1, _), (x2, y2, s2, _) = rects[1], rects[2]
+    a, b = w.atlas[y1:y1 + s1, x1:x1 + s1], w.atlas[y2:y2 + s2, x2:x2 + s2]
+    assert np.array_equal(a, b)
+    centre = a[::-1][16::32, 16::32, :3].astype(int)            # the texel centres of the source land on every 32nd output pixel
+    assert np.abs(centre - mr.astype(int)).mean() < 12
+    # everything outside the leaves stays zero
+    mask = np.ones((4096, 4096), bool)
+    for x, y, rw, rh in rects:
+        mask[y:y + rh, x:x + rw] = False
+    assert not w.atlas[mask].any()
+    # tangents were derived (no TANGENT attribute): unit length, orthogonal to the normal
+    t, n = w.per_vertex["tangent"][:, :3], w.per_vertex["normal"][:, :3]
+    assert np.allclose(np.linalg.norm(t, axis=1), 1.0, atol=1e-5) and np.allclose((t * n).sum(1), 0.0, atol=1e-5)
+
+
+def test_untextured_scenes_keep_no_atlas_and_shipped_scenes_are_unchanged(rpt, world):
+    for name in ("DarkCornell", "PBRTest"):
+        w = world(name)
+        assert w.atlas is None
+        assert not w.materials["has_albedo_texture"].any() and not w.materials["has_normal_texture"].any()
+
+
+def test_emissive_strength_is_opt_in(rpt, tmp_path):
+    pos, idx, nor, uv = _quad_with_uv()
+    mats = [{"emissiveFactor": [1.0, 0.5, 0.25], "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 4.0}}}]
+    path = write_glb(str(tmp_path / "em.glb"), pos, idx, normals=nor, uvs=uv, materials=mats)
+    ref = rpt.World.from_path(path)                               # the reference ignores the extension: x 15 (asset.rs:163-166)
+    assert np.array_equal(ref.materials[0]["emissive"], np.array([15.0, 7.5, 3.75, 15.0], np.float32))
+    ext = rpt.World.from_path(path, emissive_strength=True)
+    assert np.array_equal(ext.materials[0]["emissive"], np.array([4.0, 2.0, 1.0, 4.0], np.float32))
+    assert ext.n_emissive_triangles == ref.n_emissive_triangles == 2
+
+
+def _write_hdr(path, rgbe, rle):
+    h, w, _ = rgbe.shape
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode())
+        for row in rgbe:
+            if not rle:
+                f.write(row.tobytes())
+                continue
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for c in range(4):
+                comp = row[:, c]
+                x = 0
+                while x < w:                                      # literal runs of up to 100 bytes, and a run where values repeat
+                    run = 1
+                    while x + run < w and run < 127 and comp[x + run] == comp[x]:
+                        run += 1
+                    if run >= 3:
+                        f.write(bytes([128 + run, int(comp[x])]))
+                        x += run
+                    else:
+                        n = min(100, w - x)
+                        f.write(bytes([n]) + comp[x:x + n].tobytes())
+                        x += n
+
+
+@pytest.mark.parametrize("rle", [False, True])
+def test_hdr_skybox_is_quantised_like_the_cpu_path(rpt, tmp_path, rle):
+    """dynamic_image_to_cpu_buffer (asset.rs:266-273): whatever range the file holds, the CPU path keeps
+    round(clamp(v, 0, 1) * 255) / 255 per channel and alpha 1."""
+    rng = np.random.default_rng(4)
+    h, w = 12, 40
+    rgbe = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+    rgbe[..., 3] = rng.integers(120, 132, (h, w))               # values from ~1e-5 to ~8
+    rgbe[0, :8, 3] = 0                                           # e == 0: black
+    rgbe[1, :, 0] = 77                                           # a long run for the RLE writer
+    path = str(tmp_path / "sky.hdr")
+    _write_hdr(path, rgbe, rle)
+    got = rpt.load_skybox(path)
+    scale = np.where(rgbe[..., 3:] == 0, 0.0, np.exp2(rgbe[..., 3:].astype(np.float64) - 136.0)).astype(np.float32)
+    lin = rgbe[..., :3].astype(np.float32) * scale
+    q = np.floor(np.clip(lin, 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.float32) / np.float32(255.0)
+    assert got.shape == (h, w, 4) and np.all(got[..., 3] == 1.0)
+    assert np.array_equal(got[..., :3], q)
+    assert len(np.unique(got[..., :3])) <= 256
+
+
+def test_png_skybox_and_decoder_variants(rpt, tmp_path):
+    img = _pattern(48, 9, channels=4)
+    p = tmp_path / "sky.png"
+    p.write_bytes(png_bytes(img))
+    got = rpt.load_skybox(str(p))
+    assert np.array_equal(got[..., :3], img[..., :3].astype(np.float32) / np.float32(255.0)) and np.all(got[..., 3] == 1.0)
+    with pytest.raises(rpt.host.HostError):
+        rpt.load_skybox(str(tmp_path / "missing.png"))
+    bad = tmp_path / "bad.hdr"
+    bad.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 4 +X 4\n" + b"\x01" * 10)
+    with pytest.raises(rpt.host.HostError):
+        rpt.load_skybox(str(bad))
