@@ -257,6 +257,12 @@ int rpt_debug_trace_rays(rpt_ctx *ctx, int any_hit, size_t n,
                          const float *origins_xyz, const float *dirs_xyz, const float *max_t,
                          float *out_t, uint32_t *out_tri, uint32_t *out_flags);
 
+/* The two BSDFs of the reference's kernels crate that trace_pixel never instantiates (kernels/src/bsdf.rs:46-176,
+ * SURVEY.md 8f N4), evaluated on the device.  One item = 16 floats in: view(3) normal(3) r(3) albedo(3) ior roughness
+ * pad(2); 8 floats out: pdf, lobe (u32 bits), spectrum(3), direction(3).  kind 0 Lambertian::sample, 1 Glass::sample,
+ * 2 Lambertian::{evaluate, pdf} (sample_direction = r), 3 Glass::{evaluate, pdf} (lobe = (u32) r.x). */
+int rpt_debug_bsdf(rpt_ctx *ctx, int kind, size_t n, const float *in, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,6 +127,14 @@ class Oracle:
         assert rc == 0
         return out
 
+    def bsdf(self, kind, items):
+        """Lambertian / Glass (kernels/src/bsdf.rs:46-176) restated: (n, 16) float32 in -> (n, 8) out (see oracle_bsdf)."""
+        items = np.ascontiguousarray(items, np.float32).reshape(-1, 16)
+        out = np.zeros((len(items), 8), np.float32)
+        rc = self.lib.oracle_bsdf(C.c_int(kind), C.c_size_t(len(items)), _p(items), _p(out))
+        assert rc == 0
+        return out
+
     def sky(self, sun_direction4, origin3, dirs):
         sun = np.ascontiguousarray(sun_direction4, np.float32)
         org = np.ascontiguousarray(origin3, np.float32)

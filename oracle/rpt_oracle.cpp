@@ -67,6 +67,7 @@ inline float m_cos(float x) { return cosf(x); }
 inline float m_acos(float x) { return acosf(x); }
 inline float m_asin(float x) { return asinf(x); }
 inline float m_atan2(float y, float x) { return atan2f(y, x); }
+inline float m_atan(float x) { return atanf(x); }
 inline float m_exp(float x) { return expf(x); }
 inline float m_pow(float x, float y) { return powf(x, y); }
 #else
@@ -75,6 +76,7 @@ inline float m_cos(float x) { return rptm::cosr(x); }
 inline float m_acos(float x) { return rptm::acosr(x); }
 inline float m_asin(float x) { return rptm::asinr(x); }
 inline float m_atan2(float y, float x) { return rptm::atan2r(y, x); }
+inline float m_atan(float x) { return rptm::atanr(x); }
 inline float m_exp(float x) { return rptm::expr(x); }
 inline float m_pow(float x, float y) { return rptm::powr(x, y); }
 #endif
@@ -1056,6 +1058,81 @@ float oracle_lds(uint32_t n, uint32_t dimension, uint32_t offset, uint32_t *out_
 }
 
 /* op: 0 sin, 1 cos, 2 acos, 3 exp, 4 pow(x,y), 5 asin, 6 atan2(x,y), 7 sqrt, 8 x/y */
+/* The reference's two BSDFs that trace_pixel never instantiates (kernels/src/bsdf.rs:46-105 Lambertian, 107-176 Glass;
+ * SURVEY.md 8f N4), restated for completeness of the kernels crate: one item = view(3) normal(3) r(3) albedo(3) ior
+ * roughness pad(2) -> pdf, lobe (u32 bits), spectrum(3), direction(3).
+ * kind 0: Lambertian::sample   1: Glass::sample   2: Lambertian::{evaluate, pdf} with sample_direction = r
+ * kind 3: Glass::{evaluate, pdf} with lobe = (u32) r.x */
+int oracle_bsdf(int kind, size_t n, const float *in, float *out) {
+    auto cartesian = [](V3 up, V3 &right, V3 &forward) {                     /* util.rs:34-40 */
+        V3 temp_vec = normalize(cross(up, v3(0.1f, 0.5f, 0.9f)));
+        right = normalize(cross(temp_vec, up));
+        forward = normalize(cross(up, right));
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = in + 16 * i;
+        float *o = out + 8 * i;
+        V3 view = xyz(p), normal = xyz(p + 3), r = xyz(p + 6), albedo = xyz(p + 9);
+        float ior = p[12], roughness = p[13];
+        float pdf = 0.0f;
+        uint32_t lobe = 0u;
+        V3 spectrum = splat3(0.0f), dir = splat3(0.0f);
+        if (kind == 0) {                                                     /* bsdf.rs:71-92 */
+            V3 nt, nb;
+            cartesian(normal, nt, nb);
+            float theta = m_acos(m_sqrt(r.x)), phi = 2.0f * PI_F * r.y;      /* util.rs:24-32 */
+            V3 s = v3(m_sin(theta) * m_cos(phi), m_cos(theta), m_sin(theta) * m_sin(phi));
+            dir = normalize(v3(s.x * nb.x + s.y * normal.x + s.z * nt.x, s.x * nb.y + s.y * normal.y + s.z * nt.y,
+                               s.x * nb.z + s.y * normal.z + s.z * nt.z));
+            float cos_theta = m_max(dot(normal, dir), 0.0f);
+            pdf = cos_theta / PI_F;
+            spectrum = albedo / PI_F * cos_theta;
+            lobe = 0u;
+        } else if (kind == 1) {                                              /* bsdf.rs:130-168 */
+            bool inside = dot(normal, view) < 0.0f;
+            V3 nrm = inside ? -normal : normal;
+            float in_ior = inside ? ior : 1.0f, out_ior = inside ? 1.0f : ior;
+            float a_g = roughness * roughness;                               /* util.rs:117-142 */
+            float theta_m = m_atan((a_g * m_sqrt(r.x)) / m_sqrt(1.0f - r.x));
+            float phi_m = 2.0f * PI_F * r.y;
+            V3 m = v3(m_sin(theta_m) * m_cos(phi_m), m_cos(theta_m), m_sin(theta_m) * m_sin(phi_m));
+            V3 nt, nb;
+            cartesian(nrm, nt, nb);
+            V3 mn = normalize(v3(m.x * nb.x + m.y * nrm.x + m.z * nt.x, m.x * nb.y + m.y * nrm.y + m.z * nt.y,
+                                 m.x * nb.z + m.y * nrm.z + m.z * nt.z));
+            float f0 = (in_ior - out_ior) / (in_ior + out_ior);             /* util.rs:233-236 */
+            f0 = f0 * f0;
+            float fresnel = f0 + (1.0f - f0) * rptm::powi5(1.0f - m_max(dot(mn, view), 0.0f));
+            pdf = 1.0f;
+            if (r.z <= fresnel) {
+                dir = normalize(2.0f * rptm::absr(dot(view, mn)) * mn - view);
+                lobe = 1u;
+                spectrum = splat3(1.0f);
+            } else {
+                float eta = in_ior / out_ior;
+                float c = dot(view, mn);
+                float d = dot(view, nrm);
+                float sg = d != d ? d : ((rptm::f2u(d) >> 31) ? -1.0f : 1.0f);        /* f32::signum */
+                dir = normalize((eta * c - sg * m_sqrt(m_max(1.0f + eta * (c * c - 1.0f), 0.0f))) * mn - eta * view);
+                lobe = 3u;
+                spectrum = albedo;
+            }
+        } else if (kind == 2) {                                              /* bsdf.rs:59-69, 94-104 */
+            float cos_theta = m_max(dot(normal, r), 0.0f);
+            pdf = cos_theta / PI_F;
+            spectrum = albedo / PI_F * cos_theta;
+        } else {                                                             /* bsdf.rs:115-128, 170-176 */
+            lobe = rptm::f2u32_sat(r.x);
+            spectrum = lobe == 1u ? splat3(1.0f) : albedo;
+            pdf = 1.0f;
+        }
+        o[0] = pdf; o[1] = rptm::u2f(lobe);
+        o[2] = spectrum.x; o[3] = spectrum.y; o[4] = spectrum.z;
+        o[5] = dir.x; o[6] = dir.y; o[7] = dir.z;
+    }
+    return 0;
+}
+
 int oracle_math(int op, const float *x, const float *y, float *out, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         float r;

@@ -24,6 +24,7 @@
 #include "k_bvh_build.h"
 #include "k_shade.h"
 #include "k_sky_generate.h"
+#include "k_bsdf_extra.h"
 
 namespace {
 
@@ -936,6 +937,23 @@ int rpt_debug_math(rpt_ctx *c, int op, const float *x, const float *y, float *ou
     }
     if (e == hipSuccess) e = hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost);
     dx.release(); dy.release(); dout.release();
+    HIP_TRY(c, e);
+    return RPT_OK;
+}
+
+int rpt_debug_bsdf(rpt_ctx *c, int kind, size_t n, const float *in, float *out) {
+    if (!c || kind < 0 || kind > 3 || !in || !out) return RPT_EINVAL;
+    if (n == 0) return RPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<float> din, dout;
+    HIP_TRY(c, din.alloc(16 * n)); HIP_TRY(c, dout.alloc(8 * n));
+    hipError_t e = hipMemcpy(din.p, in, 64 * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_debug_bsdf<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(kind, n, din.p, dout.p);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, 32 * n, hipMemcpyDeviceToHost);
+    din.release(); dout.release();
     HIP_TRY(c, e);
     return RPT_OK;
 }

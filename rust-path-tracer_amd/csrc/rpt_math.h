@@ -370,5 +370,9 @@ RPT_HD float atan2r(float yf, float xf) {
     return yneg ? -rf : rf;
 }
 
+/* f32::atan (reference use: kernels/src/util.rs:125, Glass only): atan2(x, 1) is the same real number, and both are
+ * rounded once from the same double evaluation */
+RPT_HD float atanr(float x) { return atan2r(x, 1.0f); }
+
 } /* namespace rptm */
 #endif /* RPT_MATH_H */

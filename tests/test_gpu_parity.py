@@ -466,16 +466,19 @@ def test_host_dispatch_trace_gpu_furnace(rpt):
 
 
 @pytest.mark.parametrize("knob", ["RPT_LDS_STREAM=0", "RPT_NO_LDS_SCENE=1", "RPT_NO_FASTDIV=1", "RPT_SKY_THRESHOLD=4096",
-                                  "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MIN_BLOCKS=4", "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2"])
+                                  "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MAX_BLOCKS=7", "RPT_STREAM_SPAN=1024", "RPT_GSTREAM=0",
+                                  "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2"])
 def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world, knob):
     """README: every tuning knob leaves the image bit-identical (they select kernels / schedules, never arithmetic)."""
     W, H, spp = 160, 96, 6
     cfg = rpt.default_config(W, H, nee=1)
     seeds = rpt.blue_noise_seeds(W, H)
 
+    scene = "VeachMIS" if knob.startswith("RPT_GSTREAM") else "DarkCornell"     # (the global-memory walk / the LDS walk)
+
     def render():
         r = hipmod.Renderer(0)
-        r.upload_scene(world("DarkCornell"))
+        r.upload_scene(world(scene))
         r.set_config(cfg)
         r.reset(seeds)
         r.render(spp)
