@@ -133,8 +133,9 @@ struct DevState {
  * by every wave, and sharing a line made the two serialise against each other in L2 */
 #define Q_LINE 32
 enum { Q_SHADOW = 0 * Q_LINE, Q_SKY = 1 * Q_LINE, Q_ALIVE0 = 2 * Q_LINE, Q_ALIVE1 = 3 * Q_LINE, Q_REGEN0 = 4 * Q_LINE,
-       Q_REGEN1 = 5 * Q_LINE, Q_DRAINED = 6 * Q_LINE, Q_POOL0 = 7 * Q_LINE, Q_POOL1 = 8 * Q_LINE, Q_COUNT = 10 * Q_LINE };
-/* Q_POOL0/1: per iteration parity, the next unclaimed slot of the streamed traversal launch (k_traverse_nearest_stream) */
+       Q_REGEN1 = 5 * Q_LINE, Q_DRAINED = 6 * Q_LINE, Q_POOL0 = 7 * Q_LINE, Q_POOL1 = 8 * Q_LINE, Q_SPOOL = 9 * Q_LINE, Q_COUNT = 12 * Q_LINE };
+/* Q_POOL0/1: per iteration parity, the next unclaimed slot of the streamed traversal launch (k_traverse_nearest_stream);
+ * Q_SPOOL: the next unclaimed entry of the streamed shadow launch (zeroed by the shade stage that fills the queue) */
 /* Q_DRAINED: set by the sky stage of the first iteration that found nothing left; the host runs a few iterations
  * ahead of the progress report, and every stage of those surplus launches returns on this word at once. */
 #define RPT_STAT_SHARDS 64        /* sharded 64-bit counters, one 128-byte line each */

@@ -71,7 +71,8 @@ __device__ __forceinline__ void finish_in_side_stage(const DevState &st, const D
  * order, kernels/src/lib.rs:225, src/trace.rs:295), advances the pixel's rng.n by the number of samples
  * (lib.rs:226), and every done lane starts its next sample (lib.rs:36-60).  Lanes finished earlier than
  * their siblings write their radiance back and wait as HIT_DONE.  `fresh` = the sample finished in this
- * kernel (its state is not in memory yet). */
+ * kernel (its state is not in memory yet); for a done lane that is not fresh the caller passes no radiance: it is read
+ * from the slot's parked state here, and only when its generation completes. */
 __device__ __forceinline__ void complete_generations(const DevState &st, const DevConfig &cfg, uint32_t *regen_flag, uint32_t slot,
                                                      bool done, bool idle, bool fresh, F3 radiance, float4 tr, float4 rm) {
     const uint32_t shift = st.group_shift, S = 1u << shift;
@@ -105,6 +106,13 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
     const bool complete = (((done_m | idle_m) & gm) == gm) && ((done_m & gm) != 0ull);
     const bool leader = complete && lane == g0;
     const uint32_t pix = slot >> shift;
+    if (done && !fresh && complete) {
+        /* parked earlier (HIT_DONE): only now is its radiance needed — a slot that waits several iterations for its
+         * siblings (open scenes: most paths end in the sky after one bounce) costs one 8-byte look per pass, not 40 */
+        tr = st.thr_rad[slot];
+        rm = st.rad_misc[slot];
+        radiance = f3(tr.w, rm.x, rm.y);
+    }
     float4 acc = make_float4(0, 0, 0, 0);
     uint2 rs = make_uint2(0u, 0u);
     if (leader) {

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (NEE != RPT_NEE_NONE && slot == 0u) q.count[Q_SPOOL] = 0u;       /* the shadow stage that follows starts its pool at entry 0 */
     bool to_sky = false;
     bool emit_shadow = false;
     float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
@@ -169,12 +170,8 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     const bool g_idle = hit_tri == HIT_IDLE;
     F3 g_radiance = f3s(0.0f);
     float4 g_tr = make_float4(0, 0, 0, 0), g_rm = g_tr;
-    if (hit_tri == HIT_DONE) {                       /* finished earlier (sky / shadow stage, or before its siblings) */
-        g_tr = st.thr_rad[slot];
-        g_rm = st.rad_misc[slot];
-        g_radiance = f3(g_tr.w, g_rm.x, g_rm.y);
-        g_done = true;
-    }
+    if (hit_tri == HIT_DONE) g_done = true;          /* finished earlier (sky / shadow stage, or before its siblings): its parked
+                                                        radiance is fetched by complete_generations once the generation completes */
 
     if (active) {
         const float4 ra = st.ray_a[slot];

@@ -736,6 +736,83 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
     }
 }
 
+/* Shadow rays of an LDS-resident scene, streamed like the extension rays above (persistent workgroups, spans of the dense
+ * shadow queue from a launch-wide counter, refill of finished lanes).  An any-hit walk cannot be pruned by max_t (the
+ * reference prunes boxes against result.t = 1e6 until something is accepted, intersection.rs:212-213, and box-t / triangle-t
+ * round differently), so an unoccluded ray crosses every box along its line while an occluded one may stop after two
+ * visits: lane utilisation of the one-ray-per-lane kernel was 40 % (profiles/r02base_darkcornell_mis_pmc_sq.txt).
+ * Lanes only record "occluded" in the unused .w of the entry's contribution record; k_shadow_resolve then adds the NEE
+ * terms in one dense pass (all lanes busy, none of the walk's registers live). */
+template <int STACK, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc, DevState st, DevQueues q, DevStats *stats, uint32_t SPAN) {
+    constexpr uint32_t NW = THREADS / RPT_WAVE;
+    __shared__ uint16_t lds_stack[NW][STACK][RPT_WAVE];
+    __shared__ WgPool pool;
+    float4 *lds_scene = rpt_lds_dyn;
+    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
+    const uint32_t n = q.count[Q_SHADOW];
+    uint32_t *global_next = &q.count[Q_SPOOL];                 /* zeroed by the shade stage of this iteration */
+    if (blockIdx.x == 0u && threadIdx.x == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
+    const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
+    if (threadIdx.x == 0u) {
+        const uint32_t g = n ? atomicAdd(global_next, SPAN) : 0u;
+        pool.word = g < n ? ((unsigned long long)(g + SPAN < n ? g + SPAN : n) << 32) | g : 0x00000000f0000000ull;
+        pool.lock = 0u;
+    }
+    __syncthreads();
+    if ((uint32_t)(pool.word >> 32) == 0u) return;             /* block-uniform: nothing (left) to trace */
+    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);
+    uint16_t *stack = &lds_stack[wave][0][lane];
+    F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
+    float max_t = 0.0f;
+    LdsWalk w;
+    lds_walk_begin(view, w);
+    w.cur = LDS_DESC_DEAD;
+    uint32_t entry = 0u;
+    bool have = false;
+    bool pool_open = true;                                     /* wave-uniform */
+    for (;;) {
+        const unsigned long long idle_m = rpt_ballot(w.cur == LDS_DESC_DEAD);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+        if (pool_open && n_idle >= (uint32_t)RPT_STREAM_REFILL) {
+            uint32_t base = 0u, got = 0u;
+            bool finished = false;
+            if (lane == 0u) base = wg_pool_take(&pool, global_next, n, SPAN, n_idle, got, finished);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            pool_open = __builtin_amdgcn_readfirstlane((int)finished) == 0;
+            if (w.cur == LDS_DESC_DEAD) {
+                if (have) {
+                    q.sh_c[entry].w = w.res.tri == HIT_MISS ? 0.0f : 1.0f;
+                    have = false;
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                if (rank < got) {
+                    entry = base + rank;
+                    const float4 o = q.sh_o[entry], d = q.sh_d[entry];
+                    ro = f3(o.x, o.y, o.z); rd = f3(d.x, d.y, d.z);
+                    max_t = o.w;
+                    have = true;
+                    if (fastdiv_ray_ok(sc.fastdiv_ok, ro, rd)) {
+                        ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        lds_walk_begin(view, w);
+                    } else {
+                        w.res = traverse_loop_lds<STACK, true, false>(view, ro, rd, rd, max_t, stack);   /* alone; recorded at the next refill */
+                    }
+                }
+            }
+            if (got != 0u || !pool_open) continue;
+            if (idle_m == ~0ull) { __builtin_amdgcn_s_sleep(8); continue; }   /* another wave is fetching the next span */
+        }
+        if (idle_m == ~0ull) {
+            if (!pool_open) break;                             /* nothing in flight and nothing left to hand out */
+            continue;
+        }
+        lds_walk_run<STACK, true, true>(view, w, ro, rd, ird, max_t, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
+    }
+    if (have) q.sh_c[entry].w = w.res.tri == HIT_MISS ? 0.0f : 1.0f;
+}
+
 /* ---- streamed walks through GLOBAL memory (scenes too large for LDS) ----------------------------------------
  * Measured on MI355X (profiles/r02base_*): with one ray per lane the global-memory walk runs at 26 % (VeachMIS nearest),
  * 29 % (PBRTest) and 22 % (VeachMIS shadow) lane utilisation while two thirds of its wave cycles wait on L1/L2 — an
@@ -855,6 +932,14 @@ __device__ __forceinline__ void shadow_resolve(const DevState &st, const DevQueu
             st.rad_misc[slot] = rm;
         }
     }
+}
+
+/* second half of the streamed LDS shadow stage: one dense pass over the shadow queue */
+__global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQueues q, DevConfig cfg) {
+    if (q.count[Q_DRAINED] != 0u) return;
+    const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (i >= q.count[Q_SHADOW]) return;
+    shadow_resolve(st, q, cfg, i, __float_as_uint(q.sh_d[i].w), q.sh_c[i].w == 0.0f);
 }
 
 /* Shadow rays, streamed: the queue is dense already; a wave owns SPAN consecutive entries and refills lanes whose

@@ -49,6 +49,7 @@ struct rpt_ctx {
     std::string error;
     uint32_t rank = 0, world = 1;
     bool lds_stream = true;
+    bool lds_shadow_stream = true;       /* LDS scenes: streamed shadow stage (k_traverse_shadow_stream + k_shadow_resolve) */
     bool gstream = true;                 /* scenes walked from global memory: streamed kernels (k_traverse_*_gstream) */
     uint32_t gstream_min_waves = 32768;
     uint32_t stream_max_blocks = 512;    /* persistent workgroups of the streamed LDS traversal: 2 per CU (each holds 32 KB of stacks + the scene image) */
@@ -74,6 +75,7 @@ struct rpt_ctx {
     uint32_t max_group_shift = 0, max_slots = 0;   /* what the state arrays are sized for */
     uint32_t sky_wide_cfg = 32768;
     int samples_in_flight_request = 0;   /* 0 = automatic */
+    uint64_t max_slots_budget = 160ull << 20;   /* automatic S: the most slots (pixels x samples in flight) a context allocates */
     std::vector<uint32_t> pixel_xy_host;
     DevBuf<uint32_t> pixel_xy;
 

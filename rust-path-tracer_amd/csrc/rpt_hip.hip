@@ -270,7 +270,15 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
     if (NEE != RPT_NEE_NONE) {
-        if (STACK == 16 && c->scene.lds_scene)     /* (streaming the shadow queue was measured slower: 36.8 vs 32.7 ms) */
+        if (STACK == 16 && c->scene.lds_scene && c->lds_stream && c->lds_shadow_stream) {
+            const uint32_t wgs = c->stream_max_blocks;
+            uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 16u);
+            span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
+            span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
+            const uint32_t n_spans = (c->n_slots + span - 1) / span;
+            k_traverse_shadow_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
+            k_shadow_resolve<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
+        } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else if (c->gstream) {
             if (c->scene.n_nodes < 65536u) k_traverse_shadow_gstream<STACK, true><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
@@ -365,7 +373,9 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (c->timing_level < 0 || c->timing_level > 2) c->timing_level = 0;
     c->stage_timing = c->timing_level != 0;
     if (const char *e2 = getenv("RPT_LDS_STREAM")) c->lds_stream = e2[0] != '0';
+    if (const char *e10 = getenv("RPT_MAX_SLOTS")) c->max_slots_budget = (uint64_t)std::max(1ll, atoll(e10));
     if (const char *e6 = getenv("RPT_GSTREAM")) c->gstream = e6[0] != '0';
+    if (const char *e9 = getenv("RPT_LDS_SHADOW_STREAM")) c->lds_shadow_stream = e9[0] != '0';
     if (const char *e7 = getenv("RPT_GSTREAM_MIN_WAVES")) c->gstream_min_waves = (uint32_t)std::max(1, atoi(e7));
     {
         hipDeviceProp_t prop;
@@ -565,8 +575,12 @@ int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
         if (c->samples_in_flight_request > 0) {
             while (S < (uint32_t)c->samples_in_flight_request && S < 32u) S <<= 1;
         } else {
-            if (c->n_pixels < (3u << 20))       /* measured: at 4 M pixels (PBRTest 2048^2) S > 1 only costs (-10 %) */
-                while (S < 32u && (uint64_t)c->n_pixels * S * 2u <= (32ull << 20)) S <<= 1;
+            /* as many as fit in RPT_MAX_SLOTS (160 M slots x ~180 B of path state and queues = 29 GB of the 288 GB).  Round 1
+             * stopped at 32 M and used S = 1 from 3 M pixels up, where more slots only cost: with one ray per lane the dead
+             * slots of an open scene were walked as empty lanes.  The streamed walks skip them, and measured now (32-spp
+             * batches): PBRTest 2048^2 4090 / 4354 / 4505 / 4537 / 4709 Mrays/s for S = 1 / 4 / 8 / 16 / 32, VeachMIS 1080p
+             * 4388 / 4757 / 4892 for S = 8 / 16 / 32, the 1 M-triangle stand-in at 2048^2 994 / 1578 for S = 1 / 16. */
+            while (S < 32u && (uint64_t)c->n_pixels * S * 2u <= c->max_slots_budget) S <<= 1;
         }
         c->max_group_shift = 0;
         while ((1u << c->max_group_shift) < S) c->max_group_shift += 1;
