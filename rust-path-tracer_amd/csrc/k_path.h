@@ -39,15 +39,14 @@ __device__ __forceinline__ void start_path(const DevState &st, const DevConfig &
     st.ray_a[slot] = make_float4(ro.x, ro.y, ro.z, rd.x);
     st.ray_b[slot] = make_float2(rd.y, rd.z);
     st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PENDING));
-    st.thr_rad[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-    st.rad_misc[slot] = make_float4(0.0f, 0.0f, __uint_as_float(MAKE_FLAGS(0u, 0u, 2u)), __uint_as_float(todo_after));
+    st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(MAKE_FLAGS(0u, 0u, 2u)));
+    st.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(todo_after));
 }
 
 /* A path ended in a side stage (sky / shadow).  With one slot per pixel the sample is accumulated and the
  * next one started on the spot; with several, the finished radiance is parked (HIT_DONE) and the shade
  * stage of the next iteration — where the pixel's slots sit in adjacent lanes — completes the generation. */
-__device__ __forceinline__ void finish_in_side_stage(const DevState &st, const DevConfig &cfg, uint32_t slot, F3 radiance,
-                                                     float4 tr, float4 rm) {
+__device__ __forceinline__ void finish_in_side_stage(const DevState &st, const DevConfig &cfg, uint32_t slot, F3 radiance, uint32_t todo) {
     if (st.group_shift == 0u) {
         float4 acc = st.accum[slot];
         acc.x += radiance.x; acc.y += radiance.y; acc.z += radiance.z; acc.w += 1.0f;
@@ -55,12 +54,10 @@ __device__ __forceinline__ void finish_in_side_stage(const DevState &st, const D
         uint2 rs = st.rng[slot];
         rs.x += 1u;
         st.rng[slot] = rs;
-        uint32_t todo = __float_as_uint(rm.w);
         if (todo == 0u) st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
         else start_path(st, cfg, slot, rs.x, rs.y, todo - 1u);
     } else {
-        st.thr_rad[slot] = make_float4(tr.x, tr.y, tr.z, radiance.x);
-        st.rad_misc[slot] = make_float4(radiance.y, radiance.z, rm.z, rm.w);
+        st.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(todo));
         st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_DONE));
     }
 }
@@ -74,7 +71,7 @@ __device__ __forceinline__ void finish_in_side_stage(const DevState &st, const D
  * kernel (its state is not in memory yet); for a done lane that is not fresh the caller passes no radiance: it is read
  * from the slot's parked state here, and only when its generation completes. */
 __device__ __forceinline__ void complete_generations(const DevState &st, const DevConfig &cfg, uint32_t *regen_flag, uint32_t slot,
-                                                     bool done, bool idle, bool fresh, F3 radiance, float4 tr, float4 rm) {
+                                                     bool done, bool idle, bool fresh, F3 radiance, uint32_t todo) {
     const uint32_t shift = st.group_shift, S = 1u << shift;
     const uint32_t lane = __lane_id();
     if (shift == 0u) {
@@ -87,7 +84,6 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
             uint2 rs1 = st.rng[slot];
             rs1.x += 1u;
             st.rng[slot] = rs1;
-            uint32_t todo = __float_as_uint(rm.w);
             if (todo == 0u) {
                 st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
             } else {
@@ -109,9 +105,9 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
     if (done && !fresh && complete) {
         /* parked earlier (HIT_DONE): only now is its radiance needed — a slot that waits several iterations for its
          * siblings (open scenes: most paths end in the sky after one bounce) costs one 8-byte look per pass, not 40 */
-        tr = st.thr_rad[slot];
-        rm = st.rad_misc[slot];
-        radiance = f3(tr.w, rm.x, rm.y);
+        const float4 parked = st.rad[slot];
+        radiance = f3(parked.x, parked.y, parked.z);
+        todo = __float_as_uint(parked.w);
     }
     float4 acc = make_float4(0, 0, 0, 0);
     uint2 rs = make_uint2(0u, 0u);
@@ -134,17 +130,15 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
     const uint32_t new_n = (uint32_t)__shfl((int)rs.x, (int)g0, RPT_WAVE);
     const uint32_t offset = (uint32_t)__shfl((int)rs.y, (int)g0, RPT_WAVE);
     {   /* tell the host that new samples were started (one plain store per wave, every writer stores 1) */
-        unsigned long long started = rpt_ballot(done && complete && __float_as_uint(rm.w) != 0u);
+        unsigned long long started = rpt_ballot(done && complete && todo != 0u);
         if (started != 0ull && lane == (uint32_t)__ffsll((long long)started) - 1u) raise_flag(regen_flag);
     }
     if (!done) return;
     if (complete) {
-        uint32_t todo = __float_as_uint(rm.w);
         if (todo == 0u) st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
         else start_path(st, cfg, slot, new_n + (lane - g0), offset, todo - 1u);
     } else if (fresh) {
-        st.thr_rad[slot] = make_float4(tr.x, tr.y, tr.z, radiance.x);
-        st.rad_misc[slot] = make_float4(radiance.y, radiance.z, rm.z, rm.w);
+        st.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(todo));
         st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_DONE));
     }
 }

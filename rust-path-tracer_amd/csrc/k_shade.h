@@ -169,7 +169,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     bool g_done = false, g_fresh = false;
     const bool g_idle = hit_tri == HIT_IDLE;
     F3 g_radiance = f3s(0.0f);
-    float4 g_tr = make_float4(0, 0, 0, 0), g_rm = g_tr;
+    uint32_t g_todo = 0u;
     if (hit_tri == HIT_DONE) g_done = true;          /* finished earlier (sky / shadow stage, or before its siblings): its parked
                                                         radiance is fetched by complete_generations once the generation completes */
 
@@ -182,11 +182,22 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             to_sky = true;                           /* lib.rs:66-79: shaded by k_sky, which also ends the path */
             st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
         } else {
-            float4 tr = st.thr_rad[slot];
-            float4 rm = st.rad_misc[slot];
-            F3 throughput = f3(tr.x, tr.y, tr.z);
-            F3 radiance = f3(tr.w, rm.x, rm.y);
-            const uint32_t flags = __float_as_uint(rm.z);
+            const float4 tf = st.thr[slot];
+            F3 throughput = f3(tf.x, tf.y, tf.z);
+            /* radiance + samples still owed: read only by a lane whose path adds emission or ends here (never written back by
+             * this stage mid-path: the NEE terms are added by the shadow stage, everything else ends the path) */
+            F3 radiance = f3s(0.0f);
+            uint32_t todo = 0u;
+            bool rad_loaded = false;
+            auto load_rad = [&]() {
+                if (!rad_loaded) {
+                    const float4 r4 = st.rad[slot];
+                    radiance = f3(r4.x, r4.y, r4.z);
+                    todo = __float_as_uint(r4.w);
+                    rad_loaded = true;
+                }
+            };
+            const uint32_t flags = __float_as_uint(tf.w);
             const uint32_t bounce = FLAG_BOUNCE(flags);
             const bool last_spec = FLAG_LOBE_SPEC(flags) != 0u;
             constexpr bool nee = NEE != RPT_NEE_NONE;
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                 if (backface) {
                     done = true;                                                         /* :88-90 */
                 } else if (!nee || bounce == 0u || last_spec) {                          /* :97-100 */
+                    load_rad();
                     radiance = radiance + mask_nan3(throughput * emissive);
                     done = true;
                 } else if (NEE == RPT_NEE_MIS) {                                         /* :104-108, last lobe is diffuse here */
@@ -222,6 +234,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
                             contribution = f3(m2.y, m2.z, m2.w) * direct;
                         }
                     }
+                    load_rad();
                     radiance = radiance + mask_nan3(contribution);
                     done = true;
                 }
@@ -436,14 +449,13 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
 
             if (done && !emit_shadow) {
                 /* the path ends here with nothing pending: its generation may complete below */
+                load_rad();
                 g_done = g_fresh = true;
                 g_radiance = radiance;
-                g_tr = make_float4(throughput.x, throughput.y, throughput.z, radiance.x);
-                g_rm = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
+                g_todo = todo;
             } else {
-                st.thr_rad[slot] = make_float4(throughput.x, throughput.y, throughput.z, radiance.x);
-                st.rad_misc[slot] = make_float4(radiance.y, radiance.z, __uint_as_float(new_flags), rm.w);
                 if (!done) {
+                    st.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(new_flags));
                     st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
                     st.ray_b[slot] = make_float2(new_d.y, new_d.z);
                     st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PENDING));
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     }
 
     /* ---- accumulate finished generations in sample order and start the next samples ---- */
-    complete_generations(st, cfg, &q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE], slot, g_done, g_idle, g_fresh, g_radiance, g_tr, g_rm);
+    complete_generations(st, cfg, &q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE], slot, g_done, g_idle, g_fresh, g_radiance, g_todo);
 
     /* ---- side-queue emission: wave64 ballot + mbcnt prefix, one atomic per workgroup ---- */
     /* (block-uniform early outs keep the barriers inside block_push legal) */

@@ -146,10 +146,10 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
             F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
             F3 sky = sky_scatter_wide(cfg.c.sun_direction, ro, rd, j, g0);
             if (j == 0u) {
-                float4 tr = st.thr_rad[slot], rm = st.rad_misc[slot];
-                F3 throughput = f3(tr.x, tr.y, tr.z), radiance = f3(tr.w, rm.x, rm.y);
+                const float4 tf = st.thr[slot], r4 = st.rad[slot];
+                F3 throughput = f3(tf.x, tf.y, tf.z), radiance = f3(r4.x, r4.y, r4.z);
                 radiance = radiance + throughput * sky;                                       /* lib.rs:69 */
-                finish_in_side_stage(st, cfg, slot, radiance, tr, rm);
+                finish_in_side_stage(st, cfg, slot, radiance, __float_as_uint(r4.w));
             }
         }
         return;
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
         float4 ra = st.ray_a[slot];
         float2 rb = st.ray_b[slot];
         F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
-        float4 tr = st.thr_rad[slot], rm = st.rad_misc[slot];
-        F3 throughput = f3(tr.x, tr.y, tr.z), radiance = f3(tr.w, rm.x, rm.y);
+        const float4 tf = st.thr[slot], r4 = st.rad[slot];
+        F3 throughput = f3(tf.x, tf.y, tf.z), radiance = f3(r4.x, r4.y, r4.z);
         if (cfg.c.has_skybox == 0u) {
             radiance = radiance + throughput * sky_scatter(cfg.c.sun_direction, ro, rd);      /* lib.rs:69 */
         } else {                                                                             /* lib.rs:72-77 */
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
             radiance = radiance + throughput * f3(s.x, s.y, s.z) * intensity;
         }
         /* a miss always ends the path (lib.rs:79) */
-        finish_in_side_stage(st, cfg, slot, radiance, tr, rm);
+        finish_in_side_stage(st, cfg, slot, radiance, __float_as_uint(r4.w));
     }
 }
 

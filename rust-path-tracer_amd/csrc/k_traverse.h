@@ -719,19 +719,17 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
     HitRecord h = traverse_one<STACK, true>(view, sc.fastdiv_ok, f3(o.x, o.y, o.z), f3(d.x, d.y, d.z), o.w, stack);
     bool visible = h.tri == HIT_MISS;
     if (visible || finish) {
-        float4 tr = st.thr_rad[slot];
-        float4 rm = st.rad_misc[slot];
-        F3 radiance = f3(tr.w, rm.x, rm.y);
+        float4 r4 = st.rad[slot];
+        F3 radiance = f3(r4.x, r4.y, r4.z);
         if (visible) {
             float4 c = q.sh_c[i];
             radiance = radiance + mask_nan3(f3(c.x, c.y, c.z));
         }
         if (finish) {
-            finish_in_side_stage(st, cfg, slot, radiance, tr, rm);
+            finish_in_side_stage(st, cfg, slot, radiance, __float_as_uint(r4.w));
         } else {
-            tr.w = radiance.x; rm.x = radiance.y; rm.y = radiance.z;
-            st.thr_rad[slot] = tr;
-            st.rad_misc[slot] = rm;
+            r4.x = radiance.x; r4.y = radiance.y; r4.z = radiance.z;
+            st.rad[slot] = r4;
         }
     }
 }
@@ -917,19 +915,17 @@ __device__ __forceinline__ void shadow_resolve(const DevState &st, const DevQueu
     const uint32_t slot = tag & 0x7fffffffu;
     const bool finish = (tag >> 31) != 0u;
     if (visible || finish) {
-        float4 tr = st.thr_rad[slot];
-        float4 rm = st.rad_misc[slot];
-        F3 radiance = f3(tr.w, rm.x, rm.y);
+        float4 r4 = st.rad[slot];
+        F3 radiance = f3(r4.x, r4.y, r4.z);
         if (visible) {
             float4 c = q.sh_c[entry];
             radiance = radiance + mask_nan3(f3(c.x, c.y, c.z));
         }
         if (finish) {
-            finish_in_side_stage(st, cfg, slot, radiance, tr, rm);
+            finish_in_side_stage(st, cfg, slot, radiance, __float_as_uint(r4.w));
         } else {
-            tr.w = radiance.x; rm.x = radiance.y; rm.y = radiance.z;
-            st.thr_rad[slot] = tr;
-            st.rad_misc[slot] = rm;
+            r4.x = radiance.x; r4.y = radiance.y; r4.z = radiance.z;
+            st.rad[slot] = r4;
         }
     }
 }
