@@ -84,6 +84,13 @@ def main():
     ap.add_argument("--no-readback", action="store_true", help="skip the extra render -> read_accum loop (reference loop shape, src/trace.rs:182-204)")
     args = ap.parse_args()
 
+    # Rank 0 prints ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner through C stdio when
+    # a communicator is created, and it is flushed at exit — after the JSON line), so for the whole run file descriptor 1
+    # points at stderr and the JSON line goes to the real stdout, kept aside here.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     # HIP events on the render stream: after every stage kernel at N = 1 (per-stage breakdown), only around the
     # traversal kernel (the dominant one, which the roofline needs) at N > 1, where a 16-kernel batch lasts ~1.3 ms
     # and 20 event records per batch cost 7 % of it
@@ -352,7 +359,10 @@ def main():
         "cpu_baseline": cpu,
         "readback": readback,
     }
-    print(json.dumps(out))
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world_size > 1:
         dist.destroy_process_group()
 

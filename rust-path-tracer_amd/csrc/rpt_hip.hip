@@ -1084,16 +1084,32 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BvbArgs a{d_verts.p, d_tris.p, d_centroid.p, d_order.p, d_order_tmp.p, d_tmp_a.p, d_tmp_b.p, d_nodes.p, d_count.p, nt, sah_samples};
         BVB_TRY(hipEventRecord(ev0, nullptr));
         k_bvb_init<<<(nt + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(a);
+        /* a team's 64 workgroups meet at counter barriers (bvb_team_sync): every workgroup of the launch must be resident at
+         * once, so the number of teams is capped by what the device can hold (a CU-masked or partitioned device holds fewer;
+         * with room for none the big nodes simply take the one-workgroup path) */
+        uint32_t max_teams = BVB_MAX_TEAMS;
+        {
+            int per_cu = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bvb_team, BVB_TEAM_THREADS, 0) == hipSuccess &&
+                hipGetDeviceProperties(&prop, device_id) == hipSuccess && per_cu > 0 && prop.multiProcessorCount > 0) {
+                /* one block per CU less than the API says: it over-reports by one at some register counts (MI355X_MICROARCH.md) */
+                const uint32_t resident = (uint32_t)std::max(0, per_cu - 1) * (uint32_t)prop.multiProcessorCount;
+                max_teams = std::min<uint32_t>(BVB_MAX_TEAMS, resident / BVB_TEAM);
+            } else {
+                max_teams = 0;
+            }
+        }
         uint32_t begin = 0, end = 1;
         std::vector<BvbNode> level_nodes;
         std::vector<uint32_t> team_nodes;
         while (begin < end) {                               /* one launch per tree level */
             /* the huge nodes of this level (if any) are split by teams of workgroups first */
-            if (use_teams && end - begin <= 4096u) {
+            if (use_teams && max_teams != 0u && end - begin <= 4096u) {
                 level_nodes.resize(end - begin);
                 BVB_TRY(hipMemcpy(level_nodes.data(), d_nodes.p + begin, (size_t)(end - begin) * sizeof(BvbNode), hipMemcpyDeviceToHost));
                 team_nodes.clear();
-                for (uint32_t k = 0; k < end - begin && team_nodes.size() < BVB_MAX_TEAMS; ++k)
+                for (uint32_t k = 0; k < end - begin && team_nodes.size() < max_teams; ++k)
                     if (level_nodes[k].count >= team_min) team_nodes.push_back(begin + k);
                 if (!team_nodes.empty()) {
                     BVB_TRY(hipMemcpy(d_team_nodes.p, team_nodes.data(), team_nodes.size() * 4, hipMemcpyHostToDevice));

@@ -40,8 +40,13 @@ class Gatherer:
     equal-sized slot of ONE contiguous tensor on rank 0 (slot stride = the largest block), which rpt_untile
     consumes directly (block_stride_pixels = stride) — no per-step allocation, padding copy or concatenation."""
 
-    def __init__(self, width, height, device, group=None):
+    def __init__(self, width, height, device, group=None, stream=None):
+        """stream: the torch stream (e.g. torch.cuda.ExternalStream(renderer.stream_ptr())) the staging copy and the
+        collective are ordered on.  The renderer works on its own non-blocking HIP stream, so WITHOUT it the caller must
+        either wrap begin()/end() in `with torch.cuda.stream(...)` itself (bench.py does) or call renderer.wait() first —
+        otherwise the copy races with the batch that is still accumulating."""
         self.group = group
+        self.stream = stream
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.sizes = block_sizes(width, height, self.world)
@@ -63,8 +68,10 @@ class Gatherer:
         host for the gloo tests), so the renderer may go on accumulating the next batch while the blocks travel."""
         assert self._work is None, "previous gather not finished (call end())"
         n = self.sizes[self.rank]
-        self.send[:n].copy_(local_block)
-        self._work = dist.gather(self.send, gather_list=self.recv_list, dst=0, group=self.group, async_op=True)
+        import contextlib
+        with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
+            self.send[:n].copy_(local_block)
+            self._work = dist.gather(self.send, gather_list=self.recv_list, dst=0, group=self.group, async_op=True)
 
     def end(self):
         """Wait for the gather started by begin(); returns recv on rank 0 (None elsewhere, or when nothing is pending)."""
@@ -97,7 +104,9 @@ def gather_blocks(local_block, width, height, group=None):
 
 
 def device_block_as_tensor(renderer, device):
-    """Alias the renderer's tile-major accumulator block (device memory owned by librpt_hip) as a torch tensor."""
+    """Alias the renderer's tile-major accumulator block (device memory owned by librpt_hip) as a torch tensor.
+    The alias is invalidated by anything that re-allocates the path state (set_config with a new size, set_partition,
+    set_samples_in_flight): fetch it again afterwards."""
     n = renderer.local_pixels()
     ptr = renderer.local_block_device_ptr()
 
