@@ -180,6 +180,8 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
  * the n_samples this call owes the pixel. */
 __global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQueues q, DevConfig cfg, uint32_t n_samples, DevStats *stats) {
     uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (blockIdx.x == 0u)                                     /* queue counters and flags of the new call (no kernel of this call has run yet) */
+        for (uint32_t k = threadIdx.x; k < (uint32_t)Q_COUNT; k += RPT_BLOCK) q.count[k] = 0u;
     if (slot >= st.n_slots) return;
     /* Every slot must have been left idle by the previous render call: an asynchronous batch enqueues a fixed number of
      * iterations (max_bounces, + 1 with several slots per pixel) without ever looking at a progress report, so this is

@@ -233,7 +233,7 @@ constexpr int LDS_THREADS = RPT_LDS_THREADS;     /* workgroup size of the LDS-re
                                                     16-bit stacks + up to 32 KB of scene = the 64 KB a workgroup may hold) per CU = 32 waves */
 
 template <int STACK, int NEE, bool TEXTURED>
-void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
+void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool shade_only) {
     hipStream_t s = c->stream;
     const bool only_traverse = c->timing_level == 2;
     auto mark = [&](bool traverse_edge = false) {
@@ -246,7 +246,10 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     uint32_t grays = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
     grays = grays < 1u ? 1u : (grays > (uint32_t)RPT_GSTREAM_RAYS ? (uint32_t)RPT_GSTREAM_RAYS : grays);
     const uint32_t gspan = grays * RPT_WAVE, gblocks = (c->n_slots + gspan - 1) / gspan;
-    if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
+    /* shade_only: the completion pass of a batch whose iteration count is known — every path has ended, only finished
+     * generations are left to accumulate (k_shade: complete_generations); no ray to trace, no miss, no shadow ray */
+    if (shade_only) {
+    } else if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
         /* persistent workgroups (as many as stay resident: 2 per CU) that fetch spans of slots from a launch-wide counter:
          * a span = 1/16 of a workgroup's share, between 1 and 8 slots per lane (measured at 33 M slots: 8192 / 4096 / 2048
          * slots per span: traverse 82.9 / 80.9 / 83.9 ms per 8 batches) */
@@ -269,7 +272,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     mark(true);
     k_shade<NEE, TEXTURED><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
-    if (NEE != RPT_NEE_NONE) {
+    if (NEE != RPT_NEE_NONE && !shade_only) {
         if (STACK == 16 && c->scene.lds_scene && c->lds_stream && c->lds_shadow_stream) {
             const uint32_t wgs = c->stream_max_blocks;
             uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 16u);
@@ -290,25 +293,25 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         }
     }
     mark();
-    k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
+    if (!shade_only) k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     mark();
 }
 
 template <int STACK>
-void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at) {
+void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool shade_only) {
     const bool tex = c->scene.textured != 0u;
     switch (c->cfg.nee_mode) {
         case RPT_NEE_MIS:
-            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, iteration, blocks, ev, ev_at);
-            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, iteration, blocks, ev, ev_at);
+            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, iteration, blocks, ev, ev_at, shade_only);
+            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, iteration, blocks, ev, ev_at, shade_only);
             break;
         case RPT_NEE_DIRECT:
-            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, iteration, blocks, ev, ev_at);
-            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, iteration, blocks, ev, ev_at);
+            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, iteration, blocks, ev, ev_at, shade_only);
+            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, iteration, blocks, ev, ev_at, shade_only);
             break;
         default:
-            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, iteration, blocks, ev, ev_at);
-            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, iteration, blocks, ev, ev_at);
+            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, iteration, blocks, ev, ev_at, shade_only);
+            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, iteration, blocks, ev, ev_at, shade_only);
             break;
     }
 }
@@ -693,7 +696,6 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         if (rc) return rc;
     }
 
-    HIP_TRY(c, hipMemsetAsync(c->queues.count, 0, Q_COUNT * sizeof(uint32_t), s));
     if (!async) for (int k = 0; k < RING; ++k) __atomic_store_n(&c->host_ring[k], 0ull, __ATOMIC_RELAXED);
     k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples, c->dev_stats.p);
     c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
@@ -717,7 +719,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s));
     }
 
-    uint64_t it = 0;
+    uint64_t it = 0, full_iterations = 0;
     bool drained = c->cfg.c.max_bounces == 0u;
     /* RPT_TEST_SHORT_BATCH=1 (test aid): enqueue one iteration too few in an asynchronous batch, to prove that the
      * completion checks of rpt_wait / k_generate_first notice */
@@ -735,11 +737,14 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
             ev->resize(ev_at + EVENTS_PER_ITER * 64);
             for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
         }
+        /* the extra pass of a known-length batch with several slots per pixel only completes generations */
+        const bool shade_only = known_iterations != 0 && c->group_shift != 0 && it + 1 == known_iterations;
         switch (c->stack_cap) {
-            case 16: launch_iteration_stack<16>(c, (uint32_t)it, blocks, ev, ev_at); break;
-            case 24: launch_iteration_stack<24>(c, (uint32_t)it, blocks, ev, ev_at); break;
-            default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at); break;
+            case 16: launch_iteration_stack<16>(c, (uint32_t)it, blocks, ev, ev_at, shade_only); break;
+            case 24: launch_iteration_stack<24>(c, (uint32_t)it, blocks, ev, ev_at, shade_only); break;
+            default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at, shade_only); break;
         }
+        full_iterations += shade_only ? 0u : 1u;
         it += 1;
         if (it == known_iterations - short_batch) break;        /* (no report needed: nothing can be left) */
         if (known_iterations == 0 && it >= (uint64_t)lag) {
@@ -764,29 +769,32 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     if (async) {
         c->async_pending = true;
         c->stats.iterations += it;
-        c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += it;
+        c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += full_iterations;
         c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
-        c->stats.kernel_launches[RPT_STAGE_SHADOW] += c->cfg.nee_mode != RPT_NEE_NONE ? it : 0;
-        c->stats.kernel_launches[RPT_STAGE_SKY] += it;
+        c->stats.kernel_launches[RPT_STAGE_SHADOW] += c->cfg.nee_mode != RPT_NEE_NONE ? full_iterations : 0;
+        c->stats.kernel_launches[RPT_STAGE_SKY] += full_iterations;
         if (ev) c->timing_pending.push_back(rpt_ctx::TimingBatch{async_events, it});
         c->samples += n_samples;
         c->stats.samples += (uint64_t)c->n_pixels * n_samples;
         c->stats.render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return RPT_OK;
     }
+    /* a call that enqueued a fixed number of iterations must have left every slot idle: cross-check of that bound */
+    if (known_iterations != 0 && c->n_slots)
+        k_check_drained<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->hit.p, c->n_slots, c->dev_stats.p);
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
-    if (known_iterations != 0 && c->group_shift != 0 && it == known_iterations) {
-        /* the extra completion iteration must have found nothing left to do: cross-check of the bound above */
-        const unsigned long long v = c->host_ring[(it - 1) & (RING - 1)];
-        if ((v >> 32) != (it & 0xffffffffull) || (uint32_t)v != 0u) { c->error = "wavefront not drained after max_bounces + 1 iterations (internal error)"; return RPT_EHIP; }
+    if (known_iterations != 0) {
+        unsigned long long undrained = 0ull;
+        HIP_TRY(c, hipMemcpy(&undrained, &c->dev_stats.p->undrained, sizeof(undrained), hipMemcpyDeviceToHost));
+        if (undrained != 0ull) { c->error = "wavefront not drained after its known number of iterations (internal error)"; return RPT_EHIP; }
     }
     const bool nee = c->cfg.nee_mode != RPT_NEE_NONE;
     c->stats.iterations += it;
-    c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += it;
+    c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += full_iterations;
     c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
-    c->stats.kernel_launches[RPT_STAGE_SHADOW] += nee ? it : 0;
-    c->stats.kernel_launches[RPT_STAGE_SKY] += it;
+    c->stats.kernel_launches[RPT_STAGE_SHADOW] += nee ? full_iterations : 0;
+    c->stats.kernel_launches[RPT_STAGE_SKY] += full_iterations;
     if (ev) timing_accumulate(c, *ev, it);
     c->samples += n_samples;
     c->stats.samples += (uint64_t)c->n_pixels * n_samples;
