@@ -151,28 +151,14 @@ __device__ __forceinline__ Mat load_material(const DevScene &sc, uint32_t index)
 /* NEE = NextEventEstimation mode (0 none, 1 MIS, 2 direct only), TEXTURED = the
  * scene has at least one texture flag.  Specialising removes the dead halves of
  * the stage (and their registers) for the common untextured / no-NEE case. */
-template <int NEE, bool TEXTURED>
-__global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
-                                                     DevStats *stats) {
-    __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
-    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
-    const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    if (NEE != RPT_NEE_NONE && slot == 0u) q.count[Q_SPOOL] = 0u;       /* the shadow stage that follows starts its pool at entry 0 */
-    bool to_sky = false;
-    bool emit_shadow = false;
-    float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-    float2 hw = make_float2(0.0f, __uint_as_float(HIT_PARKED));
-    if (slot < st.n_slots) hw = st.hit[slot];
+/* What the stage does for ONE traversed slot (hit word `hw`): everything of lib.rs:64-181 after the intersection.  Outputs:
+ * to_sky (a miss: queued for k_sky), emit_shadow + the shadow-queue entry, and — for a path that ends here with nothing
+ * pending — its final radiance for complete_generations (g_*; !COMPACT) or parked / accumulated on the spot (COMPACT). */
+template <int NEE, bool TEXTURED, bool COMPACT>
+__device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &st, const DevQueues &q, const DevConfig &cfg, DevStats *stats,
+                                           uint32_t slot, float2 hw, bool active, bool &to_sky, bool &emit_shadow, float4 &sh_o, float4 &sh_d,
+                                           float4 &sh_c, bool &g_done, bool &g_fresh, F3 &g_radiance, uint32_t &g_todo) {
     const uint32_t hit_tri = __float_as_uint(hw.y);
-    const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;            /* traversed in this iteration */
-    /* generation bookkeeping (k_path.h: complete_generations) */
-    bool g_done = false, g_fresh = false;
-    const bool g_idle = hit_tri == HIT_IDLE;
-    F3 g_radiance = f3s(0.0f);
-    uint32_t g_todo = 0u;
-    if (hit_tri == HIT_DONE) g_done = true;          /* finished earlier (sky / shadow stage, or before its siblings): its parked
-                                                        radiance is fetched by complete_generations once the generation completes */
-
     if (active) {
         const float4 ra = st.ray_a[slot];
         const float2 rb = st.ray_b[slot];
@@ -450,9 +436,14 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             if (done && !emit_shadow) {
                 /* the path ends here with nothing pending: its generation may complete below */
                 load_rad();
-                g_done = g_fresh = true;
-                g_radiance = radiance;
-                g_todo = todo;
+                if (COMPACT) {
+                    /* one slot per pixel: accumulated and restarted on the spot; otherwise parked for the next pass */
+                    finish_in_side_stage(st, cfg, slot, radiance, todo);
+                } else {
+                    g_done = g_fresh = true;
+                    g_radiance = radiance;
+                    g_todo = todo;
+                }
             } else {
                 if (!done) {
                     st.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(new_flags));
@@ -469,11 +460,43 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
         }
     }
 
-    /* ---- accumulate finished generations in sample order and start the next samples ---- */
-    complete_generations(st, cfg, &q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE], slot, g_done, g_idle, g_fresh, g_radiance, g_todo);
+}
 
-    /* ---- side-queue emission: wave64 ballot + mbcnt prefix, one atomic per workgroup ---- */
-    /* (block-uniform early outs keep the barriers inside block_push legal) */
+/* COMPACT: a workgroup owns RPT_SHADE_ROUNDS x 256 consecutive slots; it first walks them in identity layout (where the
+ * slots of a pixel sit in adjacent lanes) to complete finished generations and to pack the slots that were traversed in
+ * this iteration into an LDS list, then shades the list 256 at a time.
+ * Why (profiles/r02_pbrtest_pmc_sq.txt, r02_veachmis): on an open scene most slots are parked after the first bounce
+ * (their paths ended in the sky and wait for the siblings of their generation).  One thread per slot, the stage ran 2.1 M
+ * waves per pass on PBRTest with 32 slots per pixel, two thirds of their cycles waiting (a dependent load or two, then
+ * four workgroup barriers for side queues nothing is pushed to), 40 % of the lanes live in what was issued — the fixed
+ * cost per wave, not the shading, was the stage.  Packed, a workgroup does the bookkeeping once per 2 048 slots with
+ * eight independent loads in flight per thread, and only full waves shade.
+ * Generations are completed at the START of the next pass instead of in the pass that ends their last path; the sum
+ * order per pixel is the same, the image bit-identical, and a known-length batch ends with a completion pass anyway. */
+#ifndef RPT_SHADE_ROUNDS
+#define RPT_SHADE_ROUNDS 8
+#endif
+__device__ __forceinline__ uint32_t block_rank(bool pred, uint32_t *scratch, uint32_t &total) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
+    constexpr uint32_t NW = RPT_BLOCK / RPT_WAVE;
+    const unsigned long long mask = rpt_ballot(pred);
+    if (lane == 0u) scratch[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = 0u, sum = 0u;
+    for (uint32_t w = 0; w < NW; ++w) {
+        if (w == wave) base = sum;
+        sum += scratch[w];
+    }
+    total = sum;
+    __syncthreads();     /* scratch may be reused */
+    return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+/* side-queue emission of one pass over up to 256 slots: wave64 ballot + mbcnt prefix, one atomic per workgroup
+ * (block-uniform early outs keep the barriers inside block_push legal) */
+template <int NEE>
+__device__ __forceinline__ void shade_emit(const DevQueues &q, uint32_t *push_scratch, uint32_t slot, bool to_sky, bool emit_shadow,
+                                           float4 sh_o, float4 sh_d, float4 sh_c) {
     uint32_t at;
     if (__syncthreads_or(to_sky)) {
         at = block_push(&q.count[Q_SKY], to_sky, push_scratch);
@@ -486,6 +509,67 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             q.sh_d[at] = sh_d;
             q.sh_c[at] = sh_c;
         }
+    }
+}
+
+template <int NEE, bool TEXTURED, bool COMPACT>
+__global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
+                                                     DevStats *stats) {
+    __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
+    __shared__ uint32_t c_slot[COMPACT ? RPT_BLOCK * RPT_SHADE_ROUNDS : 1];
+    if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
+    if (NEE != RPT_NEE_NONE && blockIdx.x == 0u && threadIdx.x == 0u) q.count[Q_SPOOL] = 0u;   /* the shadow stage that follows starts its pool at entry 0 */
+    uint32_t *regen_flag = &q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE];
+    if (COMPACT) {
+        const uint32_t base = blockIdx.x * (RPT_BLOCK * RPT_SHADE_ROUNDS);
+        if (base >= st.n_slots) return;                        /* block-uniform */
+        float2 hws[RPT_SHADE_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < RPT_SHADE_ROUNDS; ++r) {           /* all looks in flight before the first is used */
+            const uint32_t s0 = base + (uint32_t)r * RPT_BLOCK + threadIdx.x;
+            hws[r] = s0 < st.n_slots ? st.hit[s0] : make_float2(0.0f, __uint_as_float(HIT_PARKED));
+        }
+        uint32_t total = 0u;                                   /* block-uniform */
+#pragma unroll
+        for (int r = 0; r < RPT_SHADE_ROUNDS; ++r) {
+            const uint32_t s0 = base + (uint32_t)r * RPT_BLOCK + threadIdx.x;
+            const uint32_t word = __float_as_uint(hws[r].y);
+            /* generations whose last member ended in an earlier pass (or in a side stage) */
+            if (st.group_shift != 0u) complete_generations(st, cfg, regen_flag, s0, word == HIT_DONE, word == HIT_IDLE, false, f3s(0.0f), 0u);
+            const bool traversed = word < HIT_IDLE || word == HIT_MISS;
+            uint32_t n_r = 0u;
+            const uint32_t idx = block_rank(traversed, push_scratch, n_r);
+            if (traversed) c_slot[total + idx] = s0;
+            total += n_r;
+        }
+        __syncthreads();
+        for (uint32_t first = 0u; first < total; first += RPT_BLOCK) {      /* block-uniform trip count */
+            const bool active = first + threadIdx.x < total;
+            const uint32_t slot = active ? c_slot[first + threadIdx.x] : 0u;
+            const float2 hw = active ? st.hit[slot] : make_float2(0.0f, __uint_as_float(HIT_PARKED));
+            bool to_sky = false, emit_shadow = false, g_done = false, g_fresh = false;
+            float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
+            F3 g_radiance = f3s(0.0f);
+            uint32_t g_todo = 0u;
+            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, g_done, g_fresh, g_radiance, g_todo);
+            shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
+        }
+    } else {
+        const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
+        float2 hw = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+        if (slot < st.n_slots) hw = st.hit[slot];
+        const uint32_t hit_tri = __float_as_uint(hw.y);
+        const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;        /* traversed in this iteration */
+        /* generation bookkeeping (k_path.h: complete_generations): a slot that finished earlier (sky / shadow stage, or before
+         * its siblings) is HIT_DONE; its parked radiance is fetched by complete_generations once the generation completes */
+        bool to_sky = false, emit_shadow = false, g_done = hit_tri == HIT_DONE, g_fresh = false;
+        float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
+        F3 g_radiance = f3s(0.0f);
+        uint32_t g_todo = 0u;
+        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, g_done, g_fresh, g_radiance, g_todo);
+        /* accumulate finished generations in sample order and start the next samples */
+        complete_generations(st, cfg, regen_flag, slot, g_done, hit_tri == HIT_IDLE, g_fresh, g_radiance, g_todo);
+        shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
     }
 }
 

@@ -164,6 +164,10 @@ __device__ __forceinline__ bool moller_trumbore_view(const View &view, uint32_t 
 #ifndef RPT_LEAF_K
 #define RPT_LEAF_K 8
 #endif
+#ifndef RPT_LEAF_GREEDY_PCT_GLOBAL
+#define RPT_LEAF_GREEDY_PCT_GLOBAL 100   /* global-memory walks: 0 = the RPT_LEAF_K threshold rule; > 0 = one body per trip (see lds_walk_run).
+                                            Measured (K = 8 rule / 100 / 60): VeachMIS 5175 / 5506 / 5453 Mrays/s, PBRTest 4915 / 5027 / 5011 */
+#endif
 #ifndef RPT_COOP_LEAF_MIN
 #define RPT_COOP_LEAF_MIN 6        /* leaves with more triangles than this are tested by the whole wave (global-memory scenes) */
 #endif
@@ -200,7 +204,11 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
         const bool at_leaf = View::is_leaf(cur);
         const unsigned long long inner_m = rpt_ballot(at_inner), leaf_m = rpt_ballot(at_leaf);
         if ((inner_m | leaf_m) == 0ull) break;
+#if RPT_LEAF_GREEDY_PCT_GLOBAL
+        if (at_inner && !((uint32_t)__popcll(leaf_m) * 100u > (uint32_t)__popcll(inner_m) * (uint32_t)RPT_LEAF_GREEDY_PCT_GLOBAL)) {
+#else
         if (at_inner) {
+#endif
             /* inner node (:207-229): test both children against the current best t */
             float4 lmin, lmax, rmin, rmax;
             view.children(cur, lmin, lmax, rmin, rmax);
@@ -221,7 +229,12 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
                 cur = view.from_entry(stack[sp * RPT_WAVE]);
             }
         }
-        if ((uint32_t)__popcll(leaf_m) >= (uint32_t)RPT_LEAF_K || inner_m == 0ull) {       /* (wave-uniform) */
+#if RPT_LEAF_GREEDY_PCT_GLOBAL
+        const bool do_leaf = (uint32_t)__popcll(leaf_m) * 100u > (uint32_t)__popcll(inner_m) * (uint32_t)RPT_LEAF_GREEDY_PCT_GLOBAL;
+#else
+        const bool do_leaf = (uint32_t)__popcll(leaf_m) >= (uint32_t)RPT_LEAF_K || inner_m == 0ull;
+#endif
+        if (do_leaf) {                                                                       /* (wave-uniform) */
             bool accepted = false, coop_done = false;
             const uint32_t count = View::leaf_count(cur), first = View::leaf_first(cur);
             if constexpr (View::kCoopLeaves) {

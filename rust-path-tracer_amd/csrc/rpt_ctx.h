@@ -49,6 +49,9 @@ struct rpt_ctx {
     std::string error;
     uint32_t rank = 0, world = 1;
     bool lds_stream = true;
+    bool shade_compact = false;          /* shade stage variant in use: traversed slots packed per workgroup before shading (k_shade<.., COMPACT>) */
+    int shade_compact_mode = -1;         /* -1 automatic (refresh_device_stats), 0 / 1 forced by RPT_SHADE_COMPACT */
+    double shade_compact_at = 0.7;       /* automatic: on when more than this share of the samples ends in the sky */
     bool lds_shadow_stream = true;       /* LDS scenes: streamed shadow stage (k_traverse_shadow_stream + k_shadow_resolve) */
     bool gstream = true;                 /* scenes walked from global memory: streamed kernels (k_traverse_*_gstream) */
     uint32_t gstream_min_waves = 32768;

@@ -467,6 +467,7 @@ def test_host_dispatch_trace_gpu_furnace(rpt):
 
 @pytest.mark.parametrize("knob", ["RPT_LDS_STREAM=0", "RPT_NO_LDS_SCENE=1", "RPT_NO_FASTDIV=1", "RPT_SKY_THRESHOLD=4096",
                                   "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MAX_BLOCKS=7", "RPT_STREAM_SPAN=1024", "RPT_GSTREAM=0",
+                                  "RPT_SHADE_COMPACT=1", "RPT_LDS_SHADOW_STREAM=0", "RPT_MAX_SLOTS=65536",
                                   "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2"])
 def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world, knob):
     """README: every tuning knob leaves the image bit-identical (they select kernels / schedules, never arithmetic)."""
@@ -493,6 +494,33 @@ def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world
     got = render()
     assert got[1] == base[1]
     assert np.array_equal(got[0].view(np.uint32), base[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("scene,nee", [("PBRTest", 0), ("VeachMIS", 1), ("DarkCornell", 2)])
+def test_packed_shade_stage_equals_the_oracle(monkeypatch, hipmod, oracle, rpt, world, scene, nee):
+    """k_shade<.., COMPACT> (traversed slots packed per workgroup, generations completed at the start of the next pass)
+    forced on: several render calls, one of them with more samples than slots per pixel (so finished generations restart
+    from the completion step), ragged image — accumulators, rng and ray counts equal the oracle's."""
+    monkeypatch.setenv("RPT_SHADE_COMPACT", "1")
+    W, H = 200, 136
+    cfg = rpt.default_config(W, H, nee=nee)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    r.set_samples_in_flight(4)
+    r.upload_scene(world(scene))
+    r.set_config(cfg)
+    r.reset(seeds)
+    for n in (3, 9, 1):
+        r.render(n)
+    r.render_async(4)
+    r.wait()
+    acc, ns = r.read_accum()
+    st = r.stats()
+    ref, rng_ref, so = oracle.trace_cpu(cfg, oracle.scene(world(scene)), seeds, 17)
+    assert ns == 17 and st["extension_rays"] == so.extension_rays and st["shadow_rays"] == so.shadow_rays
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(r.read_rng()["n"], np.full(W * H, 17, np.uint32))
+    r.close()
 
 
 def test_error_behaviour(hipmod, rpt, world):
