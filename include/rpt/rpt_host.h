@@ -49,6 +49,7 @@ typedef struct rpt_world rpt_world;
  * the reordered indices (201-202), per-vertex packing (206-215).
  * Returns RPT_HOST_ELOAD when the file cannot be imported (the reference
  * returns None and trace_gpu silently returns, trace.rs:141-143). */
+/* path: a .glb (glTF 2.0 binary; embedded PNG textures -> atlas) or a Wavefront .obj (+ .mtl: Kd, Ke, Pm, Pr). */
 int rpt_world_load(const char *path, rpt_world **out);
 /* rpt_world_load with options.  RPT_LOAD_EMISSIVE_STRENGTH: honour KHR_materials_emissive_strength
  * (emissive = factor * strength) instead of the reference's fixed x15 (src/asset.rs:163-166) for materials that carry

@@ -84,7 +84,9 @@ int rpt_world_load_ex(const char *path, uint32_t flags, rpt_world **out) {
     rpt_world *w = nullptr;
     try {
         w = new rpt_world();
-        if (!load_glb(path, w->w, flags)) { delete w; return RPT_HOST_ELOAD; }
+        const size_t len = strlen(path);
+        const bool is_obj = len >= 4 && (!strcmp(path + len - 4, ".obj") || !strcmp(path + len - 4, ".OBJ"));
+        if (!(is_obj ? load_obj(path, w->w) : load_glb(path, w->w, flags))) { delete w; return RPT_HOST_ELOAD; }
     } catch (const std::bad_alloc &) {
         delete w;
         set_error("out of memory while loading the scene");

@@ -60,6 +60,8 @@ bool build_world_bvh(const Vec4f *vertices, size_t n_vertices, std::vector<rpt_t
 
 /* flags: RPT_LOAD_* of rpt_host.h */
 bool load_glb(const char *path, World &out, uint32_t flags = 0);
+/* Wavefront OBJ + MTL (obj_scene.cpp) */
+bool load_obj(const char *path, World &out);
 
 }  // namespace rpth
 

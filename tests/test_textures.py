@@ -145,3 +145,43 @@ def test_png_skybox_and_decoder_variants(rpt, tmp_path):
     bad.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 4 +X 4\n" + b"\x01" * 10)
     with pytest.raises(rpt.host.HostError):
         rpt.load_skybox(str(bad))
+
+
+def test_obj_and_glb_of_the_same_mesh_give_the_same_world(rpt, tmp_path):
+    """Wavefront OBJ + MTL through the same pipeline as GLB (asset.rs:78-128 treats every assimp import alike): (x, z, y)
+    positions, (0, 2, 1) winding, Kd -> albedo, Ke x 15 -> emissive, Pm / Pr -> metallic / roughness; polygons fanned,
+    negative indices, smooth normals where the file has none."""
+    (tmp_path / "m.mtl").write_text("newmtl wall\nKd 0.7 0.6 0.5\nPr 0.4\nPm 0.1\nnewmtl lamp\nKd 1 1 1\nKe 1.0 0.5 0.25\n")
+    (tmp_path / "box.obj").write_text(
+        "mtllib m.mtl\n"
+        "v -1 0 0\nv 1 0 0\nv 1 2 0\nv -1 2 0\nv -1 3 0\nv -1 3 1\nv 1 3 1\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 -1\n"
+        "usemtl wall\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"          # a quad: fanned into two triangles
+        "usemtl lamp\nf -3 -2 -1\n")                        # negative indices, no vt / vn: smooth normal generated
+    w = rpt.World.from_path(str(tmp_path / "box.obj"))
+    assert len(w.indices) == 3 and len(w.materials) == 2 and w.n_emissive_triangles == 1
+    m = w.materials
+    assert np.allclose(m[0]["albedo"], [0.7, 0.6, 0.5, 1.0]) and np.all(m[0]["roughness"] == np.float32(0.4)) and np.all(m[0]["metallic"] == np.float32(0.1))
+    assert np.array_equal(m[1]["emissive"], np.array([15.0, 7.5, 3.75, 15.0], np.float32))
+    v = w.per_vertex["vertex"]
+    assert len(v) == 7 and np.all(v[:, 3] == 1.0)                      # 4 joined quad corners + 3 lamp corners
+    assert {tuple(p) for p in v[:4, :3].tolist()} == {(-1, 0, 0), (1, 0, 0), (1, 0, 2), (-1, 0, 2)}        # (x, z, y)
+    assert np.allclose(w.per_vertex["normal"][:4, :3], [0, -1, 0])                                           # vn (0, 0, -1) swapped
+    lamp = [t for t in w.indices if t["material"] == 1][0]
+    n = w.per_vertex["normal"][[lamp["v0"], lamp["v1"], lamp["v2"]], :3]
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6) and np.allclose(n, n[0])
+    # the same geometry as GLB gives the same triangles (as sets of corner positions) and the same materials' colours
+    from scenes import write_glb
+    pos = np.array([[-1, 0, 0], [1, 0, 0], [1, 2, 0], [-1, 2, 0]], np.float32)
+    g = rpt.World.from_path(write_glb(str(tmp_path / "quad.glb"), pos, np.array([0, 1, 2, 0, 2, 3], np.uint32),
+                                      normals=np.tile(np.array([[0, 0, -1]], np.float32), (4, 1)),
+                                      materials=[{"pbrMetallicRoughness": {"baseColorFactor": [0.7, 0.6, 0.5, 1.0]}}]))
+
+    def tri_set(world, material):
+        vv = world.per_vertex["vertex"][:, :3]
+        return {tuple(sorted(map(tuple, vv[[t["v0"], t["v1"], t["v2"]]].tolist()))) for t in world.indices if t["material"] == material}
+    assert tri_set(w, 0) == tri_set(g, 0)
+    with pytest.raises(rpt.host.HostError):
+        bad = tmp_path / "bad.obj"
+        bad.write_text("v 0 0 0\nv 1 0 0\nf 1 2 9\n")
+        rpt.World.from_path(str(bad))
