@@ -636,7 +636,7 @@ int rpt_reset(rpt_ctx *c, const rpt_rng_state *seed, const float *accum_init, ui
 /* Read the device counters after a synchronisation: reports samples a fixed-length batch left in flight, and picks the
  * shade-stage variant for the batches to come.  Packing the traversed slots per workgroup before shading (k_shade<..,
  * COMPACT>) pays when most slots of a pass are parked — measured: PBRTest 2048^2 (0.94 sky hits per sample) shade 86.6 ->
- * 68.5 ms per 4 batches — and costs on scenes whose paths stay alive (DarkCornell 31.4 -> 39.2, VeachMIS with 0.42 even):
+ * 68.5 ms per 4 batches — and costs on scenes whose paths stay alive (DarkCornell 31.4 -> 39.2; VeachMIS with 0.84: even):
  * so it is switched on when more than RPT_SHADE_COMPACT_AT (default 0.7) of the samples rendered since the last reset
  * ended in the sky.  Either variant produces the same image bit for bit. */
 static int refresh_device_stats(rpt_ctx *c, const char *what) {

@@ -94,6 +94,46 @@ DEFINE_KERNEL(k_cnd_fma, CND(40) FMA(48) CND(41) FMA(49) CND(42) FMA(50) CND(43)
 // 16 x (cnd, min)
 DEFINE_KERNEL(k_cnd_min, CND(40) MIN(48) CND(41) MIN(49) CND(42) MIN(50) CND(43) MIN(51) CND(44) MIN(48) CND(45) MIN(49) CND(46) MIN(50) CND(47) MIN(51) CND(40) MIN(48) CND(41) MIN(49) CND(42) MIN(50) CND(43) MIN(51) CND(44) MIN(48) CND(45) MIN(49) CND(46) MIN(50) CND(47) MIN(51), CL)
 
+
+// ---- item 7 of round 1's review: would an f32-only (double-float) build of the shared transcendentals be cheaper than the
+// f64 Horner chains rpt_math.h uses?  One Horner step p = p * t + c, 8 independent chains x 4 steps per trip, (a) as one
+// v_fma_f64, (b) in double-float arithmetic on float pairs (two_prod by fma, two_sum, renormalise: 16 f32 instructions).
+__global__ __launch_bounds__(256) void k_horner_f64(float *out) {
+    double p[8], t = 0.999999 + threadIdx.x * 1e-9, c = 1e-3;
+    for (int k = 0; k < 8; ++k) p[k] = 1.0 + k * 1e-3 + threadIdx.x * 1e-6;
+    for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p[k] = __builtin_fma(p[k], t, c);
+    }
+    double acc = 0.0;
+    for (int k = 0; k < 8; ++k) acc += p[k];
+    if (acc == 12345.678) out[0] = (float)acc;
+}
+__global__ __launch_bounds__(256) void k_horner_df32(float *out) {
+    float ph[8], pl[8];
+    const float th = 0.999999f + threadIdx.x * 1e-9f, tl = 1e-9f, ch = 1e-3f, cl = 1e-11f;
+    for (int k = 0; k < 8; ++k) { ph[k] = 1.0f + k * 1e-3f + threadIdx.x * 1e-6f; pl[k] = 1e-9f; }
+    for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float hh = ph[k] * th, e = __builtin_fmaf(ph[k], th, -hh);           /* two_prod */
+                float lo = e + __builtin_fmaf(ph[k], tl, pl[k] * th);
+                float s = hh + ch, bb = s - hh, err = (hh - (s - bb)) + (ch - bb);   /* two_sum */
+                float l2 = err + (lo + cl);
+                float rh = s + l2;
+                ph[k] = rh;
+                pl[k] = l2 - (rh - s);
+            }
+    }
+    float acc = 0.0f;
+    for (int k = 0; k < 8; ++k) acc += ph[k] + pl[k];
+    if (acc == 12345.678f) out[0] = acc;
+}
+
 struct Case { const char *name; void (*fn)(float *); };
 
 int main(int argc, char **argv) {
@@ -112,6 +152,7 @@ int main(int argc, char **argv) {
         {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_rcp_f64", k_rcp_f64},
         {"v_mad_u64_u32", k_mad_u64_u32}, {"v_lshl_add_u64", k_lshl_add_u64}, {"ds_bpermute_b32", k_ds_bpermute},
         {"v_readlane_b32", k_readlane}, {"16x(cmp vcc+cnd vcc)", k_cmp_cnd_vcc}, {"16x(cmp s+cnd s)", k_cmp_cnd_sgpr}, {"cnd e64 vcc", k_cnd_e64_vcc}, {"cmp; 32 cnd vcc", k_cnd_after_cmp}, {"vcc=exec; 32 cnd", k_cnd_exec_full}, {"vcc=0; 32 cnd", k_cnd_zero}, {"8x(min+3fma)", k_min_fma_mix}, {"fma dependent", k_fma_x32_dep}, {"8x(cmp+3cnd)", k_cmp_3cnd}, {"10x(cmp+2cnd)+2fma", k_cmp_2cnd}, {"16x(cnd,fma)", k_cnd_fma}, {"16x(cnd,min)", k_cnd_min}, {"v_mbcnt_lo", k_mbcnt}, {"s_and_b64", k_s_and},
+        {"Horner step f64 (1 v_fma_f64)", k_horner_f64}, {"Horner step double-float (16 f32)", k_horner_df32},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("waves/SIMD %d, %d CUs\n", wps, cus);
@@ -130,7 +171,7 @@ int main(int argc, char **argv) {
         float t = time_of(c.fn);
         float base2 = time_of(k_fma_f32);
         double rel = t / (0.5 * (base + base2)) * 4.0;
-        printf("%-20s %8.3f ms (fma %.3f/%.3f)  %6.2f cycles/wave-instr (v_fma_f32 := 4)\n", c.name, t, base, base2, rel);
+        printf("%-34s %8.3f ms (fma %.3f/%.3f)  %6.2f cycles/wave-instr (v_fma_f32 := 4)\n", c.name, t, base, base2, rel);
     }
     return 0;
 }
