@@ -246,7 +246,8 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
 /* Evaluate one shared-math function on the DEVICE over n floats so tests can
  * check bit-equality with the host build of the same header. op: 0 sin, 1 cos,
  * 2 acos, 3 exp, 4 pow(x,y), 5 asin, 6 atan2(y=x_in, x=y_in), 7 sqrt, 8 IEEE x/y,
- * 9 x/y through the traversal's guarded exact fast-division path (rpt_fastdiv.h). */
+ * 9 x/y through the traversal's guarded exact fast-division path (rpt_fastdiv.h), 10 the sky march's float-only exp
+ * (rpt_math.h exp_sky). */
 int rpt_debug_math(rpt_ctx *ctx, int op, const float *x, const float *y, float *out, size_t n);
 /* Same on the HOST build (no device needed, ctx may be NULL). */
 int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size_t n);

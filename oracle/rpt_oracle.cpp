@@ -69,6 +69,7 @@ inline float m_asin(float x) { return asinf(x); }
 inline float m_atan2(float y, float x) { return atan2f(y, x); }
 inline float m_atan(float x) { return atanf(x); }
 inline float m_exp(float x) { return expf(x); }
+inline float m_exp_sky(float x) { return expf(x); }
 inline float m_pow(float x, float y) { return powf(x, y); }
 #else
 inline float m_sin(float x) { return rptm::sinr(x); }
@@ -78,6 +79,7 @@ inline float m_asin(float x) { return rptm::asinr(x); }
 inline float m_atan2(float y, float x) { return rptm::atan2r(y, x); }
 inline float m_atan(float x) { return rptm::atanr(x); }
 inline float m_exp(float x) { return rptm::expr(x); }
+inline float m_exp_sky(float x) { return rptm::exp_sky(x); }     /* skybox.rs only: see rpt_math.h */
 inline float m_pow(float x, float y) { return rptm::powr(x, y); }
 #endif
 inline float m_sqrt(float x) { return __builtin_sqrtf(x); }
@@ -680,7 +682,7 @@ inline float escape(V3 p, V3 d, float r) {
 }
 inline V2 densities_rm(V3 p) {
     float h = m_max(length(p - CENTER) - EARTH_RADIUS, 0.0f);
-    return V2{m_exp(-h / H_RAY), m_exp(-h / H_MIE)};
+    return V2{m_exp_sky(-h / H_RAY), m_exp_sky(-h / H_MIE)};
 }
 inline V2 scatter_depth_int(V3 o, V3 d, float l) {
     return densities_rm(o) * (l / 2.0f) + densities_rm(o + d * l) * (l / 2.0f);
@@ -695,7 +697,7 @@ inline void scatter_in(V3 origin, V3 direction, float depth, uint32_t steps, V3 
         total_depth_rm = total_depth_rm + d_rm;
         V2 depth_rm_sum = total_depth_rm + scatter_depth_int(p, sundir, escape(p, sundir, ATMOSPHERE_RADIUS));
         V3 e = (-RAY_EFFECTIVE_COEFF) * depth_rm_sum.x - MIE_EFFECTIVE_COEFF * depth_rm_sum.y;
-        V3 a = v3(m_exp(e.x), m_exp(e.y), m_exp(e.z));
+        V3 a = v3(m_exp_sky(e.x), m_exp_sky(e.y), m_exp_sky(e.z));
         i_r = i_r + a * d_rm.x;
         i_m = i_m + a * d_rm.y;
     }
@@ -1141,6 +1143,7 @@ int oracle_math(int op, const float *x, const float *y, float *out, size_t n) {
             case 1: r = m_cos(x[i]); break;
             case 2: r = m_acos(x[i]); break;
             case 3: r = m_exp(x[i]); break;
+            case 10: r = m_exp_sky(x[i]); break;
             case 4: r = m_pow(x[i], y[i]); break;
             case 5: r = m_asin(x[i]); break;
             case 6: r = m_atan2(x[i], y[i]); break;

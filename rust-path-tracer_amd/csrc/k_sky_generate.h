@@ -33,7 +33,7 @@ __device__ __forceinline__ float sky_escape(F3 p, F3 d, float r) {
 }
 __device__ __forceinline__ float2 sky_densities(F3 p) {
     float h = rptm::fmaxr(len3(p - f3(0.0f, -SKY_EARTH_RADIUS, 0.0f)) - SKY_EARTH_RADIUS, 0.0f);
-    return make_float2(rptm::expr(-h / SKY_H_RAY), rptm::expr(-h / SKY_H_MIE));
+    return make_float2(rptm::exp_sky(-h / SKY_H_RAY), rptm::exp_sky(-h / SKY_H_MIE));
 }
 
 __device__ F3 sky_scatter(const float *sun4, F3 origin, F3 direction) {
@@ -58,7 +58,7 @@ __device__ F3 sky_scatter(const float *sun4, F3 origin, F3 direction) {
         float sum_r = total_r + (da.x * half_l + db.x * half_l);
         float sum_m = total_m + (da.y * half_l + db.y * half_l);
         F3 e = (-ray_coeff) * sum_r - mie_effective * sum_m;
-        F3 a = f3(rptm::expr(e.x), rptm::expr(e.y), rptm::expr(e.z));
+        F3 a = f3(rptm::exp_sky(e.x), rptm::exp_sky(e.y), rptm::exp_sky(e.z));
         i_r = i_r + a * d_r;
         i_m = i_m + a * d_m;
     }
@@ -98,7 +98,7 @@ __device__ F3 sky_scatter_wide(const float *sun4, F3 origin, F3 direction, uint3
     float sum_r = total_r + (dens.x * half_l + db.x * half_l);
     float sum_m = total_m + (dens.y * half_l + db.y * half_l);
     F3 e = (-ray_coeff) * sum_r - mie_effective * sum_m;
-    F3 a = f3(rptm::expr(e.x), rptm::expr(e.y), rptm::expr(e.z));
+    F3 a = f3(rptm::exp_sky(e.x), rptm::exp_sky(e.y), rptm::exp_sky(e.z));
     F3 t_r = a * d_r, t_m = a * d_m;
     F3 i_r = f3s(0.0f), i_m = f3s(0.0f);
     for (uint32_t k = 0; k < 12u; ++k) {

@@ -937,13 +937,14 @@ __global__ void k_debug_math(int op, const float *x, const float *y, float *out,
         case 6: r = rptm::atan2r(x[i], y[i]); break;
         case 7: r = rptm::sqrtr(x[i]); break;
         case 9: r = rptm::slab_quotient(x[i], 0.0f, y[i]); break;
+        case 10: r = rptm::exp_sky(x[i]); break;
         default: r = x[i] / y[i]; break;
     }
     out[i] = r;
 }
 
 int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size_t n) {
-    if (op < 0 || op > 9 || !x || !y || !out) return RPT_EINVAL;
+    if (op < 0 || op > 10 || !x || !y || !out) return RPT_EINVAL;
     for (size_t i = 0; i < n; ++i) {
         float r;
         switch (op) {
@@ -956,6 +957,7 @@ int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size
             case 6: r = rptm::atan2r(x[i], y[i]); break;
             case 7: r = rptm::sqrtr(x[i]); break;
             case 9: r = rptm::slab_quotient(x[i], 0.0f, y[i]); break;
+        case 10: r = rptm::exp_sky(x[i]); break;
             default: r = x[i] / y[i]; break;
         }
         out[i] = r;
@@ -964,7 +966,7 @@ int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size
 }
 
 int rpt_debug_math(rpt_ctx *c, int op, const float *x, const float *y, float *out, size_t n) {
-    if (!c || op < 0 || op > 9 || !x || !y || !out) return RPT_EINVAL;
+    if (!c || op < 0 || op > 10 || !x || !y || !out) return RPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf<float> dx, dy, dout;
     HIP_TRY(c, dx.alloc(n)); HIP_TRY(c, dy.alloc(n)); HIP_TRY(c, dout.alloc(n));

@@ -221,6 +221,39 @@ RPT_HD float expr(float x) {
     return (float)exp_core((double)x);
 }
 
+/* exp for the SKY march (reference use: kernels/src/skybox.rs:37-38, 62 — 84 calls per miss, 30 % of PBRTest's time
+ * when they went through exp_core): float arithmetic only, 14 instructions instead of ~35 f64-heavy ones.  Deterministic
+ * like everything here (IEEE mul / add / fma, explicit fma only), within 1 ulp of the exact value (tests/test_math.py:
+ * max 1 ulp from the correctly rounded expr, equal on ~90 % of arguments) — NOT correctly rounded, and it need not be:
+ * the sky's radiance ends a path, no later decision of that path (lobe, light pick, roulette, hit / miss) depends on
+ * it, so a last-bit difference stays a 1e-7 relative difference of a pixel's value instead of a flipped path.
+ * RPT_SKY_EXACT_EXP = 1 routes it back through the correctly rounded expr. */
+#ifndef RPT_SKY_EXACT_EXP
+#define RPT_SKY_EXACT_EXP 0
+#endif
+RPT_HD float exp2i_f(int k) { return u2f((uint32_t)(k + 127) << 23); }       /* 2^k, k in [-126, 127] */
+RPT_HD float exp_sky(float x) {
+#if RPT_SKY_EXACT_EXP
+    return expr(x);
+#else
+    const float c[RPT_EXPF_C_N] = RPT_EXPF_C_INIT;
+    if (x != x) return x;
+    if (x > 89.0f) return u2f(0x7f800000u);
+    if (x < -104.0f) return 0.0f;
+    const float M = 12582912.0f;                        /* 1.5 * 2^23: round to nearest even integer, |t| < 2^22 */
+    float kf = (x * RPT_LOG2E_F + M) - M;
+    float r = __builtin_fmaf(-kf, RPT_LN2_HI_F, x);
+    r = __builtin_fmaf(-kf, RPT_LN2_LO_F, r);
+    float p = c[RPT_EXPF_C_N - 1];
+RPT_UNROLL
+    for (int i = RPT_EXPF_C_N - 2; i >= 0; --i) p = __builtin_fmaf(p, r, c[i]);
+    p = __builtin_fmaf(r * r, p, r) + 1.0f;             /* 1 + r + r^2 P(r) */
+    int k = (int)kf;
+    int k1 = k / 2, k2 = k - k1;                        /* 2^k in two normal factors: gradual underflow handled by the multiplies */
+    return (p * exp2i_f(k1)) * exp2i_f(k2);
+#endif
+}
+
 /* natural log of a positive finite double-representable float value */
 RPT_HD double log_core(double x) {
     RPT_COEF(k_atanh_c, RPT_ATANH_C);

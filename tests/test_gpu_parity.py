@@ -28,7 +28,7 @@ def _random_rays(rng, n, world):
     return o, d
 
 
-@pytest.mark.parametrize("op,lo,hi", [(0, -10, 10), (1, -10, 10), (2, -1, 1), (3, -100, 30), (5, -1, 1), (7, 0, 1e6)])
+@pytest.mark.parametrize("op,lo,hi", [(0, -10, 10), (1, -10, 10), (2, -1, 1), (3, -100, 30), (5, -1, 1), (7, 0, 1e6), (10, -110, 30)])
 def test_math_bitwise_device_vs_host(renderer, hipmod, oracle, op, lo, hi):
     rng = np.random.default_rng(op)
     x = rng.uniform(lo, hi, 1 << 20).astype(np.float32)
