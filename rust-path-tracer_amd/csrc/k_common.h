@@ -82,6 +82,9 @@ struct DevScene {
     const float4 *per_vertex;      /* 4 x float4 per rpt_per_vertex_data */
     const float4 *materials;       /* 6 x float4 per rpt_material_data */
     const rpt_light_pick_entry *light_pick;
+    const float4 *light_rec;       /* 8 x float4 per light-pick entry: for its triangle a, then b: (A | n.x) (B | n.y) (C | n.z) (emission | -),
+                                      n = the mean vertex normal of light_pick.rs:129 — what sample_direct_lighting gathers through the
+                                      index buffer, three 64-byte vertices and the material, in one 64-byte record */
     uint32_t n_light_pick;
     uint32_t n_nodes, n_triangles;
     uint32_t lds_scene;            /* the traversal image fits in RPT_LDS_SCENE_BYTES: traverse out of LDS */

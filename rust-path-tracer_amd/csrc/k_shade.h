@@ -364,16 +364,16 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                         const uint32_t light_index = pick_a ? e.triangle_index_a : e.triangle_index_b;
                         const float light_area = pick_a ? e.triangle_area_a : e.triangle_area_b;
                         const float light_pick_pdf = pick_a ? e.triangle_pick_pdf_a : e.triangle_pick_pdf_b;
-                        const uint4 lt = sc.indices[light_index];
-                        const float4 *la = sc.per_vertex + 4u * lt.x;
-                        const float4 *lb = sc.per_vertex + 4u * lt.y;
-                        const float4 *lc = sc.per_vertex + 4u * lt.z;
-                        const F3 light_normal = (xyz4(la[1]) + xyz4(lb[1]) + xyz4(lc[1])) / 3.0f;
-                        const F3 light_emission = xyz4(sc.materials[6u * lt.w]);
+                        /* the light triangle's corners, mean normal and emission: one 64-byte record built at upload
+                         * (was: index buffer -> three 64-byte vertices + the material, four dependent scattered loads) */
+                        const float4 *lr = sc.light_rec + 8u * idx + (pick_a ? 0u : 4u);
+                        const float4 lra = lr[0], lrb = lr[1], lrc = lr[2], lre = lr[3];
+                        const F3 light_normal = f3(lra.w, lrb.w, lrc.w);
+                        const F3 light_emission = xyz4(lre);
                         const float p1 = rng.next(), p2 = rng.next();
                         const float r1_sqrt = rptm::sqrtr(p1);
-                        const F3 light_point = (1.0f - r1_sqrt) * xyz4(la[0]) + (r1_sqrt * (1.0f - p2)) * xyz4(lb[0]) +
-                                               (r1_sqrt * p2) * xyz4(lc[0]);
+                        const F3 light_point = (1.0f - r1_sqrt) * xyz4(lra) + (r1_sqrt * (1.0f - p2)) * xyz4(lrb) +
+                                               (r1_sqrt * p2) * xyz4(lrc);
                         const F3 unorm = light_point - hit;
                         const float light_distance = len3(unorm);
                         const F3 light_direction = unorm / light_distance;

@@ -402,7 +402,7 @@ void rpt_destroy(rpt_ctx *c) {
     release_state(c);
     c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
-    c->indices.release(); c->light_pick.release(); c->atlas.release(); c->skybox.release();
+    c->indices.release(); c->light_pick.release(); c->light_rec.release(); c->atlas.release(); c->skybox.release();
     c->dev_stats.release();
     for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
     for (auto &b : c->timing_pending) for (hipEvent_t e : b.ev) (void)hipEventDestroy(e);
@@ -490,6 +490,27 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, hipMemcpy(c->materials.p, mats, nm * sizeof(rpt_material_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->indices.p, idx, nt * sizeof(rpt_triangle), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->light_pick.p, lp, nlp * sizeof(rpt_light_pick_entry), hipMemcpyHostToDevice));
+    {
+        /* per light-pick entry, for its two triangles: corners, the mean of the three vertex normals exactly as
+         * sample_direct_lighting forms it ((na + nb + nc) / 3.0, light_pick.rs:129), and the material's emission */
+        std::vector<float4> rec(8 * nlp, make_float4(0, 0, 0, 0));
+        if (!(lp[0].ratio < 0.0f))
+            for (size_t i = 0; i < nlp; ++i)
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t t = side ? lp[i].triangle_index_b : lp[i].triangle_index_a;
+                    const rpt_per_vertex_data &A = pv[idx[t].v0], &B = pv[idx[t].v1], &C = pv[idx[t].v2];
+                    float n[3];
+                    for (int k = 0; k < 3; ++k) n[k] = ((A.normal[k] + B.normal[k]) + C.normal[k]) / 3.0f;
+                    const float *em = mats[idx[t].material].emissive;
+                    float4 *r = &rec[8 * i + 4 * side];
+                    r[0] = make_float4(A.vertex[0], A.vertex[1], A.vertex[2], n[0]);
+                    r[1] = make_float4(B.vertex[0], B.vertex[1], B.vertex[2], n[1]);
+                    r[2] = make_float4(C.vertex[0], C.vertex[1], C.vertex[2], n[2]);
+                    r[3] = make_float4(em[0], em[1], em[2], 0.0f);
+                }
+        HIP_TRY(c, c->light_rec.alloc(rec.size()));
+        HIP_TRY(c, hipMemcpy(c->light_rec.p, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
 
     static const uint8_t magenta_u8[16] = {255, 0, 255, 255, 255, 0, 255, 255, 255, 0, 255, 255, 255, 0, 255, 255};
     static const float magenta_f[16] = {1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1};   /* src/asset.rs:283-290 */
@@ -504,7 +525,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     s.nodes = c->nodes.p; s.tri_geom = c->tri_geom.p; s.tri_shade = c->tri_shade.p; s.mat_lite = c->mat_lite.p;
     s.textured = textured;
     s.indices = c->indices.p; s.per_vertex = c->per_vertex.p;
-    s.materials = c->materials.p; s.light_pick = c->light_pick.p;
+    s.materials = c->materials.p; s.light_pick = c->light_pick.p; s.light_rec = c->light_rec.p;
     s.n_light_pick = (uint32_t)nlp;
     s.n_nodes = (uint32_t)nn;
     s.n_triangles = (uint32_t)nt;
