@@ -106,10 +106,8 @@ struct DevState {
     float4 *thr;          /* (thr.r, thr.g, thr.b, flags bits): what every bounce reads and rewrites */
     float4 *rad;          /* (rad.r, rad.g, rad.b, todo bits): touched only where radiance is added or a path ends — the shade stage
                              moves 16 B of path state per slot and pass each way instead of 32 (it runs at ~5 TB/s) */
-    float4 *mis0;         /* (light_area, ln.x, ln.y, ln.z)            nee == MIS only */
-    float4 *mis1;         /* (pick_pdf, em.r, em.g, em.b)                                */
-    float4 *mis2;         /* (light_tri bits, thr_pre.r, thr_pre.g, thr_pre.b)           */
-    float4 *mis3;         /* (bsdf_pdf, spec.r, spec.g, spec.b)                          */
+    float4 *mis_a;        /* (light-table entry * 2 + side bits, thr_pre.r, thr_pre.g, thr_pre.b)   nee == MIS only: last_light_sample */
+    float4 *mis_b;        /* (bsdf_pdf, spec.r, spec.g, spec.b)                                       last_bsdf_sample          */
     /* per PIXEL (pixel = slot >> group_shift): */
     uint2 *rng;           /* (n, offset), the reference's rng buffer */
     float4 *accum;        /* (sum r, sum g, sum b, sum 1), tile-major == pixel order */

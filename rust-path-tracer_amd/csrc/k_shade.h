@@ -205,19 +205,31 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                     radiance = radiance + mask_nan3(throughput * emissive);
                     done = true;
                 } else if (NEE == RPT_NEE_MIS) {                                         /* :104-108, last lobe is diffuse here */
-                    float4 m0 = st.mis0[slot], m1 = st.mis1[slot], m2 = st.mis2[slot], m3 = st.mis3[slot];
+                    /* last_light_sample / last_bsdf_sample (lib.rs:59-60): the light sample is carried as the table entry it
+                     * came from (its area, pick pdf, normal and emission are functions of the entry) + the throughput before
+                     * that bounce; the BSDF sample as pdf + spectrum — 32 bytes per slot instead of 64 */
+                    const float4 ma = st.mis_a[slot], mb = st.mis_b[slot];
+                    const uint32_t code = __float_as_uint(ma.x);
                     F3 contribution = f3s(0.0f);
-                    if (tri_index == __float_as_uint(m2.x)) {                            /* light_pick.rs:185 */
-                        F3 light_normal = f3(m0.y, m0.z, m0.w);
-                        float cos_theta = dot3(light_normal, -rd);                      /* last sampled_direction == rd */
-                        float light_pdf = cos_theta <= 0.0f ? 0.0f : rptm::powi2(hit_t) / (m0.x * cos_theta);
-                        if (light_pdf > 0.0f) {
-                            float bsdf_pdf = m3.x;
-                            float p1 = bsdf_pdf * bsdf_pdf;
-                            float weight = p1 / (p1 + light_pdf * light_pdf);
-                            F3 spectrum = f3(m3.y, m3.z, m3.w), emission = f3(m1.y, m1.z, m1.w);
-                            F3 direct = (spectrum * emission * weight / bsdf_pdf) / m1.x;
-                            contribution = f3(m2.y, m2.z, m2.w) * direct;
+                    if (code != 0xffffffffu) {                                           /* (0xffffffff: no light table, DirectLightSample::default()) */
+                        const rpt_light_pick_entry e = sc.light_pick[code >> 1];
+                        const bool side_b = (code & 1u) != 0u;
+                        const uint32_t light_tri = side_b ? e.triangle_index_b : e.triangle_index_a;
+                        if (tri_index == light_tri) {                                    /* light_pick.rs:185 */
+                            const float4 *lr = sc.light_rec + 8u * (code >> 1) + (side_b ? 4u : 0u);
+                            const float light_area = side_b ? e.triangle_area_b : e.triangle_area_a;
+                            const float light_pick_pdf = side_b ? e.triangle_pick_pdf_b : e.triangle_pick_pdf_a;
+                            F3 light_normal = f3(lr[0].w, lr[1].w, lr[2].w);
+                            float cos_theta = dot3(light_normal, -rd);                  /* last sampled_direction == rd */
+                            float light_pdf = cos_theta <= 0.0f ? 0.0f : rptm::powi2(hit_t) / (light_area * cos_theta);
+                            if (light_pdf > 0.0f) {
+                                float bsdf_pdf = mb.x;
+                                float p1 = bsdf_pdf * bsdf_pdf;
+                                float weight = p1 / (p1 + light_pdf * light_pdf);
+                                F3 spectrum = f3(mb.y, mb.z, mb.w), emission = xyz4(lr[3]);
+                                F3 direct = (spectrum * emission * weight / bsdf_pdf) / light_pick_pdf;
+                                contribution = f3(ma.y, ma.z, ma.w) * direct;
+                            }
                         }
                     }
                     load_rad();
@@ -347,11 +359,7 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                 if (nee && !spec) {
                     if (sc.no_lights) {
                         /* sentinel: DirectLightSample::default() — zero contribution, zeroed carry */
-                        if (NEE == RPT_NEE_MIS) {
-                            st.mis0[slot] = make_float4(0, 0, 0, 0);
-                            st.mis1[slot] = make_float4(0, 0, 0, 0);
-                            st.mis2[slot] = make_float4(__uint_as_float(0u), 0, 0, 0);
-                        }
+                        if (NEE == RPT_NEE_MIS) st.mis_a[slot] = make_float4(__uint_as_float(0xffffffffu), 0, 0, 0);
                     } else {
                         const float l1 = rng.next(), l2 = rng.next();
                         uint32_t idx = rptm::f2u32_sat(l1 * (float)sc.n_light_pick);
@@ -361,7 +369,6 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                         }
                         const rpt_light_pick_entry e = sc.light_pick[idx];
                         const bool pick_a = l2 < e.ratio;
-                        const uint32_t light_index = pick_a ? e.triangle_index_a : e.triangle_index_b;
                         const float light_area = pick_a ? e.triangle_area_a : e.triangle_area_b;
                         const float light_pick_pdf = pick_a ? e.triangle_pick_pdf_a : e.triangle_pick_pdf_b;
                         /* the light triangle's corners, mean normal and emission: one 64-byte record built at upload
@@ -407,14 +414,11 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                         sh_o = make_float4(so.x, so.y, so.z, light_distance - RPT_EPS * 2.0f);
                         sh_d = make_float4(light_direction.x, light_direction.y, light_direction.z, 0.0f);
                         sh_c = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
-                        if (NEE == RPT_NEE_MIS) {
-                            st.mis0[slot] = make_float4(light_area, light_normal.x, light_normal.y, light_normal.z);
-                            st.mis1[slot] = make_float4(light_pick_pdf, light_emission.x, light_emission.y, light_emission.z);
-                            st.mis2[slot] = make_float4(__uint_as_float(light_index), throughput.x, throughput.y, throughput.z);
-                        }
+                        if (NEE == RPT_NEE_MIS)
+                            st.mis_a[slot] = make_float4(__uint_as_float(2u * idx + (pick_a ? 0u : 1u)), throughput.x, throughput.y, throughput.z);
                     }
                 }
-                if (NEE == RPT_NEE_MIS) st.mis3[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
+                if (NEE == RPT_NEE_MIS) st.mis_b[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
 
                 /* ---- attenuate, respawn, roulette (lib.rs:168-181) ---- */
                 throughput = throughput * (spectrum / pdf);

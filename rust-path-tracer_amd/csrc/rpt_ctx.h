@@ -85,7 +85,7 @@ struct rpt_ctx {
     /* state */
     bool has_state = false;
     DevBuf<float2> ray_b, hit;
-    DevBuf<float4> ray_a, thr, rad, mis0, mis1, mis2, mis3, accum;
+    DevBuf<float4> ray_a, thr, rad, mis_a, mis_b, accum;
     DevBuf<uint2> rng;
     DevBuf<uint32_t> q_sky, q_count;
     DevBuf<unsigned long long> ray_shards;

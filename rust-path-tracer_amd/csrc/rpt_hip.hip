@@ -133,7 +133,7 @@ void mat3_mul_host(const float *a, const float *b, float *out) {   /* Mat3 * Mat
 
 void release_state(rpt_ctx *c) {
     c->ray_a.release(); c->ray_b.release(); c->hit.release(); c->thr.release(); c->rad.release();
-    c->mis0.release(); c->mis1.release(); c->mis2.release(); c->mis3.release();
+    c->mis_a.release(); c->mis_b.release();
     c->accum.release(); c->rng.release();
     c->q_sky.release(); c->q_count.release(); c->ray_shards.release();
     c->sh_o.release(); c->sh_d.release(); c->sh_c.release();
@@ -146,7 +146,7 @@ int alloc_state(rpt_ctx *c) {
     size_t n = c->max_slots, np = c->n_pixels;
     HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n)); HIP_TRY(c, c->hit.alloc(n));
     HIP_TRY(c, c->thr.alloc(n)); HIP_TRY(c, c->rad.alloc(n));
-    HIP_TRY(c, c->mis0.alloc(n)); HIP_TRY(c, c->mis1.alloc(n)); HIP_TRY(c, c->mis2.alloc(n)); HIP_TRY(c, c->mis3.alloc(n));
+    HIP_TRY(c, c->mis_a.alloc(n)); HIP_TRY(c, c->mis_b.alloc(n));
     HIP_TRY(c, c->accum.alloc(np)); HIP_TRY(c, c->rng.alloc(np));
     HIP_TRY(c, c->q_sky.alloc(n));
     HIP_TRY(c, c->ray_shards.alloc(RPT_STAT_SHARDS * RPT_STAT_STRIDE));
@@ -159,7 +159,7 @@ int alloc_state(rpt_ctx *c) {
     if (n) k_fill_idle<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, c->stream>>>(c->hit.p, (uint32_t)n);   /* nothing in flight */
     DevState &s = c->state;
     s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.hit = c->hit.p; s.thr = c->thr.p; s.rad = c->rad.p;
-    s.mis0 = c->mis0.p; s.mis1 = c->mis1.p; s.mis2 = c->mis2.p; s.mis3 = c->mis3.p;
+    s.mis_a = c->mis_a.p; s.mis_b = c->mis_b.p;
     s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = (uint32_t)n;
     s.n_pixels = (uint32_t)np; s.group_shift = c->group_shift;
     DevQueues &q = c->queues;
