@@ -111,7 +111,7 @@ def main():
         report("if-if (one step per iter)", [sim_if_if(*wv) for wv in waves], n_rays)
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold", "sort", "regroup", "stream")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("refill", "threshold", "sort", "regroup", "stream", "plateau")):
     main()
 
 
@@ -446,3 +446,123 @@ def main_stream():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stream":
     main_stream()
+
+
+def main_plateau():
+    """Round-2 analysis behind DESIGN.md §8 item 2: the streamed walk with one body per trip (the kernel as built: 8 trips
+    between looks, refill at >= 12 idle lanes, costs 75 / 70 / 120 VALU per inner / leaf / refill step) replayed on real
+    bounce-1 / bounce-2 rays of DarkCornell — (a) dealt in slot order, (b) dealt sorted by direction octant / direction
+    cell / origin cell / TRUE walk length inside 4 096-slot spans, (c) with 1, 2 or 3 rays per lane."""
+    scene = "DarkCornell"
+    W = H = 128
+    orc = Oracle()
+    w = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    sc = orc.scene(w)
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    order = hip.tile_order(W, H, 0, 1)
+    px = (order >> 16).astype(np.int64) * W + (order & 0xFFFF).astype(np.int64)
+    CI,CL=75.0,70.0
+    def sim_g(ev,ln,valid,R,T,F,CR,alpha=1.0):
+        tot=dict(inner=0.0,leaf=0.0,refill=0.0,inner_l=0,leaf_l=0,inner_s=0,leaf_s=0)
+        n=len(ln); span=R*64
+        for base in range(0,n,span):
+            idx=[i for i in range(base,min(base+span,n))]
+            nxt=0; ray=[-1]*64; pos=[0]*64
+            while True:
+                idle=[l for l in range(64) if ray[l]<0]
+                if nxt<len(idx) and len(idle)>=F:
+                    for l in idle:
+                        if nxt<len(idx):
+                            i=idx[nxt]; nxt+=1
+                            if valid[i] and ln[i]>0: ray[l]=i; pos[l]=0
+                    tot['refill']+=CR; continue
+                if len(idle)==64: break
+                budget=T if nxt<len(idx) else 10**9
+                t=0
+                while t<budget:
+                    live=[l for l in range(64) if ray[l]>=0]
+                    if not live: break
+                    inner=[l for l in live if ev[ray[l],pos[l]]==0]
+                    leaf=[l for l in live if ev[ray[l],pos[l]]==1]
+                    if len(leaf)>alpha*len(inner): step=leaf; tot['leaf']+=CL; tot['leaf_l']+=len(leaf); tot['leaf_s']+=1
+                    else: step=inner; tot['inner']+=CI; tot['inner_l']+=len(inner); tot['inner_s']+=1
+                    for l in step:
+                        pos[l]+=1
+                        if pos[l]>=ln[ray[l]]: ray[l]=-1
+                    t+=1
+        return tot
+    for bounce in (1,2):
+        rays=np.zeros((W*H,6),np.float32); valid=np.zeros(W*H,np.uint8)
+        orc.lib.oracle_dump_rays(C.byref(cfg),C.byref(sc),seeds.ctypes.data_as(C.c_void_p),C.c_uint32(bounce),rays.ctypes.data_as(C.c_void_p),valid.ctypes.data_as(C.c_void_p))
+        rays,valid=rays[px],valid[px]
+        ev,ln=events_for(orc,sc,np.ascontiguousarray(rays[:,:3]),np.ascontiguousarray(rays[:,3:]))
+        ln=np.where(valid==1,ln,0)
+        N=16384
+        evs,lns,vs,rs=ev[:N],ln[:N],valid[:N],rays[:N]; n=int(vs.sum())
+        ninner=sum(int((evs[i,:lns[i]]==0).sum()) for i in range(N)); nleaf=sum(int((evs[i,:lns[i]]==1).sum()) for i in range(N))
+        ideal=(ninner*CI+nleaf*CL)/64/n
+        def run(name,perm):
+            t=sim_g(evs[perm],lns[perm],vs[perm],64,8,12,120,1.0)
+            c=(t['inner']+t['leaf']+t['refill'])/n
+            print(f"  bounce {bounce} {name:34s} cyc/ray {c:6.1f} util {ideal/c*100:5.1f}% inner lanes {t['inner_l']/max(t['inner_s'],1):5.1f} leaf lanes {t['leaf_l']/max(t['leaf_s'],1):5.1f}")
+        ident=np.arange(N)
+        run("slot order",ident)
+        d=rs[:,3:6]; o=rs[:,:3]
+        octant=(d[:,0]>0)*1+(d[:,1]>0)*2+(d[:,2]>0)*4
+        span=4096
+        def sort_in_spans(key):
+            perm=np.concatenate([b+np.argsort(key[b:b+span],kind='stable') for b in range(0,N,span)])
+            return perm
+        run("octant within 4096",sort_in_spans(octant))
+        # finer: octahedral 8x8 direction cell
+        ad=np.abs(d).sum(1,keepdims=True); pxy=d[:,:2]/ad
+        neg=d[:,2]<0
+        ox=np.where(neg,(1-np.abs(pxy[:,1]))*np.sign(pxy[:,0]),pxy[:,0]); oy=np.where(neg,(1-np.abs(pxy[:,0]))*np.sign(pxy[:,1]),pxy[:,1])
+        cx=np.clip(((ox+1)*4).astype(int),0,7); cy=np.clip(((oy+1)*4).astype(int),0,7)
+        run("dir cell 8x8 within 4096",sort_in_spans(cx*8+cy))
+        lo=o.min(0); hi=o.max(0); oc=np.clip(((o-lo)/(hi-lo+1e-6)*4).astype(int),0,3)
+        okey=oc[:,0]*16+oc[:,1]*4+oc[:,2]
+        run("origin cell 4^3 then dir 8x8",sort_in_spans(okey*64+cx*8+cy))
+        run("dir 8x8 then origin 4^3",sort_in_spans((cx*8+cy)*64+okey))
+        run("walk length (oracle knowledge)",sort_in_spans(lns))
+    print("---- two rays per lane")
+    def sim_2(ev,ln,valid,CR,K=2):
+        n=len(ln); tot=0.0; inner_l=leaf_l=inner_s=leaf_s=0
+        nxt=0; ray=[[-1]*K for _ in range(64)]; pos=[[0]*K for _ in range(64)]
+        def refill():
+            nonlocal nxt,tot
+            cnt=0
+            for l in range(64):
+                for k in range(K):
+                    if ray[l][k]<0 and nxt<n:
+                        while nxt<n and not (valid[nxt] and ln[nxt]>0): nxt+=1
+                        if nxt<n: ray[l][k]=nxt; pos[l][k]=0; nxt+=1; cnt+=1
+            if cnt: tot+=CR
+        trips=0
+        while True:
+            nidle=sum(1 for l in range(64) for k in range(K) if ray[l][k]<0)
+            if nxt<n and nidle>=12*K and trips%8==0: refill()
+            live=[(l,k) for l in range(64) for k in range(K) if ray[l][k]>=0]
+            if not live:
+                if nxt>=n: break
+                refill(); continue
+            inner_lanes={}; leaf_lanes={}
+            for l,k in live:
+                t=ev[ray[l][k],pos[l][k]]
+                (inner_lanes if t==0 else leaf_lanes).setdefault(l,k)
+            if len(leaf_lanes)>len(inner_lanes): step=leaf_lanes; tot+=CL; leaf_l+=len(step); leaf_s+=1
+            else: step=inner_lanes; tot+=CI; inner_l+=len(step); inner_s+=1
+            for l,k in step.items():
+                pos[l][k]+=1
+                if pos[l][k]>=ln[ray[l][k]]: ray[l][k]=-1
+            trips+=1
+        return tot,inner_l/max(inner_s,1),leaf_l/max(leaf_s,1)
+    for K in (1,2,3):
+        t,il,ll=sim_2(evs,lns,vs,120,K)
+        print(f"  bounce {bounce} K={K} rays/lane: cyc/ray {t/n:6.1f} util {ideal/(t/n)*100:5.1f}% inner lanes {il:5.1f} leaf lanes {ll:5.1f}")
+
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "plateau":
+    main_plateau()
