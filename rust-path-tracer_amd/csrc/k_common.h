@@ -76,6 +76,8 @@ struct DevScene {
     const float4 *nodes;           /* 2 x float4 per rpt_bvh_node, reference layout */
     const float4 *tri_geom;        /* 3 x float4 per triangle: (a | d00), (e1 = b-a | d01), (e2 = c-a | d11);
                                       dNN = the triangle-constant dot products of util::barycentric */
+    const float *tri_isect;        /* 9 floats per triangle: e1, e2, a — what the intersection test reads, packed (36 instead of 48 bytes:
+                                      the walk of a 1 M-triangle scene is bound by these bytes, profiles/r02_deepbvh_*) */
     const float4 *tri_shade;       /* 4 x float4 per triangle: (na | uva.x) (nb | uva.y) (nc | material) (uvb, uvc) */
     const float4 *mat_lite;        /* 2 x float4 per material: (emissive.rgb | roughness.x) (albedo.rgb | metallic.x) */
     const uint4 *indices;          /* rpt_triangle */

@@ -68,7 +68,8 @@ __device__ __forceinline__ bool slab_test(float4 lo, float4 hi, F3 ro, F3 rd, F3
  * ballot of a compare is the compare itself; a ballot of a loop-carried bool costs two more VALU instructions). */
 struct SceneViewGlobal {
     static constexpr bool kCoopLeaves = true;               /* leaves may hold dozens of triangles: see walk_run */
-    const float4 *nodes, *tri_geom;
+    const float4 *nodes;
+    const float *tri_isect;
     typedef uint2 Cur;                                      /* x = triangle_count, y = left child / first triangle */
     __device__ __forceinline__ Cur root() const { return make_uint2(__float_as_uint(nodes[0].w), __float_as_uint(nodes[1].w)); }
     __device__ __forceinline__ static bool is_inner(Cur c) { return c.x == 0u; }
@@ -87,8 +88,14 @@ struct SceneViewGlobal {
     __device__ __forceinline__ Cur from_entry(uint32_t e) const {
         return make_uint2(__float_as_uint(nodes[2u * e].w), __float_as_uint(nodes[2u * e + 1u].w));
     }
-    __device__ __forceinline__ void edges(uint32_t ti, F3 &e1, F3 &e2) const { e1 = xyz4(tri_geom[3u * ti + 1u]); e2 = xyz4(tri_geom[3u * ti + 2u]); }
-    __device__ __forceinline__ F3 corner(uint32_t ti) const { return xyz4(tri_geom[3u * ti]); }
+    __device__ __forceinline__ void edges(uint32_t ti, F3 &e1, F3 &e2) const {
+        const float *p = tri_isect + 9u * (size_t)ti;
+        e1 = f3(p[0], p[1], p[2]); e2 = f3(p[3], p[4], p[5]);
+    }
+    __device__ __forceinline__ F3 corner(uint32_t ti) const {
+        const float *p = tri_isect + 9u * (size_t)ti + 6u;
+        return f3(p[0], p[1], p[2]);
+    }
 };
 
 /* The LDS-resident image of a small scene, built once at upload (rpt_hip.hip, build_lds_image) and copied into
@@ -511,7 +518,7 @@ __device__ __forceinline__ SceneViewLds stage_scene_lds(const DevScene &sc, floa
 template <bool LDS_SCENE, int THREADS>
 __device__ __forceinline__ typename SceneViewOf<LDS_SCENE>::type stage_scene(const DevScene &sc, float4 *lds_scene) {
     if constexpr (LDS_SCENE) return stage_scene_lds<THREADS>(sc, lds_scene);
-    else return SceneViewGlobal{sc.nodes, sc.tri_geom};
+    else return SceneViewGlobal{sc.nodes, sc.tri_isect};
 }
 
 /* Extension rays.  Thread i owns slot i; it traces the slot's ray if one is
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene 
         raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
         atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)count);
     }
-    const SceneViewGlobal view{sc.nodes, sc.tri_geom};
+    const SceneViewGlobal view{sc.nodes, sc.tri_isect};
     StackT *stack = &lds_stack[0][lane];
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     Walk<SceneViewGlobal> w;
@@ -969,7 +976,7 @@ __global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene s
     if (begin >= n) return;
     const uint32_t end = begin + SPAN < n ? begin + SPAN : n;
     {
-        const SceneViewGlobal view{sc.nodes, sc.tri_geom};
+        const SceneViewGlobal view{sc.nodes, sc.tri_isect};
         StackT *stack = &lds_stack[0][lane];
         F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
         float max_t = 0.0f;

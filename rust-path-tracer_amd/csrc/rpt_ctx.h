@@ -62,6 +62,7 @@ struct rpt_ctx {
     bool has_scene = false;
     DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials, lds_image, light_rec;
     DevBuf<uint4> indices;
+    DevBuf<float> tri_isect;
     DevBuf<rpt_light_pick_entry> light_pick;
     DevBuf<uchar4> atlas;
     DevBuf<float4> skybox;

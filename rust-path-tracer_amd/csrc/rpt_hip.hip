@@ -400,7 +400,7 @@ void rpt_destroy(rpt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rpt_comm_release(c);
     release_state(c);
-    c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_shade.release(); c->mat_lite.release();
+    c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_isect.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->light_rec.release(); c->atlas.release(); c->skybox.release();
     c->dev_stats.release();
@@ -486,6 +486,16 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, c->light_pick.alloc(nlp));
     HIP_TRY(c, hipMemcpy(c->nodes.p, nodes, nn * sizeof(rpt_bvh_node), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->tri_geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+    {
+        std::vector<float> isect(9 * nt);
+        for (size_t i = 0; i < nt; ++i) {
+            const float4 &a = geom[3 * i], &e1 = geom[3 * i + 1], &e2 = geom[3 * i + 2];
+            float *p = &isect[9 * i];
+            p[0] = e1.x; p[1] = e1.y; p[2] = e1.z; p[3] = e2.x; p[4] = e2.y; p[5] = e2.z; p[6] = a.x; p[7] = a.y; p[8] = a.z;
+        }
+        HIP_TRY(c, c->tri_isect.alloc(isect.size()));
+        HIP_TRY(c, hipMemcpy(c->tri_isect.p, isect.data(), isect.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMemcpy(c->per_vertex.p, pv, nv * sizeof(rpt_per_vertex_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->materials.p, mats, nm * sizeof(rpt_material_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->indices.p, idx, nt * sizeof(rpt_triangle), hipMemcpyHostToDevice));
@@ -522,7 +532,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, hipMemcpy(c->skybox.p, skybox, (size_t)sw * sh * 16, hipMemcpyHostToDevice));
 
     DevScene &s = c->scene;
-    s.nodes = c->nodes.p; s.tri_geom = c->tri_geom.p; s.tri_shade = c->tri_shade.p; s.mat_lite = c->mat_lite.p;
+    s.nodes = c->nodes.p; s.tri_geom = c->tri_geom.p; s.tri_isect = c->tri_isect.p; s.tri_shade = c->tri_shade.p; s.mat_lite = c->mat_lite.p;
     s.textured = textured;
     s.indices = c->indices.p; s.per_vertex = c->per_vertex.p;
     s.materials = c->materials.p; s.light_pick = c->light_pick.p; s.light_rec = c->light_rec.p;
