@@ -284,12 +284,16 @@ def main():
     roofline = None
     if kms[dominant] > 0:
         avg_ms = kms[dominant] / max(klaunch[dominant], 1)
-        if dominant == "traverse":
-            units = delta("extension_rays") / max(klaunch[dominant], 1)
-            bytes_per_unit = TRAVERSE_BYTES_PER_RAY
-        else:   # report the stage against the whole-pipeline per-ray figure
-            units = delta("extension_rays") / max(klaunch[dominant], 1)
-            bytes_per_unit = 128
+        # algorithmic bytes per unit of the stage's OWN traffic and the unit it is counted in
+        stage_model = {
+            "traverse": ("extension_rays", TRAVERSE_BYTES_PER_RAY),          # hit word 8 + ray 24 read, hit record 8 written
+            "shade": ("extension_rays", 96),                                  # hit 8 + ray 24 + thr 16 read, ray 24 + hit 8 + thr 16 written
+            "shadow": ("shadow_rays", 80),                                    # entry 32 + contribution 16 read, radiance 16 + 16 RMW
+            "sky": ("sky_evals", 76),                                         # slot id 4 + ray 24 + thr 16 + rad 16 read, rad 16 written
+            "generate": ("samples", 80),
+        }
+        unit_key, bytes_per_unit = stage_model[dominant]
+        units = delta(unit_key) / max(klaunch[dominant], 1)
         achieved = bytes_per_unit * units / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes kept under profiles/ (tools/profile_workload.sh).
         # PMC counters cannot be collected from inside this process, so the figure is only reported when it was measured
@@ -313,7 +317,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[dominant]),
-                    "units_per_launch": round(units, 1), "algorithmic_bytes_per_unit": bytes_per_unit,
+                    "units_per_launch": round(units, 1), "units_are": unit_key, "algorithmic_bytes_per_unit": bytes_per_unit,
                     "stage_ms": {k: round(v, 3) for k, v in kms.items()}}
     pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
     pipeline_gbs = pipeline_bytes / elapsed_max / 1e9
