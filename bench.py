@@ -162,18 +162,24 @@ def main():
     if world_size > 1 or args.with_gather:
         want = args.gather if args.dist_backend == "nccl" else "torch"
         if want == "rccl":
-            try:
-                ids = [hip.comm_unique_id() if rank == 0 else None]
-                if world_size > 1:
-                    dist.broadcast_object_list(ids, src=0, device=torch.device(comm_device))
-                r.comm_init(ids[0], rank, world_size)
-                gather_impl = "rccl-c-abi"
-            except Exception as e:                                   # noqa: BLE001 — recorded, never silent
-                gather_note = f"{type(e).__name__}: {e}"
-                ok = torch.tensor([0.0], device=comm_device)
-            else:
-                gather_note = None
-                ok = torch.tensor([1.0], device=comm_device)
+            gather_note = None
+            uid = None
+            if rank == 0:
+                try:
+                    uid = hip.comm_unique_id()
+                except Exception as e:                               # noqa: BLE001 — recorded, never silent
+                    gather_note = f"{type(e).__name__}: {e}"
+            ids = [uid]
+            if world_size > 1:                                       # every rank takes part, whatever rank 0 got
+                dist.broadcast_object_list(ids, src=0, device=torch.device(comm_device))
+            ok = torch.tensor([0.0], device=comm_device)
+            if ids[0] is not None:
+                try:
+                    r.comm_init(ids[0], rank, world_size)
+                    gather_impl = "rccl-c-abi"
+                    ok = torch.tensor([1.0], device=comm_device)
+                except Exception as e:                               # noqa: BLE001
+                    gather_note = f"{type(e).__name__}: {e}"
             if world_size > 1:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok[0]) < 1.0:
