@@ -120,6 +120,7 @@ __device__ F3 sky_scatter_wide(const float *sun4, F3 origin, F3 direction, uint3
  * DarkCornell run).  It is also the last kernel of an iteration, so its first thread reports progress to
  * the host through mapped pinned memory: work remains iff a ray was traced, a sample was started, or
  * misses are waiting. */
+template <bool STRIDED>
 __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
                                                    DevStats *stats) {
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
@@ -135,10 +136,15 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
     if (drained != 0u) return;                                 /* surplus launch (grid-uniform) */
     if (n < q.sky_threshold && alive != 0u) return;          /* not worth a pass yet (same test as k_traverse_nearest) */
     if (i == 0u && n) atomicAdd(&stats->sky_evals, (unsigned long long)n);
+    /* STRIDED: a fixed grid of a few thousand workgroups walks the queue with a grid stride.  On a closed scene the queue
+     * holds a few thousand misses, and a launch of n_slots / 256 workgroups that all just look at the counter costs 54 us per
+     * iteration (profiles/r02_darkcornell_kernel_stats.csv) — 8 % of a batch on 1/8 of an image.  As a loop the march needs
+     * 133 instead of 92 VGPRs (its constants are hoisted), so scenes with many misses keep one thread per entry; the host
+     * picks the variant from the share of samples that ended in the sky so far (refresh_device_stats). */
+    const uint32_t stride = STRIDED ? gridDim.x * RPT_BLOCK : 0u;
     if (cfg.c.has_skybox == 0u && n <= q.sky_wide_limit) {
         /* few misses: 16 lanes per miss (block-uniform branch) */
-        const uint32_t m = i >> 4;
-        if (m < n) {
+        for (uint32_t m = i >> 4; m < n; m += stride >> 4) {
             const uint32_t slot = q.sky[m];
             const uint32_t lane = __lane_id(), g0 = lane & ~15u, j = lane & 15u;
             float4 ra = st.ray_a[slot];
@@ -151,10 +157,11 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
                 radiance = radiance + throughput * sky;                                       /* lib.rs:69 */
                 finish_in_side_stage(st, cfg, slot, radiance, __float_as_uint(r4.w));
             }
+            if (!STRIDED) break;
         }
         return;
     }
-    if (i < n) {
+    for (; i < n; i += stride) {
         uint32_t slot = q.sky[i];
         float4 ra = st.ray_a[slot];
         float2 rb = st.ray_b[slot];
@@ -173,6 +180,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
         }
         /* a miss always ends the path (lib.rs:79) */
         finish_in_side_stage(st, cfg, slot, radiance, __float_as_uint(r4.w));
+        if (!STRIDED) break;
     }
 }
 

@@ -294,7 +294,10 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         }
     }
     mark();
-    if (!shade_only) k_sky<<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
+    if (!shade_only) {
+        if (c->sky_strided && blocks > c->sky_blocks) k_sky<true><<<c->sky_blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
+        else k_sky<false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
+    }
     mark();
 }
 
@@ -387,6 +390,9 @@ int rpt_create(int device_id, rpt_ctx **out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->stream_max_blocks = 2u * (uint32_t)prop.multiProcessorCount;
     }
+    c->sky_blocks = 16u * c->stream_max_blocks / 2u;       /* 16 workgroups of 256 per CU: the sky stage strides over its queue */
+    if (const char *e13 = getenv("RPT_SKY_BLOCKS")) c->sky_blocks = (uint32_t)std::max(1, atoi(e13));
+    if (const char *e14 = getenv("RPT_SKY_STRIDED")) { c->sky_strided_mode = e14[0] != '0' ? 1 : 0; c->sky_strided = c->sky_strided_mode == 1; }
     if (const char *e5 = getenv("RPT_STREAM_MAX_BLOCKS")) c->stream_max_blocks = (uint32_t)std::max(1, atoi(e5));
     if (const char *e8 = getenv("RPT_STREAM_SPAN")) c->stream_span = (uint32_t)std::max(0, atoi(e8));
     if (const char *e3 = getenv("RPT_SAMPLES_IN_FLIGHT")) c->samples_in_flight_request = std::min(32, std::max(0, atoi(e3)));
@@ -679,6 +685,8 @@ static int refresh_device_stats(rpt_ctx *c, const char *what) {
     }
     if (c->shade_compact_mode < 0 && c->stats.samples != 0ull)
         c->shade_compact = (double)ds.sky_evals > c->shade_compact_at * (double)c->stats.samples;
+    /* the sky stage walks its queue with a small fixed grid when misses are rare (k_sky<STRIDED>: see there) */
+    if (c->sky_strided_mode < 0 && c->stats.samples != 0ull) c->sky_strided = (double)ds.sky_evals < 0.05 * (double)c->stats.samples;
     return RPT_OK;
 }
 

@@ -468,14 +468,16 @@ def test_host_dispatch_trace_gpu_furnace(rpt):
 @pytest.mark.parametrize("knob", ["RPT_LDS_STREAM=0", "RPT_NO_LDS_SCENE=1", "RPT_NO_FASTDIV=1", "RPT_SKY_THRESHOLD=4096",
                                   "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MAX_BLOCKS=7", "RPT_STREAM_SPAN=1024", "RPT_GSTREAM=0",
                                   "RPT_SHADE_COMPACT=1", "RPT_LDS_SHADOW_STREAM=0", "RPT_MAX_SLOTS=65536",
-                                  "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2"])
+                                  "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=3",
+                                  "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=5,RPT_SKY_WIDE_LIMIT=1000000", "RPT_SKY_STRIDED=0"])
 def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world, knob):
     """README: every tuning knob leaves the image bit-identical (they select kernels / schedules, never arithmetic)."""
     W, H, spp = 160, 96, 6
     cfg = rpt.default_config(W, H, nee=1)
     seeds = rpt.blue_noise_seeds(W, H)
 
-    scene = "VeachMIS" if knob.startswith("RPT_GSTREAM") else "DarkCornell"     # (the global-memory walk / the LDS walk)
+    # (the global-memory walk / a scene open to the sky / the LDS walk)
+    scene = "VeachMIS" if knob.startswith("RPT_GSTREAM") else "PBRTest" if knob.startswith("RPT_SKY_STRIDED") else "DarkCornell"
 
     def render():
         r = hipmod.Renderer(0)
@@ -489,8 +491,9 @@ def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world
         return acc, (st["extension_rays"], st["shadow_rays"], st["sky_evals"])
 
     base = render()
-    name, value = knob.split("=")
-    monkeypatch.setenv(name, value)
+    for one in knob.split(","):
+        name, value = one.split("=")
+        monkeypatch.setenv(name, value)
     got = render()
     assert got[1] == base[1]
     assert np.array_equal(got[0].view(np.uint32), base[0].view(np.uint32))
