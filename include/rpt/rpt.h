@@ -251,6 +251,11 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
 int rpt_debug_math(rpt_ctx *ctx, int op, const float *x, const float *y, float *out, size_t n);
 /* Same on the HOST build (no device needed, ctx may be NULL). */
 int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size_t n);
+/* Exhaustive device-side check of a cheap exact operation of rpt_math.h against its IEEE form over the float bit patterns
+ * [lo_bits, lo_bits + count): op 0 sqrtr vs the correctly rounded sqrtf, op 1 div_const_nontiny(x, y, RN(1/y)) vs x / y.  Returns the
+ * number of arguments whose results differ in any bit (NaN == NaN) and the smallest such bit pattern (0xffffffff if none). */
+int rpt_debug_math_sweep(rpt_ctx *ctx, int op, uint32_t lo_bits, uint64_t count, float y, uint64_t *mismatches_out,
+                         uint32_t *first_bad_bits_out);
 /* Trace n rays through the uploaded BVH on the device. any_hit = 0: nearest
  * (kernels/src/intersection.rs:169-171) ; 1: any-hit with max_t
  * (:173-175).  Outputs per ray: t, triangle_index, flags (bit0 hit, bit1 backface). */

@@ -33,7 +33,9 @@ __device__ __forceinline__ float sky_escape(F3 p, F3 d, float r) {
 }
 __device__ __forceinline__ float2 sky_densities(F3 p) {
     float h = rptm::fmaxr(len3(p - f3(0.0f, -SKY_EARTH_RADIUS, 0.0f)) - SKY_EARTH_RADIUS, 0.0f);
-    return make_float2(rptm::exp_sky(-h / SKY_H_RAY), rptm::exp_sky(-h / SKY_H_MIE));
+    /* h is 0, NaN, or a multiple of ulp(SKY_EARTH_RADIUS) = 0.5 (a difference of two floats >= 6.36e6): never tiny */
+    return make_float2(rptm::exp_sky(rptm::div_const_nontiny(-h, SKY_H_RAY, 1.0f / SKY_H_RAY)),
+                       rptm::exp_sky(rptm::div_const_nontiny(-h, SKY_H_MIE, 1.0f / SKY_H_MIE)));
 }
 
 __device__ F3 sky_scatter(const float *sun4, F3 origin, F3 direction) {

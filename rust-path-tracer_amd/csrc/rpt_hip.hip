@@ -1021,6 +1021,44 @@ int rpt_debug_math(rpt_ctx *c, int op, const float *x, const float *y, float *ou
     return RPT_OK;
 }
 
+/* Exhaustive check of a cheap exact operation against its IEEE form, over the bit patterns [lo_bits, lo_bits + count):
+ * op 0: rptm::sqrtr == the compiler's correctly rounded sqrtf (trivially, today: the hook experiments with cheaper roots used); op 1: rptm::div_const_nontiny(x, y, RN(1 / y)) == x / y. */
+__global__ void k_debug_math_sweep(int op, uint32_t lo_bits, unsigned long long count, float y, float ry, unsigned long long *out) {
+    unsigned long long bad = 0ull;
+    uint32_t first = 0xffffffffu;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t bits = lo_bits + (uint32_t)i;
+        const float x = rptm::u2f(bits);
+        const float fast = op == 0 ? rptm::sqrtr(x) : rptm::div_const_nontiny(x, y, ry);
+        const float ieee = op == 0 ? __builtin_sqrtf(x) : x / y;
+        const bool same = rptm::f2u(fast) == rptm::f2u(ieee) || (fast != fast && ieee != ieee);
+        if (!same) { bad += 1ull; first = first < bits ? first : bits; }
+    }
+    if (bad != 0ull) {
+        atomicAdd(&out[0], bad);
+        atomicMin(&out[1], (unsigned long long)first);
+    }
+}
+
+int rpt_debug_math_sweep(rpt_ctx *c, int op, uint32_t lo_bits, uint64_t count, float y, uint64_t *mismatches_out, uint32_t *first_bad_bits_out) {
+    if (!c || op < 0 || op > 1 || !mismatches_out || count > 0x100000000ull) return RPT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<unsigned long long> d;
+    HIP_TRY(c, d.alloc(2));
+    unsigned long long h[2] = {0ull, 0xffffffffull};
+    hipError_t e = hipMemcpy(d.p, h, sizeof(h), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_debug_math_sweep<<<4096, 256, 0, c->stream>>>(op, lo_bits, (unsigned long long)count, y, 1.0f / y, d.p);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(h, d.p, sizeof(h), hipMemcpyDeviceToHost);
+    d.release();
+    HIP_TRY(c, e);
+    *mismatches_out = h[0];
+    if (first_bad_bits_out) *first_bad_bits_out = (uint32_t)h[1];
+    return RPT_OK;
+}
+
 int rpt_debug_bsdf(rpt_ctx *c, int kind, size_t n, const float *in, float *out) {
     if (!c || kind < 0 || kind > 3 || !in || !out) return RPT_EINVAL;
     if (n == 0) return RPT_OK;

@@ -85,6 +85,27 @@ RPT_HD float fmaxr(float a, float b) {
 #endif
 }
 RPT_HD float sqrtr(float x) { return __builtin_sqrtf(x); }          /* IEEE correctly rounded on both sides */
+/* (Measured and dropped, both exact where they claim to be — checked over all 2^32 floats on the device — and neither
+ * faster: the compiler's correctly rounded expansion without its denormal pre-/post-scaling (11 instead of 16 instructions,
+ * for arguments >= 2^-96: sky stage 49.2 -> 49.0 ms), and s = fma(x - s0^2, 0.5 * v_rcp_f32(s0), s0) behind a range test
+ * (7 instructions; wrong on 100 floats; its branch made the sky stage slower).  The root is not what these stages wait for.) */
+/* a / c for a compile-time constant c (rc = RN(1 / c)) and a numerator that is zero, not finite, or at least 2^-100 in
+ * magnitude: Markstein's q0 = RN(a rc), r = a - q0 c (exact), q = RN(q0 + r rc) is the correctly rounded quotient, and
+ * v_div_fixup_f32 puts back what the three steps lose on zeros and infinities (the sign of a zero, inf instead of NaN) —
+ * 4 instructions without a branch instead of the 10 of an IEEE division.  Checked on the device for every float of that
+ * domain per constant used (tests/test_gpu_math_exhaustive.py).  A TINY non-zero numerator is outside the contract (the
+ * residual would underflow); callers state why theirs cannot be one.  (With a range test and an IEEE fallback instead of the
+ * precondition the sky stage got SLOWER, 52.3 -> 55.3 ms: the branch splits the scheduling region of a latency-bound march.) */
+RPT_HD float div_const_nontiny(float a, float c, float rc) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPT_NO_DIV_CONST)
+    const float q0 = a * rc;
+    const float r = __builtin_fmaf(-q0, c, a);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(r, rc, q0), c, a);
+#else
+    (void)rc;
+    return a / c;
+#endif
+}
 RPT_HD float absr(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 RPT_HD bool finiter(float x) { return (f2u(x) & 0x7f800000u) != 0x7f800000u; }
 RPT_HD bool isnanr(float x) { return x != x; }

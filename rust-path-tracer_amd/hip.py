@@ -19,7 +19,7 @@ EXPORTS = [
     "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_set_samples_in_flight", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
     "rpt_render", "rpt_render_async", "rpt_wait", "rpt_stream", "rpt_read_accum", "rpt_resolve", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
     "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
-    "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_trace_rays", "rpt_debug_bsdf", "rpt_bvh_build_gpu",
+    "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_math_sweep", "rpt_debug_trace_rays", "rpt_debug_bsdf", "rpt_bvh_build_gpu",
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
@@ -67,6 +67,7 @@ def lib():
         L.rpt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rpt_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.rpt_debug_math_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rpt_debug_math_sweep.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.rpt_debug_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 6
         L.rpt_bvh_build_gpu.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
@@ -272,6 +273,12 @@ class Renderer:
         out = np.empty_like(x)
         self._check(lib().rpt_debug_math(self._h, op, ptr(x), ptr(y), ptr(out), x.size))
         return out
+
+    def debug_math_sweep(self, op, lo_bits, count, y=1.0):
+        """rpt_debug_math_sweep: (mismatches, first bad bit pattern) of a cheap exact operation vs its IEEE form."""
+        bad, first = C.c_uint64(), C.c_uint32()
+        self._check(lib().rpt_debug_math_sweep(self._h, op, lo_bits, count, y, C.byref(bad), C.byref(first)))
+        return bad.value, first.value
 
     def debug_bsdf(self, kind, items):
         """Lambertian / Glass of kernels/src/bsdf.rs:46-176 on the device (rpt_debug_bsdf): (n, 16) in -> (n, 8) out."""

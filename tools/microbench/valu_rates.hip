@@ -134,6 +134,31 @@ __global__ __launch_bounds__(256) void k_horner_df32(float *out) {
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// ---- does a wave64 instruction get cheaper when whole 16- or 32-lane groups of EXEC are off?  (It would make "pack the live
+// lanes of a wave into its lower half" worth building for the streamed traversal.)
+#define DEFINE_MASKED(NAME, LO, HI, ASM_LINE)                                                                 \
+    __global__ __launch_bounds__(256) void NAME(float *out) {                                               \
+        float a = threadIdx.x * 1e-3f + 1.0f, b = 1.0001f, c = 0.5f;                                        \
+        asm volatile("s_mov_b32 exec_lo, " LO "\n s_mov_b32 exec_hi, " HI ::: "memory");                                                  \
+        for (int i = 0; i < ITER; ++i) {                                                                    \
+            asm volatile(ASM_LINE : "+v"(a) : "v"(b), "v"(c) : CL);                                         \
+        }                                                                                                   \
+        asm volatile("s_mov_b64 exec, -1" ::: "memory");                                                     \
+        if (a == 12345.678f) out[0] = a;                                                                    \
+    }
+DEFINE_MASKED(k_fma_lo32, "-1", "0", R32("v_fma_f32 v", ", %0, %1, %2"))
+DEFINE_MASKED(k_fma_lo16, "0xffff", "0", R32("v_fma_f32 v", ", %0, %1, %2"))
+DEFINE_MASKED(k_fma_hi32, "0", "-1", R32("v_fma_f32 v", ", %0, %1, %2"))
+DEFINE_MASKED(k_fma_alt, "0x55555555", "0x55555555", R32("v_fma_f32 v", ", %0, %1, %2"))
+DEFINE_MASKED(k_fma_one, "1", "0", R32("v_fma_f32 v", ", %0, %1, %2"))
+DEFINE_MASKED(k_min_lo32, "-1", "0", R32("v_min_f32 v", ", %0, %1"))
+DEFINE_MASKED(k_min_lo16, "0xffff", "0", R32("v_min_f32 v", ", %0, %1"))
+DEFINE_MASKED(k_min_alt, "0x55555555", "0x55555555", R32("v_min_f32 v", ", %0, %1"))
+DEFINE_MASKED(k_f64_lo32, "-1", "0", P32("v_fma_f64 v", ", v[56:57], v[58:59], v[56:57]"))
+DEFINE_MASKED(k_f64_lo16, "0xffff", "0", P32("v_fma_f64 v", ", v[56:57], v[58:59], v[56:57]"))
+DEFINE_MASKED(k_rcp_lo32, "-1", "0", R32("v_rcp_f32 v", ", %0"))
+DEFINE_MASKED(k_rcp_lo16, "0xffff", "0", R32("v_rcp_f32 v", ", %0"))
+
 struct Case { const char *name; void (*fn)(float *); };
 
 int main(int argc, char **argv) {
@@ -152,6 +177,9 @@ int main(int argc, char **argv) {
         {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_rcp_f64", k_rcp_f64},
         {"v_mad_u64_u32", k_mad_u64_u32}, {"v_lshl_add_u64", k_lshl_add_u64}, {"ds_bpermute_b32", k_ds_bpermute},
         {"v_readlane_b32", k_readlane}, {"16x(cmp vcc+cnd vcc)", k_cmp_cnd_vcc}, {"16x(cmp s+cnd s)", k_cmp_cnd_sgpr}, {"cnd e64 vcc", k_cnd_e64_vcc}, {"cmp; 32 cnd vcc", k_cnd_after_cmp}, {"vcc=exec; 32 cnd", k_cnd_exec_full}, {"vcc=0; 32 cnd", k_cnd_zero}, {"8x(min+3fma)", k_min_fma_mix}, {"fma dependent", k_fma_x32_dep}, {"8x(cmp+3cnd)", k_cmp_3cnd}, {"10x(cmp+2cnd)+2fma", k_cmp_2cnd}, {"16x(cnd,fma)", k_cnd_fma}, {"16x(cnd,min)", k_cnd_min}, {"v_mbcnt_lo", k_mbcnt}, {"s_and_b64", k_s_and},
+        {"v_fma_f32 exec=lo32", k_fma_lo32}, {"v_fma_f32 exec=lo16", k_fma_lo16}, {"v_fma_f32 exec=hi32", k_fma_hi32}, {"v_fma_f32 exec=0x5555..", k_fma_alt}, {"v_fma_f32 exec=1", k_fma_one},
+        {"v_min_f32 exec=lo32", k_min_lo32}, {"v_min_f32 exec=lo16", k_min_lo16}, {"v_min_f32 exec=0x5555..", k_min_alt},
+        {"v_fma_f64 exec=lo32", k_f64_lo32}, {"v_fma_f64 exec=lo16", k_f64_lo16}, {"v_rcp_f32 exec=lo32", k_rcp_lo32}, {"v_rcp_f32 exec=lo16", k_rcp_lo16},
         {"Horner step f64 (1 v_fma_f64)", k_horner_f64}, {"Horner step double-float (16 f32)", k_horner_df32},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

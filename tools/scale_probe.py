@@ -14,5 +14,6 @@ for world in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
     r.wait()
     dt = time.perf_counter() - t; s1 = r.stats()
     rays = s1['extension_rays'] - s0['extension_rays']
-    print(f'world {world}: {rays/dt/1e6:.0f} Mrays/s per GPU ; ms/step {dt/8*1e3:.3f}')
+    kms = {k: round((s1['kernel_ms'][k] - s0['kernel_ms'][k]) / 8, 3) for k in s1['kernel_ms']}   # with RPT_STAGE_TIMING=1
+    print(f'world {world}: {rays/dt/1e6:.0f} Mrays/s per GPU ; ms/step {dt/8*1e3:.3f} ; stage ms/step {kms}')
     r.close()
