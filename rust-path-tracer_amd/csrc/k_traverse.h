@@ -418,6 +418,9 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
 #if RPT_LEAF_GREEDY_PCT
         /* ONE body per trip, the one with more lanes ready for it (a leaf step counts RPT_LEAF_GREEDY_PCT % of an inner one):
          * lanes on a leaf no longer sit out a fixed quota of inner steps, and no body is issued for a handful of lanes */
+        /* (the compiler evaluates this wave-uniform comparison on the vector unit, v_mov + v_cmp_gt_u64 per trip; forced into
+         * scalar registers with s_cmp / s_cselect the kernel got SLOWER, 75.8 -> 77.0 ms: the scalar chain bcnt -> mul -> cmp ->
+         * cselect -> nor -> saveexec is latency the vector form hides) */
         const bool do_leaf = (uint32_t)__popcll(leaf_m) * 100u > (uint32_t)__popcll(inner_m) * (uint32_t)RPT_LEAF_GREEDY_PCT;
         if (at_inner && !do_leaf) {
 #else
