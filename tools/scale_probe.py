@@ -9,11 +9,15 @@ cfg = rpt.default_config(1024, 1024); seeds = rpt.blue_noise_seeds(1024, 1024)
 for world in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
     r = hip.Renderer(0, rank=0, world_size=world); r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
     r.render(32)
-    s0 = r.stats(); t = time.perf_counter(); 
-    for _ in range(8): r.render_async(32)
-    r.wait()
-    dt = time.perf_counter() - t; s1 = r.stats()
-    rays = s1['extension_rays'] - s0['extension_rays']
-    kms = {k: round((s1['kernel_ms'][k] - s0['kernel_ms'][k]) / 8, 3) for k in s1['kernel_ms']}   # with RPT_STAGE_TIMING=1
+    best = None
+    for rep in range(3):
+        s0 = r.stats(); t = time.perf_counter()
+        for _ in range(8): r.render_async(32)
+        r.wait()
+        dt = time.perf_counter() - t; s1 = r.stats()
+        rays = s1['extension_rays'] - s0['extension_rays']
+        kms = {k: round((s1['kernel_ms'][k] - s0['kernel_ms'][k]) / 8, 3) for k in s1['kernel_ms']}   # with RPT_STAGE_TIMING=1
+        if best is None or dt < best[0]: best = (dt, rays, kms)
+    dt, rays, kms = best
     print(f'world {world}: {rays/dt/1e6:.0f} Mrays/s per GPU ; ms/step {dt/8*1e3:.3f} ; stage ms/step {kms}')
     r.close()
