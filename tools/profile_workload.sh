@@ -2,6 +2,8 @@
 # Judged evidence of ONE bench workload on the GPU box, into gpurun_out/profile/:
 #   ${TAG}_${WL}_bench.json          the bench line (python3 bench.py --workload WL ...)
 #   ${TAG}_${WL}_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (--no-cpu-baseline)
+#   ${TAG}_${WL}_kernel_stats_timed.txt  the same trace restricted to the timed batches (tools/trace_region.py) and
+#   ${TAG}_${WL}_bench_under_rocprof.json the bench line of that profiled run: its roofline.avg_launch_ms is the figure to compare
 #   ${TAG}_${WL}_pmc_{FETCH_SIZE,WRITE_SIZE}.txt   per-kernel per-launch averages, one --pmc pass each (--kernel-trace only)
 #   ${TAG}_${WL}_pmc_sq.txt, _pmc_cache.txt        SQ issue / lane utilisation, TCP / TCC hit passes
 #   traffic_${WL}.json               HBM bytes per launch per stage + source fingerprint (bench.py reads profiles/traffic_*.json)
@@ -13,10 +15,11 @@ OUT=$ROOT/gpurun_out/profile
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py --workload $WL"
-python3 $B "$@" 2>"$OUT/${TAG}_${WL}_bench.err" | tail -1 > "$OUT/${TAG}_${WL}_bench.json"
 rm -rf /tmp/prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $B --no-cpu-baseline "$@" > "$OUT/${TAG}_${WL}_stats_run.log" 2>&1
 cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_${WL}_kernel_stats.csv"
+python3 "$ROOT/tools/trace_region.py" "$(find /tmp/prof_stats -name '*kernel_trace.csv' | head -1)" "$@" > "$OUT/${TAG}_${WL}_kernel_stats_timed.txt" 2>&1
+grep '"metric"' "$OUT/${TAG}_${WL}_stats_run.log" | tail -1 > "$OUT/${TAG}_${WL}_bench_under_rocprof.json"
 if [ "${SKIP_PMC:-0}" != "1" ]; then
   pass() {   # name, counters...
     local name=$1; shift
@@ -37,5 +40,8 @@ if [ "${SKIP_PMC:-0}" != "1" ]; then
   pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES
   pass cache TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum
 fi
+# the bench line last: it reports `traffic` only from a traffic_*.json measured on exactly these kernel sources
+[ -s "$OUT/traffic_${WL}.json" ] && cp "$OUT/traffic_${WL}.json" "$ROOT/profiles/traffic_${WL}.json"
+python3 $B "$@" 2>"$OUT/${TAG}_${WL}_bench.err" | tail -1 > "$OUT/${TAG}_${WL}_bench.json"
 head -8 "$OUT/${TAG}_${WL}_kernel_stats.csv" | cut -c1-200
 cat "$OUT/${TAG}_${WL}_bench.json" | cut -c1-600
