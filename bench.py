@@ -304,7 +304,7 @@ def main():
         # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes kept under profiles/ (tools/profile_workload.sh).
         # PMC counters cannot be collected from inside this process, so the figure is only reported when it was measured
         # on exactly these kernel sources (tools/source_fingerprint.py); otherwise null, never a stale number.
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(tpath):
             try:
@@ -315,6 +315,7 @@ def main():
                 fp = fingerprint()
                 if tj.get("workload") == args.workload and tj.get("source_fingerprint") == fp and dominant in tj.get("stages", {}):
                     traffic = tj["stages"][dominant]["hbm_bytes_per_launch"]
+                    valu = tj["stages"][dominant].get("valu")       # SQ pass of the same profiling run: what actually bounds the kernel
                     traffic_source = f"profiles/traffic_{args.workload}.json@{fp}"
                 else:
                     traffic_source = f"profiles/traffic_{args.workload}.json is from other kernel sources ({tj.get('source_fingerprint')} != {fp}): not reported"
@@ -325,6 +326,14 @@ def main():
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[dominant]),
                     "units_per_launch": round(units, 1), "units_are": unit_key, "algorithmic_bytes_per_unit": bytes_per_unit,
                     "stage_ms": {k: round(v, 3) for k, v in kms.items()}}
+        if valu:
+            # not an HBM kernel: the VALU issue figures of the kept SQ pass (same fingerprint rule as `traffic`), and from them
+            # and THIS run's launch time the SIMD time per wave-instruction
+            cus = torch.cuda.get_device_properties(device).multi_processor_count
+            roofline["valu"] = {"lane_utilisation": valu["lane_utilisation"],
+                                "wave_instructions_per_launch": valu["wave_instructions_per_launch"],
+                                "simd_ns_per_wave_instruction": round(avg_ms * 1e6 * cus * 4 / valu["wave_instructions_per_launch"], 4),
+                                "simds": cus * 4, "note": "x 2.4 GHz = SIMD cycles per wave64 instruction; the traversal mix issues in ~2.8 (DESIGN.md 4)"}
     pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
     pipeline_gbs = pipeline_bytes / elapsed_max / 1e9
 
