@@ -536,3 +536,17 @@ def test_error_behaviour(hipmod, rpt, world):
         r.set_config(bad)
     assert e.value.code == -4
     r.close()
+
+
+@pytest.mark.parametrize("seed", [1234, 77])
+def test_randomised_configurations_equal_the_oracle(seed):
+    """A fixed-seed slice of tools/fuzz_parity.py: random scene, image size (ragged, down to 1 pixel), spp split over two
+    render calls, NEE mode, bounce limits, samples in flight, camera (some far outside the atmosphere or under the ground),
+    sun direction / intensity, lobe-pick clamp — accumulators and the three ray counters equal the oracle's, bit for bit."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.main(n_cases=14, seed=seed) == 0

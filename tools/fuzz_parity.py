@@ -15,9 +15,9 @@ from oracle_ffi import Oracle  # noqa: E402
 from scenes import deep_bvh_scene, textured_scene  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+def main(n_cases=None, seed=None, quiet=False):
+    n_cases = n_cases if n_cases is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 40)
+    rng = np.random.default_rng(seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 1234))
     orc = Oracle()
     worlds = {n: (rpt.World.from_path(rpt.fixture(n + ".glb")), None) for n in ("DarkCornell", "VeachMIS", "FurnaceTest", "PBRTest")}
     worlds["textured"] = textured_scene()
@@ -36,7 +36,17 @@ def main():
         cam = (float(rng.uniform(-2, 2)), float(rng.uniform(0.3, 3)), float(rng.uniform(-6, 0)), 0.0)
         rot = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.8, 0.8)), 0.0, 0.0)
         has_sky = int(sky is not None and rng.integers(0, 2))
-        cfg = rpt.default_config(W, H, nee=nee, min_bounces=min_b, max_bounces=max_b, cam_position=cam, cam_rotation=rot, has_skybox=has_sky)
+        over = {}
+        if rng.integers(0, 2):                         # sun anywhere (below the horizon too), any intensity (lib.rs:66-69, skybox.rs:75-94)
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            over["sun_direction"] = (float(d[0]), float(d[1]), float(d[2]), float(rng.choice([0.0, 1.0, 15.0, 40.0])))
+        if rng.integers(0, 2):                         # bsdf.rs:282 lobe-pick clamp, including an empty and an inverted range
+            a, b = rng.uniform(0, 1, 2)
+            over["specular_weight_clamp"] = (float(a), float(b))
+        if rng.integers(0, 8) == 0:                    # a camera far away / inside the ground: the sky march's degenerate inputs
+            cam = (float(rng.choice([0.0, 1e6, -3e7])), float(rng.choice([-10.0, 7e6, 1e9])), float(rng.uniform(-6, 0)), 0.0)
+        cfg = rpt.default_config(W, H, nee=nee, min_bounces=min_b, max_bounces=max_b, cam_position=cam, cam_rotation=rot, has_skybox=has_sky, **over)
         seeds = rpt.blue_noise_seeds(W, H)
         r = hip.Renderer(0)
         r.set_samples_in_flight(s_in_flight)
@@ -51,8 +61,8 @@ def main():
         print(f"{case:3d} {name:12s} {W}x{H} spp {spp} nee {nee} bounces {min_b}/{max_b} S {s_in_flight} sky {has_sky}: {'ok' if ok else 'MISMATCH'}")
         bad += 0 if ok else 1
     print("mismatches:", bad)
-    sys.exit(1 if bad else 0)
+    return bad
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(1 if main() else 0)
