@@ -126,10 +126,12 @@ bool load_obj(const char *path, World &out) {
                     if (*q == '/') { ++q; cn.vn = strtol(q, &end, 10); q = end; }
                 }
                 auto resolve = [](long i, size_t n) -> long { return i > 0 ? i - 1 : (i < 0 ? (long)n + i : -1); };
+                const bool has_vt = cn.vt != 0, has_vn = cn.vn != 0;      /* 0 / absent: no such attribute on this corner */
                 cn.v = resolve(cn.v, pos.size() / 3);
                 cn.vt = resolve(cn.vt, tex.size() / 2);
                 cn.vn = resolve(cn.vn, nor.size() / 3);
-                if (cn.v < 0 || (size_t)cn.v >= pos.size() / 3 || cn.vt >= (long)(tex.size() / 2) || cn.vn >= (long)(nor.size() / 3)) {
+                if (cn.v < 0 || (size_t)cn.v >= pos.size() / 3 || cn.vt >= (long)(tex.size() / 2) || cn.vn >= (long)(nor.size() / 3) ||
+                    (has_vt && cn.vt < 0) || (has_vn && cn.vn < 0)) {     /* (a relative index reaching before the first element) */
                     set_error("OBJ: index out of range on line " + std::to_string(line_no));
                     return false;
                 }

@@ -61,7 +61,8 @@ bool decode_png(const uint8_t *data, size_t size, Image8 &out) {
         at += 12 + (size_t)len;
     }
     int channels = color_type == 0 ? 1 : color_type == 2 ? 3 : color_type == 3 ? 1 : color_type == 4 ? 2 : color_type == 6 ? 4 : 0;
-    if (!w || !h || w > 16384 || h > 16384 || !channels || interlace || (bit_depth != 8 && bit_depth != 16) ||
+    /* (the pixel-count bound comes before anything is sized from the header: a 100-byte file may claim 16384 x 16384 x 8 bytes) */
+    if (!w || !h || w > 16384 || h > 16384 || (uint64_t)w * h > (1ull << 26) || !channels || interlace || (bit_depth != 8 && bit_depth != 16) ||
         (color_type == 3 && (bit_depth != 8 || plte.size() < 3))) {
         set_error("unsupported PNG layout");
         return false;
@@ -161,7 +162,7 @@ static bool decode_hdr(const std::vector<uint8_t> &d, std::vector<float> &rgb, u
     if (!fmt) { set_error(".hdr: only FORMAT=32-bit_rle_rgbe is supported"); return false; }
     if (!line(s)) { set_error(".hdr: missing resolution line"); return false; }
     int hh = 0, ww = 0;
-    if (sscanf(s.c_str(), "-Y %d +X %d", &hh, &ww) != 2 || hh <= 0 || ww <= 0 || hh > 32768 || ww > 32768) { set_error(".hdr: only -Y h +X w orientation is supported"); return false; }
+    if (sscanf(s.c_str(), "-Y %d +X %d", &hh, &ww) != 2 || hh <= 0 || ww <= 0 || hh > 32768 || ww > 32768 || (uint64_t)hh * (uint64_t)ww > (1ull << 26)) { set_error(".hdr: only -Y h +X w orientation, at most 2^26 pixels, is supported"); return false; }
     w = (uint32_t)ww; h = (uint32_t)hh;
     std::vector<uint8_t> px((size_t)w * h * 4);
     for (uint32_t y = 0; y < h; ++y) {

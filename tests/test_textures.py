@@ -185,3 +185,27 @@ def test_obj_and_glb_of_the_same_mesh_give_the_same_world(rpt, tmp_path):
         bad = tmp_path / "bad.obj"
         bad.write_text("v 0 0 0\nv 1 0 0\nf 1 2 9\n")
         rpt.World.from_path(str(bad))
+
+
+def test_image_headers_cannot_size_gigabytes_and_obj_relative_indices_are_bounded(rpt, tmp_path):
+    """Untrusted files: a PNG / .hdr header claiming a huge image is refused before anything is allocated from it, and an
+    OBJ corner index that reaches before the first element of its array is an error, not 'no attribute'."""
+    import struct
+    import zlib
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 16384, 16384, 16, 6, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+    (tmp_path / "bomb.png").write_bytes(bomb)
+    with pytest.raises(rpt.host.HostError):
+        rpt.load_skybox(str(tmp_path / "bomb.png"))
+    (tmp_path / "bomb.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 32768 +X 32768\n")
+    with pytest.raises(rpt.host.HostError):
+        rpt.load_skybox(str(tmp_path / "bomb.hdr"))
+    for face in ("f 1/-9 2 3", "f 1//-2 2 3", "f -4 2 3"):
+        (tmp_path / "rel.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n" + face + "\n")
+        with pytest.raises(rpt.host.HostError):
+            rpt.World.from_path(str(tmp_path / "rel.obj"))
+    (tmp_path / "ok.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1/-1/-1 2/1/1 3//1\n")
+    assert len(rpt.World.from_path(str(tmp_path / "ok.obj")).indices) == 1
