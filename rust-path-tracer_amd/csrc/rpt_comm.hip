@@ -225,6 +225,8 @@ int gather_stage(rpt_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = comm_configure(c);
     if (rc) return rc;
+    /* (a caller that re-partitioned the context behind the communicator's back must not overrun the snapshot buffer) */
+    if (cm->sizes[cm->rank] != c->n_pixels) { c->error = "gather: partition of the context and of the communicator differ"; return RPT_EINVAL; }
     if (cm->started) HIP_TRY(c, hipStreamWaitEvent(c->stream, cm->sent, 0));
     if (c->n_pixels) HIP_TRY(c, hipMemcpyAsync(cm->send.p, c->accum.p, (size_t)c->n_pixels * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(cm->staged, c->stream));
@@ -349,7 +351,11 @@ int rpt_comm_init(rpt_ctx *c, const uint8_t *unique_id, uint32_t rank, uint32_t 
     NCCL_TRY(c, rccl().CommInitRank(&comm, (int)world_size, id, (int)rank));
     int count = 0;
     NCCL_TRY(c, rccl().CommCount(comm, &count));
-    if (count != (int)world_size) { c->error = "RCCL communicator has " + std::to_string(count) + " ranks, expected " + std::to_string(world_size); return RPT_EHIP; }
+    if (count != (int)world_size) {
+        (void)rccl().CommDestroy(comm);
+        c->error = "RCCL communicator has " + std::to_string(count) + " ranks, expected " + std::to_string(world_size);
+        return RPT_EHIP;
+    }
     return comm_attach(c, comm, true, rank, world_size);
 }
 

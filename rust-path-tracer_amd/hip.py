@@ -122,6 +122,11 @@ class Renderer:
         if rc != 0:
             raise RptError(rc, lib().rpt_last_error(self._h).decode())
 
+    def set_partition(self, rank, world_size):
+        """rpt_set_partition: this context renders the tiles of `rank` of `world_size` (state is re-allocated at the next reset)."""
+        self._check(lib().rpt_set_partition(self._h, rank, world_size))
+        self.rank, self.world_size = rank, world_size
+
     def close(self):
         if getattr(self, "_h", None):
             lib().rpt_destroy(self._h)

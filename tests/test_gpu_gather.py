@@ -58,6 +58,12 @@ def test_rccl_gather_one_rank_through_the_c_abi(hipmod, rpt, world):
     assert s == 12 and np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     own, _ = r.read_accum()
     assert np.array_equal(own.view(np.uint32), ref.view(np.uint32))
+    # re-partitioning the context behind the communicator's back is refused by the gather, not a buffer overrun
+    r.set_partition(0, 2)
+    r.reset(seeds)
+    r.render_async(1)
+    with pytest.raises(hipmod.RptError):
+        r.gather_async()
     r.close()
 
 
