@@ -526,6 +526,44 @@ def main_plateau():
         run("origin cell 4^3 then dir 8x8",sort_in_spans(okey*64+cx*8+cy))
         run("dir 8x8 then origin 4^3",sort_in_spans((cx*8+cy)*64+okey))
         run("walk length (oracle knowledge)",sort_in_spans(lns))
+    def sim_sets(ev,ln,valid,CR,K=2):
+        """K ray SETS per wave, no per-lane switch: register set k of lane l holds one ray; a trip runs ONE body on ONE set
+        (K x 2 candidates), the one with the most lanes ready — what duplicated loop bodies over two register contexts
+        would do, without the select cost of sim_2."""
+        idx=np.nonzero(valid&(ln>0))[0]
+        total=0; pool=0
+        cur=np.full((64,K),-1); pos=np.zeros((64,K),int)
+        def refill():
+            nonlocal pool
+            free=np.argwhere(cur<0)
+            take=min(len(free),len(idx)-pool)
+            for (l,k),r in zip(free[:take],idx[pool:pool+take]):
+                cur[l,k]=r; pos[l,k]=0
+            pool+=take
+        refill()
+        isum=lsum=0; ic=lc=0
+        trips=0
+        while (cur>=0).any():
+            act=cur>=0
+            kinds=np.where(act, ev[np.maximum(cur,0),np.minimum(pos,ev.shape[1]-1)],255)
+            cnt=[((kinds[:,k]==0).sum(),(kinds[:,k]==1).sum()) for k in range(K)]
+            k=max(range(K),key=lambda q:max(cnt[q]))
+            leaf=cnt[k][1]>cnt[k][0]
+            adv=kinds[:,k]==(1 if leaf else 0)
+            if leaf: lsum+=adv.sum(); lc+=1
+            else: isum+=adv.sum(); ic+=1
+            total+=CL if leaf else CI
+            pos[:,k]=np.where(adv,pos[:,k]+1,pos[:,k])
+            done=act&(pos>=ln[np.maximum(cur,0)])
+            cur[done]=-1
+            trips+=1
+            if trips%8==0 and pool<len(idx) and (cur<0).sum()>=12*K:
+                refill(); total+=CR
+        return total, isum/max(ic,1), lsum/max(lc,1)
+    print("---- K register sets per wave, one body on one set per trip (no per-lane switch)")
+    for K in (1,2,3,4):
+        t,il,ll=sim_sets(evs,lns,vs==1,120.0,K)
+        print(f"  bounce {bounce} K={K} sets: cyc/ray {t/n:6.1f} util {ideal/(t/n)*100:5.1f}% inner lanes {il:5.1f} leaf lanes {ll:5.1f}")
     print("---- two rays per lane")
     def sim_2(ev,ln,valid,CR,K=2):
         n=len(ln); tot=0.0; inner_l=leaf_l=inner_s=leaf_s=0
