@@ -560,6 +560,51 @@ def main_plateau():
             if trips%8==0 and pool<len(idx) and (cur<0).sum()>=12*K:
                 refill(); total+=CR
         return total, isum/max(ic,1), lsum/max(lc,1)
+    def sim_spec(ev,ln,valid,CR,CA=15.0,CX=5.0,alpha=1.0):
+        """One ray per lane, but a lane waiting on a LEAF whose next node (the stack top: known before the leaf is tested) is an
+        inner node runs the box tests of THAT node during an inner trip and keeps (t_left, t_right, two predicate bits); when its
+        leaf trip comes it tests the leaf, then applies the kept result against the updated best t (CA instructions) and stands
+        on the chosen child — two steps of the ray in one inner + one leaf trip.  Exact: only the comparison with the best t
+        depends on the leaf's outcome, and it is made afterwards."""
+        idx=np.nonzero(valid&(ln>0))[0]
+        total=0.0; pool=0
+        cur=np.full(64,-1); pos=np.zeros(64,int); spec=np.zeros(64,bool)
+        L=ev.shape[1]
+        def refill():
+            nonlocal pool
+            free=np.nonzero(cur<0)[0]
+            take=min(len(free),len(idx)-pool)
+            cur[free[:take]]=idx[pool:pool+take]; pos[free[:take]]=0; spec[free[:take]]=False
+            pool+=take
+        refill()
+        isum=lsum=ic=lc=0; trips=0; useful=0
+        while (cur>=0).any():
+            act=cur>=0
+            c=np.maximum(cur,0)
+            kind=np.where(act,ev[c,np.minimum(pos,L-1)],255)
+            nxt_inner=act&(kind==1)&(pos+1<ln[c])&(ev[c,np.minimum(pos+1,L-1)]==0)&~spec
+            n_in=(kind==0).sum(); n_leaf=(kind==1).sum(); n_sp=nxt_inner.sum()
+            if n_leaf>alpha*(n_in+n_sp) or (n_in+n_sp)==0:
+                adv=kind==1
+                total+=CL+(CA if (adv&spec).any() else 0.0)
+                two=adv&spec
+                pos[adv]+=1; pos[two]+=1; spec[two]=False
+                lsum+=adv.sum(); lc+=1
+            else:
+                adv=kind==0
+                total+=CI+(CX if n_sp else 0.0)
+                pos[adv]+=1; spec[nxt_inner]=True
+                isum+=adv.sum()+n_sp; ic+=1
+            done=act&(pos>=ln[c])
+            cur[done]=-1
+            trips+=1
+            if trips%8==0 and pool<len(idx) and (cur<0).sum()>=12:
+                refill(); total+=CR
+        return total, isum/max(ic,1), lsum/max(lc,1)
+    print("---- speculative box tests of the stack top by lanes that wait on a leaf")
+    for alpha in (1.0,0.8,0.6):
+        t,il,ll=sim_spec(evs,lns,vs==1,120.0,alpha=alpha)
+        print(f"  bounce {bounce} alpha {alpha}: cyc/ray {t/n:6.1f} util(vs plain ideal) {ideal/(t/n)*100:5.1f}% lanes busy in inner trips {il:5.1f} in leaf trips {ll:5.1f}")
     print("---- K register sets per wave, one body on one set per trip (no per-lane switch)")
     for K in (1,2,3,4):
         t,il,ll=sim_sets(evs,lns,vs==1,120.0,K)
