@@ -517,6 +517,16 @@ __device__ __forceinline__ void shade_emit(const DevQueues &q, uint32_t *push_sc
 }
 
 template <int NEE, bool TEXTURED, bool COMPACT>
+/* Occupancy asked of the compiler where it costs no spill (left alone it stops at 68 and 104 VGPRs): the plain nee = 0
+ * variant runs at 8 waves per SIMD in 64 VGPRs (DarkCornell shade 31.7 -> 31.0 ms per 8 batches), its packed form at 5 in 96
+ * (PBRTest 69.3 -> 67.4 per 4).  The NEE variants spill when pushed (72 VGPRs: 20-44 bytes of scratch; packed: VeachMIS shade 44.0 -> 48.6) and are left alone. */
+#ifndef RPT_SHADE_WAVES_PLAIN
+#define RPT_SHADE_WAVES_PLAIN 8
+#endif
+#ifndef RPT_SHADE_WAVES_PACKED
+#define RPT_SHADE_WAVES_PACKED 5
+#endif
+__attribute__((amdgpu_waves_per_eu((NEE == RPT_NEE_NONE && !TEXTURED) ? (COMPACT ? RPT_SHADE_WAVES_PACKED : RPT_SHADE_WAVES_PLAIN) : 1, 8)))
 __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
                                                      DevStats *stats) {
     __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];

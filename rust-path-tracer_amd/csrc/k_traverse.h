@@ -854,8 +854,15 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
 #ifndef RPT_GSTREAM_REFILL
 #define RPT_GSTREAM_REFILL 16
 #endif
+/* The global-memory walks wait on memory two thirds of their cycles (profiles/r02_*_pmc_sq.txt) and live on occupancy.  Left
+ * alone the compiler settles at 68 / 77 VGPRs (7 / 6 waves per SIMD); asked for 8 it needs 57 / 58 and spills nothing:
+ * PBRTest traverse 97.3 -> 92.8 ms per 4 batches, VeachMIS traverse + shadow 91.8 -> 87.9, the 1 M-triangle stand-in's
+ * shadow stage 391 -> 366.  (32-bit stack entries cap the occupancy through LDS instead; the request is then moot.) */
+#ifndef RPT_GSTREAM_WAVES
+#define RPT_GSTREAM_WAVES 8
+#endif
 template <int STACK, bool SMALL>
-__global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
+__attribute__((amdgpu_waves_per_eu(RPT_GSTREAM_WAVES, 8))) __global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
                                                                        uint32_t SPAN /* slots per wave, <= 64 * RPT_GSTREAM_RAYS */) {
     typedef typename StackElem<SMALL>::type StackT;
     __shared__ StackT lds_stack[STACK][RPT_WAVE];
@@ -966,7 +973,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQu
  * "occluded" per entry in LDS while walking; the NEE terms are added afterwards in one dense pass over the span (all
  * lanes busy, and the registers of the walk are dead by then: 61 instead of 91 VGPRs). */
 template <int STACK, bool SMALL>
-__global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
+__attribute__((amdgpu_waves_per_eu(RPT_GSTREAM_WAVES, 8))) __global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
                                                                       uint32_t SPAN) {
     typedef typename StackElem<SMALL>::type StackT;
     __shared__ StackT lds_stack[STACK][RPT_WAVE];

@@ -127,6 +127,56 @@ def deep_bvh_scene(n_triangles=200_000, seed=1):
     return rpt.World.from_buffers(verts, normals.astype(np.float32), None, tris, m)
 
 
+def fat_leaf_scene(n_stack=300, seed=3):
+    """A leaf the builder cannot split: n_stack triangles with ONE centroid (rotated copies about it) inside a small room
+    with a light.  Every binned-SAH split leaves one side empty, so they stay one leaf of >= 128 triangles: no LDS image
+    (leaves of 64+ triangles), several 64-lane rounds of the wave-cooperative leaf test."""
+    rpt = importlib.import_module("rust-path-tracer_amd")
+    rng = np.random.default_rng(seed)
+    c = np.array([0.0, 1.2, 1.5])
+    ang = rng.uniform(0, 2 * np.pi, n_stack)
+    tilt = rng.uniform(-0.6, 0.6, n_stack)
+    r = rng.uniform(0.3, 0.9, n_stack)
+    verts, tris = [], []
+    for a, t, rad in zip(ang, tilt, r):
+        u = np.array([np.cos(a), np.sin(t), np.sin(a)])
+        u /= np.linalg.norm(u)
+        v = np.cross(u, [0.3, 1.0, 0.2])
+        v /= np.linalg.norm(v)
+        p0, p1 = c + rad * u, c + rad * (-0.5 * u + 0.866 * v)
+        p2 = 3.0 * c - p0 - p1                                    # the third corner makes the centroid exactly (up to rounding) c
+        k = len(verts)
+        verts += [p0, p1, p2]
+        tris.append([k, k + 1, k + 2, int(rng.integers(0, 2))])
+    verts = np.array(verts, np.float32)
+    p = verts.reshape(-1, 3, 3)
+    fn = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+    normals = np.repeat(fn, 3, axis=0).astype(np.float32)
+    corners = np.array([[-3, 0, -1], [3, 0, -1], [3, 0, 5], [-3, 0, 5], [-3, 4, -1], [3, 4, -1], [3, 4, 5], [-3, 4, 5]], np.float32)
+    walls = [((0, 1, 2, 3), (0, 1, 0)), ((7, 6, 5, 4), (0, -1, 0)), ((3, 2, 6, 7), (0, 0, -1)), ((0, 3, 7, 4), (1, 0, 0)), ((1, 5, 6, 2), (-1, 0, 0))]
+    ev, en, et = [], [], []
+    b = len(verts)
+    for q, nrm in walls:
+        k = b + len(ev)
+        ev += [corners[i] for i in q]
+        en += [nrm] * 4
+        et += [[k, k + 1, k + 2, 2], [k, k + 2, k + 3, 2]]
+    k = b + len(ev)
+    ev += [[-1, 3.9, 1], [1, 3.9, 1], [1, 3.9, 3], [-1, 3.9, 3]]
+    en += [(0, -1, 0)] * 4
+    et += [[k, k + 2, k + 1, 3], [k, k + 3, k + 2, 3]]
+    verts = np.concatenate([verts, np.array(ev, np.float32)])
+    normals = np.concatenate([normals, np.array(en, np.float32)])
+    tris = np.concatenate([np.array(tris, np.uint32), np.array(et, np.uint32)])
+    m = np.zeros(4, rpt._ffi.MATERIAL_DTYPE)
+    m["albedo"][:] = [[0.8, 0.3, 0.2, 1], [0.2, 0.5, 0.8, 1], [0.75, 0.75, 0.75, 1], [0, 0, 0, 1]]
+    m["roughness"][:, :] = np.array([0.4, 0.8, 1.0, 1.0], np.float32)[:, None]
+    m["metallic"][:, :] = np.array([0.6, 0.0, 0.0, 0.0], np.float32)[:, None]
+    m["emissive"][3] = [18.0, 17.0, 15.0, 15.0]
+    return rpt.World.from_buffers(verts, normals.astype(np.float32), None, tris, m)
+
+
 def write_glb(path, positions, indices, *, normals=None, uvs=None, materials=None, images=None, textures=None, accessor_patch=None,
               node_extra=None):
     """Minimal glTF 2.0 binary writer for tests: one mesh, one primitive, optional embedded PNG images.

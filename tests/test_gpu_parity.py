@@ -550,3 +550,40 @@ def test_randomised_configurations_equal_the_oracle(seed):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.main(n_cases=14, seed=seed) == 0
+
+
+@pytest.mark.parametrize("nee", [0, 1])
+def test_unsplittable_fat_leaf_parity(renderer, oracle, rpt, nee):
+    """300 triangles with one centroid stay ONE leaf (tests/scenes.py fat_leaf_scene): too fat for the LDS image, so the
+    global-memory walk with the wave-cooperative leaf test over several rounds of 64 lanes — image, rng and ray counts
+    equal the oracle's, and so does every single ray."""
+    from scenes import fat_leaf_scene
+    w = fat_leaf_scene()
+    assert w.nodes["triangle_count"].max() >= 128
+    W, H, spp = 96, 80, 4
+    cfg = rpt.default_config(W, H, nee=nee, cam_position=(0.0, 1.4, -0.8, 0.0))
+    seeds = rpt.blue_noise_seeds(W, H)
+    renderer.upload_scene(w)
+    renderer.set_config(cfg)
+    renderer.reset(seeds)
+    renderer.render(spp)
+    acc, _ = renderer.read_accum()
+    ref, rng_ref, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    g = renderer.stats()
+    assert st.error_flags == 0
+    assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(renderer.read_rng()["n"], rng_ref["n"])
+    # and ray by ray: nearest and any-hit from random origins
+    rng = np.random.default_rng(5)
+    o, d = _random_rays(rng, 20000, w)
+    sc = oracle.scene(w)
+    t_g, tri_g, fl_g = renderer.debug_trace_rays(False, o, d)
+    t_c, tri_c, fl_c, err = oracle.trace_rays(sc, 0, o, d)
+    hit = (fl_c & 1) == 1
+    assert err == 0 and np.array_equal(fl_g, fl_c) and hit.sum() > 1000
+    assert np.array_equal(t_g.view(np.uint32), t_c.view(np.uint32)) and np.array_equal(tri_g[hit], tri_c[hit])
+    max_t = (rng.random(len(o)) * 6).astype(np.float32)
+    _, _, afl_g = renderer.debug_trace_rays(True, o, d, max_t)
+    _, _, afl_c, err = oracle.trace_rays(sc, 1, o, d, max_t)
+    assert err == 0 and np.array_equal(afl_g & 1, afl_c & 1)
