@@ -260,6 +260,28 @@ def main():
         readback = {"loop": "rpt_render(spp_per_step) -> rpt_read_accum (host buffer), as src/trace.rs:182-204",
                     "ms_per_step": round(tb / args.steps * 1e3, 4), "value": round(rb_rays / tb / 1e6, 3), "unit": "Mrays/s",
                     "all_samples_arrived": bool((host_image[..., 3] == float(args.spp_per_step * (args.steps + 1))).all())}
+        # the same loop with the read-back of batch k overlapped with the rendering of batch k+1 (rpt_comm_init_local: snapshot,
+        # second stream, un-tile, DMA into pinned memory; the host sees every batch, one batch later)
+        if not args.with_gather:
+            r.comm_init_local()
+            r.reset(seeds)
+            r.render_async(args.spp_per_step)
+            r.gather_async()
+            r.gather_wait()                                  # batch 0 rendered and snapshotted before the clock starts
+            sa = r.stats()
+            ta = time.perf_counter()
+            for _ in range(args.steps):                      # timed: `steps` batches rendered, `steps` + 1 images read
+                r.render_async(args.spp_per_step)
+                r.read_gathered(host_image)
+                r.gather_async()
+            _, seen = r.read_gathered(host_image)            # the last batch: nothing left to hide it behind
+            tb = time.perf_counter() - ta
+            sb = r.stats()
+            rb_rays = (sb["extension_rays"] - sa["extension_rays"]) + (sb["shadow_rays"] - sa["shadow_rays"])
+            readback["overlapped"] = {
+                "loop": "rpt_render_async(k+1) ; rpt_read_gathered(k) ; rpt_gather_async: batch k reaches the host while k+1 renders",
+                "ms_per_step": round(tb / args.steps * 1e3, 4), "value": round(rb_rays / tb / 1e6, 3), "unit": "Mrays/s",
+                "all_samples_arrived": bool(seen == args.spp_per_step * (args.steps + 1) and (host_image[..., 3] == float(seen)).all())}
 
     local = torch.tensor([elapsed, float(delta("extension_rays")), float(delta("shadow_rays")), float(delta("samples")),
                           float(delta("sky_evals"))], dtype=torch.float64, device=comm_device if world_size > 1 else device)

@@ -192,6 +192,10 @@ int rpt_untile(rpt_ctx *ctx, const void *dev_gathered_blocks, uint64_t block_str
 #define RPT_COMM_ID_BYTES 128
 int rpt_comm_unique_id(uint8_t *id_out /* RPT_COMM_ID_BYTES */);
 int rpt_comm_init(rpt_ctx *ctx, const uint8_t *unique_id, uint32_t rank, uint32_t world_size);
+/* One GPU, no RCCL: the same snapshot / second stream / un-tile / pinned DMA for a single context, so that the reference's
+ * loop (render a batch, read it back: src/trace.rs:182-204) reads batch k while batch k+1 renders:
+ *   rpt_render_async ; rpt_gather_async ; rpt_render_async (next batch) ; rpt_read_gathered -> the image after the first. */
+int rpt_comm_init_local(rpt_ctx *ctx);
 int rpt_comm_world(rpt_ctx *ctx, uint32_t *rank_out, uint32_t *world_size_out);   /* as RCCL reports it (ncclCommCount) */
 int rpt_gather_async(rpt_ctx *ctx);
 int rpt_gather_wait(rpt_ctx *ctx);

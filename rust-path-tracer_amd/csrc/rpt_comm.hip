@@ -359,6 +359,15 @@ int rpt_comm_init(rpt_ctx *c, const uint8_t *unique_id, uint32_t rank, uint32_t 
     return comm_attach(c, comm, true, rank, world_size);
 }
 
+/* A communicator of ONE rank without RCCL: the snapshot / second-stream / un-tile / pinned-DMA machinery of the gather for
+ * a single GPU, so that the reference's loop (render a batch, read it back: src/trace.rs:182-204) can read batch k while batch
+ * k+1 renders:  rpt_render_async(k) ; rpt_gather_async ; rpt_render_async(k+1) ; rpt_read_gathered -> image after batch k. */
+int rpt_comm_init_local(rpt_ctx *c) {
+    if (!c) return RPT_EINVAL;
+    if (c->world != 1u) { c->error = "rpt_comm_init_local: the context is one rank of several (rpt_set_partition); use rpt_comm_init"; return RPT_EINVAL; }
+    return comm_attach(c, nullptr, false, 0u, 1u);
+}
+
 int rpt_comm_world(rpt_ctx *c, uint32_t *rank, uint32_t *world_size) {
     if (!c || !c->comm) return RPT_EINVAL;
     if (c->comm->comm) {
@@ -374,14 +383,16 @@ int rpt_comm_world(rpt_ctx *c, uint32_t *rank, uint32_t *world_size) {
 
 int rpt_gather_async(rpt_ctx *c) {
     if (!c) return RPT_EINVAL;
-    if (!c->comm || !c->comm->comm) { c->error = "rpt_gather_async: no communicator (rpt_comm_init)"; return RPT_EINVAL; }
+    if (!c->comm || (!c->comm->comm && c->comm->world != 1u)) { c->error = "rpt_gather_async: no communicator (rpt_comm_init / rpt_comm_init_local)"; return RPT_EINVAL; }
     int rc = gather_stage(c);
     if (rc) return rc;
-    NCCL_TRY(c, rccl().GroupStart());
-    rc = gather_exchange(c);
-    ncclResult_t ge = rccl().GroupEnd();
-    if (rc) return rc;
-    NCCL_TRY(c, ge);
+    if (c->comm->world > 1u) {                                   /* (one rank: nothing travels) */
+        NCCL_TRY(c, rccl().GroupStart());
+        rc = gather_exchange(c);
+        ncclResult_t ge = rccl().GroupEnd();
+        if (rc) return rc;
+        NCCL_TRY(c, ge);
+    }
     return gather_finish(c);
 }
 

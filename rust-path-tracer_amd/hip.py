@@ -19,7 +19,7 @@ EXPORTS = [
     "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_set_samples_in_flight", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
     "rpt_render", "rpt_render_async", "rpt_wait", "rpt_stream", "rpt_read_accum", "rpt_resolve", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
     "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
-    "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_math_sweep", "rpt_debug_trace_rays", "rpt_debug_bsdf", "rpt_bvh_build_gpu",
+    "rpt_comm_init_local", "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_math_sweep", "rpt_debug_trace_rays", "rpt_debug_bsdf", "rpt_bvh_build_gpu",
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
@@ -75,6 +75,7 @@ def lib():
         L.rpt_map_accum.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32)]
         L.rpt_comm_unique_id.argtypes = [C.c_void_p]
         L.rpt_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rpt_comm_init_local.argtypes = [C.c_void_p]
         L.rpt_comm_world.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rpt_gather_async.argtypes = [C.c_void_p]
         L.rpt_gather_wait.argtypes = [C.c_void_p]
@@ -254,6 +255,10 @@ class Renderer:
         self._check(lib().rpt_comm_init(self._h, buf, rank, world_size))
         self.rank, self.world_size = rank, world_size
 
+    def comm_init_local(self):
+        """rpt_comm_init_local: a one-rank communicator without RCCL (overlapped read-back on one GPU)."""
+        self._check(lib().rpt_comm_init_local(self._h))
+
     def comm_world(self):
         r, w = C.c_uint32(), C.c_uint32()
         self._check(lib().rpt_comm_world(self._h, C.byref(r), C.byref(w)))
@@ -265,8 +270,9 @@ class Renderer:
     def gather_wait(self):
         self._check(lib().rpt_gather_wait(self._h))
 
-    def read_gathered(self):
-        out = np.zeros((self.config.height, self.config.width, 4), np.float32)
+    def read_gathered(self, out=None):
+        if out is None:
+            out = np.zeros((self.config.height, self.config.width, 4), np.float32)
         samples = C.c_uint32()
         self._check(lib().rpt_read_gathered(self._h, ptr(out), C.byref(samples)))
         return out, samples.value

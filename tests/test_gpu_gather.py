@@ -67,6 +67,36 @@ def test_rccl_gather_one_rank_through_the_c_abi(hipmod, rpt, world):
     r.close()
 
 
+def test_local_communicator_reads_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, world):
+    """rpt_comm_init_local (one rank, no RCCL): render_async(k) ; gather_async ; render_async(k+1) ; read_gathered returns the
+    image AFTER BATCH k — the snapshot was taken before batch k+1 touched the accumulators — with k's sample count."""
+    w = world("DarkCornell")
+    W, H = 200, 104
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+    refs = [_single_image(hipmod, rpt, w, cfg, seeds, (4,) * n)[0] for n in (1, 2, 3)]
+    r = hipmod.Renderer(0)
+    r.comm_init_local()
+    assert r.comm_world() == (0, 1)
+    r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+    r.render_async(4)
+    r.gather_async()
+    for k in range(2):
+        r.render_async(4)                                   # batch k+2 is enqueued ...
+        img, s = r.read_gathered()                          # ... and the host reads the image after batch k+1
+        assert s == 4 * (k + 1) and np.array_equal(img.view(np.uint32), refs[k].view(np.uint32))
+        r.gather_async()
+    img, s = r.read_gathered()
+    assert s == 12 and np.array_equal(img.view(np.uint32), refs[2].view(np.uint32))
+    own, _ = r.read_accum()
+    assert np.array_equal(own.view(np.uint32), refs[2].view(np.uint32))
+    part = hipmod.Renderer(0, rank=1, world_size=2)
+    with pytest.raises(hipmod.RptError):
+        part.comm_init_local()                              # one rank of several needs a real communicator
+    part.close()
+    r.close()
+
+
 @pytest.mark.parametrize("ranks", [2, 3, 8])
 def test_multi_driver_image_is_independent_of_the_rank_count(hipmod, rpt, world, ranks):
     """rpt_multi_*: several ranks (here sharing the one GPU), each rendering its round-robin tiles, one gather per batch
