@@ -587,3 +587,17 @@ def test_unsplittable_fat_leaf_parity(renderer, oracle, rpt, nee):
     _, _, afl_g = renderer.debug_trace_rays(True, o, d, max_t)
     _, _, afl_c, err = oracle.trace_rays(sc, 1, o, d, max_t)
     assert err == 0 and np.array_equal(afl_g & 1, afl_c & 1)
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_random_api_sequences_stay_consistent_with_the_oracle(seed):
+    """tools/fuzz_api.py: one context driven through a random valid sequence of ABI calls (render / render_async of 0..7
+    samples, reads, new configurations, resets incl. resume, other scenes, samples-in-flight changes, the local
+    communicator's gather) while a model advances the CPU oracle by the same samples: every read equals the model."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_api", os.path.join(root, "tools", "fuzz_api.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.main(steps=160, seed=seed, quiet=True) == 0
