@@ -127,6 +127,26 @@ def test_multi_driver_image_is_independent_of_the_rank_count(hipmod, rpt, world,
     m.close()
 
 
+@pytest.mark.parametrize("W,H,ranks", [(64, 64, 8), (1, 1, 3), (130, 65, 7), (63, 200, 9)])
+def test_multi_driver_with_more_ranks_than_tiles(hipmod, rpt, world, W, H, ranks):
+    """Ranks that own NO tile (a one-tile image on 8 ranks), one-pixel images, ragged edges: empty blocks neither travel nor
+    break the gather; image, sample count and ray counts equal the single-context render."""
+    w = world("DarkCornell")
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    ref, s_ref, st_ref = _single_image(hipmod, rpt, w, cfg, seeds, (3, 2))
+    m = hipmod.MultiRenderer([0] * ranks, allow_shared_device=True)
+    m.upload_scene(w); m.set_config(cfg); m.reset(seeds)
+    for n in (3, 2):
+        m.render(n)
+    img, s = m.read_accum()
+    st = m.stats()
+    assert s == s_ref == 5
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert st["extension_rays"] == st_ref["extension_rays"] and st["shadow_rays"] == st_ref["shadow_rays"]
+    m.close()
+
+
 def test_multi_driver_with_rccl_on_the_devices_present(hipmod, rpt, world):
     """ncclCommInitAll over every GPU of the box (one here, eight on the scaling node): same image as one context."""
     import torch
