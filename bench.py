@@ -39,6 +39,9 @@ WORKLOADS = {
     # BASELINE config 5 names BreakTime.glb, absent from the reference mount: labelled procedural stand-in
     # (tests/scenes.py: 1 M clustered long thin triangles in a lit room; deep BVH, fat leaves)
     "deepbvh": ("procedural:deep_bvh_1M", 2048, 2048, 4096, {"nee": 1, "cam_position": (0.0, 2.5, -0.5, 0.0)}),
+    # the other face of a large scene: 1 M SMALL scattered triangles -> 2 M nodes, leaves of one or two triangles
+    # (32-bit stack entries in the walks; the clustered stand-in above has fat leaves and only 31 k nodes)
+    "scatter": ("procedural:scatter_1M", 2048, 2048, 4096, {"nee": 1, "cam_position": (0.0, 1.8, -0.9, 0.0)}),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
@@ -127,8 +130,8 @@ def main():
     scene, W, H, total_spp, over = WORKLOADS[args.workload]
     if scene.startswith("procedural:"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from scenes import deep_bvh_scene
-        world = deep_bvh_scene(1_000_000)
+        from scenes import deep_bvh_scene, scatter_scene
+        world = deep_bvh_scene(1_000_000) if scene.endswith("deep_bvh_1M") else scatter_scene(1_000_000)
     else:
         world = rpt.World.from_path(rpt.fixture(scene + ".glb"))
     cfg = rpt.default_config(W, H, **over)

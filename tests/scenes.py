@@ -127,6 +127,45 @@ def deep_bvh_scene(n_triangles=200_000, seed=1):
     return rpt.World.from_buffers(verts, normals.astype(np.float32), None, tris, m)
 
 
+def scatter_scene(n_triangles=60_000, seed=9):
+    """Small triangles scattered uniformly in a closed room with a light: the builder splits down to leaves of one or two
+    triangles, so the BVH has MORE THAN 65 536 nodes — 32-bit stack entries in the global-memory walks, which no shipped
+    scene reaches (PBRTest: 47 637 nodes)."""
+    rpt = importlib.import_module("rust-path-tracer_amd")
+    rng = np.random.default_rng(seed)
+    c = np.stack([rng.uniform(-2.8, 2.8, n_triangles), rng.uniform(0.2, 3.6, n_triangles), rng.uniform(-0.6, 4.6, n_triangles)], 1)
+    a = rng.normal(size=(n_triangles, 3)) * 0.03
+    b = rng.normal(size=(n_triangles, 3)) * 0.03
+    verts = np.stack([c - a, c + a, c + b], 1).reshape(-1, 3).astype(np.float32)
+    tris = np.concatenate([np.arange(3 * n_triangles).reshape(-1, 3), rng.integers(0, 2, (n_triangles, 1))], 1).astype(np.uint32)
+    p = verts.reshape(-1, 3, 3)
+    fn = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+    normals = np.repeat(fn, 3, axis=0).astype(np.float32)
+    corners = np.array([[-3, 0, -1], [3, 0, -1], [3, 0, 5], [-3, 0, 5], [-3, 4, -1], [3, 4, -1], [3, 4, 5], [-3, 4, 5]], np.float32)
+    walls = [((0, 1, 2, 3), (0, 1, 0)), ((7, 6, 5, 4), (0, -1, 0)), ((3, 2, 6, 7), (0, 0, -1)), ((0, 3, 7, 4), (1, 0, 0)), ((1, 5, 6, 2), (-1, 0, 0))]
+    ev, en, et = [], [], []
+    b0 = len(verts)
+    for q, nrm in walls:
+        k = b0 + len(ev)
+        ev += [corners[i] for i in q]
+        en += [nrm] * 4
+        et += [[k, k + 1, k + 2, 2], [k, k + 2, k + 3, 2]]
+    k = b0 + len(ev)
+    ev += [[-1, 3.9, 1], [1, 3.9, 1], [1, 3.9, 3], [-1, 3.9, 3]]
+    en += [(0, -1, 0)] * 4
+    et += [[k, k + 2, k + 1, 3], [k, k + 3, k + 2, 3]]
+    verts = np.concatenate([verts, np.array(ev, np.float32)])
+    normals = np.concatenate([normals, np.array(en, np.float32)])
+    tris = np.concatenate([tris, np.array(et, np.uint32)])
+    m = np.zeros(4, rpt._ffi.MATERIAL_DTYPE)
+    m["albedo"][:] = [[0.8, 0.3, 0.2, 1], [0.2, 0.5, 0.8, 1], [0.75, 0.75, 0.75, 1], [0, 0, 0, 1]]
+    m["roughness"][:, :] = np.array([0.4, 0.8, 1.0, 1.0], np.float32)[:, None]
+    m["metallic"][:, :] = np.array([0.6, 0.0, 0.0, 0.0], np.float32)[:, None]
+    m["emissive"][3] = [18.0, 17.0, 15.0, 15.0]
+    return rpt.World.from_buffers(verts, normals.astype(np.float32), None, tris, m)
+
+
 def fat_leaf_scene(n_stack=300, seed=3):
     """A leaf the builder cannot split: n_stack triangles with ONE centroid (rotated copies about it) inside a small room
     with a light.  Every binned-SAH split leaves one side empty, so they stay one leaf of >= 128 triangles: no LDS image

@@ -601,3 +601,38 @@ def test_random_api_sequences_stay_consistent_with_the_oracle(seed):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.main(steps=160, seed=seed, quiet=True) == 0
+
+
+@pytest.mark.parametrize("nee", [0, 1])
+def test_more_than_65536_nodes_parity(renderer, oracle, rpt, nee):
+    """60 k small scattered triangles -> 120 003 nodes (tests/scenes.py scatter_scene): the 32-bit stack entries of the
+    global-memory walks, which no shipped scene reaches — image, rng, ray counts and single rays equal the oracle's."""
+    from scenes import scatter_scene
+    w = scatter_scene()
+    assert len(w.nodes) > 65536
+    W, H, spp = 112, 80, 3
+    cfg = rpt.default_config(W, H, nee=nee, cam_position=(0.0, 1.8, -0.9, 0.0))
+    seeds = rpt.blue_noise_seeds(W, H)
+    renderer.upload_scene(w)
+    renderer.set_config(cfg)
+    renderer.reset(seeds)
+    renderer.render(spp)
+    acc, _ = renderer.read_accum()
+    sc = oracle.scene(w)
+    ref, rng_ref, st = oracle.trace_cpu(cfg, sc, seeds, spp)
+    g = renderer.stats()
+    assert st.error_flags == 0 and st.max_stack >= 8
+    assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(renderer.read_rng()["n"], rng_ref["n"])
+    rng = np.random.default_rng(6)
+    o, d = _random_rays(rng, 50000, w)
+    t_g, tri_g, fl_g = renderer.debug_trace_rays(False, o, d)
+    t_c, tri_c, fl_c, err = oracle.trace_rays(sc, 0, o, d)
+    hit = (fl_c & 1) == 1
+    assert err == 0 and np.array_equal(fl_g, fl_c) and hit.sum() > 1000
+    assert np.array_equal(t_g.view(np.uint32), t_c.view(np.uint32)) and np.array_equal(tri_g[hit], tri_c[hit])
+    max_t = (rng.random(len(o)) * 6).astype(np.float32)
+    _, _, afl_g = renderer.debug_trace_rays(True, o, d, max_t)
+    _, _, afl_c, err = oracle.trace_rays(sc, 1, o, d, max_t)
+    assert err == 0 and np.array_equal(afl_g & 1, afl_c & 1)

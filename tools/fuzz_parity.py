@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.
 rpt = importlib.import_module("rust-path-tracer_amd")
 hip = importlib.import_module("rust-path-tracer_amd.hip")
 from oracle_ffi import Oracle  # noqa: E402
-from scenes import deep_bvh_scene, fat_leaf_scene, textured_scene  # noqa: E402
+from scenes import deep_bvh_scene, fat_leaf_scene, scatter_scene, textured_scene  # noqa: E402
 
 
 def main(n_cases=None, seed=None, quiet=False):
@@ -23,6 +23,7 @@ def main(n_cases=None, seed=None, quiet=False):
     worlds["textured"] = textured_scene()
     worlds["deep"] = (deep_bvh_scene(20_000), None)
     worlds["fatleaf"] = (fat_leaf_scene(), None)
+    worlds["scatter"] = (scatter_scene(40_000), None)
     names = sorted(worlds)
     bad = 0
     for case in range(n_cases):
