@@ -636,3 +636,51 @@ def test_more_than_65536_nodes_parity(renderer, oracle, rpt, nee):
     _, _, afl_g = renderer.debug_trace_rays(True, o, d, max_t)
     _, _, afl_c, err = oracle.trace_rays(sc, 1, o, d, max_t)
     assert err == 0 and np.array_equal(afl_g & 1, afl_c & 1)
+
+
+@pytest.mark.parametrize("knobs", ["RPT_SHADE_COMPACT=1", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=3", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=2,RPT_SKY_WIDE_LIMIT=0",
+                                   "RPT_SHADE_COMPACT=1,RPT_SAMPLES_IN_FLIGHT=2"])
+@pytest.mark.parametrize("nee,has_skybox", [(0, 1), (1, 1), (2, 0)])
+def test_kernel_variants_on_the_textured_scene(monkeypatch, hipmod, oracle, rpt, knobs, nee, has_skybox):
+    """The template instantiations no shipped scene reaches together: TEXTURED x packed shade stage, and the strided sky
+    stage on the image-skybox branch (lib.rs:70-78) as well as on the procedural sky — forced on, against the oracle."""
+    from scenes import textured_scene
+    for one in knobs.split(","):
+        name, value = one.split("=")
+        monkeypatch.setenv(name, value)
+    w, skybox = textured_scene()
+    W, H, spp = 136, 88, 5
+    cfg = rpt.default_config(W, H, nee=nee, has_skybox=has_skybox, cam_position=(0.0, 1.6, -4.0, 0.0), cam_rotation=(0.05, 0.1, 0.0, 0.0))
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    r.upload_scene(w, skybox_f32=skybox)
+    r.set_config(cfg)
+    r.reset(seeds)
+    r.render(2)
+    r.render(spp - 2)
+    acc, n = r.read_accum()
+    st = r.stats()
+    r.close()
+    ref, _, so = oracle.trace_cpu(cfg, oracle.scene(w, skybox_f32=skybox), seeds, spp)
+    assert n == spp and so.error_flags == 0 and so.sky_evals > 0
+    assert (st["extension_rays"], st["shadow_rays"], st["sky_evals"]) == (so.extension_rays, so.shadow_rays, so.sky_evals)
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+
+
+def test_one_ray_per_lane_walk_with_32_bit_stack_entries(monkeypatch, hipmod, oracle, rpt):
+    """RPT_GSTREAM=0 (k_traverse_nearest / k_traverse_shadow, one ray per lane) on the scene of more than 65 536 nodes."""
+    from scenes import scatter_scene
+    monkeypatch.setenv("RPT_GSTREAM", "0")
+    w = scatter_scene()
+    W, H, spp = 96, 64, 2
+    cfg = rpt.default_config(W, H, nee=1, cam_position=(0.0, 1.8, -0.9, 0.0))
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+    r.render(spp)
+    acc, _ = r.read_accum()
+    st = r.stats()
+    r.close()
+    ref, _, so = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    assert (st["extension_rays"], st["shadow_rays"]) == (so.extension_rays, so.shadow_rays)
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
