@@ -188,7 +188,7 @@ int comm_configure(rpt_ctx *c) {
         HIP_TRY(c, cm->gathered.alloc(std::max<size_t>(map.size(), 1)));
         HIP_TRY(c, cm->full_image.alloc((size_t)W * H));
         if (!map.empty()) HIP_TRY(c, hipMemcpy(cm->map.p, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemset(cm->full_image.p, 0, (size_t)W * H * sizeof(float4)));
+        HIP_TRY(c, hipMemsetAsync(cm->full_image.p, 0, (size_t)W * H * sizeof(float4), cm->stream));   /* (on the stream that un-tiles into it: rpt_hip.hip, stream discipline) */
         if (cm->host_full_floats != (size_t)W * H * 4) {
             if (cm->host_full) (void)hipHostFree(cm->host_full);
             cm->host_full = nullptr;

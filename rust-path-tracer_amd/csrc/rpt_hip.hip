@@ -142,6 +142,11 @@ void release_state(rpt_ctx *c) {
     c->has_state = false;
 }
 
+/* Stream discipline: the context's stream is NON-BLOCKING, so nothing on the legacy default stream is ordered against it.
+ * hipMemset of device memory may return before it has run; issued on the default stream it raced the first kernels of the
+ * next render whenever other threads kept that stream busy with their own contexts (lost ray counts in
+ * test_contexts_on_different_threads).  Hence: every fill is hipMemsetAsync ON THE CONTEXT'S STREAM; host-to-device copies
+ * stay synchronous hipMemcpy (complete when they return) and are only issued after the stream has been drained. */
 int alloc_state(rpt_ctx *c) {
     size_t n = c->max_slots, np = c->n_pixels;
     HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n)); HIP_TRY(c, c->hit.alloc(n));
@@ -150,12 +155,12 @@ int alloc_state(rpt_ctx *c) {
     HIP_TRY(c, c->accum.alloc(np)); HIP_TRY(c, c->rng.alloc(np));
     HIP_TRY(c, c->q_sky.alloc(n));
     HIP_TRY(c, c->ray_shards.alloc(RPT_STAT_SHARDS * RPT_STAT_STRIDE));
-    HIP_TRY(c, hipMemset(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemsetAsync(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, c->q_count.alloc(Q_COUNT));
     HIP_TRY(c, c->sh_o.alloc(n)); HIP_TRY(c, c->sh_d.alloc(n)); HIP_TRY(c, c->sh_c.alloc(n));
     HIP_TRY(c, c->pixel_xy.alloc(np));
     if (np) HIP_TRY(c, hipMemcpy(c->pixel_xy.p, c->pixel_xy_host.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t), c->stream));
     if (n) k_fill_idle<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, c->stream>>>(c->hit.p, (uint32_t)n);   /* nothing in flight */
     DevState &s = c->state;
     s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.hit = c->hit.p; s.thr = c->thr.p; s.rad = c->rad.p;
@@ -370,7 +375,7 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->host_ring_dev), c->host_ring, 0);
     if (e != hipSuccess) { g_create_error = std::string("hipHostMalloc(mapped): ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return RPT_EHIP; }
     memset(c->host_ring, 0, RING * sizeof(unsigned long long));
-    if (c->dev_stats.alloc(1) != hipSuccess || hipMemset(c->dev_stats.p, 0, sizeof(DevStats)) != hipSuccess) {
+    if (c->dev_stats.alloc(1) != hipSuccess || hipMemsetAsync(c->dev_stats.p, 0, sizeof(DevStats), c->stream) != hipSuccess) {
         g_create_error = "device allocation failed";
         rpt_destroy(c);
         return RPT_ENOMEM;
@@ -634,8 +639,8 @@ int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
         if (rc) return rc;
         /* fresh accumulators; seeds must come from rpt_reset */
         if (c->n_pixels) {
-            HIP_TRY(c, hipMemset(c->accum.p, 0, c->n_pixels * sizeof(float4)));
-            HIP_TRY(c, hipMemset(c->rng.p, 0, c->n_pixels * sizeof(uint2)));
+            HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, c->n_pixels * sizeof(float4), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->rng.p, 0, c->n_pixels * sizeof(uint2), c->stream));
         }
         c->samples = 0;
     }
@@ -663,8 +668,8 @@ int rpt_reset(rpt_ctx *c, const rpt_rng_state *seed, const float *accum_init, ui
         HIP_TRY(c, hipMemcpy(c->rng.p, rng.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(c->accum.p, acc.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     }
-    HIP_TRY(c, hipMemset(c->dev_stats.p, 0, sizeof(DevStats)));
-    HIP_TRY(c, hipMemset(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemsetAsync(c->dev_stats.p, 0, sizeof(DevStats), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long), c->stream));
     c->samples = accum_init ? samples_init : 0u;
     c->stats = rpt_stats{};
     return RPT_OK;

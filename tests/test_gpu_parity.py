@@ -684,3 +684,42 @@ def test_one_ray_per_lane_walk_with_32_bit_stack_entries(monkeypatch, hipmod, or
     ref, _, so = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
     assert (st["extension_rays"], st["shadow_rays"]) == (so.extension_rays, so.shadow_rays)
     assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+
+
+def test_contexts_on_different_threads(hipmod, oracle, rpt, world):
+    """include/rpt/rpt.h: a context is single-caller, but DIFFERENT contexts may be driven from different threads (ctypes
+    releases the GIL for the duration of a call): four threads, each with its own context, scene and configuration, render
+    concurrently on the one GPU; every image equals the oracle's."""
+    import threading
+    jobs = [("DarkCornell", 120, 72, 0, 5), ("VeachMIS", 96, 80, 1, 4), ("DarkCornell", 64, 100, 2, 6), ("FurnaceTest", 80, 64, 1, 3)]
+    out, errors = [None] * len(jobs), []
+
+    def run(i):
+        try:
+            scene, W, H, nee, spp = jobs[i]
+            cfg = rpt.default_config(W, H, nee=nee)
+            seeds = rpt.blue_noise_seeds(W, H)
+            r = hipmod.Renderer(0)
+            r.upload_scene(world(scene)); r.set_config(cfg); r.reset(seeds)
+            for _ in range(spp):
+                r.render_async(1)
+            r.wait()
+            r.render(spp)
+            out[i] = (r.read_accum()[0], r.stats())
+            r.close()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    for name in {j[0] for j in jobs}:
+        world(name)                                             # (load the scenes once, outside the threads)
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (scene, W, H, nee, spp), (img, st) in zip(jobs, out):
+        cfg = rpt.default_config(W, H, nee=nee)
+        ref, _, so = oracle.trace_cpu(cfg, oracle.scene(world(scene)), rpt.blue_noise_seeds(W, H), 2 * spp)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), scene
+        assert (st["extension_rays"], st["shadow_rays"]) == (so.extension_rays, so.shadow_rays)
