@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <set>
 
 #include "rpt_ctx.h"
@@ -40,8 +41,12 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 
+    std::mutex mutex;                /* contexts on different threads may ask for their first communicator at the same time */
+
     bool load() {
+        std::lock_guard<std::mutex> lock(mutex);
         if (handle) return true;
+        error.clear();
         /* by soname: if the process already holds an RCCL (torch ships one) the loader hands back that very copy */
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
