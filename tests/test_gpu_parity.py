@@ -723,3 +723,34 @@ def test_contexts_on_different_threads(hipmod, oracle, rpt, world):
         ref, _, so = oracle.trace_cpu(cfg, oracle.scene(world(scene)), rpt.blue_noise_seeds(W, H), 2 * spp)
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), scene
         assert (st["extension_rays"], st["shadow_rays"]) == (so.extension_rays, so.shadow_rays)
+
+
+def test_contexts_can_be_destroyed_with_work_in_flight_and_leak_nothing(hipmod, rpt, world):
+    """rpt_destroy with an asynchronous batch (and a gather) still in flight completes it first; 60 create / upload /
+    configure / render / destroy cycles give every byte of device memory back."""
+    import torch
+    w = world("DarkCornell")
+    W, H = 256, 192
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+
+    def cycle(k):
+        r = hipmod.Renderer(0)
+        if k % 3 == 0:
+            r.comm_init_local()
+        r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+        r.render_async(8)
+        if k % 3 == 0:
+            r.gather_async()
+        if k % 2 == 0:
+            r.render_async(3)
+        r.close()                                               # nothing waited for
+
+    cycle(0)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(60):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free1 - free0) <= (8 << 20), (free0, free1)
