@@ -754,3 +754,48 @@ def test_contexts_can_be_destroyed_with_work_in_flight_and_leak_nothing(hipmod, 
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free1 - free0) <= (8 << 20), (free0, free1)
+
+
+def test_misuse_is_an_error_code_never_a_crash(hipmod, rpt, world):
+    """§8b: no aborts across the ABI — every out-of-order or out-of-range call returns a negative code with a message, and the
+    context stays usable afterwards."""
+    import ctypes as C
+    L = hipmod.lib()
+    w = world("DarkCornell")
+    W, H = 72, 40
+    cfg = rpt.default_config(W, H)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    with pytest.raises(hipmod.RptError) as e:
+        r.gather_async()                                        # no communicator
+    assert e.value.code < 0 and "communicator" in str(e.value)
+    assert L.rpt_read_gathered(r._h, None, None) != 0 and L.rpt_comm_world(r._h, None, None) != 0 and L.rpt_gather_wait(r._h) != 0
+    assert L.rpt_set_partition(r._h, 3, 3) != 0 and L.rpt_set_partition(r._h, 0, 0) != 0
+    assert L.rpt_render(None, 1) != 0 and L.rpt_wait(None) != 0 and L.rpt_set_config(r._h, None) != 0
+    r.upload_scene(w)
+    with pytest.raises(hipmod.RptError):
+        r.render(1)                                             # no config yet
+    r.set_config(cfg)
+    assert L.rpt_reset(r._h, None, None, 0) != 0                # null seeds
+    zero = rpt.default_config(0, 10)
+    with pytest.raises(hipmod.RptError):
+        r.set_config(zero)
+    r.set_config(cfg)
+    r.reset(seeds)
+    with pytest.raises(hipmod.RptError):
+        r.gather_async()                                        # still no communicator
+    r.comm_init_local()
+    assert L.rpt_read_gathered(r._h, np.zeros((H, W, 4), np.float32).ctypes.data_as(C.c_void_p), None) != 0   # nothing gathered yet
+    bad, first = C.c_uint64(), C.c_uint32()
+    assert L.rpt_debug_math_sweep(r._h, 7, 0, 1, C.c_float(1.0), C.byref(bad), C.byref(first)) != 0           # unknown op
+    assert L.rpt_debug_math_sweep(r._h, 0, 0, (1 << 32) + 1, C.c_float(1.0), C.byref(bad), C.byref(first)) != 0
+    # ... and the context still works
+    r.render(3)
+    img, n = r.read_accum()
+    ref = hipmod.Renderer(0)
+    ref.upload_scene(w); ref.set_config(cfg); ref.reset(seeds); ref.render(3)
+    assert n == 3 and np.array_equal(img.view(np.uint32), ref.read_accum()[0].view(np.uint32))
+    ref.close(); r.close()
+    for devs, flags in (([], 0), ([99], 0), ([0, 0], 0)):
+        with pytest.raises(hipmod.RptError):
+            hipmod.MultiRenderer(devs, allow_shared_device=bool(flags))
