@@ -799,3 +799,39 @@ def test_misuse_is_an_error_code_never_a_crash(hipmod, rpt, world):
     for devs, flags in (([], 0), ([99], 0), ([0, 0], 0)):
         with pytest.raises(hipmod.RptError):
             hipmod.MultiRenderer(devs, allow_shared_device=bool(flags))
+
+
+def test_malformed_scene_buffers_are_rejected_not_traversed(hipmod, oracle, rpt, world):
+    """rpt_upload_scene takes raw buffers from its host: an index, material, light-table or BVH entry that points outside its
+    array, a BVH that is not a tree, a texture flag without an atlas — RPT_ESCENE with a message, no kernel ever sees them; the
+    context then takes a valid scene and renders it correctly."""
+    import copy
+    base = world("DarkCornell")
+    r = hipmod.Renderer(0)
+
+    def broken(mutate):
+        w = copy.copy(base)
+        for name in ("per_vertex", "indices", "nodes", "materials", "light_pick"):
+            setattr(w, name, getattr(base, name).copy())
+        mutate(w)
+        with pytest.raises(hipmod.RptError) as e:
+            r.upload_scene(w)
+        assert e.value.code == -5 and len(str(e.value)) > 20, str(e.value)
+
+    nv, nt, nn = len(base.per_vertex), len(base.indices), len(base.nodes)
+    inner = int(np.nonzero(base.nodes["triangle_count"] == 0)[0][1])
+    leaf = int(np.nonzero(base.nodes["triangle_count"] > 0)[0][0])
+    broken(lambda w: w.indices["v1"].__setitem__(5, nv))
+    broken(lambda w: w.indices["material"].__setitem__(0, len(base.materials)))
+    broken(lambda w: w.light_pick["triangle_index_a"].__setitem__(0, nt + 7))
+    broken(lambda w: w.nodes["left_or_first"].__setitem__(inner, nn - 1))          # right child = nn: out of bounds
+    broken(lambda w: w.nodes["left_or_first"].__setitem__(leaf, nt))               # leaf range past the triangles
+    broken(lambda w: w.nodes["left_or_first"].__setitem__(inner, 0))               # a cycle through the root
+    broken(lambda w: w.materials["has_albedo_texture"].__setitem__(0, 1))          # no atlas supplied
+    W, H = 80, 56
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r.upload_scene(base); r.set_config(cfg); r.reset(seeds); r.render(3)
+    ref, _, _ = oracle.trace_cpu(cfg, oracle.scene(base), seeds, 3)
+    assert np.array_equal(r.read_accum()[0].view(np.uint32), ref.view(np.uint32))
+    r.close()
