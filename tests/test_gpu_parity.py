@@ -835,3 +835,16 @@ def test_malformed_scene_buffers_are_rejected_not_traversed(hipmod, oracle, rpt,
     ref, _, _ = oracle.trace_cpu(cfg, oracle.scene(base), seeds, 3)
     assert np.array_equal(r.read_accum()[0].view(np.uint32), ref.view(np.uint32))
     r.close()
+
+
+def test_nan_and_infinite_inputs_follow_the_reference_too():
+    """tools/nan_probe.py: NaN / infinite / zero camera, rotation, sun and lobe-clamp values, a NaN vertex, a NaN box —
+    nothing hangs, and image (NaN for NaN) and ray counts equal the oracle's on the LDS walk and the global-memory walk."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "nan_probe.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if " ok" in l or "MISMATCH" in l]
+    assert len(lines) == 38 and not any("MISMATCH" in l for l in lines), out.stdout[-2000:]
