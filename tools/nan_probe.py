@@ -1,3 +1,6 @@
+"""NaN / infinite / degenerate inputs (GPU box): camera, rotation, sun, lobe clamp set to NaN, inf, zero or absurd values, a NaN
+vertex and a NaN box — the HIP path must neither hang nor differ from the oracle (NaN pixels compared as NaN).
+usage: python tools/nan_probe.py"""
 import importlib, sys, os, copy
 import numpy as np
 ROOT=os.environ.get('GRAFT_REPO_ROOT','/root/repo')
