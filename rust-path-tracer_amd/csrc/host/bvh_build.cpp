@@ -210,13 +210,18 @@ size_t bvh_build(const Vec4f *vertices, rpt_triangle *triangles, size_t n_triang
     return n;
 }
 
+/* Depth of the tree under node 0; 0xffffffff if the array is NOT a tree (a node reached more often than there are nodes: a
+ * cycle or shared children in a file that did not come from the builder — an .rptscene cache is untrusted input, and an
+ * unbounded walk here was a hang found by tools/fuzz_glb.py) or a child index leaves the array. */
 uint32_t bvh_max_depth(const std::vector<rpt_bvh_node> &nodes) {
     if (nodes.empty()) return 0;
     uint32_t best = 0;
+    size_t visited = 0;
     std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 0u}};
     while (!st.empty()) {
         auto [idx, d] = st.back();
         st.pop_back();
+        if (++visited > nodes.size() || idx >= nodes.size()) return 0xffffffffu;
         if (d > best) best = d;
         const rpt_bvh_node &n = nodes[idx];
         if (n.triangle_count == 0) {

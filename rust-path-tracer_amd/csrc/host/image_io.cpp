@@ -129,8 +129,13 @@ int rpt_world_load_cache(const char *path, rpt_world **out) {
         if (ok && (t.v0 >= h.n_vertices || t.v1 >= h.n_vertices || t.v2 >= h.n_vertices || t.material >= h.n_materials)) ok = false;
     for (const rpt_bvh_node &n : d.nodes)
         if (ok && (n.triangle_count ? (uint64_t)n.left_or_first + n.triangle_count > h.n_triangles : (uint64_t)n.left_or_first + 1 >= h.n_nodes)) ok = false;
+    for (const rpt_light_pick_entry &e : d.light_pick)
+        if (ok && !(d.light_pick[0].ratio < 0.0f) && (e.triangle_index_a >= h.n_triangles || e.triangle_index_b >= h.n_triangles)) ok = false;
+    if (ok) {
+        d.max_depth = bvh_max_depth(d.nodes);
+        if (d.max_depth == 0xffffffffu) ok = false;           /* a cycle, shared children: not a tree */
+    }
     if (!ok) { delete w; set_error("truncated or inconsistent .rptscene file"); return RPT_HOST_ELOAD; }
-    d.max_depth = bvh_max_depth(d.nodes);
     d.n_emissive = 0;
     for (const rpt_triangle &t : d.indices) {
         const float *e = d.materials[t.material].emissive;

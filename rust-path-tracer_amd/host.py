@@ -22,7 +22,7 @@ def lib():
     """Load librpt_host.so (built in-tree by `make host` / __graft_entry__.build())."""
     global _lib
     if _lib is None:
-        path = os.path.join(_ffi.LIB_DIR, "librpt_host.so")
+        path = os.environ.get("RPT_HOST_LIB") or os.path.join(_ffi.LIB_DIR, "librpt_host.so")   # (RPT_HOST_LIB: a sanitizer build, tools/fuzz_glb.py)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make host` (or __graft_entry__.build())")
         L = C.CDLL(path)

@@ -136,3 +136,34 @@ def test_crafted_glb_is_rejected_without_reading_out_of_bounds(rpt, tmp_path):
     for k, patch in enumerate((huge_count, negative_count, offset_past_end, wrapping_stride, fractional)):
         with pytest.raises(rpt.host.HostError):
             rpt.World.from_path(write_glb(str(tmp_path / f"acc{k}.glb"), pos, idx, accessor_patch=patch))
+
+
+def test_scene_cache_with_a_cyclic_bvh_is_rejected_at_once(rpt, tmp_path):
+    """An .rptscene file is untrusted input: a node array that is not a tree (here an inner node pointing back at the root —
+    found as a HANG by tools/fuzz_glb.py) is an error, not an endless walk."""
+    import time
+    w = rpt.World.from_path(rpt.fixture("DarkCornell.glb"))
+    good = tmp_path / "good.rptscene"
+    w.save(str(good))
+    data = bytearray(good.read_bytes())
+    off = 8 + 6 * 8 + len(w.per_vertex) * 64 + len(w.indices) * 16           # the node array
+    inner = int(np.nonzero(w.nodes["triangle_count"] == 0)[0][3])
+    data[off + inner * 32 + 28: off + inner * 32 + 32] = (0).to_bytes(4, "little")     # left_or_first = 0: a cycle through the root
+    bad = tmp_path / "bad.rptscene"
+    bad.write_bytes(bytes(data))
+    t = time.time()
+    with pytest.raises(rpt.host.HostError):
+        rpt.World.from_cache(str(bad))
+    assert time.time() - t < 5.0
+    assert len(rpt.World.from_cache(str(good)).nodes) == len(w.nodes)
+
+
+def test_loader_mutation_fuzz_slice():
+    """A fixed-seed slice of tools/fuzz_glb.py (bit flips, truncations, splices, digit and length mutations of .glb, .obj,
+    .png, .hdr and .rptscene files): every file is loaded or rejected, none crashes or hangs the loader."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_glb.py"), "160", "21"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "0 crashes" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]

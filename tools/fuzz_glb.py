@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Mutation fuzzer for the host-side loaders (CPU only): flips, truncations and splices of the shipped .glb files, a PNG and an
+.hdr; rpt_world_load / rpt_skybox_load must return an error or a world, never crash or hang.  Each batch runs in a child
+process so that a crash is counted, not fatal.   python tools/fuzz_glb.py [cases] [seed]"""
+import importlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def mutate(data, rng):
+    b = bytearray(data)
+    kind = rng.integers(0, 6)
+    n = len(b)
+    if kind == 0:                                   # flip a few bytes anywhere
+        for _ in range(int(rng.integers(1, 8))):
+            b[int(rng.integers(0, n))] = int(rng.integers(0, 256))
+    elif kind == 1:                                 # ... in the first 4 KB (headers, JSON)
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, min(n, 4096)))] = int(rng.integers(0, 256))
+    elif kind == 2:                                 # truncate
+        b = b[:int(rng.integers(0, n))]
+    elif kind == 3:                                 # a digit in the JSON becomes another (counts, offsets, indices)
+        digits = [i for i in range(min(n, 20000)) if 48 <= b[i] <= 57]
+        for _ in range(int(rng.integers(1, 5))):
+            if digits:
+                b[digits[int(rng.integers(0, len(digits)))]] = 48 + int(rng.integers(0, 10))
+    elif kind == 4:                                 # splice a block from elsewhere
+        a, c, l = int(rng.integers(0, n)), int(rng.integers(0, n)), int(rng.integers(1, 256))
+        b[a:a + l] = b[c:c + l]
+    else:                                           # a 32-bit little-endian field becomes huge
+        i = int(rng.integers(0, max(1, n - 4)))
+        b[i:i + 4] = (0xfffffff0 + int(rng.integers(0, 16))).to_bytes(4, "little")
+    return bytes(b)
+
+
+def child(paths):
+    sys.path.insert(0, ROOT)
+    rpt = importlib.import_module("rust-path-tracer_amd")
+    ok = err = 0
+    for p in paths:
+        try:
+            if p.endswith(".rptscene"):
+                rpt.World.from_cache(p)
+            elif p.endswith(".glb") or p.endswith(".obj"):
+                rpt.World.from_path(p)
+            else:
+                rpt.load_skybox(p)
+            ok += 1
+        except rpt.host.HostError:
+            err += 1
+    print(ok, err)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        return child(sys.argv[2:])
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import png_bytes
+    seeds = {}
+    for name in ("DarkCornell.glb", "FurnaceTest.glb"):
+        seeds[name] = open(os.path.join(ROOT, "fixtures", name), "rb").read()
+    # a textured GLB (three small embedded PNGs -> atlas, resize, gamma) and an OBJ with its MTL beside it
+    from scenes import write_glb
+    with tempfile.TemporaryDirectory() as t0:
+        pos = np.array([[-1, 0, 0], [1, 0, 0], [1, 2, 0], [-1, 2, 0]], np.float32)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+        img = lambda n, k, c=3: ((np.arange(n * n * c).reshape(n, n, c) * k) % 256).astype(np.uint8)   # noqa: E731
+        mats = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1}}, "normalTexture": {"index": 2},
+                 "emissiveFactor": [1.0, 0.5, 0.2]}]
+        path = write_glb(os.path.join(t0, "t.glb"), pos, np.array([0, 1, 2, 0, 2, 3], np.uint32), normals=np.tile(np.array([[0, 0, -1]], np.float32), (4, 1)),
+                         uvs=uv, materials=mats, images=[png_bytes(img(24, 7)), png_bytes(img(8, 3)), png_bytes(img(16, 5, 4))])
+        seeds["textured.glb"] = open(path, "rb").read()
+    rpt = importlib.import_module("rust-path-tracer_amd")
+    with tempfile.TemporaryDirectory() as t1:                       # the buffer cache of a loaded scene
+        rpt.World.from_path(os.path.join(ROOT, "fixtures", "DarkCornell.glb")).save(os.path.join(t1, "c.rptscene"))
+        seeds["cache.rptscene"] = open(os.path.join(t1, "c.rptscene"), "rb").read()
+    seeds["mesh.obj"] = (b"v -1 0 0\nv 1 0 0\nv 1 2 0\nv -1 2 0\nv 0 3 1\nvt 0 0\nvt 1 0\nvt 1 1\nvn 0 0 -1\n"
+                         b"f 1/1/1 2/2/1 3/3/1 4\nf -3 -2 -1\nf 1//1 3//1 5//1\n")
+    seeds["sky.png"] = png_bytes((np.arange(48 * 32 * 3).reshape(32, 48, 3) % 251).astype(np.uint8))
+    seeds["sky.hdr"] = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 8 +X 16\n" + bytes((np.arange(8 * 16 * 4) % 200 + 20).astype(np.uint8))
+    names = sorted(seeds)
+    crashes = loaded = rejected = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        batch = []
+        for i in range(cases):
+            name = names[int(rng.integers(0, len(names)))]
+            path = os.path.join(tmp, f"{i}_{name}")
+            open(path, "wb").write(mutate(seeds[name], rng))
+            batch.append(path)
+            if len(batch) == 50 or i == cases - 1:
+                try:
+                    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + batch, capture_output=True, text=True, timeout=300)
+                    failed = p.returncode != 0
+                except subprocess.TimeoutExpired:
+                    failed = True
+                if failed:
+                    # find the culprit(s) one by one
+                    for q in batch:
+                        try:
+                            pq = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", q], capture_output=True, text=True, timeout=90)
+                        except subprocess.TimeoutExpired:
+                            crashes += 1
+                            keep = os.path.join(ROOT, "gpurun_out", "fuzz_glb_hang_" + os.path.basename(q))
+                            os.makedirs(os.path.dirname(keep), exist_ok=True)
+                            open(keep, "wb").write(open(q, "rb").read())
+                            print("HANG (> 90 s)", q)
+                            continue
+                        if pq.returncode != 0:
+                            crashes += 1
+                            keep = os.path.join(ROOT, "gpurun_out", "fuzz_glb_crash_" + os.path.basename(q))
+                            os.makedirs(os.path.dirname(keep), exist_ok=True)
+                            open(keep, "wb").write(open(q, "rb").read())
+                            print("CRASH", q, pq.returncode, pq.stderr[-300:])
+                        else:
+                            a, b = map(int, pq.stdout.split())
+                            loaded += a; rejected += b
+                else:
+                    a, b = map(int, p.stdout.split())
+                    loaded += a; rejected += b
+                batch = []
+    print(f"{cases} mutated files: {loaded} loaded, {rejected} rejected, {crashes} crashes")
+    return 1 if crashes else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
