@@ -1142,6 +1142,14 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
             g_create_error = "rpt_bvh_build_gpu: vertex index out of range";
             return RPT_ESCENE;
         }
+    /* The ordered 64-bit keys that reproduce the builder's f32::min / max folds (k_bvh_build.h) have no place for a NaN, which
+     * those folds SKIP (src/bvh.rs via f32::min): with a NaN coordinate this build and the sequential one part ways (found by
+     * tools/bvh_nan_probe.py; infinities, denormals and coincident points are fine).  Said, not built around. */
+    for (size_t i = 0; i < n_vertices; ++i)
+        if (vertices_xyzw[4 * i] != vertices_xyzw[4 * i] || vertices_xyzw[4 * i + 1] != vertices_xyzw[4 * i + 1] || vertices_xyzw[4 * i + 2] != vertices_xyzw[4 * i + 2]) {
+            g_create_error = "rpt_bvh_build_gpu: a vertex coordinate is NaN — such a scene must be built by the host builder (rpt_bvh_build)";
+            return RPT_ESCENE;
+        }
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev == 0) { g_create_error = "no HIP device"; return RPT_ENODEV; }
