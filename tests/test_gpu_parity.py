@@ -848,3 +848,14 @@ def test_nan_and_infinite_inputs_follow_the_reference_too():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if " ok" in l or "MISMATCH" in l]
     assert len(lines) == 38 and not any("MISMATCH" in l for l in lines), out.stdout[-2000:]
+
+
+def test_one_triangle_scenes_and_scenes_without_lights():
+    """tools/tiny_scene_probe.py: 1 / 2 / 3 / 5 triangles (a root that is a leaf; the LDS image of a single pair), no emissive
+    triangle at all (the light table's sentinel entry) with every NEE mode, everything emissive — 36 cases against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "tiny_scene_probe.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
