@@ -859,3 +859,14 @@ def test_one_triangle_scenes_and_scenes_without_lights():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "tiny_scene_probe.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+def test_hostile_texture_coordinates():
+    """tools/uv_probe.py: NaN / infinite / huge / negative / exactly-one / denormal uvs on the textured scene, atlas and image
+    skybox: addressing follows the oracle's casts (image_polyfill.rs:38-55) and stays inside the atlas."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "uv_probe.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
