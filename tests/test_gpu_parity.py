@@ -870,3 +870,14 @@ def test_hostile_texture_coordinates():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "uv_probe.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+def test_hostile_material_values():
+    """tools/material_probe.py: roughness / metallic / albedo / emissive set to 0, 1, tiny, huge, negative, NaN, infinite in
+    random combinations: NaN throughput, infinite pdfs and all — the HIP path makes of them what the oracle does."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "material_probe.py"), "40", "5"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
