@@ -881,3 +881,27 @@ def test_hostile_material_values():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "material_probe.py"), "40", "5"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+def test_resolve_on_hostile_accumulators(renderer, oracle, rpt, world):
+    """rpt_resolve (mean + the six tonemappers, render.wgsl:36-153) on accumulators holding NaN, infinities, negative, huge,
+    denormal and zero values (loaded through the resume path): device == oracle, NaN for NaN; pow / division inside the
+    curves included.  Tonemap op out of range: an error."""
+    W, H = 64, 40
+    cfg = rpt.default_config(W, H)
+    renderer.upload_scene(world("DarkCornell"))
+    renderer.set_config(cfg)
+    rng = np.random.default_rng(8)
+    vals = np.array([0.0, -0.0, 1.0, 0.18, 1e-42, 1e-30, 1e30, 3e38, -1.0, -1e30, np.nan, np.inf, -np.inf, 7.5, 0.999], np.float32)
+    init = vals[rng.integers(0, len(vals), (H, W, 4))].copy()
+    init[..., 3] = 5.0
+    renderer.reset(rpt.blue_noise_seeds(W, H), accum_init=init, samples_init=5)
+    acc, n = renderer.read_accum()
+    assert n == 5
+    for op in range(7):
+        got = renderer.resolve(op)
+        want = oracle.resolve(acc, float(n), op)
+        ng, nw = np.isnan(got), np.isnan(want)
+        assert np.array_equal(ng, nw) and np.array_equal(got[~ng].view(np.uint32), want[~nw].view(np.uint32)), f"tonemap op {op}"
+    with pytest.raises(Exception):
+        renderer.resolve(9)
