@@ -119,6 +119,9 @@ uint32_t rpt_tracing_state_samples(rpt_tracing_state *s);
 void rpt_tracing_state_set_running(rpt_tracing_state *s, int running);
 void rpt_tracing_state_set_sync_rate(rpt_tracing_state *s, uint32_t sync_rate);
 void rpt_tracing_state_set_dirty(rpt_tracing_state *s, int dirty);
+/* state.config.write() from another thread while rpt_trace_gpu runs (taken under the state's lock); then set dirty: the
+ * loop re-reads the configuration and restarts accumulation (src/trace.rs:216-222).  A new width / height ends the call. */
+void rpt_tracing_state_set_config(rpt_tracing_state *s, const rpt_tracing_config *config);
 /* setup_trace(width, height, samples) (src/trace.rs:331-344) — but exact: the
  * render stops after precisely `samples` samples (the reference's watcher
  * thread can overshoot). */

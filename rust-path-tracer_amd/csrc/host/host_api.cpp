@@ -232,6 +232,13 @@ uint32_t rpt_tracing_state_samples(rpt_tracing_state *s) { return s->samples.loa
 void rpt_tracing_state_set_running(rpt_tracing_state *s, int r) { s->running.store(r != 0, std::memory_order_relaxed); }
 void rpt_tracing_state_set_sync_rate(rpt_tracing_state *s, uint32_t r) { s->sync_rate.store(r ? r : 1, std::memory_order_relaxed); }
 void rpt_tracing_state_set_dirty(rpt_tracing_state *s, int d) { s->dirty.store(d != 0, std::memory_order_relaxed); }
+/* state.config.write() of the UI thread (src/app.rs) while trace_gpu runs: under the lock the render loop takes when it
+ * re-reads the configuration on a flush (trace.rs:216-222); follow with rpt_tracing_state_set_dirty(s, 1) */
+void rpt_tracing_state_set_config(rpt_tracing_state *s, const rpt_tracing_config *c) {
+    if (!s || !c) return;
+    std::lock_guard<std::mutex> g(s->lock);
+    s->config = *c;
+}
 
 rpt_tracing_state *rpt_setup_trace(uint32_t width, uint32_t height, uint32_t samples) {
     rpt_tracing_state *s = rpt_tracing_state_new(width, height);

@@ -37,6 +37,10 @@ def lib():
         L.rpt_tracing_state_samples.argtypes = [C.c_void_p]
         L.rpt_tracing_state_free.argtypes = [C.c_void_p]
         L.rpt_tracing_state_set_sync_rate.argtypes = [C.c_void_p, C.c_uint32]
+        L.rpt_tracing_state_set_running.argtypes = [C.c_void_p, C.c_int]
+        L.rpt_tracing_state_set_dirty.argtypes = [C.c_void_p, C.c_int]
+        L.rpt_tracing_state_set_config.argtypes = [C.c_void_p, C.POINTER(TracingConfig)]
+        L.rpt_tracing_state_new.argtypes = [C.c_uint32, C.c_uint32]
         L.rpt_trace_gpu.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_char_p]
         L.rpt_world_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.rpt_world_load_ex.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -219,6 +223,16 @@ class TracingState:
 
     def set_sync_rate(self, n):
         lib().rpt_tracing_state_set_sync_rate(self._h, C.c_uint32(n))
+
+    def set_running(self, running):
+        lib().rpt_tracing_state_set_running(self._h, C.c_int(1 if running else 0))
+
+    def set_dirty(self, dirty=True):
+        lib().rpt_tracing_state_set_dirty(self._h, C.c_int(1 if dirty else 0))
+
+    def set_config(self, config):
+        """state.config.write() while trace_gpu runs on another thread (locked copy); follow with set_dirty()."""
+        lib().rpt_tracing_state_set_config(self._h, C.byref(config))
 
     def close(self):
         if self._h:

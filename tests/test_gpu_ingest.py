@@ -65,3 +65,51 @@ def test_host_dispatch_with_a_skybox_file(oracle, rpt, world, tmp_path):
         assert state.samples == spp
         assert np.array_equal(frame.view(np.uint32), want.view(np.uint32))
         state.close()
+
+
+def test_host_dispatch_flush_from_another_thread(oracle, rpt, world):
+    """The reference's interaction path (src/trace.rs:216-222): the render thread runs until told to stop; the UI thread
+    writes a new configuration and raises `dirty`; the loop re-reads the configuration, zeroes the accumulators, restarts
+    the sample count — and what it ends with is exactly the new view's image for the samples rendered since."""
+    import threading
+    import time
+    W, H = 96, 64
+    state = rpt.TracingState(rpt.host.lib().rpt_tracing_state_new(W, H))
+    state.config.nee = 1
+    state.set_sync_rate(2)
+    state.set_running(True)
+    errors = []
+
+    def run():
+        try:
+            rpt.trace_gpu(rpt.fixture("DarkCornell.glb"), None, state)
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=run)
+    t.start()
+    deadline = time.time() + 120
+    while state.samples < 6 and time.time() < deadline and t.is_alive():
+        time.sleep(0.001)
+    moved = rpt.default_config(W, H, nee=1, cam_position=(0.6, 1.4, -4.0, 0.0), cam_rotation=(0.05, -0.15, 0.0, 0.0))
+    state.set_config(moved)
+    state.set_dirty()
+    seen_restart = False
+    last = state.samples
+    while time.time() < deadline and t.is_alive():
+        s = state.samples
+        if s < last:
+            seen_restart = True
+        last = s
+        if seen_restart and s >= 6:
+            break
+        time.sleep(0.0005)
+    state.set_running(False)
+    t.join(120)
+    assert not t.is_alive() and not errors, errors
+    assert seen_restart
+    n = state.samples
+    frame = state.framebuffer()
+    ref, _, _ = oracle.trace_cpu(moved, oracle.scene(world("DarkCornell")), rpt.blue_noise_seeds(W, H), n)
+    assert n >= 2 and np.array_equal(frame.view(np.uint32), (ref[..., :3] / np.float32(n)).view(np.uint32))
+    state.close()
