@@ -905,3 +905,14 @@ def test_resolve_on_hostile_accumulators(renderer, oracle, rpt, world):
         assert np.array_equal(ng, nw) and np.array_equal(got[~ng].view(np.uint32), want[~nw].view(np.uint32)), f"tonemap op {op}"
     with pytest.raises(Exception):
         renderer.resolve(9)
+
+
+def test_images_at_the_coordinate_limits():
+    """tools/skinny_image_probe.py: 65535 x 1, 1 x 65535, 65535 x 2, 3 x 40000, 70 x 65535 as one rank and as three ranks whose
+    partial images add up to the oracle's; 65536 and 0 are refused by rpt_set_config."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "skinny_image_probe.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout and "ACCEPTED" not in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
