@@ -30,6 +30,32 @@
 
 template <bool SMALL> struct StackElem { typedef uint32_t type; };      /* node indices on the stack */
 template <> struct StackElem<true> { typedef uint16_t type; };          /* < 65 536 nodes (and every LDS-resident scene) */
+/* The stack of a lane is a column of an LDS array, [entry][lane].  Three entry widths: 16 bits (< 65 536 nodes and every
+ * LDS-resident scene), 32 bits, and — for the streamed global-memory walks, whose occupancy the LDS footprint caps once
+ * indices need more than 16 bits — 24 bits as a 16-bit and an 8-bit column (< 2^24 nodes): 32 entries cost a wave 6 KB
+ * instead of 8 KB, 5.5 instead of 4.25 waves per SIMD fit beside each other. */
+template <typename T> __device__ __forceinline__ void stack_put(T *s, int sp, uint32_t v) { s[sp * RPT_WAVE] = (T)v; }
+template <typename T> __device__ __forceinline__ uint32_t stack_get(T *s, int sp) { return (uint32_t)s[sp * RPT_WAVE]; }
+struct Stack24 {
+    uint16_t *lo;
+    uint8_t *hi;
+};
+__device__ __forceinline__ void stack_put(Stack24 s, int sp, uint32_t v) {
+    s.lo[sp * RPT_WAVE] = (uint16_t)v;
+    s.hi[sp * RPT_WAVE] = (uint8_t)(v >> 16);
+}
+__device__ __forceinline__ uint32_t stack_get(Stack24 s, int sp) { return (uint32_t)s.lo[sp * RPT_WAVE] | ((uint32_t)s.hi[sp * RPT_WAVE] << 16); }
+/* the LDS arrays of one wave's stack for an entry width, and the handle walk_run takes */
+template <int STACK, int WIDTH> struct WaveStack {                       /* WIDTH 16 / 32 */
+    typedef typename StackElem<WIDTH == 16>::type T;
+    T cells[STACK][RPT_WAVE];
+    __device__ __forceinline__ T *column(uint32_t lane) { return &cells[0][lane]; }
+};
+template <int STACK> struct WaveStack<STACK, 24> {
+    uint16_t lo[STACK][RPT_WAVE];
+    uint8_t hi[STACK][RPT_WAVE];
+    __device__ __forceinline__ Stack24 column(uint32_t lane) { return Stack24{&lo[0][lane], &hi[0][lane]}; }
+};
 
 struct HitRecord {
     float t;
@@ -200,8 +226,8 @@ __device__ __forceinline__ bool walk_dead(const Walk<View> &w) { return !View::i
 
 /* At most `budget` trips of the deferred-leaf loop for the lanes of this wave; returns early when no lane has anything
  * left.  Per ray the visiting order and every comparison are the reference's. */
-template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackT>
-__device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro, F3 rd, F3 ird, float max_t, StackT *stack, int budget) {
+template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackRef>
+__device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro, F3 rd, F3 ird, float max_t, StackRef stack, int budget) {
     typedef typename View::Cur Cur;
     HitRecord res = w.res;
     int sp = w.sp;
@@ -225,7 +251,7 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
             const bool swap = hit_r && (!hit_l || tl > tr);     /* strict: ties keep left first */
             if (hit_l || hit_r) {
                 if (hit_l && hit_r && sp < STACK) {
-                    stack[sp * RPT_WAVE] = (StackT)view.far_entry(cur, swap);
+                    stack_put(stack, sp, view.far_entry(cur, swap));
                     sp += 1;
                 }
                 cur = View::enter(swap, lmin, lmax, rmin, rmax);
@@ -233,7 +259,7 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
                 cur = View::dead();
             } else {
                 sp -= 1;
-                cur = view.from_entry(stack[sp * RPT_WAVE]);
+                cur = view.from_entry(stack_get(stack, sp));
             }
         }
 #if RPT_LEAF_GREEDY_PCT_GLOBAL
@@ -317,7 +343,7 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
                     cur = View::dead();
                 } else {
                     sp -= 1;
-                    cur = view.from_entry(stack[sp * RPT_WAVE]);
+                    cur = view.from_entry(stack_get(stack, sp));
                 }
             }
         }
@@ -327,8 +353,8 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
     w.res = res;
 }
 
-template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackT>
-__device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 rd, F3 ird, float max_t, StackT *stack) {
+template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackRef>
+__device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 rd, F3 ird, float max_t, StackRef stack) {
     Walk<View> w;
     walk_begin(view, w);
     walk_run<STACK, ANY_HIT, FAST>(view, w, ro, rd, ird, max_t, stack, 0x7fffffff);
@@ -857,15 +883,14 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
 /* The global-memory walks wait on memory two thirds of their cycles (profiles/r02_*_pmc_sq.txt) and live on occupancy.  Left
  * alone the compiler settles at 68 / 77 VGPRs (7 / 6 waves per SIMD); asked for 8 it needs 57 / 58 and spills nothing:
  * PBRTest traverse 97.3 -> 92.8 ms per 4 batches, VeachMIS traverse + shadow 91.8 -> 87.9, the 1 M-triangle stand-in's
- * shadow stage 391 -> 366.  (32-bit stack entries cap the occupancy through LDS instead; the request is then moot.) */
+ * shadow stage 391 -> 366.  (Wider stack entries cap the occupancy through LDS instead: hence the 24-bit form, WaveStack.) */
 #ifndef RPT_GSTREAM_WAVES
 #define RPT_GSTREAM_WAVES 8
 #endif
-template <int STACK, bool SMALL>
+template <int STACK, int WIDTH /* bits of a stack entry: 16, 24, 32 */>
 __attribute__((amdgpu_waves_per_eu(RPT_GSTREAM_WAVES, 8))) __global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
                                                                        uint32_t SPAN /* slots per wave, <= 64 * RPT_GSTREAM_RAYS */) {
-    typedef typename StackElem<SMALL>::type StackT;
-    __shared__ StackT lds_stack[STACK][RPT_WAVE];
+    __shared__ WaveStack<STACK, WIDTH> lds_stack;
     __shared__ uint16_t pend[RPT_WAVE * RPT_GSTREAM_RAYS];
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     const uint32_t lane = threadIdx.x;
@@ -897,7 +922,7 @@ __attribute__((amdgpu_waves_per_eu(RPT_GSTREAM_WAVES, 8))) __global__ __launch_b
         atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)count);
     }
     const SceneViewGlobal view{sc.nodes, sc.tri_isect};
-    StackT *stack = &lds_stack[0][lane];
+    const auto stack = lds_stack.column(lane);
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     Walk<SceneViewGlobal> w;
     walk_begin(view, w);
@@ -972,11 +997,10 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQu
  * any-hit walk has ended (found an occluder after two visits, or crossed the whole scene without one).  Lanes only note
  * "occluded" per entry in LDS while walking; the NEE terms are added afterwards in one dense pass over the span (all
  * lanes busy, and the registers of the walk are dead by then: 61 instead of 91 VGPRs). */
-template <int STACK, bool SMALL>
+template <int STACK, int WIDTH>
 __attribute__((amdgpu_waves_per_eu(RPT_GSTREAM_WAVES, 8))) __global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
                                                                       uint32_t SPAN) {
-    typedef typename StackElem<SMALL>::type StackT;
-    __shared__ StackT lds_stack[STACK][RPT_WAVE];
+    __shared__ WaveStack<STACK, WIDTH> lds_stack;
     __shared__ uint8_t occluded[RPT_WAVE * RPT_GSTREAM_RAYS];
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     const uint32_t lane = threadIdx.x;
@@ -987,7 +1011,7 @@ __attribute__((amdgpu_waves_per_eu(RPT_GSTREAM_WAVES, 8))) __global__ __launch_b
     const uint32_t end = begin + SPAN < n ? begin + SPAN : n;
     {
         const SceneViewGlobal view{sc.nodes, sc.tri_isect};
-        StackT *stack = &lds_stack[0][lane];
+        const auto stack = lds_stack.column(lane);
         F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
         float max_t = 0.0f;
         Walk<SceneViewGlobal> w;

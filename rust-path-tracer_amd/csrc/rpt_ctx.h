@@ -57,6 +57,7 @@ struct rpt_ctx {
     uint32_t gstream_min_waves = 32768;
     uint32_t stream_max_blocks = 512;    /* persistent workgroups of the streamed LDS traversal: 2 per CU (each holds 32 KB of stacks + the scene image) */
     uint32_t stream_span = 0;            /* slots a workgroup fetches at a time; 0 = automatic */
+    int stack_bits_min = 16;             /* RPT_STACK_BITS: narrowest stack entry the streamed global-memory walks may use (16 / 24 / 32) */
     uint32_t sky_blocks = 4096;          /* grid of the strided sky stage */
     bool sky_strided = false;            /* sky stage variant in use: fixed grid + grid stride (few misses) or one thread per entry */
     int sky_strided_mode = -1;           /* -1 automatic, 0 / 1 forced by RPT_SKY_STRIDED */

@@ -267,8 +267,9 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else if (c->gstream) {
-        if (c->scene.n_nodes < 65536u) k_traverse_nearest_gstream<STACK, true><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
-        else k_traverse_nearest_gstream<STACK, false><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
+        if (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) k_traverse_nearest_gstream<STACK, 16><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
+        else if (c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) k_traverse_nearest_gstream<STACK, 24><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
+        else k_traverse_nearest_gstream<STACK, 32><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
     } else {
         const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
         if (c->scene.n_nodes < 65536u) k_traverse_nearest<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
@@ -290,8 +291,9 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else if (c->gstream) {
-            if (c->scene.n_nodes < 65536u) k_traverse_shadow_gstream<STACK, true><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
-            else k_traverse_shadow_gstream<STACK, false><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+            if (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) k_traverse_shadow_gstream<STACK, 16><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+            else if (c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) k_traverse_shadow_gstream<STACK, 24><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+            else k_traverse_shadow_gstream<STACK, 32><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
         } else {
             const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
             if (c->scene.n_nodes < 65536u) k_traverse_shadow<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
@@ -391,6 +393,7 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (const char *e12 = getenv("RPT_SHADE_COMPACT_AT")) c->shade_compact_at = atof(e12);
     if (const char *e9 = getenv("RPT_LDS_SHADOW_STREAM")) c->lds_shadow_stream = e9[0] != '0';
     if (const char *e7 = getenv("RPT_GSTREAM_MIN_WAVES")) c->gstream_min_waves = (uint32_t)std::max(1, atoi(e7));
+    if (const char *e17 = getenv("RPT_STACK_BITS")) c->stack_bits_min = atoi(e17);      /* test aid: wider stack entries than the scene needs */
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->stream_max_blocks = 2u * (uint32_t)prop.multiProcessorCount;

@@ -469,7 +469,7 @@ def test_host_dispatch_trace_gpu_furnace(rpt):
                                   "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MAX_BLOCKS=7", "RPT_STREAM_SPAN=1024", "RPT_GSTREAM=0",
                                   "RPT_SHADE_COMPACT=1", "RPT_LDS_SHADOW_STREAM=0", "RPT_MAX_SLOTS=65536",
                                   "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=3",
-                                  "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=5,RPT_SKY_WIDE_LIMIT=1000000", "RPT_SKY_STRIDED=0"])
+                                  "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=5,RPT_SKY_WIDE_LIMIT=1000000", "RPT_SKY_STRIDED=0", "RPT_GSTREAM=1,RPT_STACK_BITS=24", "RPT_GSTREAM=1,RPT_STACK_BITS=32"])
 def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world, knob):
     """README: every tuning knob leaves the image bit-identical (they select kernels / schedules, never arithmetic)."""
     W, H, spp = 160, 96, 6
