@@ -667,6 +667,24 @@ def test_kernel_variants_on_the_textured_scene(monkeypatch, hipmod, oracle, rpt,
     assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
 
 
+def test_deep_tree_with_24_bit_stack_entries(renderer, oracle, rpt):
+    """300 k scattered triangles: 599 965 nodes, depth 24 — the 32-entry stack with 24-bit entries (WaveStack<32, 24>), the
+    shape a real large scene has; image and ray counts against the oracle."""
+    from scenes import scatter_scene
+    w = scatter_scene(300_000)
+    assert len(w.nodes) > 65536 and w.bvh_max_depth >= 24
+    W, H, spp = 80, 56, 2
+    cfg = rpt.default_config(W, H, nee=1, cam_position=(0.0, 1.8, -0.9, 0.0))
+    seeds = rpt.blue_noise_seeds(W, H)
+    renderer.upload_scene(w); renderer.set_config(cfg); renderer.reset(seeds)
+    renderer.render(spp)
+    acc, _ = renderer.read_accum()
+    st = renderer.stats()
+    ref, _, so = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    assert so.max_stack >= 10 and (st["extension_rays"], st["shadow_rays"]) == (so.extension_rays, so.shadow_rays)
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+
+
 def test_one_ray_per_lane_walk_with_32_bit_stack_entries(monkeypatch, hipmod, oracle, rpt):
     """RPT_GSTREAM=0 (k_traverse_nearest / k_traverse_shadow, one ray per lane) on the scene of more than 65 536 nodes."""
     from scenes import scatter_scene
