@@ -113,3 +113,34 @@ def test_host_dispatch_flush_from_another_thread(oracle, rpt, world):
     ref, _, _ = oracle.trace_cpu(moved, oracle.scene(world("DarkCornell")), rpt.blue_noise_seeds(W, H), n)
     assert n >= 2 and np.array_equal(frame.view(np.uint32), (ref[..., :3] / np.float32(n)).view(np.uint32))
     state.close()
+
+
+def test_host_dispatch_refuses_a_resize_while_rendering(rpt):
+    """Every buffer of a trace_gpu call is sized for the resolution it started with (src/trace.rs:146-148): a configuration
+    with another width / height written while it runs ends the call with an error instead of overrunning them."""
+    import threading
+    import time
+    W, H = 64, 48
+    state = rpt.TracingState(rpt.host.lib().rpt_tracing_state_new(W, H))
+    state.set_sync_rate(2)
+    state.set_running(True)
+    result = []
+
+    def run():
+        try:
+            rpt.trace_gpu(rpt.fixture("DarkCornell.glb"), None, state)
+            result.append("returned")
+        except rpt.host.HostError as e:
+            result.append(str(e))
+
+    t = threading.Thread(target=run)
+    t.start()
+    deadline = time.time() + 120
+    while state.samples < 4 and time.time() < deadline and t.is_alive():
+        time.sleep(0.001)
+    state.set_config(rpt.default_config(W * 2, H))
+    state.set_dirty()
+    t.join(120)
+    state.set_running(False)
+    assert not t.is_alive() and result and "resolution changed" in result[0], result
+    state.close()
