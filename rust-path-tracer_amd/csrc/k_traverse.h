@@ -874,6 +874,17 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
 #ifndef RPT_GSTREAM_RAYS
 #define RPT_GSTREAM_RAYS 8         /* most slots per lane of a wave (the host lowers it for small launches) */
 #endif
+/* The nearest-hit walk streams better over a longer list — its pending list costs LDS (2 bytes per slot), and LDS is what caps
+ * the waves of these kernels, so only where the stack is small: 16 slots per lane with a 16-bit stack of <= 24 entries (3 KB
+ * + 2 KB per wave: still 8 waves per SIMD).  Measured, PBRTest traverse per 4 batches: 8 / 12 / 16 / 24 slots per lane
+ * 92.9 / 89.0 / 86.9 / 95.1 ms; with a 32-entry stack 16 slots cost (the stand-in 439 -> 468 ms), and the any-hit walk
+ * prefers 8 everywhere (VeachMIS shadow 56.6 / 58.0 / 57.6 / 60.8). */
+#ifndef RPT_GSTREAM_RAYS_NEAREST_SMALL
+#define RPT_GSTREAM_RAYS_NEAREST_SMALL 16
+#endif
+__host__ __device__ constexpr int gstream_rays_nearest(int stack, int width) {
+    return (stack <= 24 && width == 16) ? RPT_GSTREAM_RAYS_NEAREST_SMALL : RPT_GSTREAM_RAYS;
+}
 #ifndef RPT_GSTREAM_TRIPS
 #define RPT_GSTREAM_TRIPS 8
 #endif
@@ -888,10 +899,11 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
 #define RPT_GSTREAM_WAVES 8
 #endif
 template <int STACK, int WIDTH /* bits of a stack entry: 16, 24, 32 */>
-__attribute__((amdgpu_waves_per_eu(RPT_GSTREAM_WAVES, 8))) __global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
-                                                                       uint32_t SPAN /* slots per wave, <= 64 * RPT_GSTREAM_RAYS */) {
+__attribute__((amdgpu_waves_per_eu((WIDTH == 16 || (WIDTH == 24 && STACK <= 24)) ? RPT_GSTREAM_WAVES : 1, 8)))   /* (where LDS allows it at all) */
+ __global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
+                                                                       uint32_t SPAN /* slots per wave, <= 64 * gstream_rays_nearest(STACK, WIDTH) */) {
     __shared__ WaveStack<STACK, WIDTH> lds_stack;
-    __shared__ uint16_t pend[RPT_WAVE * RPT_GSTREAM_RAYS];
+    __shared__ uint16_t pend[RPT_WAVE * gstream_rays_nearest(STACK, WIDTH)];
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x == 0u && lane == 0u) {
@@ -998,7 +1010,8 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQu
  * "occluded" per entry in LDS while walking; the NEE terms are added afterwards in one dense pass over the span (all
  * lanes busy, and the registers of the walk are dead by then: 61 instead of 91 VGPRs). */
 template <int STACK, int WIDTH>
-__attribute__((amdgpu_waves_per_eu(RPT_GSTREAM_WAVES, 8))) __global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
+__attribute__((amdgpu_waves_per_eu((WIDTH == 16 || (WIDTH == 24 && STACK <= 24)) ? RPT_GSTREAM_WAVES : 1, 8)))   /* (where LDS allows it at all) */
+ __global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
                                                                       uint32_t SPAN) {
     __shared__ WaveStack<STACK, WIDTH> lds_stack;
     __shared__ uint8_t occluded[RPT_WAVE * RPT_GSTREAM_RAYS];

@@ -248,9 +248,11 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
     /* streamed global-memory walks: slots per wave — as many as keep >= gstream_min_waves waves in the launch, at most RPT_GSTREAM_RAYS per lane */
-    uint32_t grays = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
-    grays = grays < 1u ? 1u : (grays > (uint32_t)RPT_GSTREAM_RAYS ? (uint32_t)RPT_GSTREAM_RAYS : grays);
-    const uint32_t gspan = grays * RPT_WAVE, gblocks = (c->n_slots + gspan - 1) / gspan;
+    const int stack_width = (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) ? 16 : ((c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) ? 24 : 32);
+    const uint32_t grays_wanted = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
+    auto span_of = [&](uint32_t most) { uint32_t g = grays_wanted < 1u ? 1u : (grays_wanted > most ? most : grays_wanted); return g * RPT_WAVE; };
+    const uint32_t gspan = span_of((uint32_t)RPT_GSTREAM_RAYS), gblocks = (c->n_slots + gspan - 1) / gspan;             /* any-hit walk */
+    const uint32_t gspan_n = span_of((uint32_t)gstream_rays_nearest(STACK, stack_width)), gblocks_n = (c->n_slots + gspan_n - 1) / gspan_n;
     /* shade_only: the completion pass of a batch whose iteration count is known — every path has ended, only finished
      * generations are left to accumulate (k_shade: complete_generations); no ray to trace, no miss, no shadow ray */
     if (shade_only) {
@@ -267,9 +269,9 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else if (c->gstream) {
-        if (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) k_traverse_nearest_gstream<STACK, 16><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
-        else if (c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) k_traverse_nearest_gstream<STACK, 24><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
-        else k_traverse_nearest_gstream<STACK, 32><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan);
+        if (stack_width == 16) k_traverse_nearest_gstream<STACK, 16><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
+        else if (stack_width == 24) k_traverse_nearest_gstream<STACK, 24><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
+        else k_traverse_nearest_gstream<STACK, 32><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
     } else {
         const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
         if (c->scene.n_nodes < 65536u) k_traverse_nearest<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
@@ -291,8 +293,8 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else if (c->gstream) {
-            if (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) k_traverse_shadow_gstream<STACK, 16><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
-            else if (c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) k_traverse_shadow_gstream<STACK, 24><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+            if (stack_width == 16) k_traverse_shadow_gstream<STACK, 16><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+            else if (stack_width == 24) k_traverse_shadow_gstream<STACK, 24><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
             else k_traverse_shadow_gstream<STACK, 32><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
         } else {
             const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
