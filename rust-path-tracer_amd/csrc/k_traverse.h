@@ -30,7 +30,7 @@
 
 template <bool SMALL> struct StackElem { typedef uint32_t type; };      /* node indices on the stack */
 template <> struct StackElem<true> { typedef uint16_t type; };          /* < 65 536 nodes (and every LDS-resident scene) */
-/* The stack of a lane is a column of an LDS array, [entry][lane].  Three entry widths: 16 bits (< 65 536 nodes and every
+/* The stack of a lane is a column of an LDS array, [entry][lane].  Entry widths: 16 bits (< 65 536 nodes and every
  * LDS-resident scene), 32 bits, and — for the streamed global-memory walks, whose occupancy the LDS footprint caps once
  * indices need more than 16 bits — 24 bits as a 16-bit and an 8-bit column (< 2^24 nodes): 32 entries cost a wave 6 KB
  * instead of 8 KB, 5.5 instead of 4.25 waves per SIMD fit beside each other. */
@@ -45,11 +45,35 @@ __device__ __forceinline__ void stack_put(Stack24 s, int sp, uint32_t v) {
     s.hi[sp * RPT_WAVE] = (uint8_t)(v >> 16);
 }
 __device__ __forceinline__ uint32_t stack_get(Stack24 s, int sp) { return (uint32_t)s.lo[sp * RPT_WAVE] | ((uint32_t)s.hi[sp * RPT_WAVE] << 16); }
+/* 16 + K bits per entry at the LDS cost of 16: the low half in the 16-bit column, bit 16 + k of level sp in bit sp of a per-lane
+ * mask register (stacks have at most 32 levels).  One LDS operation per push / pop like the 16-bit stack, a few VALU
+ * instructions per extra bit instead of the second column's LDS operation and its 1.5 KB per wave. */
+template <int K> struct StackBits {
+    uint16_t *lo;
+    uint32_t hi[K];
+};
+template <int K> __device__ __forceinline__ void stack_put(StackBits<K> &s, int sp, uint32_t v) {
+    s.lo[sp * RPT_WAVE] = (uint16_t)v;
+    const uint32_t keep = ~(1u << sp);
+#pragma unroll
+    for (int k = 0; k < K; ++k) s.hi[k] = (s.hi[k] & keep) | (((v >> (16 + k)) & 1u) << sp);
+}
+template <int K> __device__ __forceinline__ uint32_t stack_get(const StackBits<K> &s, int sp) {
+    uint32_t v = (uint32_t)s.lo[sp * RPT_WAVE];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v |= ((s.hi[k] >> sp) & 1u) << (16 + k);
+    return v;
+}
 /* the LDS arrays of one wave's stack for an entry width, and the handle walk_run takes */
 template <int STACK, int WIDTH> struct WaveStack {                       /* WIDTH 16 / 32 */
     typedef typename StackElem<WIDTH == 16>::type T;
     T cells[STACK][RPT_WAVE];
     __device__ __forceinline__ T *column(uint32_t lane) { return &cells[0][lane]; }
+};
+template <int STACK> struct WaveStack<STACK, 21> {                      /* < 2^21 nodes: 16 bits in LDS + 5 mask registers */
+    static_assert(STACK <= 32, "one mask bit per stack level");
+    uint16_t lo[STACK][RPT_WAVE];
+    __device__ __forceinline__ StackBits<5> column(uint32_t lane) { return StackBits<5>{&lo[0][lane], {0u, 0u, 0u, 0u, 0u}}; }
 };
 template <int STACK> struct WaveStack<STACK, 24> {
     uint16_t lo[STACK][RPT_WAVE];
@@ -227,7 +251,7 @@ __device__ __forceinline__ bool walk_dead(const Walk<View> &w) { return !View::i
 /* At most `budget` trips of the deferred-leaf loop for the lanes of this wave; returns early when no lane has anything
  * left.  Per ray the visiting order and every comparison are the reference's. */
 template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackRef>
-__device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro, F3 rd, F3 ird, float max_t, StackRef stack, int budget) {
+__device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro, F3 rd, F3 ird, float max_t, StackRef &stack, int budget) {
     typedef typename View::Cur Cur;
     HitRecord res = w.res;
     int sp = w.sp;
@@ -354,7 +378,7 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
 }
 
 template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackRef>
-__device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 rd, F3 ird, float max_t, StackRef stack) {
+__device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 rd, F3 ird, float max_t, StackRef &stack) {
     Walk<View> w;
     walk_begin(view, w);
     walk_run<STACK, ANY_HIT, FAST>(view, w, ro, rd, ird, max_t, stack, 0x7fffffff);
@@ -883,7 +907,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
 #define RPT_GSTREAM_RAYS_NEAREST_SMALL 16
 #endif
 __host__ __device__ constexpr int gstream_rays_nearest(int stack, int width) {
-    return (stack <= 24 && width == 16) ? RPT_GSTREAM_RAYS_NEAREST_SMALL : RPT_GSTREAM_RAYS;
+    return (stack <= 24 && width <= 21) ? RPT_GSTREAM_RAYS_NEAREST_SMALL : RPT_GSTREAM_RAYS;
 }
 #ifndef RPT_GSTREAM_TRIPS
 #define RPT_GSTREAM_TRIPS 8
@@ -899,7 +923,7 @@ __host__ __device__ constexpr int gstream_rays_nearest(int stack, int width) {
 #define RPT_GSTREAM_WAVES 8
 #endif
 template <int STACK, int WIDTH /* bits of a stack entry: 16, 24, 32 */>
-__attribute__((amdgpu_waves_per_eu((WIDTH == 16 || (WIDTH == 24 && STACK <= 24)) ? RPT_GSTREAM_WAVES : 1, 8)))   /* (where LDS allows it at all) */
+__attribute__((amdgpu_waves_per_eu((WIDTH <= 21 || (WIDTH == 24 && STACK <= 24)) ? RPT_GSTREAM_WAVES : 1, 8)))   /* (where LDS allows it at all) */
  __global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
                                                                        uint32_t SPAN /* slots per wave, <= 64 * gstream_rays_nearest(STACK, WIDTH) */) {
     __shared__ WaveStack<STACK, WIDTH> lds_stack;
@@ -934,7 +958,7 @@ __attribute__((amdgpu_waves_per_eu((WIDTH == 16 || (WIDTH == 24 && STACK <= 24))
         atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)count);
     }
     const SceneViewGlobal view{sc.nodes, sc.tri_isect};
-    const auto stack = lds_stack.column(lane);
+    auto stack = lds_stack.column(lane);
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     Walk<SceneViewGlobal> w;
     walk_begin(view, w);
@@ -1010,7 +1034,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQu
  * "occluded" per entry in LDS while walking; the NEE terms are added afterwards in one dense pass over the span (all
  * lanes busy, and the registers of the walk are dead by then: 61 instead of 91 VGPRs). */
 template <int STACK, int WIDTH>
-__attribute__((amdgpu_waves_per_eu((WIDTH == 16 || (WIDTH == 24 && STACK <= 24)) ? RPT_GSTREAM_WAVES : 1, 8)))   /* (where LDS allows it at all) */
+__attribute__((amdgpu_waves_per_eu((WIDTH <= 21 || (WIDTH == 24 && STACK <= 24)) ? RPT_GSTREAM_WAVES : 1, 8)))   /* (where LDS allows it at all) */
  __global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
                                                                       uint32_t SPAN) {
     __shared__ WaveStack<STACK, WIDTH> lds_stack;
@@ -1024,7 +1048,7 @@ __attribute__((amdgpu_waves_per_eu((WIDTH == 16 || (WIDTH == 24 && STACK <= 24))
     const uint32_t end = begin + SPAN < n ? begin + SPAN : n;
     {
         const SceneViewGlobal view{sc.nodes, sc.tri_isect};
-        const auto stack = lds_stack.column(lane);
+        auto stack = lds_stack.column(lane);
         F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
         float max_t = 0.0f;
         Walk<SceneViewGlobal> w;

@@ -248,7 +248,9 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
     /* streamed global-memory walks: slots per wave — as many as keep >= gstream_min_waves waves in the launch, at most RPT_GSTREAM_RAYS per lane */
-    const int stack_width = (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) ? 16 : ((c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) ? 24 : 32);
+    const int stack_width = (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) ? 16
+                          : (c->scene.n_nodes < (1u << 21) && c->stack_bits_min <= 21) ? 21
+                          : (c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) ? 24 : 32;
     const uint32_t grays_wanted = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
     auto span_of = [&](uint32_t most) { uint32_t g = grays_wanted < 1u ? 1u : (grays_wanted > most ? most : grays_wanted); return g * RPT_WAVE; };
     const uint32_t gspan = span_of((uint32_t)RPT_GSTREAM_RAYS), gblocks = (c->n_slots + gspan - 1) / gspan;             /* any-hit walk */
@@ -270,6 +272,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else if (c->gstream) {
         if (stack_width == 16) k_traverse_nearest_gstream<STACK, 16><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
+        else if (stack_width == 21) k_traverse_nearest_gstream<STACK, 21><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
         else if (stack_width == 24) k_traverse_nearest_gstream<STACK, 24><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
         else k_traverse_nearest_gstream<STACK, 32><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
     } else {
@@ -294,6 +297,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else if (c->gstream) {
             if (stack_width == 16) k_traverse_shadow_gstream<STACK, 16><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+            else if (stack_width == 21) k_traverse_shadow_gstream<STACK, 21><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
             else if (stack_width == 24) k_traverse_shadow_gstream<STACK, 24><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
             else k_traverse_shadow_gstream<STACK, 32><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
         } else {

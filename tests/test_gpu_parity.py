@@ -469,7 +469,7 @@ def test_host_dispatch_trace_gpu_furnace(rpt):
                                   "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MAX_BLOCKS=7", "RPT_STREAM_SPAN=1024", "RPT_GSTREAM=0",
                                   "RPT_SHADE_COMPACT=1", "RPT_LDS_SHADOW_STREAM=0", "RPT_MAX_SLOTS=65536",
                                   "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=3",
-                                  "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=5,RPT_SKY_WIDE_LIMIT=1000000", "RPT_SKY_STRIDED=0", "RPT_GSTREAM=1,RPT_STACK_BITS=24", "RPT_GSTREAM=1,RPT_STACK_BITS=32"])
+                                  "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=5,RPT_SKY_WIDE_LIMIT=1000000", "RPT_SKY_STRIDED=0", "RPT_GSTREAM=1,RPT_STACK_BITS=21", "RPT_GSTREAM=1,RPT_STACK_BITS=24", "RPT_GSTREAM=1,RPT_STACK_BITS=32"])
 def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world, knob):
     """README: every tuning knob leaves the image bit-identical (they select kernels / schedules, never arithmetic)."""
     W, H, spp = 160, 96, 6
@@ -667,9 +667,10 @@ def test_kernel_variants_on_the_textured_scene(monkeypatch, hipmod, oracle, rpt,
     assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
 
 
-def test_deep_tree_with_24_bit_stack_entries(renderer, oracle, rpt):
-    """300 k scattered triangles: 599 965 nodes, depth 24 — the 32-entry stack with 24-bit entries (WaveStack<32, 24>), the
-    shape a real large scene has; image and ray counts against the oracle."""
+def test_deep_tree_with_wide_stack_entries(renderer, oracle, rpt):
+    """300 k scattered triangles: 599 965 nodes, depth 24 — the 32-entry stack with entries wider than 16 bits (16 in LDS + 5
+    mask registers, WaveStack<32, 21>; RPT_STACK_BITS forces the 24- and 32-bit forms elsewhere), the shape a real large scene
+    has; image and ray counts against the oracle."""
     from scenes import scatter_scene
     w = scatter_scene(300_000)
     assert len(w.nodes) > 65536 and w.bvh_max_depth >= 24
