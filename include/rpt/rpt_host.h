@@ -122,6 +122,10 @@ void rpt_tracing_state_set_dirty(rpt_tracing_state *s, int dirty);
 /* state.config.write() from another thread while rpt_trace_gpu runs (taken under the state's lock); then set dirty: the
  * loop re-reads the configuration and restarts accumulation (src/trace.rs:216-222).  A new width / height ends the call. */
 void rpt_tracing_state_set_config(rpt_tracing_state *s, const rpt_tracing_config *config);
+/* rpt_trace_gpu reads the image after batch k while batch k+1 renders (rpt_comm_init_local + rpt_gather_async /
+ * rpt_read_gathered instead of rpt_read_accum): the framebuffer and sample count the caller sees run one batch behind the
+ * device; final images, flush behaviour and sample totals are the same.  Set before rpt_trace_gpu is called. */
+void rpt_tracing_state_set_overlap(rpt_tracing_state *s, int on);
 /* setup_trace(width, height, samples) (src/trace.rs:331-344) — but exact: the
  * render stops after precisely `samples` samples (the reference's watcher
  * thread can overshoot). */

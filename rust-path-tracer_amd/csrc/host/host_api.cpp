@@ -38,6 +38,7 @@ struct rpt_tracing_state {
     std::atomic<bool> interacting{false};
     std::atomic<bool> dirty{false};
     uint32_t target_samples = 0;           /* setup_trace: stop after exactly this many (0 = run until !running) */
+    std::atomic<bool> overlap{false};      /* rpt_trace_gpu reads batch k back while batch k+1 renders (rpt_comm_init_local) */
 };
 
 extern "C" {
@@ -234,6 +235,7 @@ void rpt_tracing_state_set_sync_rate(rpt_tracing_state *s, uint32_t r) { s->sync
 void rpt_tracing_state_set_dirty(rpt_tracing_state *s, int d) { s->dirty.store(d != 0, std::memory_order_relaxed); }
 /* state.config.write() of the UI thread (src/app.rs) while trace_gpu runs: under the lock the render loop takes when it
  * re-reads the configuration on a flush (trace.rs:216-222); follow with rpt_tracing_state_set_dirty(s, 1) */
+void rpt_tracing_state_set_overlap(rpt_tracing_state *s, int on) { if (s) s->overlap.store(on != 0, std::memory_order_relaxed); }
 void rpt_tracing_state_set_config(rpt_tracing_state *s, const rpt_tracing_config *c) {
     if (!s || !c) return;
     std::lock_guard<std::mutex> g(s->lock);
@@ -319,6 +321,10 @@ struct HipApi {
     decltype(&rpt_reset) reset;
     decltype(&rpt_render) render;
     decltype(&rpt_read_accum) read_accum;
+    decltype(&rpt_render_async) render_async;
+    decltype(&rpt_comm_init_local) comm_init_local;
+    decltype(&rpt_gather_async) gather_async;
+    decltype(&rpt_read_gathered) read_gathered;
     decltype(&rpt_destroy) destroy;
     decltype(&rpt_last_error) last_error;
 };
@@ -345,6 +351,8 @@ bool load_hip_api(const char *path, HipApi &api) {
     return sym(api.handle, "rpt_create", api.create) && sym(api.handle, "rpt_upload_scene", api.upload_scene) &&
            sym(api.handle, "rpt_set_config", api.set_config) && sym(api.handle, "rpt_reset", api.reset) &&
            sym(api.handle, "rpt_render", api.render) && sym(api.handle, "rpt_read_accum", api.read_accum) &&
+           sym(api.handle, "rpt_render_async", api.render_async) && sym(api.handle, "rpt_comm_init_local", api.comm_init_local) &&
+           sym(api.handle, "rpt_gather_async", api.gather_async) && sym(api.handle, "rpt_read_gathered", api.read_gathered) &&
            sym(api.handle, "rpt_destroy", api.destroy) && sym(api.handle, "rpt_last_error", api.last_error);
 }
 }  // namespace
@@ -418,10 +426,26 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
     if ((rc = api.reset(ctx, seeds(), accum_init.data(), samples_init))) return fail(rc);
 
     std::vector<float> image_raw(pixel_count * 4), image(pixel_count * 3);
+    /* Overlapped form (rpt_tracing_state_set_overlap): batch k+1 is enqueued before the image after batch k
+     * is read — the read-back (device un-tile, DMA, host copy) hides behind the rendering; the framebuffer and `samples` the UI
+     * sees are those of the image just read, one batch behind the device.  Same images, same flush semantics. */
+    const bool overlap = state->overlap.load(std::memory_order_relaxed);
+    if (overlap && (rc = api.comm_init_local(ctx))) return fail(rc);
+    uint32_t in_flight = 0;                              /* overlap: samples of the batch that was enqueued but not read yet */
+    auto publish = [&](uint32_t samples_of_image) {
+        float sample_count = (float)samples_of_image;
+        for (size_t i = 0; i < pixel_count; ++i) {
+            image[3 * i + 0] = image_raw[4 * i + 0] / sample_count;
+            image[3 * i + 1] = image_raw[4 * i + 1] / sample_count;
+            image[3 * i + 2] = image_raw[4 * i + 2] / sample_count;
+        }
+        std::lock_guard<std::mutex> g(state->lock);
+        state->framebuffer = image;
+    };
     while (state->running.load(std::memory_order_relaxed)) {
         uint32_t n = state->sync_rate.load(std::memory_order_relaxed);
         if (state->target_samples) {
-            uint32_t done = state->samples.load(std::memory_order_relaxed);
+            uint32_t done = state->samples.load(std::memory_order_relaxed) + in_flight;
             uint32_t left = state->target_samples > done ? state->target_samples - done : 0;
             if (n > left) n = left;
         }
@@ -429,25 +453,34 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
          * (trace.rs:187); one rpt_render call covers the whole batch, so the
          * poll happens once per batch */
         bool flush = state->interacting.load(std::memory_order_relaxed) || state->dirty.load(std::memory_order_relaxed);
-        if (n) {
-            if ((rc = api.render(ctx, n))) return fail(rc);
-            state->samples.fetch_add(n, std::memory_order_relaxed);
-        }
-        uint32_t device_samples = 0;
-        if ((rc = api.read_accum(ctx, image_raw.data(), &device_samples))) return fail(rc);
-        float sample_count = (float)state->samples.load(std::memory_order_relaxed);
-        for (size_t i = 0; i < pixel_count; ++i) {
-            image[3 * i + 0] = image_raw[4 * i + 0] / sample_count;
-            image[3 * i + 1] = image_raw[4 * i + 1] / sample_count;
-            image[3 * i + 2] = image_raw[4 * i + 2] / sample_count;
-        }
-        {
-            std::lock_guard<std::mutex> g(state->lock);
-            state->framebuffer = image;
+        if (!overlap) {
+            if (n) {
+                if ((rc = api.render(ctx, n))) return fail(rc);
+                state->samples.fetch_add(n, std::memory_order_relaxed);
+            }
+            uint32_t device_samples = 0;
+            if ((rc = api.read_accum(ctx, image_raw.data(), &device_samples))) return fail(rc);
+            publish(state->samples.load(std::memory_order_relaxed));
+        } else {
+            if (n && (rc = api.render_async(ctx, n))) return fail(rc);          /* batch k+1 ... */
+            if (in_flight) {                                                    /* ... while the image after batch k comes back */
+                uint32_t device_samples = 0;
+                if ((rc = api.read_gathered(ctx, image_raw.data(), &device_samples))) return fail(rc);
+                state->samples.store(device_samples, std::memory_order_relaxed);
+                publish(device_samples);
+            }
+            if (n && (rc = api.gather_async(ctx))) return fail(rc);             /* snapshot after batch k+1 */
+            in_flight = n;
+            if (!n && !flush) {                                                 /* nothing left to enqueue: the last image is in */
+                if (state->target_samples && state->samples.load(std::memory_order_relaxed) >= state->target_samples)
+                    state->running.store(false, std::memory_order_relaxed);
+                continue;
+            }
         }
         if (flush) {
             state->dirty.store(false, std::memory_order_relaxed);
             state->samples.store(0, std::memory_order_relaxed);
+            in_flight = 0;                                                      /* (what was enqueued is discarded by the reset) */
             { std::lock_guard<std::mutex> g(state->lock); config = state->config; }
             if (config.width != W || config.height != H) {
                 /* every buffer of this call (seeds, read-back image, the state's framebuffer) is sized for the
@@ -461,8 +494,14 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
             if ((rc = api.set_config(ctx, &config))) return fail(rc);
             if ((rc = api.reset(ctx, seeds(), nullptr, 0))) return fail(rc);
         }
-        if (state->target_samples && state->samples.load(std::memory_order_relaxed) >= state->target_samples)
+        if (!overlap && state->target_samples && state->samples.load(std::memory_order_relaxed) >= state->target_samples)
             state->running.store(false, std::memory_order_relaxed);
+    }
+    if (overlap && in_flight) {                          /* stopped from outside: the batch still in flight is read too */
+        uint32_t device_samples = 0;
+        if ((rc = api.read_gathered(ctx, image_raw.data(), &device_samples))) return fail(rc);
+        state->samples.store(device_samples, std::memory_order_relaxed);
+        publish(device_samples);
     }
     api.destroy(ctx);
     rpt_world_free(world);

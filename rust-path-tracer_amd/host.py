@@ -39,6 +39,7 @@ def lib():
         L.rpt_tracing_state_set_sync_rate.argtypes = [C.c_void_p, C.c_uint32]
         L.rpt_tracing_state_set_running.argtypes = [C.c_void_p, C.c_int]
         L.rpt_tracing_state_set_dirty.argtypes = [C.c_void_p, C.c_int]
+        L.rpt_tracing_state_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.rpt_tracing_state_set_config.argtypes = [C.c_void_p, C.POINTER(TracingConfig)]
         L.rpt_tracing_state_new.argtypes = [C.c_uint32, C.c_uint32]
         L.rpt_trace_gpu.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_char_p]
@@ -229,6 +230,10 @@ class TracingState:
 
     def set_dirty(self, dirty=True):
         lib().rpt_tracing_state_set_dirty(self._h, C.c_int(1 if dirty else 0))
+
+    def set_overlap(self, on=True):
+        """trace_gpu reads batch k back while batch k+1 renders (rpt_tracing_state_set_overlap)."""
+        lib().rpt_tracing_state_set_overlap(self._h, C.c_int(1 if on else 0))
 
     def set_config(self, config):
         """state.config.write() while trace_gpu runs on another thread (locked copy); follow with set_dirty()."""

@@ -67,7 +67,25 @@ def test_host_dispatch_with_a_skybox_file(oracle, rpt, world, tmp_path):
         state.close()
 
 
-def test_host_dispatch_flush_from_another_thread(oracle, rpt, world):
+@pytest.mark.parametrize("sync_rate,target", [(3, 8), (4, 8), (32, 5), (1, 3)])
+def test_host_dispatch_with_overlapped_read_back(oracle, rpt, world, sync_rate, target):
+    """rpt_tracing_state_set_overlap: batch k+1 is enqueued before the image after batch k is read; the framebuffer the call
+    ends with, and the sample count, are exactly those of the sequential loop — whatever the batch split."""
+    W, H = 88, 60
+    state = rpt.setup_trace(W, H, target)
+    state.config.nee = 1
+    state.set_sync_rate(sync_rate)
+    state.set_overlap()
+    rpt.trace_gpu(rpt.fixture("DarkCornell.glb"), None, state)
+    cfg = rpt.default_config(W, H, nee=1)
+    ref, _, _ = oracle.trace_cpu(cfg, oracle.scene(world("DarkCornell")), rpt.blue_noise_seeds(W, H), target)
+    assert state.samples == target
+    assert np.array_equal(state.framebuffer().view(np.uint32), (ref[..., :3] / np.float32(target)).view(np.uint32))
+    state.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_host_dispatch_flush_from_another_thread(oracle, rpt, world, overlap):
     """The reference's interaction path (src/trace.rs:216-222): the render thread runs until told to stop; the UI thread
     writes a new configuration and raises `dirty`; the loop re-reads the configuration, zeroes the accumulators, restarts
     the sample count — and what it ends with is exactly the new view's image for the samples rendered since."""
@@ -77,6 +95,7 @@ def test_host_dispatch_flush_from_another_thread(oracle, rpt, world):
     state = rpt.TracingState(rpt.host.lib().rpt_tracing_state_new(W, H))
     state.config.nee = 1
     state.set_sync_rate(2)
+    state.set_overlap(overlap)
     state.set_running(True)
     errors = []
 
