@@ -50,6 +50,10 @@ def main(n_cases=None, seed=None, quiet=False):
             cam = (float(rng.choice([0.0, 1e6, -3e7])), float(rng.choice([-10.0, 7e6, 1e9])), float(rng.uniform(-6, 0)), 0.0)
         cfg = rpt.default_config(W, H, nee=nee, min_bounces=min_b, max_bounces=max_b, cam_position=cam, cam_rotation=rot, has_skybox=has_sky, **over)
         seeds = rpt.blue_noise_seeds(W, H)
+        only = os.environ.get("FUZZ_ONLY")
+        if only is not None and int(only) != case:
+            rng.integers(0, spp + 1)                   # (the draw the skipped case would have made)
+            continue
         r = hip.Renderer(0)
         r.set_samples_in_flight(s_in_flight)
         r.upload_scene(w, skybox_f32=sky)
@@ -58,9 +62,17 @@ def main(n_cases=None, seed=None, quiet=False):
         r.render(first); r.render(spp - first)
         acc, n = r.read_accum(); g = r.stats(); r.close()
         ref, _, st = orc.trace_cpu(cfg, orc.scene(w, skybox_f32=sky), seeds, spp)
-        ok = (n == spp and np.array_equal(acc.view(np.uint32), ref.view(np.uint32)) and g["extension_rays"] == st.extension_rays
+        na, nb = np.isnan(acc), np.isnan(ref)                    # a NaN radiance (both sides, same pixel) may differ in sign / payload
+        ok = (n == spp and np.array_equal(na, nb) and np.array_equal(acc[~na].view(np.uint32), ref[~nb].view(np.uint32)) and g["extension_rays"] == st.extension_rays
               and g["shadow_rays"] == st.shadow_rays and g["sky_evals"] == st.sky_evals)
         print(f"{case:3d} {name:12s} {W}x{H} spp {spp} nee {nee} bounces {min_b}/{max_b} S {s_in_flight} sky {has_sky}: {'ok' if ok else 'MISMATCH'}")
+        if not ok:
+            a, b = acc.view(np.uint32), ref.view(np.uint32)
+            diff = np.argwhere(((a != b) & ~(na & nb)).any(axis=-1))
+            print("   config:", {k: (list(getattr(cfg, k)) if hasattr(getattr(cfg, k), "__len__") else getattr(cfg, k)) for k, _ in cfg._fields_},
+                  "first render", first)
+            print("   samples", n, "rays gpu", (g["extension_rays"], g["shadow_rays"], g["sky_evals"]), "oracle", (st.extension_rays, st.shadow_rays, st.sky_evals),
+                  "differing pixels", len(diff), "first", diff[:3].tolist(), "gpu", acc[tuple(diff[0])] if len(diff) else None, "oracle", ref[tuple(diff[0])] if len(diff) else None)
         bad += 0 if ok else 1
     print("mismatches:", bad)
     return bad
