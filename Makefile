@@ -23,7 +23,7 @@ HIPFLAGS := --offload-arch=gfx950 -std=c++20 -O3 -fPIC -ffp-contract=off -fno-fa
             -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero \
             -Wall -Wno-unused-function
 
-all: host oracle hip
+all: host oracle hip fake_rccl
 
 host: $(LIBDIR)/librpt_host.so
 oracle: oracle/liboracle.so oracle/liboracle_libm.so
@@ -43,7 +43,13 @@ $(LIBDIR)/librpt_hip.so: $(HIP_DEPS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -ldl
 
-clean:
-	rm -f $(LIBDIR)/*.so oracle/*.so
+# test infrastructure: a stand-in for RCCL's point-to-point calls over shared memory, so that N PROCESSES on a one-GPU test box run
+# the product's gather unchanged (tests/test_gpu_multiprocess.py; selected with RPT_RCCL_LIBRARY, never linked by the product)
+fake_rccl: tests/fake_rccl/librccl_fake.so
+tests/fake_rccl/librccl_fake.so: tests/fake_rccl/fake_rccl.cpp
+	$(HIPCC) -x c++ -std=c++17 -O2 -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o $@ $< -L/opt/rocm/lib -lamdhip64 -lrt -pthread
 
-.PHONY: all host oracle hip clean
+clean:
+	rm -f $(LIBDIR)/*.so oracle/*.so tests/fake_rccl/*.so
+
+.PHONY: all host oracle hip fake_rccl clean

@@ -197,6 +197,10 @@ int rpt_comm_init(rpt_ctx *ctx, const uint8_t *unique_id, uint32_t rank, uint32_
  *   rpt_render_async ; rpt_gather_async ; rpt_render_async (next batch) ; rpt_read_gathered -> the image after the first. */
 int rpt_comm_init_local(rpt_ctx *ctx);
 int rpt_comm_world(rpt_ctx *ctx, uint32_t *rank_out, uint32_t *world_size_out);   /* as RCCL reports it (ncclCommCount) */
+/* Which collective library the process resolved (dlopen): "librccl.so.1" ..., "" before the first communicator, or the path
+ * given in RPT_RCCL_LIBRARY — an override that exists for tests/fake_rccl (N processes on a one-GPU test box); a
+ * measurement made with it set is not a measurement of RCCL, and bench.py refuses to run then. */
+const char *rpt_comm_library(void);
 int rpt_gather_async(rpt_ctx *ctx);
 int rpt_gather_wait(rpt_ctx *ctx);
 int rpt_read_gathered(rpt_ctx *ctx, float *out_rgba, uint32_t *out_samples);

@@ -115,16 +115,23 @@ rpt_tracing_state *rpt_tracing_state_new(uint32_t width, uint32_t height);   /* 
 void rpt_tracing_state_free(rpt_tracing_state *s);
 rpt_tracing_config *rpt_tracing_state_config(rpt_tracing_state *s);          /* state.config (caller mutates before tracing) */
 const float *rpt_tracing_state_framebuffer(rpt_tracing_state *s, size_t *n_floats); /* W*H*3 mean RGB */
+/* the same image copied under the state's lock — for a reader on another thread while rpt_trace_gpu runs (framebuffer.read()) */
+int rpt_tracing_state_copy_framebuffer(rpt_tracing_state *s, float *out, size_t n_floats);
 uint32_t rpt_tracing_state_samples(rpt_tracing_state *s);
 void rpt_tracing_state_set_running(rpt_tracing_state *s, int running);
 void rpt_tracing_state_set_sync_rate(rpt_tracing_state *s, uint32_t sync_rate);
 void rpt_tracing_state_set_dirty(rpt_tracing_state *s, int dirty);
+/* state.interacting (src/trace.rs:50): raised by the UI for as long as the camera is dragged; while it is up every batch is
+ * rendered from zero samples, published, and discarded (src/trace.rs:187, 216-222). */
+void rpt_tracing_state_set_interacting(rpt_tracing_state *s, int on);
 /* state.config.write() from another thread while rpt_trace_gpu runs (taken under the state's lock); then set dirty: the
  * loop re-reads the configuration and restarts accumulation (src/trace.rs:216-222).  A new width / height ends the call. */
 void rpt_tracing_state_set_config(rpt_tracing_state *s, const rpt_tracing_config *config);
-/* rpt_trace_gpu reads the image after batch k while batch k+1 renders (rpt_comm_init_local + rpt_gather_async /
+/* DEFAULT ON: rpt_trace_gpu reads the image after batch k while batch k+1 renders (rpt_comm_init_local + rpt_gather_async /
  * rpt_read_gathered instead of rpt_read_accum): the framebuffer and sample count the caller sees run one batch behind the
- * device; final images, flush behaviour and sample totals are the same.  Set before rpt_trace_gpu is called. */
+ * device; final images, flush behaviour (a flushing iteration still publishes the batch it rendered) and sample totals are
+ * the same.  on = 0 selects the blocking loop rpt_render ; rpt_read_accum, the literal shape of src/trace.rs:182-204
+ * (8 % slower on DarkCornell 1024^2).  Set before rpt_trace_gpu is called. */
 void rpt_tracing_state_set_overlap(rpt_tracing_state *s, int on);
 /* setup_trace(width, height, samples) (src/trace.rs:331-344) — but exact: the
  * render stops after precisely `samples` samples (the reference's watcher

@@ -38,7 +38,7 @@ struct rpt_tracing_state {
     std::atomic<bool> interacting{false};
     std::atomic<bool> dirty{false};
     uint32_t target_samples = 0;           /* setup_trace: stop after exactly this many (0 = run until !running) */
-    std::atomic<bool> overlap{false};      /* rpt_trace_gpu reads batch k back while batch k+1 renders (rpt_comm_init_local) */
+    std::atomic<bool> overlap{true};       /* rpt_trace_gpu reads batch k back while batch k+1 renders (rpt_comm_init_local): the default */
 };
 
 extern "C" {
@@ -229,10 +229,20 @@ const float *rpt_tracing_state_framebuffer(rpt_tracing_state *s, size_t *n) {
     if (n) *n = s->framebuffer.size();
     return s->framebuffer.data();
 }
+/* state.framebuffer.read() from another thread while rpt_trace_gpu runs: a copy taken under the state's lock */
+int rpt_tracing_state_copy_framebuffer(rpt_tracing_state *s, float *out, size_t n_floats) {
+    if (!s || !out) return RPT_EINVAL;
+    std::lock_guard<std::mutex> g(s->lock);
+    if (n_floats != s->framebuffer.size()) return RPT_EINVAL;
+    memcpy(out, s->framebuffer.data(), n_floats * sizeof(float));
+    return 0;
+}
 uint32_t rpt_tracing_state_samples(rpt_tracing_state *s) { return s->samples.load(std::memory_order_relaxed); }
 void rpt_tracing_state_set_running(rpt_tracing_state *s, int r) { s->running.store(r != 0, std::memory_order_relaxed); }
 void rpt_tracing_state_set_sync_rate(rpt_tracing_state *s, uint32_t r) { s->sync_rate.store(r ? r : 1, std::memory_order_relaxed); }
 void rpt_tracing_state_set_dirty(rpt_tracing_state *s, int d) { s->dirty.store(d != 0, std::memory_order_relaxed); }
+/* state.interacting (src/trace.rs:50; the UI raises it while the camera is dragged, src/app.rs): every batch flushes while it is up */
+void rpt_tracing_state_set_interacting(rpt_tracing_state *s, int on) { if (s) s->interacting.store(on != 0, std::memory_order_relaxed); }
 /* state.config.write() of the UI thread (src/app.rs) while trace_gpu runs: under the lock the render loop takes when it
  * re-reads the configuration on a flush (trace.rs:216-222); follow with rpt_tracing_state_set_dirty(s, 1) */
 void rpt_tracing_state_set_overlap(rpt_tracing_state *s, int on) { if (s) s->overlap.store(on != 0, std::memory_order_relaxed); }
@@ -426,9 +436,13 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
     if ((rc = api.reset(ctx, seeds(), accum_init.data(), samples_init))) return fail(rc);
 
     std::vector<float> image_raw(pixel_count * 4), image(pixel_count * 3);
-    /* Overlapped form (rpt_tracing_state_set_overlap): batch k+1 is enqueued before the image after batch k
-     * is read — the read-back (device un-tile, DMA, host copy) hides behind the rendering; the framebuffer and `samples` the UI
-     * sees are those of the image just read, one batch behind the device.  Same images, same flush semantics. */
+    /* Overlapped form (the default): batch k+1 is enqueued before the image after batch k is read — the
+     * read-back (device un-tile, DMA, host copy) hides behind the rendering; the framebuffer and `samples` the UI sees are
+     * those of the image just read, one batch behind the device.  Same images, same flush semantics: an iteration that
+     * flushes (`interacting | dirty`) reads and publishes the batch it has just enqueued before the reset, exactly as the
+     * reference publishes on every iteration (trace.rs:198-213 run before 216-222) — so a camera drag, which holds
+     * `interacting` for many batches, keeps updating the framebuffer.  rpt_tracing_state_set_overlap(state, 0) selects the
+     * blocking loop (rpt_render ; rpt_read_accum), the reference's literal shape. */
     const bool overlap = state->overlap.load(std::memory_order_relaxed);
     if (overlap && (rc = api.comm_init_local(ctx))) return fail(rc);
     uint32_t in_flight = 0;                              /* overlap: samples of the batch that was enqueued but not read yet */
@@ -471,6 +485,12 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
             }
             if (n && (rc = api.gather_async(ctx))) return fail(rc);             /* snapshot after batch k+1 */
             in_flight = n;
+            if (flush && in_flight) {                                           /* the reset below discards device state: this image is shown first */
+                uint32_t device_samples = 0;
+                if ((rc = api.read_gathered(ctx, image_raw.data(), &device_samples))) return fail(rc);
+                state->samples.store(device_samples, std::memory_order_relaxed);
+                publish(device_samples);
+            }
             if (!n && !flush) {                                                 /* nothing left to enqueue: the last image is in */
                 if (state->target_samples && state->samples.load(std::memory_order_relaxed) >= state->target_samples)
                     state->running.store(false, std::memory_order_relaxed);
@@ -480,7 +500,7 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
         if (flush) {
             state->dirty.store(false, std::memory_order_relaxed);
             state->samples.store(0, std::memory_order_relaxed);
-            in_flight = 0;                                                      /* (what was enqueued is discarded by the reset) */
+            in_flight = 0;                                                      /* (overlap: already read and published above) */
             { std::lock_guard<std::mutex> g(state->lock); config = state->config; }
             if (config.width != W || config.height != H) {
                 /* every buffer of this call (seeds, read-back image, the state's framebuffer) is sized for the

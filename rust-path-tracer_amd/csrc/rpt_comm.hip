@@ -40,6 +40,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
+    std::string library;             /* what was loaded: a soname of RCCL, or the RPT_RCCL_LIBRARY override */
 
     std::mutex mutex;                /* contexts on different threads may ask for their first communicator at the same time */
 
@@ -47,10 +48,19 @@ struct RcclApi {
         std::lock_guard<std::mutex> lock(mutex);
         if (handle) return true;
         error.clear();
-        /* by soname: if the process already holds an RCCL (torch ships one) the loader hands back that very copy */
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (handle) break;
+        /* RPT_RCCL_LIBRARY: load THIS library instead of RCCL.  It exists for tests/fake_rccl (N processes on the one GPU of a
+           test box, where RCCL refuses a second rank per device); rpt_comm_library() reports it and bench.py refuses to run with it. */
+        const char *override_path = getenv("RPT_RCCL_LIBRARY");
+        if (override_path && *override_path) {
+            handle = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+            if (!handle) { error = std::string("RPT_RCCL_LIBRARY: cannot load ") + override_path + ": " + dlerror(); return false; }
+            library = override_path;
+        } else {
+            /* by soname: if the process already holds an RCCL (torch ships one) the loader hands back that very copy */
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (handle) { library = name; break; }
+            }
         }
         if (!handle) { error = std::string("cannot load RCCL: ") + dlerror(); return false; }
         auto sym = [&](const char *n) { void *p = dlsym(handle, n); if (!p && error.empty()) error = std::string("RCCL lacks ") + n; return p; };
@@ -64,7 +74,7 @@ struct RcclApi {
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-        if (!error.empty()) { dlclose(handle); handle = nullptr; return false; }
+        if (!error.empty()) { dlclose(handle); handle = nullptr; library.clear(); return false; }
         return true;
     }
 };
@@ -344,6 +354,8 @@ int rpt_comm_unique_id(uint8_t *id_out) {
     memcpy(id_out, &id, sizeof(id));
     return RPT_OK;
 }
+
+const char *rpt_comm_library(void) { return rccl().library.c_str(); }
 
 int rpt_comm_init(rpt_ctx *c, const uint8_t *unique_id, uint32_t rank, uint32_t world_size) {
     if (!c || !unique_id) return RPT_EINVAL;

@@ -40,6 +40,8 @@ def lib():
         L.rpt_tracing_state_set_running.argtypes = [C.c_void_p, C.c_int]
         L.rpt_tracing_state_set_dirty.argtypes = [C.c_void_p, C.c_int]
         L.rpt_tracing_state_set_overlap.argtypes = [C.c_void_p, C.c_int]
+        L.rpt_tracing_state_set_interacting.argtypes = [C.c_void_p, C.c_int]
+        L.rpt_tracing_state_copy_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rpt_tracing_state_set_config.argtypes = [C.c_void_p, C.POINTER(TracingConfig)]
         L.rpt_tracing_state_new.argtypes = [C.c_uint32, C.c_uint32]
         L.rpt_trace_gpu.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_char_p]
@@ -218,9 +220,11 @@ class TracingState:
 
     def framebuffer(self):
         n = C.c_size_t()
-        p = lib().rpt_tracing_state_framebuffer(self._h, C.byref(n))
+        lib().rpt_tracing_state_framebuffer(self._h, C.byref(n))
         cfg = self.config
-        return np.ctypeslib.as_array(p, shape=(n.value,)).copy().reshape(cfg.height, cfg.width, 3)
+        out = np.empty(n.value, np.float32)
+        _check(lib().rpt_tracing_state_copy_framebuffer(self._h, ptr(out), n.value))      # locked copy: the render thread may be publishing
+        return out.reshape(cfg.height, cfg.width, 3)
 
     def set_sync_rate(self, n):
         lib().rpt_tracing_state_set_sync_rate(self._h, C.c_uint32(n))
@@ -230,6 +234,10 @@ class TracingState:
 
     def set_dirty(self, dirty=True):
         lib().rpt_tracing_state_set_dirty(self._h, C.c_int(1 if dirty else 0))
+
+    def set_interacting(self, on=True):
+        """state.interacting (src/trace.rs:50): while up, every batch flushes (camera drag)."""
+        lib().rpt_tracing_state_set_interacting(self._h, C.c_int(1 if on else 0))
 
     def set_overlap(self, on=True):
         """trace_gpu reads batch k back while batch k+1 renders (rpt_tracing_state_set_overlap)."""

@@ -110,7 +110,7 @@ def test_rust_binding_declares_the_whole_abi():
     assert bound <= declared, sorted(bound - declared)
     optional = {s for s in declared if s.startswith("rpt_debug_")} | {
         "rpt_set_partition", "rpt_set_samples_in_flight", "rpt_stream", "rpt_read_rng", "rpt_tile_order", "rpt_local_pixels",
-        "rpt_local_block_device_ptr", "rpt_rank_pixels", "rpt_untile", "rpt_comm_world"}
+        "rpt_local_block_device_ptr", "rpt_rank_pixels", "rpt_untile", "rpt_comm_world", "rpt_comm_library"}
     assert declared - bound <= optional, sorted(declared - bound - optional)
     assert "RPT_COMM_ID_BYTES: usize = 128" in text and "pub struct rpt_stats" in text
 

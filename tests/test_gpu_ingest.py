@@ -134,6 +134,56 @@ def test_host_dispatch_flush_from_another_thread(oracle, rpt, world, overlap):
     state.close()
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_host_dispatch_keeps_publishing_while_interacting(oracle, rpt, world, overlap):
+    """A camera drag holds `interacting` for many batches (src/app.rs): every iteration renders sync_rate samples from zero,
+    PUBLISHES them (src/trace.rs:198-213 run before the flush of 216-222) and discards them.  The framebuffer therefore
+    follows the camera while the drag lasts — in the overlapped loop too, where a flushing iteration must read the batch it
+    has just enqueued before the reset throws it away."""
+    import threading
+    import time
+    W, H, rate = 96, 64, 3
+    state = rpt.TracingState(rpt.host.lib().rpt_tracing_state_new(W, H))
+    state.config.nee = 1
+    state.set_sync_rate(rate)
+    state.set_overlap(overlap)
+    state.set_interacting(True)                                 # the drag starts before the first batch
+    state.set_running(True)
+    errors = []
+
+    def run():
+        try:
+            rpt.trace_gpu(rpt.fixture("DarkCornell.glb"), None, state)
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=run)
+    t.start()
+    sc = oracle.scene(world("DarkCornell"))
+    seeds = rpt.blue_noise_seeds(W, H)
+    deadline = time.time() + 120
+    views = [rpt.default_config(W, H, nee=1),
+             rpt.default_config(W, H, nee=1, cam_position=(0.6, 1.4, -4.0, 0.0), cam_rotation=(0.05, -0.15, 0.0, 0.0)),
+             rpt.default_config(W, H, nee=1, cam_position=(-0.4, 1.1, -3.5, 0.0), cam_rotation=(0.0, 0.2, 0.0, 0.0))]
+    shown = []
+    for k, view in enumerate(views):
+        if k:
+            state.set_config(view)                              # (picked up by the very next iteration: interacting flushes each one)
+        ref, _, _ = oracle.trace_cpu(view, sc, seeds, rate)
+        want = (ref[..., :3] / np.float32(rate)).view(np.uint32)
+        ok = False
+        while time.time() < deadline and t.is_alive() and not ok:
+            ok = np.array_equal(state.framebuffer().view(np.uint32), want)     # the drag's current view, `rate` samples, from zero
+            time.sleep(0.001)
+        shown.append(ok)
+    state.set_interacting(False)
+    state.set_running(False)
+    t.join(120)
+    assert not t.is_alive() and not errors, errors
+    assert shown == [True, True, True], shown
+    state.close()
+
+
 def test_host_dispatch_refuses_a_resize_while_rendering(rpt):
     """Every buffer of a trace_gpu call is sized for the resolution it started with (src/trace.rs:146-148): a configuration
     with another width / height written while it runs ends the call with an error instead of overrunning them."""

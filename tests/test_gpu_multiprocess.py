@@ -1,0 +1,111 @@
+"""The product's N-rank gather, executed: N PROCESSES (one per rank, as `bench.py --gpus N` starts them) run
+rpt_comm_init -> rpt_render_async -> rpt_gather_async -> rpt_read_gathered of csrc/rpt_comm.hip unchanged.
+
+RCCL refuses two ranks on one device and every GPU box this build reaches has one GPU, so the ten RCCL entry points the
+library resolves with dlsym come from tests/fake_rccl/librccl_fake.so here (RPT_RCCL_LIBRARY; stream-ordered send / receive
+with per-channel rendezvous over shared memory).  Everything else — partition, snapshot, second stream, grouped
+point-to-point calls to rank 0, strides, un-tile map, overlap with the next batch — is the code an 8-GPU run executes.
+Reference: one caller, one image (src/trace.rs:136-224); the image must not depend on how many ranks rendered it.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl", "librccl_fake.so")
+WORKER = os.path.join(ROOT, "tests", "fake_rccl", "rank_worker.py")
+
+
+def _env():
+    env = dict(os.environ)
+    env["RPT_RCCL_LIBRARY"] = FAKE
+    env["RPT_FAKE_RCCL_TIMEOUT_S"] = "60"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def _unique_id():
+    """rpt_comm_unique_id in a process of its own that resolves the stand-in (this pytest process may hold real RCCL)."""
+    code = ("import importlib,sys; sys.path.insert(0, %r); hip = importlib.import_module('rust-path-tracer_amd.hip'); "
+            "print(hip.comm_unique_id().hex()); print(hip.comm_library())" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=120, check=True).stdout.split()
+    assert out[1] == FAKE
+    return out[0]
+
+
+def _run_ranks(tmp_path, world, extra=()):
+    assert os.path.exists(FAKE), "tests/fake_rccl/librccl_fake.so is missing: make fake_rccl"
+    uid = _unique_id()
+    procs = []
+    for rank in range(world):
+        log = open(tmp_path / f"rank{rank}.log", "w")
+        procs.append((subprocess.Popen([sys.executable, WORKER, "--uid", uid, "--rank", str(rank), "--world", str(world), "--out", str(tmp_path), *extra],
+                                       env=_env(), stdout=log, stderr=subprocess.STDOUT), log))
+    failed = []
+    for rank, (p, log) in enumerate(procs):
+        try:
+            rc = p.wait(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = -9
+        log.close()
+        if rc != 0:
+            failed.append((rank, rc, open(tmp_path / f"rank{rank}.log").read()[-2000:]))
+    assert not failed, failed
+    return [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+
+
+def _single(hipmod, rpt, world, W, H, nee, batches):
+    w = world("DarkCornell")
+    cfg = rpt.default_config(W, H, nee=nee)
+    r = hipmod.Renderer(0)
+    r.upload_scene(w); r.set_config(cfg); r.reset(rpt.blue_noise_seeds(W, H))
+    images = []
+    for n in batches:
+        r.render(n)
+        images.append(r.read_accum()[0].copy())
+    st = r.stats()
+    r.close()
+    return images, st
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_n_processes_gather_the_one_rank_image(hipmod, rpt, world, tmp_path, ranks):
+    """2, 3 and 8 processes: the image rank 0 reads equals the 1-rank render bit for bit, the communicator has N ranks as the
+    collective library itself reports, the ranks' pixel blocks partition the image and their ray counts add up."""
+    W, H, batches = 200, 136, (4, 4, 2)
+    ref, st_ref = _single(hipmod, rpt, world, W, H, 1, batches)
+    infos = _run_ranks(tmp_path, ranks, ["--width", str(W), "--height", str(H), "--nee", "1", "--batches", ",".join(map(str, batches)), "--second-image"])
+    for r, info in enumerate(infos):
+        assert (info["rank"], info["world"]) == (r, ranks) and info["library"] == FAKE
+    assert sum(i["pixels"] for i in infos) == W * H
+    assert infos[0]["gathered_samples"] == sum(batches)
+    img = np.load(tmp_path / "image.npy")
+    assert np.array_equal(img.view(np.uint32), ref[-1].view(np.uint32))
+    assert sum(i["extension_rays"] for i in infos) == st_ref["extension_rays"]           # (counted before the second image)
+    assert sum(i["shadow_rays"] for i in infos) == st_ref["shadow_rays"]
+    # flush path on the same communicator: reset + one 3-sample batch
+    ref2, _ = _single(hipmod, rpt, world, W, H, 1, (3,))
+    assert infos[0]["second_samples"] == 3
+    assert np.array_equal(np.load(tmp_path / "image2.npy").view(np.uint32), ref2[0].view(np.uint32))
+
+
+def test_overlapped_reads_see_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, world, tmp_path):
+    """Rank 0 reads the gathered image after every batch while the next one renders on all ranks: each read is exactly the
+    1-rank image after that many batches (the snapshot precedes the next batch; the send buffer is not reused early)."""
+    W, H, batches = 264, 200, (3, 3, 3, 3)
+    ref, st_ref = _single(hipmod, rpt, world, W, H, 0, batches)
+    infos = _run_ranks(tmp_path, 4, ["--width", str(W), "--height", str(H), "--nee", "0", "--batches", ",".join(map(str, batches)), "--read-every-batch"])
+    assert infos[0]["per_batch_samples"] == [3, 6, 9]
+    for k in range(3):
+        got = np.load(tmp_path / f"image_after_batch{k}.npy")
+        assert np.array_equal(got.view(np.uint32), ref[k].view(np.uint32)), k
+    assert np.array_equal(np.load(tmp_path / "image.npy").view(np.uint32), ref[-1].view(np.uint32))
+    assert sum(i["extension_rays"] for i in infos) == st_ref["extension_rays"]
+    assert sum(i["samples"] for i in infos) == W * H * sum(batches)
