@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the per-batch gather runs inside librpt_hip.so (C ABI, RCCL); torch: tiles.Gatherer over torch.distributed")
     ap.add_argument("--with-gather", action="store_true", help="N = 1 only: still run the per-batch gather (a 1-rank communicator), to exercise that path")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed comparison of windows of the rendered image with the CPU oracle")
     ap.add_argument("--no-readback", action="store_true", help="skip the extra render -> read_accum loop (reference loop shape, src/trace.rs:182-204)")
     args = ap.parse_args()
 
@@ -116,6 +117,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if os.environ.get("RPT_RCCL_LIBRARY"):
+        raise SystemExit("bench.py: RPT_RCCL_LIBRARY is set — that override loads a stand-in for RCCL (tests/fake_rccl); nothing measured with it is a measurement")
     if args.all_ranks_on_device0:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -155,12 +158,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The single collective per sample batch.  Default: inside the library, behind the C ABI (rpt_comm_init = RCCL
-    # ncclCommInitRank, rpt_gather_async = grouped ncclSend/ncclRecv to rank 0 on the library's second HIP stream,
-    # root un-tile with a map built once): stream-ordered after the batch, nothing on the host per step, batch k+1
-    # renders while the blocks of batch k travel.  torch.distributed only carries the 128-byte unique id, the barrier
-    # and the final statistics.  --gather torch keeps the round-1 path (tiles.Gatherer over torch.distributed); it is
-    # also what the bench falls back to — loudly, recorded in the JSON — if RCCL cannot be initialised from the library.
+    # The single collective per sample batch: inside the library, behind the C ABI (rpt_comm_init = RCCL ncclCommInitRank,
+    # rpt_gather_async = grouped ncclSend/ncclRecv to rank 0 on the library's second HIP stream, root un-tile with a map
+    # built once): stream-ordered after the batch, nothing on the host per step, batch k+1 renders while the blocks of
+    # batch k travel.  torch.distributed only carries the 128-byte unique id, the barrier and the final statistics.
+    # If RCCL cannot be initialised from the library the bench FAILS (non-zero exit): a number from another gather would not
+    # be the product's.  --gather torch (tiles.Gatherer over torch.distributed, the round-1 path) exists only as an explicit
+    # choice and says so in `config.gather`.
     gather_impl = None
     if world_size > 1 or args.with_gather:
         want = args.gather if args.dist_backend == "nccl" else "torch"
@@ -170,7 +174,7 @@ def main():
             if rank == 0:
                 try:
                     uid = hip.comm_unique_id()
-                except Exception as e:                               # noqa: BLE001 — recorded, never silent
+                except Exception as e:                               # noqa: BLE001 — reported below, on every rank
                     gather_note = f"{type(e).__name__}: {e}"
             ids = [uid]
             if world_size > 1:                                       # every rank takes part, whatever rank 0 got
@@ -179,18 +183,22 @@ def main():
             if ids[0] is not None:
                 try:
                     r.comm_init(ids[0], rank, world_size)
-                    gather_impl = "rccl-c-abi"
+                    if r.comm_world() != (rank, world_size):
+                        raise RuntimeError(f"communicator reports {r.comm_world()}, expected {(rank, world_size)}")
                     ok = torch.tensor([1.0], device=comm_device)
                 except Exception as e:                               # noqa: BLE001
                     gather_note = f"{type(e).__name__}: {e}"
             if world_size > 1:
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok[0]) < 1.0:
-                gather_impl = "torch.distributed (fallback: " + (gather_note or "another rank failed rpt_comm_init") + ")"
-                if rank == 0:
-                    print("bench: RCCL inside the library failed, falling back to torch.distributed gather: " + str(gather_note), file=sys.stderr)
+                print(f"bench: rank {rank}: the library's RCCL gather could not be set up ({gather_note or 'another rank failed'}); "
+                      "no fallback — `--gather torch` is a different, explicitly chosen code path", file=sys.stderr)
+                if world_size > 1:
+                    dist.destroy_process_group()
+                raise SystemExit(3)
+            gather_impl = "rccl-c-abi"
         else:
-            gather_impl = "torch.distributed"
+            gather_impl = "torch.distributed (explicit --gather torch / --dist-backend gloo: NOT the product's gather)"
     use_lib_gather = gather_impl == "rccl-c-abi"
     gatherer = lib_stream = local_block = staged = None
     if gather_impl and not use_lib_gather:
@@ -242,6 +250,12 @@ def main():
 
     def delta(key):
         return s1[key] - s0[key]
+
+    # (untimed) the image the timed loop produced — every batch since the reset above, warm-up included — for the parity check
+    bench_image, bench_image_spp = None, 0
+    if rank == 0 and not args.no_parity_check and (gatherer is None):
+        bench_image, bench_image_spp = r.read_gathered() if use_lib_gather else r.read_accum()
+        bench_image = bench_image.copy()
 
     # The reference's own loop shape (src/trace.rs:182-204): render sync_rate samples, read the accumulators back to
     # the host, repeat.  Timed separately — it is not `value` (inputs and outputs of `value` stay in HBM) — so that the
@@ -383,6 +397,43 @@ def main():
                "sample": f"{scene}.glb {W}x{H} {spp} spp, same config and seeds, {st.seconds:.1f} s on {st.threads} threads",
                "samples_per_s": round(st.samples / st.seconds, 1)}
 
+    # --- parity inside the benchmark run: windows of the image the timed loop rendered vs the CPU oracle at the same sample
+    # count (same scene buffers, config, seeds) — accumulators must be equal BIT FOR BIT (sum order over all samples is part of
+    # the result, kernels/src/lib.rs:225-226); a mismatch fails the bench.
+    parity = None
+    if bench_image is not None:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle_ffi import Oracle
+        orc = Oracle("rpt_math")
+        osc = orc.scene(world)
+        want_spp = args.spp_per_step * (args.warmup + args.steps)
+        ww, wh = min(48, W), min(40, H)
+        # centre, across a 64 x 64 tile seam (x = 64 k: two ranks' tiles when N > 1), bottom-right corner
+        seam_x, seam_y = 64 * max(1, W // 192), 64 * max(1, H // 320)         # a tile corner away from the centre (1024^2: 320, 192)
+        clampx, clampy = (lambda v: max(0, min(W - ww, v))), (lambda v: max(0, min(H - wh, v)))
+        rects = [(clampx((W - ww) // 2), clampy((H - wh) // 2)), (clampx(seam_x - ww // 2), clampy(seam_y - wh // 2)), (W - ww, H - wh)]
+        budget_s = 40.0
+        t_par = time.perf_counter()
+        n_win, bitwise, num, den, worst = 0, True, 0.0, 0.0, 0
+        for (x0, y0) in rects:
+            if n_win >= 2 and time.perf_counter() - t_par > budget_s:
+                break
+            ref, _, _ = orc.trace_cpu(cfg, osc, seeds, want_spp, rect=(x0, y0, x0 + ww, y0 + wh), threads=usable_cores())
+            a = bench_image[y0:y0 + wh, x0:x0 + ww]
+            b = ref[y0:y0 + wh, x0:x0 + ww]
+            same = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+            bitwise = bitwise and same
+            worst = max(worst, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+            num += float(((a[..., :3].astype(np.float64) - b[..., :3]) ** 2).sum())
+            den += float((b[..., :3].astype(np.float64) ** 2).sum())
+            n_win += 1
+        parity = {"windows": n_win, "window_px": [ww, wh], "spp": int(want_spp), "image_spp": int(bench_image_spp), "bitwise": bitwise,
+                  "rel_l2": (num / den) ** 0.5 if den > 0 else 0.0, "differing_words": worst,
+                  "against": "oracle/rpt_oracle.cpp trace_cpu(rect) at the same spp, config, seeds", "seconds": round(time.perf_counter() - t_par, 2)}
+        if bench_image_spp != want_spp:
+            parity["bitwise"] = False
+            parity["error"] = f"image carries {bench_image_spp} spp, expected {want_spp}"
+
     out = {
         "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True,
@@ -392,7 +443,7 @@ def main():
         "config": {"workload": f"{scene}.glb {W}x{H}, {args.steps}x{args.spp_per_step} spp (config total {total_spp}), "
                                f"nee={cfg.nee}, bounces {cfg.min_bounces}/{cfg.max_bounces}",
                    "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU",
-                   "gather": gather_impl},
+                   "gather": gather_impl, "collective_library": hip.comm_library() or None},
         "samples_per_s": round(n_samples / elapsed_max, 1),
         "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
                  "per_sample": round(rays / max(n_samples, 1), 4)},
@@ -401,6 +452,7 @@ def main():
                               "frac": round(pipeline_gbs / HBM_PEAK_GBS, 6),
                               "formula": "128*N_ext + 96*N_shadow + 128*N_mis + 40*samples (SURVEY.md 8d)"},
         "cpu_baseline": cpu,
+        "parity_check": parity,
         "readback": readback,
     }
     import ctypes
@@ -409,6 +461,9 @@ def main():
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world_size > 1:
         dist.destroy_process_group()
+    if parity is not None and not (parity["bitwise"] and parity["rel_l2"] <= 1e-4):
+        print("bench: PARITY CHECK FAILED: " + json.dumps(parity), file=sys.stderr)
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -96,11 +96,12 @@ bool load_obj(const char *path, World &out) {
         while (*p == ' ' || *p == '\t') ++p;
         float a, b, c;
         char name[512];
-        if (p[0] == 'v' && p[1] == ' ' && sscanf(p + 2, "%f %f %f", &a, &b, &c) == 3) {
+        auto blank = [](char ch) { return ch == ' ' || ch == '\t'; };   /* (a line that is exactly "vn" ends at p[2]: nothing beyond it is read) */
+        if (p[0] == 'v' && blank(p[1]) && sscanf(p + 2, "%f %f %f", &a, &b, &c) == 3) {
             pos.insert(pos.end(), {a, b, c});
-        } else if (p[0] == 'v' && p[1] == 'n' && sscanf(p + 3, "%f %f %f", &a, &b, &c) == 3) {
+        } else if (p[0] == 'v' && p[1] == 'n' && blank(p[2]) && sscanf(p + 3, "%f %f %f", &a, &b, &c) == 3) {
             nor.insert(nor.end(), {a, b, c});
-        } else if (p[0] == 'v' && p[1] == 't' && sscanf(p + 3, "%f %f", &a, &b) >= 2) {
+        } else if (p[0] == 'v' && p[1] == 't' && blank(p[2]) && sscanf(p + 3, "%f %f", &a, &b) >= 2) {
             tex.insert(tex.end(), {a, b});
         } else if (!strncmp(p, "mtllib ", 7) && sscanf(p + 7, "%511s", name) == 1) {
             std::string mt;

@@ -194,7 +194,11 @@ int comm_configure(rpt_ctx *c) {
         cm->sizes[r] = orders[r].size();
         cm->stride = std::max<uint64_t>(cm->stride, orders[r].size());
     }
-    if (cm->sizes[cm->rank] != c->n_pixels) { c->error = "gather: partition of the context and of the communicator differ"; return RPT_EINVAL; }
+    if (cm->rank != c->rank || cm->world != c->world || cm->sizes[cm->rank] != c->n_pixels) {
+        c->error = "gather: partition of the context and of the communicator differ";
+        return RPT_EINVAL;
+    }
+    cm->started = false;             /* no gathered image exists for this configuration yet (rpt_read_gathered refuses until one does) */
     HIP_TRY(c, cm->send.alloc(std::max<uint64_t>(cm->stride, 1)));
     if (cm->rank == 0) {
         std::vector<uint32_t> map((size_t)cm->world * cm->stride, 0xffffffffu);
@@ -240,8 +244,12 @@ int gather_stage(rpt_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = comm_configure(c);
     if (rc) return rc;
-    /* (a caller that re-partitioned the context behind the communicator's back must not overrun the snapshot buffer) */
-    if (cm->sizes[cm->rank] != c->n_pixels) { c->error = "gather: partition of the context and of the communicator differ"; return RPT_EINVAL; }
+    /* a caller that re-partitioned the context behind the communicator's back must neither overrun the snapshot buffer nor —
+       same block size, other rank — have its block un-tiled through another rank's map */
+    if (cm->rank != c->rank || cm->world != c->world || cm->sizes[cm->rank] != c->n_pixels) {
+        c->error = "gather: partition of the context and of the communicator differ";
+        return RPT_EINVAL;
+    }
     if (cm->started) HIP_TRY(c, hipStreamWaitEvent(c->stream, cm->sent, 0));
     if (c->n_pixels) HIP_TRY(c, hipMemcpyAsync(cm->send.p, c->accum.p, (size_t)c->n_pixels * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(cm->staged, c->stream));
@@ -425,6 +433,10 @@ int rpt_gather_wait(rpt_ctx *c) {
 int rpt_gathered_device_ptr(rpt_ctx *c, void **p) {
     if (!c || !p) return RPT_EINVAL;
     if (!c->comm || c->comm->rank != 0 || !c->comm->full_image.p) { c->error = "gathered image exists on rank 0 after the first gather"; return RPT_EINVAL; }
+    if (!c->has_config || c->comm->conf_w != c->cfg.c.width || c->comm->conf_h != c->cfg.c.height) {
+        c->error = "rpt_gathered_device_ptr: the configuration was resized since the last gather";
+        return RPT_EINVAL;
+    }
     *p = c->comm->full_image.p;
     return RPT_OK;
 }
@@ -433,6 +445,13 @@ int rpt_read_gathered(rpt_ctx *c, float *out, uint32_t *out_samples) {
     if (!c || !out) return RPT_EINVAL;
     rpt_comm *cm = c->comm;
     if (!cm || cm->rank != 0 || !cm->full_image.p || !cm->started) { c->error = "gathered image exists on rank 0 after the first gather"; return RPT_EINVAL; }
+    /* `out` is sized by the caller for the CURRENT configuration; the gathered image has the size of the configuration it was
+       gathered under — after a resize there is no image to hand out until the next gather */
+    if (!c->has_config || cm->conf_w != c->cfg.c.width || cm->conf_h != c->cfg.c.height) {
+        c->error = "rpt_read_gathered: the configuration was resized since the last gather (" + std::to_string(cm->conf_w) + "x" + std::to_string(cm->conf_h) +
+                   " gathered): call rpt_gather_async first";
+        return RPT_EINVAL;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(cm->host_full, cm->full_image.p, cm->host_full_floats * sizeof(float), hipMemcpyDeviceToHost, cm->stream));
     HIP_TRY(c, hipStreamSynchronize(cm->stream));
@@ -533,7 +552,16 @@ int rpt_multi_create(const int *device_ids, int n_devices, uint32_t flags, rpt_m
     }
     for (int r = 0; r < n_devices; ++r) {
         int rc = comm_attach(m->ctx[(size_t)r], comms[(size_t)r], !shared, (uint32_t)r, (uint32_t)n_devices);
-        if (rc) { rpt_create_error() = m->ctx[(size_t)r]->error; rpt_multi_destroy(m); return rc; }
+        if (rc) {
+            rpt_create_error() = m->ctx[(size_t)r]->error;
+            /* communicators of the ranks after r belong to no context yet: rpt_multi_destroy cannot reach them */
+            if (!shared)
+                for (int k = r + 1; k < n_devices; ++k)
+                    if (comms[(size_t)k]) (void)rccl().CommDestroy(comms[(size_t)k]);
+            if (!shared && !m->ctx[(size_t)r]->comm && comms[(size_t)r]) (void)rccl().CommDestroy(comms[(size_t)r]);
+            rpt_multi_destroy(m);
+            return rc;
+        }
     }
     *out = m;
     return RPT_OK;
@@ -554,7 +582,10 @@ int rpt_multi_upload_scene(rpt_multi *m, const rpt_per_vertex_data *pv, size_t n
 }
 
 int rpt_multi_set_config(rpt_multi *m, const rpt_tracing_config *cfg) {
-    if (!m) return RPT_EINVAL;
+    if (!m || !cfg) return RPT_EINVAL;
+    rpt_ctx *root = m->ctx[0];
+    if (!root->has_config || root->cfg.c.width != cfg->width || root->cfg.c.height != cfg->height)
+        m->gathered = false;         /* a resize: the root's gathered image belongs to the old size (rpt_multi_read_accum gathers afresh) */
     for (rpt_ctx *c : m->ctx) {
         int rc = rpt_set_config(c, cfg);
         if (rc) return multi_fail(m, c, rc);

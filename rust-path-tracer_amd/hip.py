@@ -357,6 +357,12 @@ class MultiRenderer:
     def size(self):
         return lib().rpt_multi_size(self._h)
 
+    def ctx_handle(self, rank):
+        """rpt_multi_ctx: the borrowed rpt_ctx of one rank (for rpt_set_samples_in_flight / rpt_get_stats per GPU)."""
+        lib().rpt_multi_ctx.restype = C.c_void_p
+        lib().rpt_multi_ctx.argtypes = [C.c_void_p, C.c_int]
+        return C.c_void_p(lib().rpt_multi_ctx(self._h, rank))
+
     def upload_scene(self, world, skybox_f32=None):
         atlas = getattr(world, "atlas", None)
         aw = ah = sw = sh = 0

@@ -147,6 +147,54 @@ def test_multi_driver_with_more_ranks_than_tiles(hipmod, rpt, world, W, H, ranks
     m.close()
 
 
+def test_gathered_image_is_refused_after_a_resize_until_the_next_gather(hipmod, rpt, world):
+    """rpt_read_gathered copies the image of the configuration it was GATHERED under; a caller that resized the configuration
+    sizes its buffer for the new one.  Until the next gather there is no image of that size: an error, not an overrun."""
+    w = world("DarkCornell")
+    big, small = rpt.default_config(200, 136), rpt.default_config(72, 40)
+    r = hipmod.Renderer(0)
+    r.comm_init_local()
+    r.upload_scene(w); r.set_config(big); r.reset(rpt.blue_noise_seeds(200, 136))
+    r.render_async(2); r.gather_async()
+    assert r.read_gathered()[1] == 2
+    r.set_config(small); r.reset(rpt.blue_noise_seeds(72, 40))
+    with pytest.raises(hipmod.RptError, match="resized"):
+        r.read_gathered()                                   # (hip.py allocates 72 x 40: the old code copied 200 x 136 into it)
+    r.render_async(3); r.gather_async()
+    img, s = r.read_gathered()
+    ref, _, _ = _single_image(hipmod, rpt, w, small, rpt.blue_noise_seeds(72, 40), (3,))
+    assert s == 3 and img.shape == (40, 72, 4) and np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    r.close()
+    # the one-process driver: a resize between two images, the second read without a render in between
+    m = hipmod.MultiRenderer([0] * 3, allow_shared_device=True)
+    m.upload_scene(w); m.set_config(big); m.reset(rpt.blue_noise_seeds(200, 136))
+    m.render(2)
+    assert m.read_accum()[1] == 2
+    m.set_config(small); m.reset(rpt.blue_noise_seeds(72, 40))
+    z, s0 = m.read_accum()
+    assert s0 == 0 and z.shape == (40, 72, 4) and not z.any()
+    m.render(3)
+    img, s = m.read_accum()
+    assert s == 3 and np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    m.close()
+
+
+def test_gather_refuses_a_context_repartitioned_to_another_rank_of_equal_size(hipmod, rpt, world):
+    """128 x 64 on two ranks: one tile each, equal block sizes.  A context whose partition was swapped behind its communicator's
+    back would pass a size check and have its block un-tiled through the other rank's map — the gather compares rank and world."""
+    w = world("DarkCornell")
+    cfg = rpt.default_config(128, 64)
+    m = hipmod.MultiRenderer([0, 0], allow_shared_device=True)
+    m.upload_scene(w); m.set_config(cfg); m.reset(rpt.blue_noise_seeds(128, 64))
+    m.render(1)
+    m.wait()
+    assert hipmod.lib().rpt_set_partition(m.ctx_handle(0), 1, 2) == 0
+    m.reset(rpt.blue_noise_seeds(128, 64))
+    with pytest.raises(hipmod.RptError, match="partition"):
+        m.render(1)
+    m.close()
+
+
 def test_multi_driver_with_rccl_on_the_devices_present(hipmod, rpt, world):
     """ncclCommInitAll over every GPU of the box (one here, eight on the scaling node): same image as one context."""
     import torch

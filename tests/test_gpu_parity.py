@@ -214,6 +214,40 @@ def test_full_size_other_baseline_configs_windows(hipmod, oracle, rpt, world, sc
     r.close()
 
 
+@pytest.mark.parametrize("scene,W,H,nee,spp", [("DarkCornell", 1024, 1024, 0, 256), ("VeachMIS", 1920, 1080, 1, 1024), ("PBRTest", 2048, 2048, 0, 512)])
+def test_baseline_configs_at_their_own_sample_counts(hipmod, oracle, rpt, world, scene, W, H, nee, spp):
+    """BASELINE configs [1], [2], [3] at their full resolution AND their full sample counts (256 / 1024 / 512 spp), rendered
+    the way the reference's loop does — batches of sync_rate = 32 samples (src/trace.rs:75, 182-194): three windows of
+    the final accumulators (centre, across a 64 x 64 tile corner, a far corner) equal the oracle's render of those windows
+    at the same spp BIT FOR BIT — the f32 sum over all samples in sample order is part of the result
+    (kernels/src/lib.rs:225-226) — every pixel carries exactly spp samples, rng[i].x == spp."""
+    cfg = rpt.default_config(W, H, nee=nee)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    r.upload_scene(world(scene))
+    r.set_config(cfg)
+    r.reset(seeds)
+    for _ in range(spp // 32):
+        r.render_async(32)
+    r.wait()
+    a, s = r.read_accum()
+    st = r.stats()
+    rng = r.read_rng()
+    assert s == spp and np.all(a[..., 3] == spp) and np.isfinite(a).all()
+    assert np.all(rng["n"] == spp)
+    assert st["samples"] == W * H * spp and W * H * spp <= st["extension_rays"] <= W * H * spp * cfg.max_bounces
+    sc = oracle.scene(world(scene))
+    ww, wh = 48, 40
+    ext = 0
+    for (x0, y0) in ((W // 2 - ww // 2, H // 2 - wh // 2), (64 * (W // 192) - ww // 2, 64 * (H // 320) - wh // 2), (W - ww, H - wh)):
+        rect = (x0, y0, x0 + ww, y0 + wh)
+        ref, rng_ref, ost = oracle.trace_cpu(cfg, sc, seeds, spp, rect=rect)
+        assert np.array_equal(a[y0:y0 + wh, x0:x0 + ww].view(np.uint32), ref[y0:y0 + wh, x0:x0 + ww].view(np.uint32)), rect
+        ext += ost.extension_rays
+    assert ext > ww * wh * spp                         # (the windows really traced: more than one ray per sample)
+    r.close()
+
+
 @pytest.mark.parametrize("scene,nee,spp", [("DarkCornell", 0, 7), ("VeachMIS", 1, 5), ("PBRTest", 2, 3)])
 def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp):
     """Any number of samples of a pixel in flight gives the sequential sample-order sum, bit for bit

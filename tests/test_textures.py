@@ -209,3 +209,10 @@ def test_image_headers_cannot_size_gigabytes_and_obj_relative_indices_are_bounde
             rpt.World.from_path(str(tmp_path / "rel.obj"))
     (tmp_path / "ok.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1/-1/-1 2/1/1 3//1\n")
     assert len(rpt.World.from_path(str(tmp_path / "ok.obj")).indices) == 1
+    # lines that END at the keyword ("vn", "vt", "v", also behind long leading blanks, which puts the line on the heap): the
+    # scanner must not start one byte past the terminator; such lines carry no data and are skipped; "vnormal" is no keyword
+    pad = " " * 300
+    (tmp_path / "bare.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn\nvt\nv\n" + pad + "vn\n" + pad + "vt\n" + pad + "v\nvn\t0 0 1\nvt\t0 0\n"
+                                       "vnormal 9 9 9\nf 1/1/1 2/1/1 3/1/1\nvn")
+    wb = rpt.World.from_path(str(tmp_path / "bare.obj"))
+    assert len(wb.indices) == 1 and np.allclose(wb.per_vertex["normal"][:, :3], [[0, 1, 0]] * 3)      # (0,0,1) after the (x,z,y) swap

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""export_parity_kit.py — the files a maintainer WITH a Rust toolchain needs to check the CPU oracle (and through it the HIP
+kernels, which equal the oracle bit for bit) against the real reference: `kernels::trace_pixel` (kernels/src/lib.rs:21-186) run on
+byte-identical inputs, compared with committed accumulators.  There is no rustc in the build image, so this is the one way
+"oracle faithful by reading" can ever become "oracle == reference"; ffi/parity_test.rs is the Rust side.
+
+Written to tests/golden/parity_kit/ (regenerated and compared byte for byte by tests/test_parity_kit.py):
+
+  <Scene>.rptscene          the World's five POD buffers (+ atlas), include/rpt/rpt_host.h — what World::from_path would hand
+                            to the kernels, from this repository's loader (assimp is not available either: parity is defined at
+                            the buffer boundary)
+  seeds_<W>x<H>.bin         rng buffer: UVec2 (0, blue-noise seed) per pixel, src/trace.rs:245-256
+  <case>.config.bin         TracingConfig, 80 bytes (shared_structs/src/lib.rs:12-25)
+  <case>.accum.bin          expected output buffer after `spp` samples: Vec4 (sum r, g, b, sample count) per pixel, row-major
+  <case>.accum_libm.bin     the same from the oracle built against the platform libm (glibc here) instead of the shared correctly
+                            rounded rpt_math.h — what the reference's CPU path calls (f32::sin ... -> libm).  On a machine with the
+                            same glibc the Rust build can equal THIS file bit for bit; that is reported, not required
+  manifest.json             cases, sizes, sha256 of every file, the oracle's ray counts and the furnace pixel value
+
+usage: python tools/export_parity_kit.py [out_dir]
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+CASES = [
+    # name, scene, W, H, spp, nee      (128 x 128 x 32 spp = the reference's own furnace test, tests/correctness_tests.rs:14-33)
+    ("furnace_nee0", "FurnaceTest", 128, 128, 32, 0),
+    ("furnace_mis", "FurnaceTest", 128, 128, 32, 1),
+    ("darkcornell_nee0", "DarkCornell", 128, 128, 32, 0),
+    ("darkcornell_mis", "DarkCornell", 128, 128, 32, 1),
+]
+
+
+def sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def export(out_dir):
+    from oracle_ffi import Oracle
+    rpt = importlib.import_module("rust-path-tracer_amd")
+    orc = Oracle("rpt_math")
+    orc_libm = Oracle("libm")
+    os.makedirs(out_dir, exist_ok=True)
+    files, cases, worlds = {}, [], {}
+
+    def put(name, data):
+        with open(os.path.join(out_dir, name), "wb") as f:
+            f.write(data)
+        files[name] = {"bytes": len(data), "sha256": hashlib.sha256(data).hexdigest()}
+
+    for name, scene, W, H, spp, nee in CASES:
+        if scene not in worlds:
+            worlds[scene] = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+            path = os.path.join(out_dir, scene + ".rptscene")
+            worlds[scene].save(path)
+            files[scene + ".rptscene"] = {"bytes": os.path.getsize(path), "sha256": sha256(path)}
+        seeds_name = f"seeds_{W}x{H}.bin"
+        seeds = rpt.blue_noise_seeds(W, H)
+        if seeds_name not in files:
+            put(seeds_name, seeds.tobytes())
+        cfg = rpt.default_config(W, H, nee=nee)
+        put(name + ".config.bin", bytes(cfg))
+        accum, rng_after, st = orc.trace_cpu(cfg, orc.scene(worlds[scene]), seeds, spp)
+        assert np.all(rng_after["n"] == spp) and np.all(accum[..., 3] == spp)
+        put(name + ".accum.bin", np.ascontiguousarray(accum, np.float32).tobytes())
+        accum_libm, _, _ = orc_libm.trace_cpu(cfg, orc_libm.scene(worlds[scene]), seeds, spp)
+        put(name + ".accum_libm.bin", np.ascontiguousarray(accum_libm, np.float32).tobytes())
+        case = {"name": name, "scene": scene + ".rptscene", "seeds": seeds_name, "config": name + ".config.bin", "accum": name + ".accum.bin",
+                "accum_libm": name + ".accum_libm.bin",
+                "width": W, "height": H, "spp": spp, "nee": nee, "extension_rays": int(st.extension_rays), "shadow_rays": int(st.shadow_rays),
+                "tolerance_rel_l2": 1e-4}
+        if scene == "FurnaceTest":
+            px = accum[75, 65, :3] / np.float32(spp)             # the reference's assertion: pixel (65, 75) ^ (1/2.2) = 0.8 +- 0.02
+            case["furnace_pixel_65_75_gamma"] = [float(v) for v in np.power(px.astype(np.float64), 1 / 2.2)]
+        cases.append(case)
+    import platform
+    manifest = {"format": 1, "libm": " ".join(platform.libc_ver()),
+                "what": "inputs + expected accumulators for kernels::trace_pixel; expected values from oracle/rpt_oracle.cpp (shared rpt_math.h "
+                        "transcendentals: the reference's libm may differ in the last bit, hence rel-L2 <= 1e-4 rather than bitwise)",
+                "layouts": {"rptscene": "include/rpt/rpt_host.h", "seeds": "UVec2 per pixel, row-major", "config": "TracingConfig, 80 bytes",
+                            "accum": "Vec4 per pixel, row-major, (sum r, sum g, sum b, samples)"},
+                "cases": cases, "files": files}
+    with open(os.path.join(out_dir, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+        f.write("\n")
+    return manifest
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "parity_kit")
+    m = export(out)
+    total = sum(v["bytes"] for v in m["files"].values())
+    print(f"{len(m['cases'])} cases, {len(m['files'])} files, {total / 1e6:.2f} MB -> {out}")
+    for c in m["cases"]:
+        print(" ", c["name"], c.get("furnace_pixel_65_75_gamma", ""))
