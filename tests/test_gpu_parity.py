@@ -220,7 +220,13 @@ def test_baseline_configs_at_their_own_sample_counts(hipmod, oracle, rpt, world,
     the way the reference's loop does — batches of sync_rate = 32 samples (src/trace.rs:75, 182-194): three windows of
     the final accumulators (centre, across a 64 x 64 tile corner, a far corner) equal the oracle's render of those windows
     at the same spp BIT FOR BIT — the f32 sum over all samples in sample order is part of the result
-    (kernels/src/lib.rs:225-226) — every pixel carries exactly spp samples, rng[i].x == spp."""
+    (kernels/src/lib.rs:225-226) — every pixel carries exactly spp samples, rng[i].x == spp.
+
+    Found by this test: at 1024 spp VeachMIS has a handful of NaN pixels IN THE REFERENCE'S SEMANTICS — the sky term is the one
+    radiance contribution that is not wrapped in mask_nan (`radiance += throughput * skybox::scatter(..)`, lib.rs:69), and a
+    glossy bounce with pdf = 0 leaves a NaN throughput (spectrum / pdf, lib.rs:168) that then escapes to the sky.  The oracle
+    has the NaN in the same pixels from the same sample on; parity means reproducing it, so every non-finite pixel of the GPU
+    image is checked against the oracle's value for that pixel (NaN for NaN), and they must stay rare."""
     cfg = rpt.default_config(W, H, nee=nee)
     seeds = rpt.blue_noise_seeds(W, H)
     r = hipmod.Renderer(0)
@@ -233,10 +239,17 @@ def test_baseline_configs_at_their_own_sample_counts(hipmod, oracle, rpt, world,
     a, s = r.read_accum()
     st = r.stats()
     rng = r.read_rng()
-    assert s == spp and np.all(a[..., 3] == spp) and np.isfinite(a).all()
+    assert s == spp and np.all(a[..., 3] == spp)
     assert np.all(rng["n"] == spp)
     assert st["samples"] == W * H * spp and W * H * spp <= st["extension_rays"] <= W * H * spp * cfg.max_bounces
     sc = oracle.scene(world(scene))
+    bad = np.argwhere(~np.isfinite(a).all(axis=2))
+    assert len(bad) <= 16, len(bad)                     # (measured: DarkCornell 0, VeachMIS 4 of 2 M pixels, PBRTest 0)
+    for (y, x) in bad:
+        ref, _, _ = oracle.trace_cpu(cfg, sc, seeds, spp, rect=(int(x), int(y), int(x) + 1, int(y) + 1))
+        assert np.array_equal(a[y, x], ref[y, x], equal_nan=True), (int(x), int(y), a[y, x], ref[y, x])
+    if scene == "DarkCornell":
+        assert len(bad) == 0                            # a closed scene never reaches the unmasked sky term
     ww, wh = 48, 40
     ext = 0
     for (x0, y0) in ((W // 2 - ww // 2, H // 2 - wh // 2), (64 * (W // 192) - ww // 2, 64 * (H // 320) - wh // 2), (W - ww, H - wh)):

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 rpt = importlib.import_module("rust-path-tracer_amd")
 
 
-def gpu_run(samples, reps=3, overlap=False):
+def gpu_run(samples, reps=3, overlap=True):
     best = 1e9
     for _ in range(reps):
         t = time.perf_counter()
@@ -45,8 +45,8 @@ def cpu_run(samples):
 
 
 if __name__ == "__main__":
-    print(f"160 samples (GPU), DarkCornell 1280x720 incl. startup: {gpu_run(160):.3f} s   (reference comment: 2.408 s)")
-    print(f"  the same with the read-back of batch k overlapped with batch k+1: {gpu_run(160, overlap=True):.3f} s")
+    print(f"160 samples (GPU), DarkCornell 1280x720 incl. startup: {gpu_run(160):.3f} s   (reference comment: 2.408 s; rpt_trace_gpu default = overlapped read-back)")
+    print(f"  the same with the blocking loop (rpt_render ; rpt_read_accum, rpt_tracing_state_set_overlap(0)): {gpu_run(160, overlap=False):.3f} s")
     print(f"Startup time (GPU), DarkCornell, 0 samples:            {gpu_run(0):.3f} s   (reference: 3.021 s on BreakTime.glb)")
     dt, th = cpu_run(32)
     print(f"32 samples (CPU oracle, {th} threads) incl. startup:       {dt:.3f} s   (reference comment: 12.891 s)")
