@@ -33,11 +33,11 @@ $(LIBDIR)/librpt_host.so: $(HOST_SRCS) $(CSRC)/host/host_internal.h $(CSRC)/rpt_
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS_COMMON) -shared -o $@ $(HOST_SRCS) -lz -ldl -pthread
 
-oracle/liboracle.so: oracle/rpt_oracle.cpp $(CSRC)/rpt_math.h $(CSRC)/rpt_math_consts.h include/rpt/shared_structs.h
-	$(CXX) $(ORACLE_FLAGS) -shared -o $@ oracle/rpt_oracle.cpp
+oracle/liboracle.so: oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp $(CSRC)/rpt_math.h $(CSRC)/rpt_math_consts.h include/rpt/shared_structs.h
+	$(CXX) $(ORACLE_FLAGS) -shared -o $@ oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp
 
-oracle/liboracle_libm.so: oracle/rpt_oracle.cpp $(CSRC)/rpt_math.h $(CSRC)/rpt_math_consts.h include/rpt/shared_structs.h
-	$(CXX) $(ORACLE_FLAGS) -DORACLE_USE_LIBM -shared -o $@ oracle/rpt_oracle.cpp -lm
+oracle/liboracle_libm.so: oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp $(CSRC)/rpt_math.h $(CSRC)/rpt_math_consts.h include/rpt/shared_structs.h
+	$(CXX) $(ORACLE_FLAGS) -DORACLE_USE_LIBM -shared -o $@ oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp -lm
 
 $(LIBDIR)/librpt_hip.so: $(HIP_DEPS)
 	@mkdir -p $(LIBDIR)

@@ -95,6 +95,20 @@ class Oracle:
             raise RuntimeError(f"oracle_trace_cpu failed: {rc}")
         return accum, rng, st
 
+    def bvh_build(self, vertices_xyzw, triangles, sah_samples=128):
+        """BVHBuilder::new(vertices, indices).sah_samples(n).build() (reference: src/bvh.rs:59-324), restated in oracle/bvh_oracle.cpp.
+        Returns (nodes, reordered triangles) as arrays of the input dtypes' layouts (nodes: 32-byte records as 8 x u32)."""
+        v = np.ascontiguousarray(vertices_xyzw, np.float32).reshape(-1, 4)
+        t = np.ascontiguousarray(triangles).copy()
+        assert t.dtype.itemsize == 16
+        nodes = np.zeros((2 * len(t) - 1, 8), np.uint32)
+        n = C.c_size_t()
+        rc = self.lib.oracle_bvh_build(_p(v), C.c_size_t(len(v)), _p(t), C.c_size_t(len(t)), C.c_uint32(sah_samples), _p(nodes),
+                                       C.c_size_t(len(nodes)), C.byref(n))
+        if rc != 0:
+            raise RuntimeError(f"oracle_bvh_build failed: {rc}")
+        return nodes[:n.value].copy(), t
+
     def trace_rays(self, scene, mode, origins, dirs, max_t=None):
         origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
         dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)

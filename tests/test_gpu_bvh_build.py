@@ -1,6 +1,7 @@
-"""the GPU BVH build (rpt_bvh_build_gpu, csrc/k_bvh_build.h) against the sequential host restatement of
-the reference builder (src/bvh.rs:59-324 -> csrc/host/bvh_build.cpp): node pool and reordered index buffer must be
-identical bit for bit — node order, leaf ranges, bounds including the sign of zero."""
+"""the GPU BVH build (rpt_bvh_build_gpu, csrc/k_bvh_build.h) against the ORACLE's sequential restatement of the
+reference builder (src/bvh.rs:59-324 -> oracle/bvh_oracle.cpp, test infrastructure that shares no code with the product):
+node pool and reordered index buffer must be identical bit for bit — node order, leaf ranges, bounds including the sign of
+zero.  The product's own host builder (csrc/host/bvh_build.cpp) is held to the same oracle here and in tests/test_host.py."""
 import importlib
 import os
 import sys
@@ -29,6 +30,22 @@ def _original_soup(world):
     return v, t[rng.permutation(len(t))]
 
 
+_ORACLE = None
+
+
+def _oracle_build(v, t, bins=128):
+    """(nodes, triangles) from oracle/bvh_oracle.cpp; the product's host builder must give the same bytes."""
+    global _ORACLE
+    if _ORACLE is None:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle_ffi import Oracle
+        _ORACLE = Oracle("rpt_math")
+    on, ot = _ORACLE.bvh_build(v, t, bins)
+    hn, ht = importlib.import_module("rust-path-tracer_amd.host").bvh_build(v, t, bins)
+    assert hn.tobytes() == on.tobytes() and ht.tobytes() == ot.tobytes(), "host builder differs from the oracle builder"
+    return on, ot
+
+
 def _assert_same(a_nodes, a_tris, b_nodes, b_tris):
     assert len(a_nodes) == len(b_nodes)
     assert a_tris.tobytes() == b_tris.tobytes()
@@ -39,7 +56,7 @@ def _assert_same(a_nodes, a_tris, b_nodes, b_tris):
 def test_gpu_build_equals_host_build_on_shipped_scenes(scene):
     rpt, hip, host = _mods()
     v, t = _original_soup(rpt.World.from_path(rpt.fixture(scene + ".glb")))
-    hn, ht = host.bvh_build(v, t)
+    hn, ht = _oracle_build(v, t)
     gn, gt, ms = hip.bvh_build_gpu(v, t)
     _assert_same(gn, gt, hn, ht)
 
@@ -62,7 +79,7 @@ def test_gpu_build_bin_counts_and_signed_zeros(bins):
     names = t.dtype.names
     t[names[0]], t[names[1]], t[names[2]] = idx[:, 0], idx[:, 1], idx[:, 2]
     t[names[3]] = rng.integers(0, 4, n)
-    hn, ht = host.bvh_build(v, t, bins)
+    hn, ht = _oracle_build(v, t, bins)
     gn, gt, _ = hip.bvh_build_gpu(v, t, bins)
     _assert_same(gn, gt, hn, ht)
 
@@ -77,6 +94,8 @@ def test_gpu_build_large_standin_and_timing():
     t0 = time.perf_counter(); hn, ht = host.bvh_build(v, t); t_host = time.perf_counter() - t0
     t0 = time.perf_counter(); gn, gt, ms = hip.bvh_build_gpu(v, t); t_gpu = time.perf_counter() - t0
     _assert_same(gn, gt, hn, ht)
+    on, ot = _oracle_build(v, t)
+    _assert_same(gn, gt, on, ot)
     print(f"\n200k-triangle build: host {t_host * 1e3:.0f} ms, GPU {t_gpu * 1e3:.0f} ms wall ({ms:.0f} ms device), {len(gn)} nodes")
 
 
@@ -116,7 +135,7 @@ def test_team_kernels_on_small_nodes(monkeypatch, team_min):
     rpt, hip, host = _mods()
     for scene in ("DarkCornell", "VeachMIS", "PBRTest"):
         v, t = _original_soup(rpt.World.from_path(rpt.fixture(scene + ".glb")))
-        hn, ht = host.bvh_build(v, t)
+        hn, ht = _oracle_build(v, t)
         gn, gt, _ = hip.bvh_build_gpu(v, t)
         _assert_same(gn, gt, hn, ht)
     rng = np.random.default_rng(99)
@@ -130,7 +149,7 @@ def test_team_kernels_on_small_nodes(monkeypatch, team_min):
     idx = np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
     t["v0"], t["v1"], t["v2"] = idx[:, 0], idx[:, 1], idx[:, 2]
     for bins in (3, 128):
-        hn, ht = host.bvh_build(v, t, bins)
+        hn, ht = _oracle_build(v, t, bins)
         gn, gt, _ = hip.bvh_build_gpu(v, t, bins)
         _assert_same(gn, gt, hn, ht)
 
@@ -162,11 +181,11 @@ def test_gpu_build_on_hostile_coordinates():
         for poison in (inf_mix, lambda v, r: v.__setitem__(slice(None), 1.5), lambda v, r: v.__imul__(np.float32(1e38)),
                        lambda v, r: v.__imul__(np.float32(1e-42)), lambda v, r: v.__setitem__(slice(0, 600), 0.25)):
             v, t = soup(poison)
-            hn, ht = host.bvh_build(v, t.copy())
+            hn, ht = _oracle_build(v, t.copy())
             gn, gt, _ = hip.bvh_build_gpu(v, t.copy())
             _assert_same(gn, gt, hn, ht)
     v, t = soup(lambda v, r: v.__setitem__((5, 1), np.nan))
     with pytest.raises(hip.RptError) as e:
         hip.bvh_build_gpu(v, t.copy())
     assert "NaN" in str(e.value)
-    assert len(host.bvh_build(v, t.copy())[0]) >= 1
+    assert len(_oracle_build(v, t.copy())[0]) >= 1          # (host and oracle builders agree on the NaN soup too: f32::min / max skip it)
