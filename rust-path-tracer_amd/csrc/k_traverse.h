@@ -116,8 +116,11 @@ __device__ __forceinline__ bool slab_test(float4 lo, float4 hi, F3 ro, F3 rd, F3
  * contiguous bytes = half a cache line through L1/L2) and the (a, e1, e2) triangle records.  A finished lane
  * carries count = 0x80000000 so that "at an inner node" / "at a leaf" are single compares on the register (a
  * ballot of a compare is the compare itself; a ballot of a loop-carried bool costs two more VALU instructions). */
-struct SceneViewGlobal {
-    static constexpr bool kCoopLeaves = true;               /* leaves may hold dozens of triangles: see walk_run */
+template <bool COOP>
+struct SceneViewGlobalT {
+    static constexpr bool kCoopLeaves = COOP;               /* leaves may hold dozens of triangles: see walk_run.  The streamed walks are
+                                                               built both ways and the host picks by the scene's largest leaf: the cooperative
+                                                               leaf code costs registers the walk of a thin-leaf scene (every shipped one) needs */
     const float4 *nodes;
     const float *tri_isect;
     typedef uint2 Cur;                                      /* x = triangle_count, y = left child / first triangle */
@@ -147,6 +150,7 @@ struct SceneViewGlobal {
         return f3(p[0], p[1], p[2]);
     }
 };
+typedef SceneViewGlobalT<true> SceneViewGlobal;
 
 /* The LDS-resident image of a small scene, built once at upload (rpt_hip.hip, build_lds_image) and copied into
  * LDS by every workgroup.  Measured on MI355X (tools/microbench/valu_rates.hip, SQ counters in profiles/): the
@@ -195,6 +199,26 @@ __device__ __forceinline__ bool moller_trumbore_view(const View &view, uint32_t 
     if (rptm::absr(det) < 1e-6f) return false;
     float inv_det = 1.0f / det;
     F3 tv = ro - view.corner(ti);
+    float u = dot3(tv, pv) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    F3 qv = cross3(tv, edge1);
+    float v = dot3(rd, qv) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = dot3(edge2, qv) * inv_det;
+    if (t < 0.0f) return false;
+    out_t = t;
+    return true;
+}
+
+/* the same test on a record the caller already holds in registers (the wave-cooperative leaves load a leaf once for all the
+ * lanes that wait at it) */
+__device__ __forceinline__ bool moller_trumbore_regs(F3 edge1, F3 edge2, F3 corner, F3 ro, F3 rd, float &out_t, bool &backface) {
+    F3 pv = cross3(rd, edge2);
+    float det = dot3(edge1, pv);
+    backface = (rptm::f2u(det) >> 31) != 0u;
+    if (rptm::absr(det) < 1e-6f) return false;
+    float inv_det = 1.0f / det;
+    F3 tv = ro - corner;
     float u = dot3(tv, pv) * inv_det;
     if (u < 0.0f || u > 1.0f) return false;
     F3 qv = cross3(tv, edge1);
@@ -303,46 +327,60 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
                  * accepts t_i < running best in index order, i.e. ends with the smallest t and, among equal t, the lowest
                  * index (any-hit: the lowest index that passes) — which is what the scalar scan below selects. */
                 const bool fat = at_leaf && count > (uint32_t)RPT_COOP_LEAF_MIN;
-                unsigned long long fat_m = rpt_ballot(fat);
-                if (fat_m != 0ull) {
+                unsigned long long todo = rpt_ballot(fat);
+                if (todo != 0ull) {
                     const unsigned long long exec_m = rpt_ballot(true);
                     const uint32_t n_act = (uint32_t)__popcll(exec_m);
                     const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(exec_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)exec_m, 0u));
                     coop_done = fat;
                     do {
-                        const int L = __ffsll((long long)fat_m) - 1;
-                        fat_m &= fat_m - 1ull;
-                        const F3 bo = f3(rpt_readlane(ro.x, L), rpt_readlane(ro.y, L), rpt_readlane(ro.z, L));
-                        const F3 bd = f3(rpt_readlane(rd.x, L), rpt_readlane(rd.y, L), rpt_readlane(rd.z, L));
-                        const uint32_t b_count = rpt_readlane_u(count, L), b_first = rpt_readlane_u(first, L);
-                        const float b_max = ANY_HIT ? rpt_readlane(max_t, L) : 0.0f;
-                        uint32_t best_bits = __float_as_uint(rpt_readlane(res.t, L));      /* positive floats order like their bits */
-                        uint32_t best_tri = HIT_MISS;
+                        /* ONE load of the leaf's records serves every lane of the wave that waits at this very leaf: the slots of
+                         * a pixel are adjacent lanes, so after generation (and for shadow rays towards one light) most of a wave
+                         * stands on the same leaf — each used to fetch the 2.3 KB again */
+                        const int lead = __ffsll((long long)todo) - 1;
+                        const uint32_t b_count = rpt_readlane_u(count, lead), b_first = rpt_readlane_u(first, lead);
+                        const unsigned long long group = rpt_ballot(fat && first == b_first && count == b_count) & todo;
+                        todo &= ~group;
                         for (uint32_t base = 0; base < b_count; base += n_act) {
+                            const bool mine = base + my_rank < b_count;
                             const uint32_t ti = b_first + base + my_rank;
-                            float t = 0.0f;
-                            bool bf = false;
-                            const bool acc = base + my_rank < b_count && moller_trumbore_view(view, ti, bo, bd, t, bf) && t > 0.001f &&
-                                             __float_as_uint(t) < best_bits && (!ANY_HIT || t <= b_max);
-                            unsigned long long am = rpt_ballot(acc);
-                            while (am != 0ull) {                                          /* scalar scan, lowest triangle first */
-                                const int l = __ffsll((long long)am) - 1;
-                                am &= am - 1ull;
-                                const uint32_t tb = __float_as_uint(rpt_readlane(t, l));
-                                if (tb < best_bits) {
-                                    best_bits = tb;
-                                    best_tri = rpt_readlane_u(ti, l) | (rpt_readlane_u(bf ? 1u : 0u, l) << 31);
-                                    if (ANY_HIT) break;
+                            F3 e1 = f3(0, 0, 0), e2 = f3(0, 0, 0), corner = f3(0, 0, 0);
+                            if (mine) {
+                                view.edges(ti, e1, e2);
+                                corner = view.corner(ti);
+                            }
+                            unsigned long long g = ANY_HIT ? (group & ~rpt_ballot(accepted)) : group;
+                            while (g != 0ull) {
+                                const int L = __ffsll((long long)g) - 1;
+                                g &= g - 1ull;
+                                const F3 bo = f3(rpt_readlane(ro.x, L), rpt_readlane(ro.y, L), rpt_readlane(ro.z, L));
+                                const F3 bd = f3(rpt_readlane(rd.x, L), rpt_readlane(rd.y, L), rpt_readlane(rd.z, L));
+                                const float b_max = ANY_HIT ? rpt_readlane(max_t, L) : 0.0f;
+                                uint32_t best_bits = __float_as_uint(rpt_readlane(res.t, L));      /* positive floats order like their bits */
+                                uint32_t best_tri = HIT_MISS;
+                                float t = 0.0f;
+                                bool bf = false;
+                                const bool acc = mine && moller_trumbore_regs(e1, e2, corner, bo, bd, t, bf) && t > 0.001f &&
+                                                 __float_as_uint(t) < best_bits && (!ANY_HIT || t <= b_max);
+                                unsigned long long am = rpt_ballot(acc);
+                                while (am != 0ull) {                                          /* scalar scan, lowest triangle first */
+                                    const int l = __ffsll((long long)am) - 1;
+                                    am &= am - 1ull;
+                                    const uint32_t tb = __float_as_uint(rpt_readlane(t, l));
+                                    if (tb < best_bits) {
+                                        best_bits = tb;
+                                        best_tri = rpt_readlane_u(ti, l) | (rpt_readlane_u(bf ? 1u : 0u, l) << 31);
+                                        if (ANY_HIT) break;
+                                    }
+                                }
+                                if ((int)__lane_id() == L && best_tri != HIT_MISS) {
+                                    res.t = __uint_as_float(best_bits);
+                                    res.tri = best_tri;
+                                    accepted = true;
                                 }
                             }
-                            if (ANY_HIT && best_tri != HIT_MISS) break;
                         }
-                        if ((int)__lane_id() == L && best_tri != HIT_MISS) {
-                            res.t = __uint_as_float(best_bits);
-                            res.tri = best_tri;
-                            accepted = true;
-                        }
-                    } while (fat_m != 0ull);
+                    } while (todo != 0ull);
                 }
             }
             if (at_leaf && !coop_done) {
@@ -922,8 +960,21 @@ __host__ __device__ constexpr int gstream_rays_nearest(int stack, int width) {
 #ifndef RPT_GSTREAM_WAVES
 #define RPT_GSTREAM_WAVES 8
 #endif
-template <int STACK, int WIDTH /* bits of a stack entry: 16, 24, 32 */>
-__attribute__((amdgpu_waves_per_eu((WIDTH <= 21 || (WIDTH == 24 && STACK <= 24)) ? RPT_GSTREAM_WAVES : 1, 8)))   /* (where LDS allows it at all) */
+#ifndef RPT_GSTREAM_WAVES_COOP
+#define RPT_GSTREAM_WAVES_COOP 8   /* the fat-leaf build holds a leaf's triangle records in registers: 63 / 64 VGPRs, no spill.  Requesting the NEXT
+                                      leaf's records one leaf ahead (9 more registers) was measured and lost at every occupancy: the 1 M-triangle
+                                      stand-in 2 343 Mrays/s without, 2 008 / 2 164 / 2 099 with it at 8 (spilling) / 7 / 6 waves per SIMD */
+#endif
+__host__ __device__ constexpr int gstream_waves(int stack, int width, bool coop) {
+    return (width <= 21 || (width == 24 && stack <= 24)) ? (coop ? (width == 21 ? 7 : RPT_GSTREAM_WAVES_COOP) : RPT_GSTREAM_WAVES) : 1;   /* (where LDS allows it at all;
+                                                             fat leaves + 21-bit entries: 8 waves would spill 18 registers) */
+}
+/* XCD-aware span mapping was measured on these kernels and rejected (profiles/r03_deepbvh_experiments.txt): workgroup id i runs on XCD
+ * i % 8, so span = id spreads neighbouring pixels over all eight L2s.  Giving each XCD one contiguous eighth of the launch: 2 x
+ * SLOWER on the 1 M-triangle stand-in (the XCD that owns the expensive part of the image finishes alone); runs of 64 consecutive
+ * spans per XCD inside groups of 512: +-0; runs of 512: -14 %.  The identity mapping stays. */
+template <int STACK, int WIDTH /* bits of a stack entry: 16, 21, 24, 32 */, bool COOP /* the scene has leaves of more than RPT_COOP_LEAF_MIN triangles */>
+__attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
  __global__ __launch_bounds__(RPT_WAVE) void k_traverse_nearest_gstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
                                                                        uint32_t SPAN /* slots per wave, <= 64 * gstream_rays_nearest(STACK, WIDTH) */) {
     __shared__ WaveStack<STACK, WIDTH> lds_stack;
@@ -957,12 +1008,13 @@ __attribute__((amdgpu_waves_per_eu((WIDTH <= 21 || (WIDTH == 24 && STACK <= 24))
         raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
         atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)count);
     }
-    const SceneViewGlobal view{sc.nodes, sc.tri_isect};
+    typedef SceneViewGlobalT<COOP> View;
+    const View view{sc.nodes, sc.tri_isect};
     auto stack = lds_stack.column(lane);
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
-    Walk<SceneViewGlobal> w;
+    Walk<View> w;
     walk_begin(view, w);
-    w.cur = SceneViewGlobal::dead();
+    w.cur = View::dead();
     uint32_t slot = 0u, next = 0u;                             /* next: wave-uniform position in the list */
     bool have = false;                                         /* this lane holds a ray whose result is not written yet */
     for (;;) {
@@ -1033,8 +1085,8 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQu
  * any-hit walk has ended (found an occluder after two visits, or crossed the whole scene without one).  Lanes only note
  * "occluded" per entry in LDS while walking; the NEE terms are added afterwards in one dense pass over the span (all
  * lanes busy, and the registers of the walk are dead by then: 61 instead of 91 VGPRs). */
-template <int STACK, int WIDTH>
-__attribute__((amdgpu_waves_per_eu((WIDTH <= 21 || (WIDTH == 24 && STACK <= 24)) ? RPT_GSTREAM_WAVES : 1, 8)))   /* (where LDS allows it at all) */
+template <int STACK, int WIDTH, bool COOP>
+__attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
  __global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
                                                                       uint32_t SPAN) {
     __shared__ WaveStack<STACK, WIDTH> lds_stack;
@@ -1047,13 +1099,14 @@ __attribute__((amdgpu_waves_per_eu((WIDTH <= 21 || (WIDTH == 24 && STACK <= 24))
     if (begin >= n) return;
     const uint32_t end = begin + SPAN < n ? begin + SPAN : n;
     {
-        const SceneViewGlobal view{sc.nodes, sc.tri_isect};
+        typedef SceneViewGlobalT<COOP> View;
+        const View view{sc.nodes, sc.tri_isect};
         auto stack = lds_stack.column(lane);
         F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
         float max_t = 0.0f;
-        Walk<SceneViewGlobal> w;
+        Walk<View> w;
         walk_begin(view, w);
-        w.cur = SceneViewGlobal::dead();
+        w.cur = View::dead();
         uint32_t entry = 0u, next = begin;                     /* next: wave-uniform */
         bool have = false;
         for (;;) {

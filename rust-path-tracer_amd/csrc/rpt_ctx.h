@@ -54,6 +54,8 @@ struct rpt_ctx {
     double shade_compact_at = 0.7;       /* automatic: on when more than this share of the samples ends in the sky */
     bool lds_shadow_stream = true;       /* LDS scenes: streamed shadow stage (k_traverse_shadow_stream + k_shadow_resolve) */
     bool gstream = true;                 /* scenes walked from global memory: streamed kernels (k_traverse_*_gstream) */
+    bool fat_leaves = false;             /* some leaf holds more than RPT_COOP_LEAF_MIN triangles: the streamed walks' wave-cooperative build
+                                            (RPT_COOP_LEAVES=0/1 forces the other build for tests; both give the same image) */
     uint32_t gstream_min_waves = 32768;
     uint32_t stream_max_blocks = 512;    /* persistent workgroups of the streamed LDS traversal: 2 per CU (each holds 32 KB of stacks + the scene image) */
     uint32_t stream_span = 0;            /* slots a workgroup fetches at a time; 0 = automatic */

@@ -271,10 +271,15 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else if (c->gstream) {
-        if (stack_width == 16) k_traverse_nearest_gstream<STACK, 16><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
-        else if (stack_width == 21) k_traverse_nearest_gstream<STACK, 21><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
-        else if (stack_width == 24) k_traverse_nearest_gstream<STACK, 24><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
-        else k_traverse_nearest_gstream<STACK, 32><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n);
+#define RPT_LAUNCH_NEAREST(W, COOP) k_traverse_nearest_gstream<STACK, W, COOP><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n)
+        if (c->fat_leaves) {
+            if (stack_width == 16) RPT_LAUNCH_NEAREST(16, true); else if (stack_width == 21) RPT_LAUNCH_NEAREST(21, true);
+            else if (stack_width == 24) RPT_LAUNCH_NEAREST(24, true); else RPT_LAUNCH_NEAREST(32, true);
+        } else {
+            if (stack_width == 16) RPT_LAUNCH_NEAREST(16, false); else if (stack_width == 21) RPT_LAUNCH_NEAREST(21, false);
+            else if (stack_width == 24) RPT_LAUNCH_NEAREST(24, false); else RPT_LAUNCH_NEAREST(32, false);
+        }
+#undef RPT_LAUNCH_NEAREST
     } else {
         const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
         if (c->scene.n_nodes < 65536u) k_traverse_nearest<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
@@ -296,10 +301,15 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else if (c->gstream) {
-            if (stack_width == 16) k_traverse_shadow_gstream<STACK, 16><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
-            else if (stack_width == 21) k_traverse_shadow_gstream<STACK, 21><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
-            else if (stack_width == 24) k_traverse_shadow_gstream<STACK, 24><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
-            else k_traverse_shadow_gstream<STACK, 32><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);
+#define RPT_LAUNCH_SHADOW(W, COOP) k_traverse_shadow_gstream<STACK, W, COOP><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan)
+            if (c->fat_leaves) {
+                if (stack_width == 16) RPT_LAUNCH_SHADOW(16, true); else if (stack_width == 21) RPT_LAUNCH_SHADOW(21, true);
+                else if (stack_width == 24) RPT_LAUNCH_SHADOW(24, true); else RPT_LAUNCH_SHADOW(32, true);
+            } else {
+                if (stack_width == 16) RPT_LAUNCH_SHADOW(16, false); else if (stack_width == 21) RPT_LAUNCH_SHADOW(21, false);
+                else if (stack_width == 24) RPT_LAUNCH_SHADOW(24, false); else RPT_LAUNCH_SHADOW(32, false);
+            }
+#undef RPT_LAUNCH_SHADOW
         } else {
             const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
             if (c->scene.n_nodes < 65536u) k_traverse_shadow<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
@@ -464,6 +474,10 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;
+    c->fat_leaves = false;
+    for (size_t i = 0; i < nn; ++i)
+        if (nodes[i].triangle_count > (uint32_t)RPT_COOP_LEAF_MIN) c->fat_leaves = true;
+    if (const char *env = getenv("RPT_COOP_LEAVES")) c->fat_leaves = env[0] != '0';
 
     /* derived per-triangle records, computed with the very f32 operations the reference performs per hit:
      *   tri_geom : a, e1 = b - a, e2 = c - a (muller_trumbore, intersection.rs:13-14; barycentric v0, v1, util.rs:239-240)
