@@ -84,6 +84,10 @@ def main():
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the per-batch gather runs inside librpt_hip.so (C ABI, RCCL); torch: tiles.Gatherer over torch.distributed")
     ap.add_argument("--with-gather", action="store_true", help="N = 1 only: still run the per-batch gather (a 1-rank communicator), to exercise that path")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="dress rehearsal of the N > 1 path on a box with ONE GPU: N processes on device 0, torch.distributed over gloo, the "
+                         "library's gather over the test stand-in for RCCL (RPT_RCCL_LIBRARY).  Exercises every line the scaling run executes; "
+                         "the JSON line is marked and its value is not a measurement")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed comparison of windows of the rendered image with the CPU oracle")
     ap.add_argument("--no-readback", action="store_true", help="skip the extra render -> read_accum loop (reference loop shape, src/trace.rs:182-204)")
     args = ap.parse_args()
@@ -117,7 +121,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    if os.environ.get("RPT_RCCL_LIBRARY"):
+    if args.rehearsal:
+        args.dist_backend, args.all_ranks_on_device0 = "gloo", True
+        if not os.environ.get("RPT_RCCL_LIBRARY"):
+            raise SystemExit("--rehearsal needs RPT_RCCL_LIBRARY=tests/fake_rccl/librccl_fake.so (real RCCL refuses two ranks on one device)")
+    elif os.environ.get("RPT_RCCL_LIBRARY"):
         raise SystemExit("bench.py: RPT_RCCL_LIBRARY is set — that override loads a stand-in for RCCL (tests/fake_rccl); nothing measured with it is a measurement")
     if args.all_ranks_on_device0:
         local_rank = 0
@@ -167,7 +175,7 @@ def main():
     # choice and says so in `config.gather`.
     gather_impl = None
     if world_size > 1 or args.with_gather:
-        want = args.gather if args.dist_backend == "nccl" else "torch"
+        want = args.gather if (args.dist_backend == "nccl" or args.rehearsal) else "torch"
         if want == "rccl":
             gather_note = None
             uid = None
@@ -434,7 +442,10 @@ def main():
             parity["bitwise"] = False
             parity["error"] = f"image carries {bench_image_spp} spp, expected {want_spp}"
 
-    out = {
+    out = {}
+    if args.rehearsal:
+        out["rehearsal"] = "NOT A MEASUREMENT: all ranks share one GPU, gather over tests/fake_rccl (shared memory), torch.distributed over gloo"
+    out.update({
         "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -454,7 +465,7 @@ def main():
         "cpu_baseline": cpu,
         "parity_check": parity,
         "readback": readback,
-    }
+    })
     import ctypes
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)

@@ -109,3 +109,31 @@ def test_overlapped_reads_see_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, 
     assert np.array_equal(np.load(tmp_path / "image.npy").view(np.uint32), ref[-1].view(np.uint32))
     assert sum(i["extension_rays"] for i in infos) == st_ref["extension_rays"]
     assert sum(i["samples"] for i in infos) == W * H * sum(batches)
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks):
+    """`bench.py --gpus N` exactly as the driver's scaling run starts it (torch.distributed.run, one process per rank), except that
+    every rank sits on the one GPU of this box (--rehearsal: gloo for torch.distributed, the stand-in for RCCL inside the library).
+    Every line the 2 / 4 / 8-GPU run executes runs here: unique id broadcast, rpt_comm_init, render + gather per step, drain,
+    barriers, statistics reduction, rank 0's JSON line — whose image (gathered from all ranks) must pass the bitwise parity
+    check against the oracle, with the gather reported as the library's.  The number itself is not a measurement and says so."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--rehearsal"]
+    p = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert "rehearsal" in out and out["n_gpus"] == ranks and out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"]["gather"] == "rccl-c-abi" and out["config"]["collective_library"] == FAKE
+    assert out["parity_check"]["bitwise"] is True and out["parity_check"]["windows"] >= 2 and out["parity_check"]["image_spp"] == 96
+    assert out["rays"]["extension"] > 1024 * 1024 * 64 and out["roofline"]["kernel"] == "k_traverse"
+    # and WITHOUT the rehearsal flag the stand-in is refused: a scaling number can only come from RCCL
+    cmd_real = [c for c in cmd if c != "--rehearsal"]
+    p2 = subprocess.run(cmd_real, env=_env(), capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert p2.returncode != 0 and "RPT_RCCL_LIBRARY" in (p2.stderr + p2.stdout)
