@@ -270,6 +270,12 @@ int rpt_debug_math_sweep(rpt_ctx *ctx, int op, uint32_t lo_bits, uint64_t count,
 int rpt_debug_trace_rays(rpt_ctx *ctx, int any_hit, size_t n,
                          const float *origins_xyz, const float *dirs_xyz, const float *max_t,
                          float *out_t, uint32_t *out_tri, uint32_t *out_flags);
+/* Nearest hits of n rays through the PRODUCTION traversal stage — the kernel and grid an iteration of rpt_render uses for the
+ * context's scene and state (persistent LDS stream, streamed global-memory walk, ... per scene and developer knobs), fed through
+ * the context's own slots; same outputs as rpt_debug_trace_rays(any_hit = 0).  Needs a configuration with at least n slots;
+ * afterwards the context is as after rpt_reset with nothing rendered (call rpt_reset before rendering again). */
+int rpt_debug_trace_rays_production(rpt_ctx *ctx, size_t n, const float *origins_xyz, const float *dirs_xyz,
+                                    float *out_t, uint32_t *out_tri, uint32_t *out_flags);
 
 /* The two BSDFs of the reference's kernels crate that trace_pixel never instantiates (kernels/src/bsdf.rs:46-176,
  * SURVEY.md 8f N4), evaluated on the device.  One item = 16 floats in: view(3) normal(3) r(3) albedo(3) ior roughness

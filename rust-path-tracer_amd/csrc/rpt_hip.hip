@@ -237,28 +237,29 @@ constexpr int GLOBAL_THREADS = RPT_GLOBAL_THREADS;   /* workgroup size of the gl
 constexpr int LDS_THREADS = RPT_LDS_THREADS;     /* workgroup size of the LDS-resident-scene traversal variants: 2 x (32 KB of
                                                     16-bit stacks + up to 32 KB of scene = the 64 KB a workgroup may hold) per CU = 32 waves */
 
-template <int STACK, int NEE, bool TEXTURED>
-void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool shade_only) {
+/* streamed global-memory walks: width of a stack entry for the scene, and slots per wave — as many as keep >= gstream_min_waves
+ * waves in the launch, at most `most` per lane */
+static int gstream_stack_width(const rpt_ctx *c) {
+    return (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) ? 16
+         : (c->scene.n_nodes < (1u << 21) && c->stack_bits_min <= 21) ? 21
+         : (c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) ? 24 : 32;
+}
+static uint32_t gstream_span(const rpt_ctx *c, uint32_t most) {
+    const uint32_t wanted = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
+    const uint32_t g = wanted < 1u ? 1u : (wanted > most ? most : wanted);
+    return g * RPT_WAVE;
+}
+
+/* The nearest-hit traversal stage for the context's scene and state: which kernel, which grid.  Used by every iteration of a
+ * render call and by rpt_debug_trace_rays_production (per-ray parity of exactly these kernels). */
+template <int STACK>
+void launch_nearest(rpt_ctx *c, uint32_t iteration) {
     hipStream_t s = c->stream;
-    const bool only_traverse = c->timing_level == 2;
-    auto mark = [&](bool traverse_edge = false) {
-        if (ev && (!only_traverse || traverse_edge)) (void)hipEventRecord((*ev)[ev_at++], s);
-    };
-    if (only_traverse) mark(true);
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
-    /* streamed global-memory walks: slots per wave — as many as keep >= gstream_min_waves waves in the launch, at most RPT_GSTREAM_RAYS per lane */
-    const int stack_width = (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) ? 16
-                          : (c->scene.n_nodes < (1u << 21) && c->stack_bits_min <= 21) ? 21
-                          : (c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) ? 24 : 32;
-    const uint32_t grays_wanted = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
-    auto span_of = [&](uint32_t most) { uint32_t g = grays_wanted < 1u ? 1u : (grays_wanted > most ? most : grays_wanted); return g * RPT_WAVE; };
-    const uint32_t gspan = span_of((uint32_t)RPT_GSTREAM_RAYS), gblocks = (c->n_slots + gspan - 1) / gspan;             /* any-hit walk */
-    const uint32_t gspan_n = span_of((uint32_t)gstream_rays_nearest(STACK, stack_width)), gblocks_n = (c->n_slots + gspan_n - 1) / gspan_n;
-    /* shade_only: the completion pass of a batch whose iteration count is known — every path has ended, only finished
-     * generations are left to accumulate (k_shade: complete_generations); no ray to trace, no miss, no shadow ray */
-    if (shade_only) {
-    } else if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
+    const int stack_width = gstream_stack_width(c);
+    const uint32_t gspan_n = gstream_span(c, (uint32_t)gstream_rays_nearest(STACK, stack_width)), gblocks_n = (c->n_slots + gspan_n - 1) / gspan_n;
+    if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
         /* persistent workgroups (as many as stay resident: 2 per CU) that fetch spans of slots from a launch-wide counter:
          * a span = 1/16 of a workgroup's share, between 1 and 8 slots per lane (measured at 33 M slots: 8192 / 4096 / 2048
          * slots per span: traverse 82.9 / 80.9 / 83.9 ms per 8 batches) */
@@ -285,6 +286,23 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         if (c->scene.n_nodes < 65536u) k_traverse_nearest<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
         else k_traverse_nearest<STACK, false, GLOBAL_THREADS><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
     }
+}
+
+template <int STACK, int NEE, bool TEXTURED>
+void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool shade_only) {
+    hipStream_t s = c->stream;
+    const bool only_traverse = c->timing_level == 2;
+    auto mark = [&](bool traverse_edge = false) {
+        if (ev && (!only_traverse || traverse_edge)) (void)hipEventRecord((*ev)[ev_at++], s);
+    };
+    if (only_traverse) mark(true);
+    const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
+    const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
+    const int stack_width = gstream_stack_width(c);
+    const uint32_t gspan = gstream_span(c, (uint32_t)RPT_GSTREAM_RAYS), gblocks = (c->n_slots + gspan - 1) / gspan;             /* any-hit walk */
+    /* shade_only: the completion pass of a batch whose iteration count is known — every path has ended, only finished
+     * generations are left to accumulate (k_shade: complete_generations); no ray to trace, no miss, no shadow ray */
+    if (!shade_only) launch_nearest<STACK>(c, iteration);
     mark(true);
     if (c->shade_compact) k_shade<NEE, TEXTURED, true><<<(c->n_slots + RPT_BLOCK * RPT_SHADE_ROUNDS - 1) / (RPT_BLOCK * RPT_SHADE_ROUNDS), RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     else k_shade<NEE, TEXTURED, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
@@ -1144,6 +1162,61 @@ int rpt_debug_trace_rays(rpt_ctx *c, int any_hit, size_t n, const float *origins
     if (e == hipSuccess) e = hipMemcpy(out_flags, d_fl.p, 4 * n, hipMemcpyDeviceToHost);
     d_o.release(); d_d.release(); d_m.release(); d_t.release(); d_tri.release(); d_fl.release();
     HIP_TRY(c, e);
+    return RPT_OK;
+}
+
+/* The same question through the PRODUCTION nearest-hit stage: the rays are written into the context's own slots as pending
+ * extension rays, the traversal stage is launched exactly as an iteration of rpt_render launches it for this scene and state
+ * (launch_nearest: persistent LDS stream / streamed global-memory walk with or without cooperative leaves / one-shot kernels,
+ * per the developer knobs), and the hit records it wrote are read back.  Needs a configuration (the slots); leaves the
+ * context as after rpt_reset with nothing rendered — call rpt_reset before rendering again. */
+__global__ __launch_bounds__(RPT_BLOCK) void k_debug_load_rays(DevState st, uint32_t n, const float *origins, const float *dirs) {
+    const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    st.ray_a[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], dirs[3 * i]);
+    st.ray_b[i] = make_float2(dirs[3 * i + 1], dirs[3 * i + 2]);
+    st.hit[i] = make_float2(0.0f, __uint_as_float(HIT_PENDING));
+}
+
+int rpt_debug_trace_rays_production(rpt_ctx *c, size_t n, const float *origins, const float *dirs, float *out_t, uint32_t *out_tri, uint32_t *out_flags) {
+    if (!c || !origins || !dirs || !out_t || !out_tri || !out_flags) return RPT_EINVAL;
+    if (!c->has_scene || !c->has_state) { c->error = "rpt_debug_trace_rays_production: needs a scene and a configuration"; return RPT_EINVAL; }
+    if (n == 0) return RPT_OK;
+    if (n > c->n_slots) { c->error = "rpt_debug_trace_rays_production: more rays than the context has slots (" + std::to_string(c->n_slots) + ")"; return RPT_EINVAL; }
+    int rc = rpt_wait(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<float> d_o, d_d;
+    HIP_TRY(c, d_o.alloc(3 * n)); HIP_TRY(c, d_d.alloc(3 * n));
+    HIP_TRY(c, hipMemcpy(d_o.p, origins, 12 * n, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_d.p, dirs, 12 * n, hipMemcpyHostToDevice));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t), s));
+    k_fill_idle<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->hit.p, c->n_slots);
+    k_debug_load_rays<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, s>>>(c->state, (uint32_t)n, d_o.p, d_d.p);
+    switch (c->stack_cap) {
+        case 16: launch_nearest<16>(c, 0u); break;
+        case 24: launch_nearest<24>(c, 0u); break;
+        default: launch_nearest<32>(c, 0u); break;
+    }
+    std::vector<float2> hits(n);
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(hits.data(), c->hit.p, n * sizeof(float2), hipMemcpyDeviceToHost);
+    /* back to "nothing in flight" */
+    if (e == hipSuccess) e = hipMemsetAsync(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t), s);
+    k_fill_idle<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->hit.p, c->n_slots);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    d_o.release(); d_d.release();
+    HIP_TRY(c, e);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t w;
+        memcpy(&w, &hits[i].y, 4);
+        if (w == HIT_PENDING || w == HIT_IDLE) { c->error = "rpt_debug_trace_rays_production: ray " + std::to_string(i) + " was not traversed"; return RPT_EHIP; }
+        out_t[i] = hits[i].x;
+        out_tri[i] = (w == HIT_MISS) ? 0u : (w & 0x7fffffffu);
+        out_flags[i] = (w == HIT_MISS) ? 0u : (1u | ((w >> 31) << 1));
+    }
     return RPT_OK;
 }
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
-    "rpt_multi_last_error", "rpt_comm_library",
+    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production",
 ]
 COMM_ID_BYTES = 128
 MULTI_ALLOW_SHARED_DEVICE = 1
@@ -69,6 +69,7 @@ def lib():
         L.rpt_debug_math_host.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.rpt_debug_math_sweep.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.rpt_debug_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_size_t] + [C.c_void_p] * 6
+        L.rpt_debug_trace_rays_production.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 5
         L.rpt_bvh_build_gpu.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
         L.rpt_debug_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -310,6 +311,17 @@ class Renderer:
         flags = np.zeros(n, np.uint32)
         self._check(lib().rpt_debug_trace_rays(self._h, int(bool(any_hit)), n, ptr(origins), ptr(dirs), ptr(max_t),
                                                ptr(t), ptr(tri), ptr(flags)))
+        return t, tri, flags
+
+    def debug_trace_rays_production(self, origins, dirs):
+        """rpt_debug_trace_rays_production: nearest hits through the traversal stage rpt_render itself launches for this scene / state."""
+        origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(origins)
+        t = np.zeros(n, np.float32)
+        tri = np.zeros(n, np.uint32)
+        flags = np.zeros(n, np.uint32)
+        self._check(lib().rpt_debug_trace_rays_production(self._h, n, ptr(origins), ptr(dirs), ptr(t), ptr(tri), ptr(flags)))
         return t, tri, flags
 
 

@@ -92,6 +92,56 @@ def test_ray_parity_nearest_and_any(renderer, oracle, world, scene):
     assert np.array_equal(afl_g & 1, afl_c & 1)
 
 
+@pytest.mark.parametrize("scene,knob", [("DarkCornell", None), ("DarkCornell", "RPT_LDS_STREAM=0"), ("DarkCornell", "RPT_NO_LDS_SCENE=1"),
+                                        ("VeachMIS", None), ("VeachMIS", "RPT_GSTREAM=0"), ("FurnaceTest", None), ("PBRTest", None),
+                                        ("PBRTest", "RPT_COOP_LEAVES=1"), ("deep_bvh", None), ("deep_bvh", "RPT_COOP_LEAVES=0"),
+                                        ("deep_bvh", "RPT_STACK_BITS=21"), ("scatter", None)])
+def test_ray_parity_through_the_production_traversal_stage(monkeypatch, hipmod, oracle, rpt, world, scene, knob):
+    """intersect_front_to_back (intersection.rs:177-234) per ray — t, triangle, backface bit for bit against the oracle — through
+    the kernels rpt_render itself launches (rpt_debug_trace_rays_production): the persistent LDS-pool stream for DarkCornell, the
+    streamed global-memory walks for the others (without the cooperative leaf code for thin-leaf scenes, with it for the fat-leaf
+    stand-in, and each forced the other way), the one-shot kernels behind their knobs, 21-bit stack entries.  The rays are
+    incoherent (random origins inside the scene, random directions) and include axis-parallel directions with exact zeros,
+    which leave the exact-division fast path."""
+    if knob:
+        k, v = knob.split("=")
+        monkeypatch.setenv(k, v)
+    if scene == "deep_bvh":
+        from scenes import deep_bvh_scene
+        w = deep_bvh_scene(60_000)
+    elif scene == "scatter":
+        from scenes import scatter_scene
+        w = scatter_scene(80_000)                                # > 65 536 nodes: stack entries wider than 16 bits
+    else:
+        w = world(scene)
+    n = 150_000
+    rng = np.random.default_rng(17)
+    o, d = _random_rays(rng, n, w)
+    d[:300, 0] = 0.0                                             # a zero direction component: infinite slab distances
+    d[300:600, 1] = 0.0
+    d[600:700] = np.array([0.0, 0.0, 1.0], np.float32)
+    r = hipmod.Renderer(0)
+    r.upload_scene(w)
+    r.set_config(rpt.default_config(512, 512))                   # 512 x 512 x slots per pixel >= n slots
+    r.reset(rpt.blue_noise_seeds(512, 512))
+    t_g, tri_g, fl_g = r.debug_trace_rays_production(o, d)
+    t_c, tri_c, fl_c, err = oracle.trace_rays(oracle.scene(w), 0, o, d)
+    assert err == 0
+    hit = (fl_c & 1) == 1
+    assert hit.sum() > 1000 and (~hit).sum() >= 0
+    assert np.array_equal(fl_g, fl_c)
+    assert np.array_equal(t_g.view(np.uint32), t_c.view(np.uint32))
+    assert np.array_equal(tri_g[hit], tri_c[hit])
+    # the context is usable afterwards (after a reset): one sample renders and equals the oracle's
+    cfg = rpt.default_config(64, 48)
+    r.set_config(cfg); r.reset(rpt.blue_noise_seeds(64, 48))
+    r.render(1)
+    acc, _ = r.read_accum()
+    ref, _, _ = oracle.trace_cpu(cfg, oracle.scene(w), rpt.blue_noise_seeds(64, 48), 1)
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    r.close()
+
+
 CASES = [
     # scene, W, H, spp, nee, config overrides
     ("FurnaceTest", 128, 128, 8, 0, {}),
