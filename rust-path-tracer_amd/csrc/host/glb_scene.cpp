@@ -470,8 +470,7 @@ bool load_gltf_texture(const Glb &g, const JValue *texinfo, Image8 &img, bool &p
     double off = views->arr[bv]->number_or("byteOffset", 0), len = views->arr[bv]->number_or("byteLength", 0);
     if (!(off >= 0) || !(len >= 8) || off + len > (double)g.bin.size()) { set_error("GLB image bufferView out of range"); return false; }
     const uint8_t *p = g.bin.data() + (size_t)off;
-    if (p[0] == 0xff && p[1] == 0xd8) { set_error("GLB image is a JPEG: only PNG textures are decoded"); return false; }
-    if (!decode_png(p, (size_t)len, img)) return false;
+    if (!decode_image(p, (size_t)len, img)) return false;      /* PNG or JPEG (the two formats glTF allows) */
     present = true;
     return true;
 }

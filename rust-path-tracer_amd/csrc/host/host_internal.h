@@ -29,6 +29,8 @@ std::vector<rpt_light_pick_entry> build_light_pick_table(const Vec4f *vertices, 
 struct Image8 { uint32_t w = 0, h = 0; std::vector<uint8_t> rgba; };
 bool read_file(const char *path, std::vector<uint8_t> &data);
 bool decode_png(const uint8_t *data, size_t size, Image8 &out);
+bool decode_jpeg(const uint8_t *data, size_t size, Image8 &out);     /* jpeg_decode.cpp: baseline + progressive, grey / YCbCr, as jpeg-decoder 0.3 */
+bool decode_image(const uint8_t *data, size_t size, Image8 &out);    /* PNG or JPEG by signature (image::load_from_memory) */
 void albedo_gamma_to_linear(Image8 &img);
 void resize_lanczos3(const Image8 &src, uint32_t dw, uint32_t dh, Image8 &dst);
 void pack_textures(const std::vector<Image8> &textures, uint32_t atlas_w, uint32_t atlas_h, std::vector<uint8_t> &atlas,

@@ -15,8 +15,7 @@
  * that is not under /root/reference.  The resize below is the same filter in the Pillow-style 22-bit fixed point that
  * crate descends from; a texture whose size equals its leaf's is copied exactly either way (the Lanczos3 weights of a 1:1
  * resize are 1 at the centre and 0 at every other integer), anything else may differ from the reference in the last bit
- * of a texel.  Decoders: PNG (this file, zlib); Radiance .hdr (RGBE, RLE and flat).  JPEG is not decoded: the loader
- * reports it instead of guessing.
+ * of a texel.  Decoders: PNG (this file, zlib); Radiance .hdr (RGBE, RLE and flat); JPEG (jpeg_decode.cpp).
  */
 #include <zlib.h>
 
@@ -219,7 +218,7 @@ bool load_skybox_file(const char *path, std::vector<float> &rgba, uint32_t &w, u
         }
     } else {
         Image8 img;
-        if (!decode_png(data.data(), data.size(), img)) return false;
+        if (!decode_image(data.data(), data.size(), img)) return false;      /* .png / .jpg */
         w = img.w; h = img.h;
         rgb8.resize((size_t)w * h * 3);
         for (size_t i = 0; i < (size_t)w * h; ++i)

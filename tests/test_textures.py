@@ -3,6 +3,8 @@
 them (src/asset.rs:238-273)."""
 import struct
 
+import os
+
 import numpy as np
 import pytest
 
@@ -216,3 +218,86 @@ def test_image_headers_cannot_size_gigabytes_and_obj_relative_indices_are_bounde
                                        "vnormal 9 9 9\nf 1/1/1 2/1/1 3/1/1\nvn")
     wb = rpt.World.from_path(str(tmp_path / "bare.obj"))
     assert len(wb.indices) == 1 and np.allclose(wb.per_vertex["normal"][:, :3], [[0, 1, 0]] * 3)      # (0,0,1) after the (x,z,y) swap
+
+
+JPEG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+# sha256[:16] of the RGBA8 this decoder produces for the committed files (regression), and what libjpeg-turbo (Pillow) gave
+# for them when they were made (tests/golden/jpeg/*.libjpeg.npy): two conforming decoders differ by a couple of LSBs
+JPEG_EXPECTED = {"baseline_420_rst.jpg": "acced68f27089f48", "baseline_444.jpg": "c313e3e5c1665414", "grey.jpg": "f1c64c873ac52b14",
+                 "progressive_422.jpg": "9e342789d67d204f"}
+
+
+def test_jpeg_decoder_on_committed_files(rpt):
+    """JPEG textures / skyboxes (csrc/host/jpeg_decode.cpp, restating jpeg-decoder 0.3 = what the reference's `image` crate
+    uses): baseline 4:2:0 with restart markers, baseline 4:4:4, progressive 4:2:2, greyscale — decoded bytes are stable, within
+    3 LSB of libjpeg-turbo's decode of the same files (mean error < 0.25), alpha 255, grey replicated."""
+    import hashlib
+    for name, want in JPEG_EXPECTED.items():
+        got = (rpt.load_skybox(os.path.join(JPEG_DIR, name)) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+        assert got.shape == (35, 45, 4) and np.all(got[..., 3] == 255)
+        assert hashlib.sha256(got.tobytes()).hexdigest()[:16] == want, name
+        ref = np.load(os.path.join(JPEG_DIR, name[:-4] + ".libjpeg.npy")).astype(np.int32)
+        d = np.abs(got[..., :3].astype(np.int32) - ref)
+        assert d.max() <= 3 and d.mean() < 0.25, (name, d.max(), d.mean())
+        if name == "grey.jpg":
+            assert np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
+
+
+def test_jpeg_decoder_against_pillow_over_encoder_settings(rpt, tmp_path):
+    """Every combination a glTF exporter produces — quality 60..95, 4:4:4 / 4:2:2 / 4:2:0, baseline / progressive / optimised
+    tables, restart intervals, greyscale, sizes that are not multiples of the MCU down to 1 x 1 — against Pillow's decoder."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+
+    def picture(w, h):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([128 + 100 * np.sin(x / 7.0) * np.cos(y / 11.0), x * 255 // max(w - 1, 1), y * 255 // max(h - 1, 1)], -1).astype(np.float64)
+        img[h // 4:h // 2, w // 4:w // 2] = [250, 10, 30]
+        return np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+
+    settings = [dict(quality=90, subsampling=0), dict(quality=75, subsampling=1), dict(quality=60, subsampling=2),
+                dict(quality=85, subsampling=2, progressive=True), dict(quality=95, subsampling=0, progressive=True),
+                dict(quality=80, subsampling=1, progressive=True, optimize=True), dict(quality=80, subsampling=2, restart_marker_blocks=3),
+                dict(quality=80, subsampling=2, progressive=True, restart_marker_blocks=5)]
+    n = 0
+    for (w, h) in [(64, 48), (97, 61), (8, 8), (1, 1), (17, 3), (200, 133)]:
+        for k, opts in enumerate(settings + [dict(quality=85)]):
+            im = Image.fromarray(picture(w, h))
+            if k == len(settings):
+                im = im.convert("L")
+            path = str(tmp_path / "t.jpg")
+            try:
+                im.save(path, "JPEG", **opts)
+            except TypeError:
+                continue                                        # an older Pillow without restart_marker_blocks
+            ref = np.asarray(Image.open(path).convert("RGB")).astype(np.int32)
+            got = (rpt.load_skybox(path)[..., :3] * np.float32(255.0) + np.float32(0.5)).astype(np.int32)
+            d = np.abs(got - ref)
+            assert got.shape == ref.shape and d.max() <= 4 and d.mean() < (0.3 if w * h >= 1000 else 0.6), (w, h, opts, d.max(), d.mean())
+            n += 1
+    assert n >= 40
+
+
+def test_glb_with_a_jpeg_texture_loads_like_its_png_twin(rpt, tmp_path):
+    """A GLB whose base-colour image is a JPEG (glTF allows PNG and JPEG) goes through the same atlas path as a PNG: same
+    atlas geometry and material flags, texels within JPEG's own error of the lossless twin."""
+    Image = pytest.importorskip("PIL.Image")
+    import io
+    from scenes import png_bytes, write_glb
+    yy, xx = np.mgrid[0:32, 0:32]
+    rgb = np.stack([60 + 5 * xx, 200 - 4 * yy, 90 + 2 * xx + 2 * yy], -1).astype(np.uint8)      # smooth: JPEG at quality 95 is nearly lossless on it
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, "JPEG", quality=95, subsampling=0)
+    pos = np.array([[-1, 0, 0], [1, 0, 0], [1, 2, 0], [-1, 2, 0]], np.float32)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    mats = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]
+    worlds = []
+    for name, blob in (("p.glb", png_bytes(rgb)), ("j.glb", buf.getvalue())):
+        path = write_glb(str(tmp_path / name), pos, np.array([0, 1, 2, 0, 2, 3], np.uint32), normals=np.tile(np.array([[0, 0, -1]], np.float32), (4, 1)),
+                         uvs=uv, materials=mats, images=[blob])
+        worlds.append(rpt.World.from_path(path))
+    wp, wj = worlds
+    assert wj.atlas is not None and wp.atlas.shape == wj.atlas.shape
+    assert wp.materials.tobytes() == wj.materials.tobytes()
+    d = np.abs(wp.atlas.astype(np.int32) - wj.atlas.astype(np.int32))
+    assert d.max() <= 12 and d.mean() < 1.5                     # (albedo gamma -> linear amplifies JPEG's small error)

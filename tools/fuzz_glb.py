@@ -86,6 +86,9 @@ def main():
                          b"f 1/1/1 2/2/1 3/3/1 4\nf -3 -2 -1\nf 1//1 3//1 5//1\n")
     seeds["sky.png"] = png_bytes((np.arange(48 * 32 * 3).reshape(32, 48, 3) % 251).astype(np.uint8))
     seeds["sky.hdr"] = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 8 +X 16\n" + bytes((np.arange(8 * 16 * 4) % 200 + 20).astype(np.uint8))
+    for jn in ("baseline_420_rst.jpg", "progressive_422.jpg", "grey.jpg"):                       # JPEG skyboxes / textures (jpeg_decode.cpp)
+        seeds["sky_" + jn] = open(os.path.join(ROOT, "tests", "golden", "jpeg", jn), "rb").read()
+    seeds["bare.obj"] = b"v 0 0 0\nv 1 0 0\nv 0 1 0\nvn\nvt\nv\n" + b" " * 300 + b"vn\nvn\t0 0 1\nvt\t0 0\nf 1/1/1 2/1/1 3/1/1\nvn"
     names = sorted(seeds)
     crashes = loaded = rejected = 0
     with tempfile.TemporaryDirectory() as tmp:
