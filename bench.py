@@ -84,6 +84,10 @@ def main():
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the per-batch gather runs inside librpt_hip.so (C ABI, RCCL); torch: tiles.Gatherer over torch.distributed")
     ap.add_argument("--with-gather", action="store_true", help="N = 1 only: still run the per-batch gather (a 1-rank communicator), to exercise that path")
+    ap.add_argument("--pipelines", type=int, default=1,
+                    help="contexts per rank, each with its own stream and share of the rank's pixels (rpt_comm_add_pipeline).  Measured on one "
+                         "GPU with the per-batch gather (tools/pipeline_probe.py, profiles/r03_pipeline_probe.txt): 2 pipelines + 1.1 %% at 1/8 of "
+                         "the image, - 0.3 %% at 1/4, 3 pipelines lose everywhere — so the default is 1")
     ap.add_argument("--rehearsal", action="store_true",
                     help="dress rehearsal of the N > 1 path on a box with ONE GPU: N processes on device 0, torch.distributed over gloo, the "
                          "library's gather over the test stand-in for RCCL (RPT_RCCL_LIBRARY).  Exercises every line the scaling run executes; "
@@ -208,6 +212,23 @@ def main():
         else:
             gather_impl = "torch.distributed (explicit --gather torch / --dist-backend gloo: NOT the product's gather)"
     use_lib_gather = gather_impl == "rccl-c-abi"
+    # more than one pipeline per rank (only with the library's gather, which snapshots every pipeline's block on its own stream)
+    pipelines = max(1, args.pipelines)
+    if pipelines > 1 and not use_lib_gather:
+        raise SystemExit("--pipelines > 1 needs the library's gather (N > 1, or --with-gather)")
+    ctxs = [r]
+    if pipelines > 1:
+        for _ in range(pipelines - 1):
+            e = hip.Renderer(local_rank)
+            r.comm_add_pipeline(e)                                   # re-partitions r and e: sub-ranks of world_size * pipelines
+            ctxs.append(e)
+        for p in ctxs:                                               # set-up again for the new partition, as above
+            p.upload_scene(world)
+            p.set_config(cfg)
+            p.reset(seeds)
+            for _ in range(2):
+                p.render(args.spp_per_step)
+            p.reset(seeds)
     gatherer = lib_stream = local_block = staged = None
     if gather_impl and not use_lib_gather:
         local_block = tiles.device_block_as_tensor(r, device)
@@ -227,7 +248,8 @@ def main():
             r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)     # launch only, on the same stream
 
     def step():
-        r.render_async(args.spp_per_step)
+        for p in ctxs:
+            p.render_async(args.spp_per_step)
         if use_lib_gather:
             r.gather_async()                                         # stream-ordered; returns at once
         elif gatherer is not None:
@@ -241,20 +263,32 @@ def main():
         elif gatherer is not None:
             with torch.cuda.stream(lib_stream):
                 finish_gather()
-        r.wait()
+        for p in ctxs:
+            p.wait()
+
+    COUNTERS = ("extension_rays", "shadow_rays", "samples", "sky_evals")
+
+    def rank_stats():
+        """counters summed over this rank's pipelines; kernel times and launches of the first one (the roofline's kernel)"""
+        all_st = [p.stats() for p in ctxs]
+        st = dict(all_st[0])
+        for k in COUNTERS:
+            st[k] = sum(a[k] for a in all_st)
+            st["first_" + k] = all_st[0][k]
+        return st
 
     for _ in range(args.warmup):
         step()
     drain()
     barrier()
-    s0 = r.stats()
+    s0 = rank_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()                                                          # the last batch's image is complete inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
-    s1 = r.stats()
+    s1 = rank_stats()
 
     def delta(key):
         return s1[key] - s0[key]
@@ -269,7 +303,7 @@ def main():
     # the host, repeat.  Timed separately — it is not `value` (inputs and outputs of `value` stay in HBM) — so that the
     # PCIe-inclusive rate is a measurement too.  One device-side un-tile + one DMA into pinned memory per read-back.
     readback = None
-    if world_size == 1 and not args.no_readback:
+    if world_size == 1 and not args.no_readback and pipelines == 1:
         host_image = np.empty((H, W, 4), np.float32)
         r.reset(seeds)
         r.render(args.spp_per_step)
@@ -346,7 +380,7 @@ def main():
             "generate": ("samples", 80),
         }
         unit_key, bytes_per_unit = stage_model[dominant]
-        units = delta(unit_key) / max(klaunch[dominant], 1)
+        units = delta("first_" + unit_key) / max(klaunch[dominant], 1)       # (of the pipeline whose launches were timed)
         achieved = bytes_per_unit * units / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes kept under profiles/ (tools/profile_workload.sh).
         # PMC counters cannot be collected from inside this process, so the figure is only reported when it was measured
@@ -454,7 +488,7 @@ def main():
         "config": {"workload": f"{scene}.glb {W}x{H}, {args.steps}x{args.spp_per_step} spp (config total {total_spp}), "
                                f"nee={cfg.nee}, bounces {cfg.min_bounces}/{cfg.max_bounces}",
                    "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU",
-                   "gather": gather_impl, "collective_library": hip.comm_library() or None},
+                   "gather": gather_impl, "collective_library": hip.comm_library() or None, "pipelines_per_rank": pipelines},
         "samples_per_s": round(n_samples / elapsed_max, 1),
         "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
                  "per_sample": round(rays / max(n_samples, 1), 4)},

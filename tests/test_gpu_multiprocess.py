@@ -96,6 +96,27 @@ def test_n_processes_gather_the_one_rank_image(hipmod, rpt, world, tmp_path, ran
     assert np.array_equal(np.load(tmp_path / "image2.npy").view(np.uint32), ref2[0].view(np.uint32))
 
 
+@pytest.mark.parametrize("ranks,pipelines", [(2, 2), (4, 2), (3, 3)])
+def test_several_pipelines_per_rank_gather_the_one_rank_image(hipmod, rpt, world, tmp_path, ranks, pipelines):
+    """rpt_comm_add_pipeline: every rank drives K contexts on its device (sub-ranks of world * K, each on its own stream, never
+    fenced against each other); the owner's gather snapshots all K blocks and the image rank 0 reads is still the 1-rank image
+    bit for bit — also across a reset, and with rank 0 reading batch k while batch k+1 renders."""
+    W, H, batches = 264, 200, (3, 3, 2)
+    ref, st_ref = _single(hipmod, rpt, world, W, H, 1, batches)
+    infos = _run_ranks(tmp_path, ranks, ["--width", str(W), "--height", str(H), "--nee", "1", "--batches", ",".join(map(str, batches)),
+                                         "--pipelines", str(pipelines), "--second-image", "--read-every-batch"])
+    for r, info in enumerate(infos):
+        assert (info["rank"], info["world"]) == (r, ranks)
+    assert sum(i["pixels"] for i in infos) == W * H
+    assert infos[0]["per_batch_samples"] == [3, 6]
+    for k in range(2):
+        assert np.array_equal(np.load(tmp_path / f"image_after_batch{k}.npy").view(np.uint32), ref[k].view(np.uint32)), k
+    assert np.array_equal(np.load(tmp_path / "image.npy").view(np.uint32), ref[-1].view(np.uint32))
+    assert sum(i["extension_rays"] for i in infos) == st_ref["extension_rays"] and sum(i["shadow_rays"] for i in infos) == st_ref["shadow_rays"]
+    ref2, _ = _single(hipmod, rpt, world, W, H, 1, (3,))
+    assert np.array_equal(np.load(tmp_path / "image2.npy").view(np.uint32), ref2[0].view(np.uint32))
+
+
 def test_overlapped_reads_see_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, world, tmp_path):
     """Rank 0 reads the gathered image after every batch while the next one renders on all ranks: each read is exactly the
     1-rank image after that many batches (the snapshot precedes the next batch; the send buffer is not reused early)."""
@@ -111,8 +132,8 @@ def test_overlapped_reads_see_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, 
     assert sum(i["samples"] for i in infos) == W * H * sum(batches)
 
 
-@pytest.mark.parametrize("ranks", [2, 8])
-def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks):
+@pytest.mark.parametrize("ranks,pipelines", [(2, 1), (8, 1), (4, 2)])
+def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks, pipelines):
     """`bench.py --gpus N` exactly as the driver's scaling run starts it (torch.distributed.run, one process per rank), except that
     every rank sits on the one GPU of this box (--rehearsal: gloo for torch.distributed, the stand-in for RCCL inside the library).
     Every line the 2 / 4 / 8-GPU run executes runs here: unique id broadcast, rpt_comm_init, render + gather per step, drain,
@@ -123,7 +144,7 @@ def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--rehearsal"]
+           os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--rehearsal", "--pipelines", str(pipelines)]
     p = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -131,6 +152,7 @@ def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks):
     out = json.loads(lines[0])
     assert "rehearsal" in out and out["n_gpus"] == ranks and out["steps"] == 2 and out["warmup"] == 1
     assert out["config"]["gather"] == "rccl-c-abi" and out["config"]["collective_library"] == FAKE
+    assert out["config"]["pipelines_per_rank"] == pipelines
     assert out["parity_check"]["bitwise"] is True and out["parity_check"]["windows"] >= 2 and out["parity_check"]["image_spp"] == 96
     assert out["rays"]["extension"] > 1024 * 1024 * 64 and out["roofline"]["kernel"] == "k_traverse"
     # and WITHOUT the rehearsal flag the stand-in is refused: a scaling number can only come from RCCL
