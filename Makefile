@@ -39,9 +39,11 @@ oracle/liboracle.so: oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp $(CSRC)/rpt_mat
 oracle/liboracle_libm.so: oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp $(CSRC)/rpt_math.h $(CSRC)/rpt_math_consts.h include/rpt/shared_structs.h
 	$(CXX) $(ORACLE_FLAGS) -DORACLE_USE_LIBM -shared -o $@ oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp -lm
 
-$(LIBDIR)/librpt_hip.so: $(HIP_DEPS)
+# the fingerprint of the device-side sources is compiled in (rpt_build_fingerprint): bench.py reports PMC-derived figures only for the
+# sources the LOADED library was built from, and says so when the library is older than the source tree
+$(LIBDIR)/librpt_hip.so: $(HIP_DEPS) tools/source_fingerprint.py
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS) -ldl
+	$(HIPCC) $(HIPFLAGS) -DRPT_BUILD_FINGERPRINT=\"$$(python3 tools/source_fingerprint.py)\" -shared -o $@ $(HIP_SRCS) -ldl
 
 # test infrastructure: a stand-in for RCCL's point-to-point calls over shared memory, so that N PROCESSES on a one-GPU test box run
 # the product's gather unchanged (tests/test_gpu_multiprocess.py; selected with RPT_RCCL_LIBRARY, never linked by the product)

@@ -393,7 +393,9 @@ def main():
                 from source_fingerprint import fingerprint
                 with open(tpath) as f:
                     tj = json.load(f)
-                fp = fingerprint()
+                fp = hip.build_fingerprint()             # of the LOADED library, not of whatever the source tree holds now
+                if fp != fingerprint():
+                    print(f"bench: librpt_hip.so was built from other sources ({fp}) than the tree holds ({fingerprint()}): run make", file=sys.stderr)
                 if tj.get("workload") == args.workload and tj.get("source_fingerprint") == fp and dominant in tj.get("stages", {}):
                     traffic = tj["stages"][dominant]["hbm_bytes_per_launch"]
                     valu = tj["stages"][dominant].get("valu")       # SQ pass of the same profiling run: what actually bounds the kernel
@@ -488,7 +490,7 @@ def main():
         "config": {"workload": f"{scene}.glb {W}x{H}, {args.steps}x{args.spp_per_step} spp (config total {total_spp}), "
                                f"nee={cfg.nee}, bounces {cfg.min_bounces}/{cfg.max_bounces}",
                    "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU",
-                   "gather": gather_impl, "collective_library": hip.comm_library() or None, "pipelines_per_rank": pipelines},
+                   "kernel_sources": hip.build_fingerprint(), "gather": gather_impl, "collective_library": hip.comm_library() or None, "pipelines_per_rank": pipelines},
         "samples_per_s": round(n_samples / elapsed_max, 1),
         "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
                  "per_sample": round(rays / max(n_samples, 1), 4)},

@@ -43,6 +43,7 @@ pub struct rpt_stats {
 
 extern "C" {
     pub fn rpt_abi_version() -> c_int;                                              // == 2
+    pub fn rpt_build_fingerprint() -> *const c_char;                                // fingerprint of the kernel sources the library was built from
     pub fn rpt_last_error(ctx: *mut rpt_ctx) -> *const c_char;
 
     // --- one GPU: what trace_gpu needs (each line: the reference call it replaces) -------------------------------

@@ -246,6 +246,9 @@ void rpt_destroy(rpt_ctx *ctx);
 /* ctx may be NULL: returns the last error of a failed rpt_create on this thread. */
 const char *rpt_last_error(rpt_ctx *ctx);
 int rpt_abi_version(void);
+/* tools/source_fingerprint.py of the device-side sources this library was built from ("unknown" for a build outside the Makefile):
+ * profiles/traffic_*.json carry the same value, and bench.py reports counter-derived figures only when they match. */
+const char *rpt_build_fingerprint(void);
 
 /* --- scene preparation on the device ---------------------- */
 /* BVHBuilder::new(vertices, indices).sah_samples(n).build()  (reference src/bvh.rs:59-324, the call at

@@ -389,6 +389,11 @@ extern "C" {
 
 int rpt_abi_version(void) { return RPT_ABI_VERSION; }
 
+#ifndef RPT_BUILD_FINGERPRINT
+#define RPT_BUILD_FINGERPRINT "unknown"
+#endif
+const char *rpt_build_fingerprint(void) { return RPT_BUILD_FINGERPRINT; }
+
 const char *rpt_last_error(rpt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 int rpt_create(int device_id, rpt_ctx **out) {

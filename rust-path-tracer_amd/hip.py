@@ -23,7 +23,7 @@ EXPORTS = [
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
-    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_comm_add_pipeline",
+    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_comm_add_pipeline", "rpt_build_fingerprint",
 ]
 COMM_ID_BYTES = 128
 MULTI_ALLOW_SHARED_DEVICE = 1
@@ -75,6 +75,8 @@ def lib():
         L.rpt_debug_bsdf.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rpt_map_accum.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32)]
         L.rpt_comm_unique_id.argtypes = [C.c_void_p]
+        L.rpt_build_fingerprint.restype = C.c_char_p
+        L.rpt_build_fingerprint.argtypes = []
         L.rpt_comm_library.restype = C.c_char_p
         L.rpt_comm_library.argtypes = []
         L.rpt_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -338,6 +340,11 @@ def comm_unique_id():
     if rc != 0:
         raise RptError(rc, lib().rpt_last_error(None).decode())
     return bytes(buf)
+
+
+def build_fingerprint():
+    """rpt_build_fingerprint: tools/source_fingerprint.py of the sources the loaded library was built from."""
+    return lib().rpt_build_fingerprint().decode()
 
 
 def comm_library():

@@ -5,4 +5,4 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/rust-path-tracer_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++20 -O3 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
-  -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function "$@" -shared -o $ROOT/rust-path-tracer_amd/lib/variants/$NAME.so $C/rpt_hip.hip $C/rpt_comm.hip -ldl
+  -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function -DRPT_BUILD_FINGERPRINT=\"$(python3 $ROOT/tools/source_fingerprint.py)+$NAME\" "$@" -shared -o $ROOT/rust-path-tracer_amd/lib/variants/$NAME.so $C/rpt_hip.hip $C/rpt_comm.hip -ldl
