@@ -171,6 +171,12 @@ struct DevConfig {
     uint32_t nee_mode;     /* NextEventEstimation::from_u32 */
 };
 
+/* every lane takes the value of the lane to its left (lane 0 keeps its own): one full-rate DPP move (wave_shr:1, GFX9) instead of
+ * a ds_bpermute through the LDS crossbar */
+__device__ __forceinline__ float rpt_wave_shr1(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
 /* wave64 ballot + prefix compaction: every lane calls it (converged); lanes with
  * pred get a dense index in the queue, one atomic per wave. */
 __device__ __forceinline__ uint32_t wave_push(uint32_t *counter, bool pred) {

@@ -120,22 +120,37 @@ __device__ __forceinline__ void complete_generations(const DevState &st, const D
         radiance = f3(parked.x, parked.y, parked.z);
         todo = __float_as_uint(parked.w);
     }
-    float4 acc = make_float4(0, 0, 0, 0);
+    /* The sequential f32 sum  acc = ((acc + r_0) + r_1) + ...  over the group's finished slots in slot order (= sample order:
+     * part of the result).  The ACCUMULATOR travels along the lanes: the group's first lane loads it, and in every step each
+     * lane takes its left neighbour's value (one DPP wave shift per component) and adds its own radiance if its sample
+     * finished — after S - 1 shifts the group's last lane holds the sum and stores it.  (Round 2 had the first lane fetch one
+     * slot per step through three ds_bpermute, ~26 cycles each: ~2 500 cycles per wave, 0.44 ms of the last shade launch of
+     * a DarkCornell batch.)  */
+    float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
     uint2 rs = make_uint2(0u, 0u);
     if (leader) {
-        acc = st.accum[pix];
+        const float4 acc = st.accum[pix];
+        ax = acc.x; ay = acc.y; az = acc.z; aw = acc.w;
         rs = st.rng[pix];
     }
-    for (uint32_t k = 0; k < S; ++k) {                 /* wave-uniform trip count */
-        int src = (int)(g0 + k);
-        float rx = __shfl(radiance.x, src, RPT_WAVE), ry = __shfl(radiance.y, src, RPT_WAVE), rz = __shfl(radiance.z, src, RPT_WAVE);
-        if (leader && ((done_m >> (g0 + k)) & 1ull)) {
-            acc.x += rx; acc.y += ry; acc.z += rz; acc.w += 1.0f;
-        }
+    const bool adds = done && complete;
+    if (adds) { ax += radiance.x; ay += radiance.y; az += radiance.z; }        /* (step 0: only the first lane's value is a real sum) */
+    for (uint32_t k = 1; k < S; ++k) {                 /* wave-uniform trip count */
+        ax = rpt_wave_shr1(ax); ay = rpt_wave_shr1(ay); az = rpt_wave_shr1(az);
+        if (adds) { ax += radiance.x; ay += radiance.y; az += radiance.z; }
+    }
+    if (complete && lane == g0 + S - 1u) {
+        float *out = reinterpret_cast<float *>(&st.accum[pix]);
+        out[0] = ax; out[1] = ay; out[2] = az;
     }
     if (leader) {
-        st.accum[pix] = acc;
-        rs.x += (uint32_t)__popcll(done_m & gm);
+        const uint32_t n_done = (uint32_t)__popcll(done_m & gm);
+        /* .w += 1.0 per finished sample (lib.rs:185): for a whole count below 2^24 - 64 that IS + n_done in one step (every
+           intermediate is exactly representable); anything else a caller resumed from takes the additions one by one */
+        if (aw >= 0.0f && aw < 16777152.0f && aw == rptm::floorr(aw)) aw += (float)n_done;
+        else for (uint32_t i = 0; i < n_done; ++i) aw += 1.0f;
+        reinterpret_cast<float *>(&st.accum[pix])[3] = aw;
+        rs.x += n_done;
         st.rng[pix] = rs;
     }
     const uint32_t new_n = (uint32_t)__shfl((int)rs.x, (int)g0, RPT_WAVE);
