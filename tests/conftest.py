@@ -5,6 +5,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch first: it ships its own copy of the HIP runtime, and a process that lets librpt_hip.so bring in the system's libamdhip64
+# BEFORE torch is imported leaves torch unable to see the GPU ("No HIP GPUs are available" at its first CUDA call) — whether a
+# test that needs both worked used to depend on which test happened to import torch first.  bench.py has the same order.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
