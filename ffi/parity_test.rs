@@ -6,7 +6,7 @@
 //!      on: kernels, shared_structs, glam, bytemuck, rayon);
 //!   2. `RPT_PARITY_KIT=<backend checkout>/tests/golden/parity_kit cargo test --release --test parity_kit -- --nocapture`
 //!
-//! Per case the test replays exactly what `trace_cpu` does per sample (src/trace.rs:278-298: `trace_pixel(UVec3(x, y, 1), ...)`,
+//! Five cases (FurnaceTest and DarkCornell with nee 0 / MIS, VeachMIS with MIS).  Per case the test replays exactly what `trace_cpu` does per sample (src/trace.rs:278-298: `trace_pixel(UVec3(x, y, 1), ...)`,
 //! `output[x] += radiance`, `rng[x] = rng_state`) `spp` times and asserts  rel-L2(accumulators) <= 1e-4  — BASELINE's bar.
 //! It also REPORTS how many 32-bit words differ from `<case>.accum.bin` (the oracle with correctly rounded shared
 //! transcendentals) and from `<case>.accum_libm.bin` (the oracle calling glibc, as the Rust std f32 functions do on Linux):
@@ -158,6 +158,12 @@ fn darkcornell_mis() {
     run_case("darkcornell_mis", "DarkCornell.rptscene", 128, 128, 32);
 }
 
+/// An open scene: most paths end in the procedural sky (skybox.rs:18-94), glossy plates, NEE + MIS.
+#[test]
+fn veachmis_mis() {
+    run_case("veachmis_mis", "VeachMIS.rptscene", 128, 128, 32);
+}
+
 /// The buffers themselves: does the reference's own importer + BVH builder + light table produce the kit's `.rptscene`?
 /// (assimp's vertex joining may legitimately reorder vertices; a mismatch here localises a later image difference to the
 /// INPUT side instead of the kernels.)  Needs `World` to be reachable from tests (`rustic::asset::World`).
@@ -165,7 +171,7 @@ fn darkcornell_mis() {
 #[ignore = "informational: compares World::from_path buffers with the kit's; run with --ignored"]
 fn world_buffers_match_the_kit() {
     use rustic::asset::World;
-    for (glb, file) in [("scenes/FurnaceTest.glb", "FurnaceTest.rptscene"), ("scenes/DarkCornell.glb", "DarkCornell.rptscene")] {
+    for (glb, file) in [("scenes/FurnaceTest.glb", "FurnaceTest.rptscene"), ("scenes/DarkCornell.glb", "DarkCornell.rptscene"), ("scenes/VeachMIS.glb", "VeachMIS.rptscene")] {
         let world = World::from_path(glb).expect("scene");
         let kit = load_scene(&kit_dir().join(file));
         let same = |a: &[u8], b: &[u8]| a == b;

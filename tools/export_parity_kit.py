@@ -37,6 +37,9 @@ CASES = [
     ("furnace_mis", "FurnaceTest", 128, 128, 32, 1),
     ("darkcornell_nee0", "DarkCornell", 128, 128, 32, 0),
     ("darkcornell_mis", "DarkCornell", 128, 128, 32, 1),
+    # an OPEN scene: most paths end in skybox::scatter (skybox.rs:18-94) — the one function whose exp the oracle evaluates with the kernels'
+    # float-only exp_sky instead of a correctly rounded one — and the glossy plates exercise the specular lobe and MIS
+    ("veachmis_mis", "VeachMIS", 128, 128, 32, 1),
 ]
 
 
