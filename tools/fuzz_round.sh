@@ -5,11 +5,11 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 OUT=gpurun_out/fuzz_$TAG.txt
 echo "# kernel sources $(python3 tools/source_fingerprint.py)" > $OUT
-for seed in 1001 2002 3003; do
+for seed in ${FUZZ_PARITY_SEEDS:-1001 2002 3003}; do
   echo "## tools/fuzz_parity.py 300 $seed" >> $OUT
   timeout 1500 python3 tools/fuzz_parity.py 300 $seed 2>&1 | grep -E "cases ok|mismatches|MISMATCH|Error|error" | head -20 >> $OUT
 done
-for seed in 31 32 33 34; do
+for seed in ${FUZZ_API_SEEDS:-31 32 33 34}; do
   echo "## tools/fuzz_api.py 500 $seed" >> $OUT
   timeout 1500 python3 tools/fuzz_api.py 500 $seed 2>&1 | tail -3 >> $OUT
 done
