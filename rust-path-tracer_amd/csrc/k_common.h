@@ -8,11 +8,11 @@
  * 16-byte records so a wave reads 1 KiB per load instruction.
  *
  * Several samples of one pixel may be in flight at once (S = 2^group_shift slots
- * per pixel, adjacent lanes of one wave) so that a GPU owning only a few tiles
- * still fills its 256 CUs.  Slot k takes samples k, k+S, k+2S, ...; the S samples
- * of a "generation" are summed into the accumulator in k order by one lane once
+ * per pixel, 64 slots apart: slot_pix / slot_k below) so that a GPU owning only a few
+ * tiles still fills its 256 CUs.  Slot k takes samples k, k+S, k+2S, ...; the S samples
+ * of a "generation" are summed into the accumulator in k order by the pixel's thread once
  * all of them have finished, which reproduces the reference's sample-order f32 sum
- * bit for bit whatever S is (k_path.h: complete_generations).
+ * bit for bit whatever S is (k_path.h: k_complete).
  *
  * Extension rays need no queue: a finished path is regenerated in place, so
  * (except in the last few iterations of a render call) every slot always has
@@ -25,7 +25,9 @@
  * prefix sums, aggregated per workgroup through LDS so that one atomic serves
  * 256 lanes (a single queue counter sustains only ~90 returning atomics/us on
  * MI355X — MI355X_MICROARCH.md "dequeue" — which at one atomic per wave was
- * the measured bottleneck of the first version of the shade stage).
+ * the measured bottleneck of the first version of the shade stage, and at one
+ * per workgroup still cost a third of a late shade launch: the queues are
+ * sharded, RPT_Q_SHARDS below).
  */
 #ifndef RPT_K_COMMON_H
 #define RPT_K_COMMON_H
@@ -131,17 +133,48 @@ struct DevState {
 #define HIT_IDLE 0xfffffffbu      /* the slot has no sample left to take in this render call                           */
 
 /* ---- queues ---------------------------------------------------------------- */
-/* counter words: sizes of the two side queues; per iteration parity, "the traversal pass traced a ray" and
+/* counter words: per iteration parity, "the traversal pass traced a ray" and
  * "the shade pass started a new sample" (together with a non-empty sky queue: work remains) */
 /* each word sits in its own 128-byte line: queue counters take atomics while flags are polled and raised
  * by every wave, and sharing a line made the two serialise against each other in L2 */
 #define Q_LINE 32
-enum { Q_SHADOW = 0 * Q_LINE, Q_SKY = 1 * Q_LINE, Q_ALIVE0 = 2 * Q_LINE, Q_ALIVE1 = 3 * Q_LINE, Q_REGEN0 = 4 * Q_LINE,
+enum { /* lines 0 and 1: free (the side-queue counters are sharded, DevQueues::sky_cnt / shadow_cnt) */ Q_ALIVE0 = 2 * Q_LINE, Q_ALIVE1 = 3 * Q_LINE, Q_REGEN0 = 4 * Q_LINE,
        Q_REGEN1 = 5 * Q_LINE, Q_DRAINED = 6 * Q_LINE, Q_POOL0 = 7 * Q_LINE, Q_POOL1 = 8 * Q_LINE, Q_SPOOL = 9 * Q_LINE, Q_COUNT = 12 * Q_LINE };
 /* Q_POOL0/1: per iteration parity, the next unclaimed slot of the streamed traversal launch (k_traverse_nearest_stream);
  * Q_SPOOL: the next unclaimed entry of the streamed shadow launch (zeroed by the shade stage that fills the queue) */
 /* Q_DRAINED: set by the sky stage of the first iteration that found nothing left; the host runs a few iterations
  * ahead of the progress report, and every stage of those surplus launches returns on this word at once. */
+/* The two side queues are SHARDED.  A queue reservation is a device-scope atomic with return on one word, and those execute one
+ * after the other at the memory side — measured ~4 ns each (profiles/r03_shade_queue_atomics.txt): with one reservation per shade
+ * workgroup, 96 k of them in the last shade launch of a DarkCornell batch cost 0.43 ms of a 1.2 ms launch.  So workgroup b
+ * reserves in shard b % 16, whose counter lives in its own 4 KB of memory, and the shards are interleaved in chunks of 256
+ * entries: entry e of shard s sits at position ((e / 256) * 16 + s) * 256 + e % 256.  As the shards fill evenly (neighbouring
+ * workgroups alternate) the positions stay dense up to the tails of the shards; consumers sweep q_extent() positions and skip the
+ * few that are not filled (q_filled: bit arithmetic + one cached counter load, uniform per wave). */
+#define RPT_Q_SHARDS 16
+#define RPT_Q_SHARD_STRIDE 1088  /* words between shard counters (4 352 bytes: different channels under 256 B and 4 KB interleaving alike) */
+#define RPT_Q_SLACK (RPT_Q_SHARDS * (2048u + 256u))   /* positions beyond the slot count a queue array must hold (a shard's share of the
+                                                        workgroups rounded up, by at most one workgroup of 2 048 slots, + its last chunk) */
+__host__ __device__ __forceinline__ uint32_t q_position(uint32_t shard, uint32_t e) { return ((((e >> 8) * RPT_Q_SHARDS) | shard) << 8) | (e & 255u); }
+__device__ __forceinline__ bool q_filled(const uint32_t *cnt, uint32_t p) {
+    return ((((p >> 8) / RPT_Q_SHARDS) << 8) | (p & 255u)) < cnt[((p >> 8) % RPT_Q_SHARDS) * RPT_Q_SHARD_STRIDE];
+}
+/* positions a consumer has to sweep, and the entries among them */
+__device__ __forceinline__ void q_extent(const uint32_t *cnt, uint32_t &positions, uint32_t &total) {
+    uint32_t most = 0u, sum = 0u;
+    for (uint32_t s = 0; s < RPT_Q_SHARDS; ++s) {
+        const uint32_t c = cnt[s * RPT_Q_SHARD_STRIDE];
+        most = c > most ? c : most;
+        sum += c;
+    }
+    positions = ((most + 255u) >> 8) * (256u * RPT_Q_SHARDS);
+    total = sum;
+}
+__device__ __forceinline__ void q_clear(uint32_t *cnt) {
+    for (uint32_t s = 0; s < RPT_Q_SHARDS; ++s) cnt[s * RPT_Q_SHARD_STRIDE] = 0u;
+}
+
+#define Q_WORDS ((size_t)Q_COUNT + 2u * RPT_Q_SHARDS * RPT_Q_SHARD_STRIDE)   /* the counter allocation: Q_COUNT words, then the shard counters of both queues */
 #define RPT_STAT_SHARDS 64        /* sharded 64-bit counters, one 128-byte line each */
 #define RPT_STAT_STRIDE 16
 
@@ -151,6 +184,7 @@ struct DevQueues {
     float4 *sh_d;      /* (dx, dy, dz, slot bits | bit31 = path ends after this NEE) */
     float4 *sh_c;      /* (contribution r, g, b if unoccluded, unused) */
     uint32_t *count;   /* Q_COUNT words, see the enum above */
+    uint32_t *sky_cnt, *shadow_cnt;   /* RPT_Q_SHARDS counters each, RPT_Q_SHARD_STRIDE words apart: entries reserved per shard */
     uint32_t sky_threshold;   /* the sky stage runs once this many misses are queued (or nothing else is left) */
     uint32_t sky_wide_limit;  /* up to this many queued misses the sky march runs 16 lanes per miss */
     unsigned long long *ray_shards;  /* RPT_STAT_SHARDS x RPT_STAT_STRIDE: extension rays traced */
@@ -171,11 +205,14 @@ struct DevConfig {
     uint32_t nee_mode;     /* NextEventEstimation::from_u32 */
 };
 
-/* every lane takes the value of the lane to its left (lane 0 keeps its own): one full-rate DPP move (wave_shr:1, GFX9) instead of
- * a ds_bpermute through the LDS crossbar */
-__device__ __forceinline__ float rpt_wave_shr1(float v) {
-    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
+/* Slot <-> (pixel, k).  The slots of 64 consecutive pixels (an 8 x 8 pixel block of the tile-major pixel order) form a CHUNK of
+ * 64 x S slots laid out sample-major: slot = chunk * 64 S + k * 64 + (pixel % 64).  A wave of 64 consecutive slots is 64
+ * PIXELS at one sample index k (coherent primary rays), and the S samples of a pixel sit 64 slots apart — so the in-order sum of
+ * a finished generation is a loop over k in ONE lane per pixel with coalesced loads (k_complete), not a chain across the lanes
+ * of a wave.  Pixels are padded to a multiple of 64; the padding slots stay idle.  S = 1: slot == pixel. */
+__device__ __forceinline__ uint32_t slot_k(const DevState &st, uint32_t slot) { return (slot >> 6) & ((1u << st.group_shift) - 1u); }
+__device__ __forceinline__ uint32_t slot_pix(const DevState &st, uint32_t slot) { return ((slot >> (6u + st.group_shift)) << 6) | (slot & 63u); }
+__device__ __forceinline__ uint32_t pix_slot(const DevState &st, uint32_t pix, uint32_t k) { return ((pix >> 6) << (6u + st.group_shift)) | (k << 6) | (pix & 63u); }
 
 /* wave64 ballot + prefix compaction: every lane calls it (converged); lanes with
  * pred get a dense index in the queue, one atomic per wave. */
@@ -201,7 +238,8 @@ __device__ __forceinline__ void raise_flag(uint32_t *flag) {
 }
 
 /* Workgroup-aggregated variant: one atomic per 256 lanes.  Every thread of the
- * block must call it (two barriers inside).  `scratch` is RPT_BLOCK/RPT_WAVE + 1 words of LDS. */
+ * block must call it (two barriers inside).  `scratch` is RPT_BLOCK/RPT_WAVE + 1 words of LDS.
+ * `counter` is the workgroup's shard of a side queue; the return value is the entry's index WITHIN the shard (q_position). */
 __device__ __forceinline__ uint32_t block_push(uint32_t *counter, bool pred, uint32_t *scratch) {
     const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
     constexpr uint32_t NW = RPT_BLOCK / RPT_WAVE;

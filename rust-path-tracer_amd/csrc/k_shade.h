@@ -152,12 +152,12 @@ __device__ __forceinline__ Mat load_material(const DevScene &sc, uint32_t index)
  * scene has at least one texture flag.  Specialising removes the dead halves of
  * the stage (and their registers) for the common untextured / no-NEE case. */
 /* What the stage does for ONE traversed slot (hit word `hw`): everything of lib.rs:64-181 after the intersection.  Outputs:
- * to_sky (a miss: queued for k_sky), emit_shadow + the shadow-queue entry, and — for a path that ends here with nothing
- * pending — its final radiance for complete_generations (g_*; !COMPACT) or parked / accumulated on the spot (COMPACT). */
+ * to_sky (a miss: queued for k_sky), emit_shadow + the shadow-queue entry; a path that ends here with nothing pending is
+ * finished through finish_in_side_stage (k_path.h). */
 template <int NEE, bool TEXTURED, bool COMPACT>
 __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &st, const DevQueues &q, const DevConfig &cfg, DevStats *stats,
                                            uint32_t slot, float2 hw, bool active, bool &to_sky, bool &emit_shadow, float4 &sh_o, float4 &sh_d,
-                                           float4 &sh_c, bool &g_done, bool &g_fresh, F3 &g_radiance, uint32_t &g_todo) {
+                                           float4 &sh_c) {
     const uint32_t hit_tri = __float_as_uint(hw.y);
     if (active) {
         const float4 ra = st.ray_a[slot];
@@ -301,8 +301,8 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                 bsdf.clamp_hi = cfg.c.specular_weight_clamp[1];
 
                 /* ---- PBR::sample (bsdf.rs:272-334) ---- */
-                const uint2 rs = st.rng[slot >> st.group_shift];
-                Rng rng{rs.x + (slot & ((1u << st.group_shift) - 1u)) + rs.y, FLAG_DIM(flags)};
+                const uint2 rs = st.rng[slot_pix(st, slot)];
+                Rng rng{rs.x + slot_k(st, slot) + rs.y, FLAG_DIM(flags)};
                 const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
                 const F3 view = -rd;
                 const float w_spec = bsdf.specular_weight(view, normal);
@@ -438,16 +438,10 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
             }
 
             if (done && !emit_shadow) {
-                /* the path ends here with nothing pending: its generation may complete below */
+                /* the path ends here with nothing pending: one slot per pixel — accumulated and restarted on the spot; several —
+                 * parked as HIT_DONE for k_complete */
                 load_rad();
-                if (COMPACT) {
-                    /* one slot per pixel: accumulated and restarted on the spot; otherwise parked for the next pass */
-                    finish_in_side_stage(st, cfg, slot, radiance, todo);
-                } else {
-                    g_done = g_fresh = true;
-                    g_radiance = radiance;
-                    g_todo = todo;
-                }
+                finish_in_side_stage(st, cfg, slot, radiance, todo);
             } else {
                 if (!done) {
                     st.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(new_flags));
@@ -466,17 +460,14 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
 
 }
 
-/* COMPACT: a workgroup owns RPT_SHADE_ROUNDS x 256 consecutive slots; it first walks them in identity layout (where the
- * slots of a pixel sit in adjacent lanes) to complete finished generations and to pack the slots that were traversed in
- * this iteration into an LDS list, then shades the list 256 at a time.
+/* COMPACT: a workgroup owns RPT_SHADE_ROUNDS x 256 consecutive slots; it first walks them in identity layout to pack the slots
+ * that were traversed in this iteration into an LDS list, then shades the list 256 at a time.
  * Why (profiles/r02_pbrtest_pmc_sq.txt, r02_veachmis): on an open scene most slots are parked after the first bounce
  * (their paths ended in the sky and wait for the siblings of their generation).  One thread per slot, the stage ran 2.1 M
  * waves per pass on PBRTest with 32 slots per pixel, two thirds of their cycles waiting (a dependent load or two, then
  * four workgroup barriers for side queues nothing is pushed to), 40 % of the lanes live in what was issued — the fixed
  * cost per wave, not the shading, was the stage.  Packed, a workgroup does the bookkeeping once per 2 048 slots with
- * eight independent loads in flight per thread, and only full waves shade.
- * Generations are completed at the START of the next pass instead of in the pass that ends their last path; the sum
- * order per pixel is the same, the image bit-identical, and a known-length batch ends with a completion pass anyway. */
+ * eight independent loads in flight per thread, and only full waves shade.  (Generations are completed by k_complete.) */
 #ifndef RPT_SHADE_ROUNDS
 #define RPT_SHADE_ROUNDS 8
 #endif
@@ -501,13 +492,14 @@ __device__ __forceinline__ uint32_t block_rank(bool pred, uint32_t *scratch, uin
 template <int NEE>
 __device__ __forceinline__ void shade_emit(const DevQueues &q, uint32_t *push_scratch, uint32_t slot, bool to_sky, bool emit_shadow,
                                            float4 sh_o, float4 sh_d, float4 sh_c) {
+    const uint32_t shard = blockIdx.x % RPT_Q_SHARDS;
     uint32_t at;
     if (__syncthreads_or(to_sky)) {
-        at = block_push(&q.count[Q_SKY], to_sky, push_scratch);
+        at = q_position(shard, block_push(&q.sky_cnt[shard * RPT_Q_SHARD_STRIDE], to_sky, push_scratch));
         if (to_sky) q.sky[at] = slot;
     }
     if (NEE != RPT_NEE_NONE && __syncthreads_or(emit_shadow)) {
-        at = block_push(&q.count[Q_SHADOW], emit_shadow, push_scratch);
+        at = q_position(shard, block_push(&q.shadow_cnt[shard * RPT_Q_SHARD_STRIDE], emit_shadow, push_scratch));
         if (emit_shadow) {
             q.sh_o[at] = sh_o;
             q.sh_d[at] = sh_d;
@@ -533,7 +525,6 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     __shared__ uint32_t c_slot[COMPACT ? RPT_BLOCK * RPT_SHADE_ROUNDS : 1];
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     if (NEE != RPT_NEE_NONE && blockIdx.x == 0u && threadIdx.x == 0u) q.count[Q_SPOOL] = 0u;   /* the shadow stage that follows starts its pool at entry 0 */
-    uint32_t *regen_flag = &q.count[Q_REGEN0 + (iteration & 1u) * Q_LINE];
     if (COMPACT) {
         const uint32_t base = blockIdx.x * (RPT_BLOCK * RPT_SHADE_ROUNDS);
         if (base >= st.n_slots) return;                        /* block-uniform */
@@ -548,8 +539,6 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
         for (int r = 0; r < RPT_SHADE_ROUNDS; ++r) {
             const uint32_t s0 = base + (uint32_t)r * RPT_BLOCK + threadIdx.x;
             const uint32_t word = __float_as_uint(hws[r].y);
-            /* generations whose last member ended in an earlier pass (or in a side stage) */
-            if (st.group_shift != 0u) complete_generations(st, cfg, regen_flag, s0, word == HIT_DONE, word == HIT_IDLE, false, f3s(0.0f), 0u);
             const bool traversed = word < HIT_IDLE || word == HIT_MISS;
             uint32_t n_r = 0u;
             const uint32_t idx = block_rank(traversed, push_scratch, n_r);
@@ -561,11 +550,9 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             const bool active = first + threadIdx.x < total;
             const uint32_t slot = active ? c_slot[first + threadIdx.x] : 0u;
             const float2 hw = active ? st.hit[slot] : make_float2(0.0f, __uint_as_float(HIT_PARKED));
-            bool to_sky = false, emit_shadow = false, g_done = false, g_fresh = false;
+            bool to_sky = false, emit_shadow = false;
             float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-            F3 g_radiance = f3s(0.0f);
-            uint32_t g_todo = 0u;
-            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, g_done, g_fresh, g_radiance, g_todo);
+            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c);
             shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
         }
     } else {
@@ -574,15 +561,9 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
         if (slot < st.n_slots) hw = st.hit[slot];
         const uint32_t hit_tri = __float_as_uint(hw.y);
         const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;        /* traversed in this iteration */
-        /* generation bookkeeping (k_path.h: complete_generations): a slot that finished earlier (sky / shadow stage, or before
-         * its siblings) is HIT_DONE; its parked radiance is fetched by complete_generations once the generation completes */
-        bool to_sky = false, emit_shadow = false, g_done = hit_tri == HIT_DONE, g_fresh = false;
+        bool to_sky = false, emit_shadow = false;
         float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-        F3 g_radiance = f3s(0.0f);
-        uint32_t g_todo = 0u;
-        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, g_done, g_fresh, g_radiance, g_todo);
-        /* accumulate finished generations in sample order and start the next samples */
-        complete_generations(st, cfg, regen_flag, slot, g_done, hit_tri == HIT_IDLE, g_fresh, g_radiance, g_todo);
+        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c);
         shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
     }
 }

@@ -126,7 +126,8 @@ template <bool STRIDED>
 __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
                                                    DevStats *stats) {
     uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    const uint32_t n = q.count[Q_SKY];
+    uint32_t positions, n;                                     /* queue positions to sweep (k_common.h: sharded queue), misses among them */
+    q_extent(q.sky_cnt, positions, n);
     const uint32_t alive = q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE];
     const uint32_t drained = q.count[Q_DRAINED];
     if (i == 0u) {
@@ -144,9 +145,13 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
      * 133 instead of 92 VGPRs (its constants are hoisted), so scenes with many misses keep one thread per entry; the host
      * picks the variant from the share of samples that ended in the sky so far (refresh_device_stats). */
     const uint32_t stride = STRIDED ? gridDim.x * RPT_BLOCK : 0u;
-    if (cfg.c.has_skybox == 0u && n <= q.sky_wide_limit) {
+    if (cfg.c.has_skybox == 0u && positions <= q.sky_wide_limit) {
         /* few misses: 16 lanes per miss (block-uniform branch) */
-        for (uint32_t m = i >> 4; m < n; m += stride >> 4) {
+        for (uint32_t m = i >> 4; m < positions; m += stride >> 4) {
+            if (!q_filled(q.sky_cnt, m)) {                     /* (uniform over the 16 lanes of the miss) */
+                if (!STRIDED) break;
+                continue;
+            }
             const uint32_t slot = q.sky[m];
             const uint32_t lane = __lane_id(), g0 = lane & ~15u, j = lane & 15u;
             float4 ra = st.ray_a[slot];
@@ -163,7 +168,11 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
         }
         return;
     }
-    for (; i < n; i += stride) {
+    for (; i < positions; i += stride) {
+        if (!q_filled(q.sky_cnt, i)) {
+            if (!STRIDED) break;
+            continue;
+        }
         uint32_t slot = q.sky[i];
         float4 ra = st.ray_a[slot];
         float2 rb = st.ray_b[slot];
@@ -192,12 +201,17 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQu
     uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
     if (blockIdx.x == 0u)                                     /* queue counters and flags of the new call (no kernel of this call has run yet) */
         for (uint32_t k = threadIdx.x; k < (uint32_t)Q_COUNT; k += RPT_BLOCK) q.count[k] = 0u;
+    if (blockIdx.x == 0u && threadIdx.x < RPT_Q_SHARDS) q.sky_cnt[threadIdx.x * RPT_Q_SHARD_STRIDE] = q.shadow_cnt[threadIdx.x * RPT_Q_SHARD_STRIDE] = 0u;
     if (slot >= st.n_slots) return;
     /* Every slot must have been left idle by the previous render call: an asynchronous batch enqueues a fixed number of
      * iterations (max_bounces, + 1 with several slots per pixel) without ever looking at a progress report, so this is
      * where a wrong bound would show — a sample still in flight here would be overwritten and lost. */
     if (__float_as_uint(st.hit[slot].y) != HIT_IDLE) atomicAdd(&stats->undrained, 1ull);
-    const uint32_t S = 1u << st.group_shift, k = slot & (S - 1u), pix = slot >> st.group_shift;
+    const uint32_t S = 1u << st.group_shift, k = slot_k(st, slot), pix = slot_pix(st, slot);
+    if (pix >= st.n_pixels) {                                 /* padding of the last chunk of 64 pixels: never holds a path */
+        st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
+        return;
+    }
     uint2 rs = st.rng[pix];
     if (cfg.c.max_bounces == 0u) {
         /* the bounce loop never runs (lib.rs:62): every sample adds (0,0,0,1) */

@@ -334,8 +334,8 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
                     const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(exec_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)exec_m, 0u));
                     coop_done = fat;
                     do {
-                        /* ONE load of the leaf's records serves every lane of the wave that waits at this very leaf: the slots of
-                         * a pixel are adjacent lanes, so after generation (and for shadow rays towards one light) most of a wave
+                        /* ONE load of the leaf's records serves every lane of the wave that waits at this very leaf: a wave is one
+                         * 8 x 8 pixel block, so after generation (and for shadow rays towards one light) most of a wave
                          * stands on the same leaf — each used to fetch the 2.3 KB again */
                         const int lead = __ffsll((long long)todo) - 1;
                         const uint32_t b_count = rpt_readlane_u(count, lead), b_first = rpt_readlane_u(first, lead);
@@ -612,6 +612,20 @@ __device__ __forceinline__ typename SceneViewOf<LDS_SCENE>::type stage_scene(con
     else return SceneViewGlobal{sc.nodes, sc.tri_isect};
 }
 
+/* Per-iteration bookkeeping that needs no kernel of its own (one thread of the traversal launch).  The shadow queue was
+ * consumed by the previous iteration's shadow kernel (same stream).  The sky stage is lazy (k_sky): it drained its queue last
+ * iteration only if enough misses had piled up or nothing else was left — the same decision is re-derived here from the same,
+ * still unmodified words. */
+__device__ __forceinline__ void iteration_bookkeeping(const DevQueues &q, uint32_t iteration) {
+    const uint32_t prev = (iteration + 1u) & 1u;
+    uint32_t positions, waiting;
+    q_extent(q.sky_cnt, positions, waiting);
+    q_clear(q.shadow_cnt);
+    if (waiting >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q_clear(q.sky_cnt);
+    q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
+    q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
+}
+
 /* Extension rays.  Thread i owns slot i; it traces the slot's ray if one is
  * pending (HIT_PENDING) and writes the hit record into hit[slot].  A wave that
  * found work raises this iteration's alive flag (plain store, every writer
@@ -626,15 +640,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     const uint32_t slot = blockIdx.x * THREADS + threadIdx.x;
     if (slot == 0u) {
-        /* Per-iteration bookkeeping that needs no kernel of its own.  The shadow queue was consumed by the
-         * previous iteration's shadow kernel (same stream).  The sky stage is lazy (k_sky): it drained its
-         * queue last iteration only if enough misses had piled up or nothing else was left — the same
-         * decision is re-derived here from the same, still unmodified words. */
-        const uint32_t prev = (iteration + 1u) & 1u;
-        q.count[Q_SHADOW] = 0u;
-        if (q.count[Q_SKY] >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q.count[Q_SKY] = 0u;
-        q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
-        q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
+        iteration_bookkeeping(q, iteration);
     }
     bool pending = false;
     if (slot < st.n_slots) pending = __float_as_uint(st.hit[slot].y) == HIT_PENDING;
@@ -723,12 +729,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
     uint32_t *global_next = &q.count[Q_POOL0 + (iteration & 1u) * Q_LINE];
     if (blockIdx.x == 0u && threadIdx.x == 0u) {
         /* per-iteration bookkeeping, as in k_traverse_nearest (+ the other parity's slot counter, unused in this launch) */
-        const uint32_t prev = (iteration + 1u) & 1u;
-        q.count[Q_SHADOW] = 0u;
-        if (q.count[Q_SKY] >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q.count[Q_SKY] = 0u;
-        q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
-        q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
-        q.count[Q_POOL0 + prev * Q_LINE] = 0u;
+        iteration_bookkeeping(q, iteration);
+        q.count[Q_POOL0 + ((iteration + 1u) & 1u) * Q_LINE] = 0u;
     }
     const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
     if (threadIdx.x == 0u) {
@@ -803,8 +805,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
     }
 }
 
-/* Shadow rays (kernels/src/light_pick.rs:141-148): any-hit over the compacted
- * shadow queue; if unoccluded the pre-weighted NEE contribution is added to the
+/* Shadow rays (kernels/src/light_pick.rs:141-148): any-hit over the positions of the
+ * shadow queue (k_common.h: sharded, dense up to the shards' tails); if unoccluded the pre-weighted NEE contribution is added to the
  * path's radiance (lib.rs:164).  A path that ended at this bounce (bit 31 of
  * the tag) is finished here: accumulated and, if samples remain, regenerated
  * in place (its slot becomes HIT_PENDING again). */
@@ -817,11 +819,12 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
     float4 *lds_scene = rpt_lds_dyn;
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     uint32_t i = blockIdx.x * THREADS + threadIdx.x;
-    uint32_t n = q.count[Q_SHADOW];
+    uint32_t positions, n;
+    q_extent(q.shadow_cnt, positions, n);
     if (i == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
-    if (blockIdx.x * THREADS >= n) return;                     /* block-uniform */
+    if (blockIdx.x * THREADS >= positions) return;             /* block-uniform */
     const auto view = stage_scene<LDS_SCENE, THREADS>(sc, lds_scene);
-    if (i >= n) return;
+    if (i >= positions || !q_filled(q.shadow_cnt, i)) return;
     float4 o = q.sh_o[i], d = q.sh_d[i];
     uint32_t tag = __float_as_uint(d.w);
     uint32_t slot = tag & 0x7fffffffu;
@@ -859,9 +862,10 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
     __shared__ WgPool pool;
     float4 *lds_scene = rpt_lds_dyn;
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
-    const uint32_t n = q.count[Q_SHADOW];
+    uint32_t n, n_entries;                                     /* n: queue positions to hand out */
+    q_extent(q.shadow_cnt, n, n_entries);
     uint32_t *global_next = &q.count[Q_SPOOL];                 /* zeroed by the shade stage of this iteration */
-    if (blockIdx.x == 0u && threadIdx.x == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
+    if (blockIdx.x == 0u && threadIdx.x == 0u && n_entries) atomicAdd(&stats->shadow_rays, (unsigned long long)n_entries);
     const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
     if (threadIdx.x == 0u) {
         const uint32_t g = n ? atomicAdd(global_next, SPAN) : 0u;
@@ -896,7 +900,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
                     have = false;
                 }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                if (rank < got) {
+                if (rank < got && q_filled(q.shadow_cnt, base + rank)) {   /* (a position in the tail of a shard may be empty) */
                     entry = base + rank;
                     const float4 o = q.sh_o[entry], d = q.sh_d[entry];
                     ro = f3(o.x, o.y, o.z); rd = f3(d.x, d.y, d.z);
@@ -986,11 +990,7 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x == 0u && lane == 0u) {
         /* per-iteration bookkeeping, as in k_traverse_nearest */
-        const uint32_t prev = (iteration + 1u) & 1u;
-        q.count[Q_SHADOW] = 0u;
-        if (q.count[Q_SKY] >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q.count[Q_SKY] = 0u;
-        q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
-        q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
+        iteration_bookkeeping(q, iteration);
     }
     const uint32_t span_begin = blockIdx.x * SPAN;
     if (span_begin >= st.n_slots) return;
@@ -1080,11 +1080,13 @@ __device__ __forceinline__ void shadow_resolve(const DevState &st, const DevQueu
 __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQueues q, DevConfig cfg) {
     if (q.count[Q_DRAINED] != 0u) return;
     const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
-    if (i >= q.count[Q_SHADOW]) return;
+    uint32_t positions, n;
+    q_extent(q.shadow_cnt, positions, n);
+    if (i >= positions || !q_filled(q.shadow_cnt, i)) return;
     shadow_resolve(st, q, cfg, i, __float_as_uint(q.sh_d[i].w), q.sh_c[i].w == 0.0f);
 }
 
-/* Shadow rays, streamed: the queue is dense already; a wave owns SPAN consecutive entries and refills lanes whose
+/* Shadow rays, streamed: the queue is dense already (up to the tails of its shards); a wave owns SPAN consecutive positions and refills lanes whose
  * any-hit walk has ended (found an occluder after two visits, or crossed the whole scene without one).  Lanes only note
  * "occluded" per entry in LDS while walking; the NEE terms are added afterwards in one dense pass over the span (all
  * lanes busy, and the registers of the walk are dead by then: 61 instead of 91 VGPRs). */
@@ -1096,8 +1098,9 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
     __shared__ uint8_t occluded[RPT_WAVE * RPT_GSTREAM_RAYS];
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     const uint32_t lane = threadIdx.x;
-    const uint32_t n = q.count[Q_SHADOW];
-    if (blockIdx.x == 0u && lane == 0u && n) atomicAdd(&stats->shadow_rays, (unsigned long long)n);
+    uint32_t n, n_entries;                                     /* n: queue positions of the launch */
+    q_extent(q.shadow_cnt, n, n_entries);
+    if (blockIdx.x == 0u && lane == 0u && n_entries) atomicAdd(&stats->shadow_rays, (unsigned long long)n_entries);
     const uint32_t begin = blockIdx.x * SPAN;
     if (begin >= n) return;
     const uint32_t end = begin + SPAN < n ? begin + SPAN : n;
@@ -1123,7 +1126,7 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
                         have = false;
                     }
                     const uint32_t at = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                    if (at < end) {
+                    if (at < end && q_filled(q.shadow_cnt, at)) {
                         const float4 o = q.sh_o[at], d = q.sh_d[at];
                         ro = f3(o.x, o.y, o.z); rd = f3(d.x, d.y, d.z);
                         max_t = o.w;
@@ -1148,7 +1151,7 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
     __builtin_amdgcn_wave_barrier();
     for (uint32_t base = begin; base < end; base += RPT_WAVE) {
         const uint32_t e = base + lane;
-        if (e < end) shadow_resolve(st, q, cfg, e, __float_as_uint(q.sh_d[e].w), occluded[e - begin] == 0u);
+        if (e < end && q_filled(q.shadow_cnt, e)) shadow_resolve(st, q, cfg, e, __float_as_uint(q.sh_d[e].w), occluded[e - begin] == 0u);
     }
 }
 

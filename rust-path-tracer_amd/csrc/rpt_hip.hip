@@ -153,14 +153,14 @@ int alloc_state(rpt_ctx *c) {
     HIP_TRY(c, c->thr.alloc(n)); HIP_TRY(c, c->rad.alloc(n));
     HIP_TRY(c, c->mis_a.alloc(n)); HIP_TRY(c, c->mis_b.alloc(n));
     HIP_TRY(c, c->accum.alloc(np)); HIP_TRY(c, c->rng.alloc(np));
-    HIP_TRY(c, c->q_sky.alloc(n));
+    HIP_TRY(c, c->q_sky.alloc(n + RPT_Q_SLACK));     /* side queues: positions, not entries (k_common.h: sharded queues) */
     HIP_TRY(c, c->ray_shards.alloc(RPT_STAT_SHARDS * RPT_STAT_STRIDE));
     HIP_TRY(c, hipMemsetAsync(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, c->q_count.alloc(Q_COUNT));
-    HIP_TRY(c, c->sh_o.alloc(n)); HIP_TRY(c, c->sh_d.alloc(n)); HIP_TRY(c, c->sh_c.alloc(n));
+    HIP_TRY(c, c->q_count.alloc(Q_WORDS));
+    HIP_TRY(c, c->sh_o.alloc(n + RPT_Q_SLACK)); HIP_TRY(c, c->sh_d.alloc(n + RPT_Q_SLACK)); HIP_TRY(c, c->sh_c.alloc(n + RPT_Q_SLACK));
     HIP_TRY(c, c->pixel_xy.alloc(np));
     if (np) HIP_TRY(c, hipMemcpy(c->pixel_xy.p, c->pixel_xy_host.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemsetAsync(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->q_count.p, 0, Q_WORDS * sizeof(uint32_t), c->stream));
     if (n) k_fill_idle<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, c->stream>>>(c->hit.p, (uint32_t)n);   /* nothing in flight */
     DevState &s = c->state;
     s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.hit = c->hit.p; s.thr = c->thr.p; s.rad = c->rad.p;
@@ -170,6 +170,7 @@ int alloc_state(rpt_ctx *c) {
     DevQueues &q = c->queues;
     q.sky = c->q_sky.p; q.ray_shards = c->ray_shards.p;
     q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p; q.count = c->q_count.p;
+    q.sky_cnt = c->q_count.p + Q_COUNT; q.shadow_cnt = q.sky_cnt + RPT_Q_SHARDS * RPT_Q_SHARD_STRIDE;
     q.host_ring = c->host_ring_dev; q.ring_mask = RING - 1;
     /* 1 = shade misses in the iteration that found them.  Letting them pile up (threshold ~ n/64) removes most
      * of the near-empty sky launches on closed scenes, but the parked pixels finish later and lengthen the tail:
@@ -237,6 +238,8 @@ constexpr int GLOBAL_THREADS = RPT_GLOBAL_THREADS;   /* workgroup size of the gl
 constexpr int LDS_THREADS = RPT_LDS_THREADS;     /* workgroup size of the LDS-resident-scene traversal variants: 2 x (32 KB of
                                                     16-bit stacks + up to 32 KB of scene = the 64 KB a workgroup may hold) per CU = 32 waves */
 
+static uint32_t padded_pixels(uint32_t n_pixels) { return (n_pixels + 63u) & ~63u; }      /* whole chunks of 64 pixels (k_common.h, slot_pix) */
+
 /* streamed global-memory walks: width of a stack entry for the scene, and slots per wave — as many as keep >= gstream_min_waves
  * waves in the launch, at most `most` per lane */
 static int gstream_stack_width(const rpt_ctx *c) {
@@ -289,7 +292,7 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration) {
 }
 
 template <int STACK, int NEE, bool TEXTURED>
-void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool shade_only) {
+void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool complete_each) {
     hipStream_t s = c->stream;
     const bool only_traverse = c->timing_level == 2;
     auto mark = [&](bool traverse_edge = false) {
@@ -297,17 +300,20 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     };
     if (only_traverse) mark(true);
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
-    const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
+    /* the consumers of a side queue cover its POSITIONS: up to RPT_Q_SLACK more than there are slots (k_common.h) */
+    const uint32_t q_positions = c->n_slots + RPT_Q_SLACK, blocks_q = (q_positions + RPT_BLOCK - 1) / RPT_BLOCK;
+    const uint32_t blocks_lds = (q_positions + LDS_THREADS - 1) / LDS_THREADS;
     const int stack_width = gstream_stack_width(c);
-    const uint32_t gspan = gstream_span(c, (uint32_t)RPT_GSTREAM_RAYS), gblocks = (c->n_slots + gspan - 1) / gspan;             /* any-hit walk */
-    /* shade_only: the completion pass of a batch whose iteration count is known — every path has ended, only finished
-     * generations are left to accumulate (k_shade: complete_generations); no ray to trace, no miss, no shadow ray */
-    if (!shade_only) launch_nearest<STACK>(c, iteration);
+    const uint32_t gspan = gstream_span(c, (uint32_t)RPT_GSTREAM_RAYS), gblocks = (q_positions + gspan - 1) / gspan;            /* any-hit walk */
+    launch_nearest<STACK>(c, iteration);
     mark(true);
     if (c->shade_compact) k_shade<NEE, TEXTURED, true><<<(c->n_slots + RPT_BLOCK * RPT_SHADE_ROUNDS - 1) / (RPT_BLOCK * RPT_SHADE_ROUNDS), RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     else k_shade<NEE, TEXTURED, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
+    /* generations are completed (and the next samples started) after every shade stage only where slots take more than one
+     * sample in this call; a batch of known length completes them once, after its last iteration (render_impl) */
+    if (complete_each) k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, iteration, 0u);
     mark();
-    if (NEE != RPT_NEE_NONE && !shade_only) {
+    if (NEE != RPT_NEE_NONE) {
         if (STACK == 16 && c->scene.lds_scene && c->lds_stream && c->lds_shadow_stream) {
             const uint32_t wgs = c->stream_max_blocks;
             uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 16u);
@@ -315,7 +321,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
             const uint32_t n_spans = (c->n_slots + span - 1) / span;
             k_traverse_shadow_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
-            k_shadow_resolve<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
+            k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else if (c->gstream) {
@@ -329,34 +335,34 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             }
 #undef RPT_LAUNCH_SHADOW
         } else {
-            const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
+            const uint32_t nb = (q_positions + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
             if (c->scene.n_nodes < 65536u) k_traverse_shadow<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
             else k_traverse_shadow<STACK, false, GLOBAL_THREADS><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         }
     }
     mark();
-    if (!shade_only) {
+    {
         if (c->sky_strided && blocks > c->sky_blocks) k_sky<true><<<c->sky_blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
-        else k_sky<false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
+        else k_sky<false><<<blocks_q, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     }
     mark();
 }
 
 template <int STACK>
-void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool shade_only) {
+void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool complete_each) {
     const bool tex = c->scene.textured != 0u;
     switch (c->cfg.nee_mode) {
         case RPT_NEE_MIS:
-            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, iteration, blocks, ev, ev_at, shade_only);
-            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, iteration, blocks, ev, ev_at, shade_only);
+            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, iteration, blocks, ev, ev_at, complete_each);
+            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, iteration, blocks, ev, ev_at, complete_each);
             break;
         case RPT_NEE_DIRECT:
-            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, iteration, blocks, ev, ev_at, shade_only);
-            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, iteration, blocks, ev, ev_at, shade_only);
+            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, iteration, blocks, ev, ev_at, complete_each);
+            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, iteration, blocks, ev, ev_at, complete_each);
             break;
         default:
-            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, iteration, blocks, ev, ev_at, shade_only);
-            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, iteration, blocks, ev, ev_at, shade_only);
+            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, iteration, blocks, ev, ev_at, complete_each);
+            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, iteration, blocks, ev, ev_at, complete_each);
             break;
     }
 }
@@ -678,7 +684,7 @@ int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
         }
         c->max_group_shift = 0;
         while ((1u << c->max_group_shift) < S) c->max_group_shift += 1;
-        c->max_slots = c->n_pixels << c->max_group_shift;
+        c->max_slots = padded_pixels(c->n_pixels) << c->max_group_shift;       /* chunks of 64 pixels x S slots (k_common.h, slot_pix) */
         c->group_shift = c->max_group_shift;
         c->n_slots = c->max_slots;
         int rc = alloc_state(c);
@@ -780,7 +786,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         uint32_t shift = 0;
         while (shift < c->max_group_shift && (1u << shift) < n_samples) shift += 1;
         c->group_shift = shift;
-        c->n_slots = c->n_pixels << shift;
+        c->n_slots = padded_pixels(c->n_pixels) << shift;
         c->state.group_shift = shift;
         c->state.n_slots = c->n_slots;
         c->queues.sky_wide_limit = std::min(c->n_slots / 16u, c->sky_wide_cfg);   /* the wide sky pass spends 16 threads of the grid per miss */
@@ -791,7 +797,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
      * iteration) — so exactly that many iterations are enqueued and no progress report is awaited (saves the run-ahead's
      * surplus launches, 4 % of a 1.3 ms batch on 1/8 of an image). */
     const uint64_t known_iterations =
-        (n_samples <= (1u << c->group_shift) && c->queues.sky_threshold <= 1u) ? (uint64_t)c->cfg.c.max_bounces + (c->group_shift ? 1u : 0u) : 0u;
+        (n_samples <= (1u << c->group_shift) && c->queues.sky_threshold <= 1u) ? (uint64_t)c->cfg.c.max_bounces : 0u;
     HIP_TRY(c, hipSetDevice(c->device));
     auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = c->stream;
@@ -844,16 +850,19 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
             ev->resize(ev_at + EVENTS_PER_ITER * 64);
             for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
         }
-        /* the extra pass of a known-length batch with several slots per pixel only completes generations */
-        const bool shade_only = known_iterations != 0 && c->group_shift != 0 && it + 1 == known_iterations;
+        const bool complete_each = known_iterations == 0 && c->group_shift != 0;
         switch (c->stack_cap) {
-            case 16: launch_iteration_stack<16>(c, (uint32_t)it, blocks, ev, ev_at, shade_only); break;
-            case 24: launch_iteration_stack<24>(c, (uint32_t)it, blocks, ev, ev_at, shade_only); break;
-            default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at, shade_only); break;
+            case 16: launch_iteration_stack<16>(c, (uint32_t)it, blocks, ev, ev_at, complete_each); break;
+            case 24: launch_iteration_stack<24>(c, (uint32_t)it, blocks, ev, ev_at, complete_each); break;
+            default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at, complete_each); break;
         }
-        full_iterations += shade_only ? 0u : 1u;
+        full_iterations += 1u;
         it += 1;
-        if (it == known_iterations - short_batch) break;        /* (no report needed: nothing can be left) */
+        if (it == known_iterations - short_batch) {             /* (no report needed: nothing can be left) */
+            /* every path of the batch has ended (max_bounces iterations, side stages included): the one completion of the batch */
+            if (c->group_shift != 0) k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, (uint32_t)it, 1u);
+            break;
+        }
         if (known_iterations == 0 && it >= (uint64_t)lag) {
             /* the sky kernel of iteration j published (j + 1) << 32 | "work remains after iteration j" */
             uint64_t j = it - lag;
@@ -1196,7 +1205,7 @@ int rpt_debug_trace_rays_production(rpt_ctx *c, size_t n, const float *origins, 
     HIP_TRY(c, hipMemcpy(d_o.p, origins, 12 * n, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d_d.p, dirs, 12 * n, hipMemcpyHostToDevice));
     hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemsetAsync(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->q_count.p, 0, Q_WORDS * sizeof(uint32_t), s));
     k_fill_idle<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->hit.p, c->n_slots);
     k_debug_load_rays<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, s>>>(c->state, (uint32_t)n, d_o.p, d_d.p);
     switch (c->stack_cap) {
@@ -1209,7 +1218,7 @@ int rpt_debug_trace_rays_production(rpt_ctx *c, size_t n, const float *origins, 
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(hits.data(), c->hit.p, n * sizeof(float2), hipMemcpyDeviceToHost);
     /* back to "nothing in flight" */
-    if (e == hipSuccess) e = hipMemsetAsync(c->q_count.p, 0, Q_COUNT * sizeof(uint32_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(c->q_count.p, 0, Q_WORDS * sizeof(uint32_t), s);
     k_fill_idle<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->hit.p, c->n_slots);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     d_o.release(); d_d.release();
