@@ -43,6 +43,25 @@ __device__ __forceinline__ void start_path(const DevState &st, const DevConfig &
     st.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(todo_after));
 }
 
+/* The first paths of a render call (k_generate_first) store only their ray: throughput 1, radiance 0, bounce 0 and the samples
+ * the slot still owes are functions of the slot, and the shade stage of iteration 0 — where EVERY traversed slot is such a path
+ * — takes them as given instead of reading them (and writes the records for whoever reads them later: the continuing path, the
+ * sky and shadow stages).  Saves a 32-byte write and a 16-byte read per slot and call: 1.6 GB of a DarkCornell batch. */
+#define RPT_FRESH_FLAGS MAKE_FLAGS(0u, 0u, 2u)
+__device__ __forceinline__ void start_first_path(const DevState &st, const DevConfig &cfg, uint32_t slot, uint32_t n, uint32_t offset) {
+    uint32_t pxy = st.pixel_xy[slot_pix(st, slot)];
+    F3 ro, rd;
+    camera_ray(cfg, pxy & 0xffffu, pxy >> 16, n + offset, ro, rd);
+    st.ray_a[slot] = make_float4(ro.x, ro.y, ro.z, rd.x);
+    st.ray_b[slot] = make_float2(rd.y, rd.z);
+    st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PENDING));
+}
+/* samples slot `slot` owes after its first one in a call of n_samples (the slot has one: it was started) */
+__device__ __forceinline__ uint32_t first_path_todo(const DevState &st, uint32_t slot, uint32_t n_samples) {
+    const uint32_t S = 1u << st.group_shift;
+    return (n_samples - slot_k(st, slot) + S - 1u) / S - 1u;
+}
+
 /* A path ended in a side stage (sky / shadow).  With one slot per pixel the sample is accumulated and the
  * next one started on the spot; with several, the finished radiance is parked (HIT_DONE) and k_complete, which sees all
  * the slots of a pixel, completes the generation.  Every stage that ends a path — shade, shadow, sky — ends it through here. */
@@ -71,7 +90,8 @@ __device__ __forceinline__ void finish_in_side_stage(const DevState &st, const D
  * every wave (ds_bpermute, then a DPP shift chain: 2 of 64 lanes useful), 0.45 ms of the last shade launch of a DarkCornell
  * batch + a 0.19 ms completion pass.  A batch of known length (no slot takes a second sample) runs this once, after its last
  * iteration; otherwise it follows every shade stage. */
-__global__ __launch_bounds__(RPT_BLOCK) void k_complete(DevState st, DevQueues q, DevConfig cfg, uint32_t iteration, uint32_t final_pass) {
+__global__ __launch_bounds__(RPT_BLOCK) void k_complete(DevState st, DevQueues q, DevConfig cfg, uint32_t iteration, uint32_t final_pass,
+                                                        DevStats *stats) {
     /* a surplus launch of the run-ahead returns at once (grid-uniform) — but not the one completion of a batch of known length:
      * "drained" there only says that no RAY was left in an earlier iteration, the finished samples still wait to be added */
     if (!final_pass && q.count[Q_DRAINED] != 0u) return;
@@ -107,6 +127,12 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_complete(DevState st, DevQueues q
             st.accum[pix] = acc;
             rs.x = new_n;
             st.rng[pix] = rs;
+        } else if (final_pass && !all) {
+            /* the one completion of a batch of known length found a sample still in flight: the bound on its iterations was
+             * wrong (must never happen; rpt_wait / rpt_render report it).  Counted like k_check_drained would: slots not idle. */
+            uint32_t bad = 0u;
+            for (uint32_t k = 0; k < S; ++k) bad += __float_as_uint(st.hit[base + (k << 6)].y) != HIT_IDLE ? 1u : 0u;
+            atomicAdd(&stats->undrained, (unsigned long long)bad);
         }
     }
     /* tell the host that new samples were started (one plain store per wave, every writer stores 1) */

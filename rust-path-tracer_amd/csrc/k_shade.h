@@ -157,7 +157,8 @@ __device__ __forceinline__ Mat load_material(const DevScene &sc, uint32_t index)
 template <int NEE, bool TEXTURED, bool COMPACT>
 __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &st, const DevQueues &q, const DevConfig &cfg, DevStats *stats,
                                            uint32_t slot, float2 hw, bool active, bool &to_sky, bool &emit_shadow, float4 &sh_o, float4 &sh_d,
-                                           float4 &sh_c) {
+                                           float4 &sh_c, bool first /* iteration 0 of the call: every path is a first path (k_path.h) */,
+                                           uint32_t n_samples) {
     const uint32_t hit_tri = __float_as_uint(hw.y);
     if (active) {
         const float4 ra = st.ray_a[slot];
@@ -167,8 +168,12 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
         if (hit_tri == HIT_MISS) {
             to_sky = true;                           /* lib.rs:66-79: shaded by k_sky, which also ends the path */
             st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+            if (first) {                             /* k_sky reads the path state */
+                st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RPT_FRESH_FLAGS));
+                st.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(first_path_todo(st, slot, n_samples)));
+            }
         } else {
-            const float4 tf = st.thr[slot];
+            const float4 tf = first ? make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RPT_FRESH_FLAGS)) : st.thr[slot];
             F3 throughput = f3(tf.x, tf.y, tf.z);
             /* radiance + samples still owed: read only by a lane whose path adds emission or ends here (never written back by
              * this stage mid-path: the NEE terms are added by the shadow stage, everything else ends the path) */
@@ -177,9 +182,13 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
             bool rad_loaded = false;
             auto load_rad = [&]() {
                 if (!rad_loaded) {
-                    const float4 r4 = st.rad[slot];
-                    radiance = f3(r4.x, r4.y, r4.z);
-                    todo = __float_as_uint(r4.w);
+                    if (first) {
+                        todo = first_path_todo(st, slot, n_samples);     /* radiance 0 */
+                    } else {
+                        const float4 r4 = st.rad[slot];
+                        radiance = f3(r4.x, r4.y, r4.z);
+                        todo = __float_as_uint(r4.w);
+                    }
                     rad_loaded = true;
                 }
             };
@@ -443,6 +452,10 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                 load_rad();
                 finish_in_side_stage(st, cfg, slot, radiance, todo);
             } else {
+                if (first) {                         /* the path goes on (or waits for its shadow ray): its radiance record begins here */
+                    load_rad();
+                    st.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(todo));
+                }
                 if (!done) {
                     st.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(new_flags));
                     st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
@@ -520,7 +533,8 @@ template <int NEE, bool TEXTURED, bool COMPACT>
 #endif
 __attribute__((amdgpu_waves_per_eu((NEE == RPT_NEE_NONE && !TEXTURED) ? (COMPACT ? RPT_SHADE_WAVES_PACKED : RPT_SHADE_WAVES_PLAIN) : 1, 8)))
 __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
-                                                     DevStats *stats) {
+                                                     DevStats *stats, uint32_t n_samples /* of this render call */) {
+    const bool first_paths = iteration == 0u;                  /* every traversed slot holds the first path of its call (k_path.h) */
     __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
     __shared__ uint32_t c_slot[COMPACT ? RPT_BLOCK * RPT_SHADE_ROUNDS : 1];
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
@@ -552,7 +566,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             const float2 hw = active ? st.hit[slot] : make_float2(0.0f, __uint_as_float(HIT_PARKED));
             bool to_sky = false, emit_shadow = false;
             float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c);
+            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples);
             shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
         }
     } else {
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
         const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;        /* traversed in this iteration */
         bool to_sky = false, emit_shadow = false;
         float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c);
+        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples);
         shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
     }
 }

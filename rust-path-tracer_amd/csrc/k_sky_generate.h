@@ -227,7 +227,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_generate_first(DevState st, DevQu
     }
     uint32_t count = n_samples > k ? (n_samples - k + S - 1u) / S : 0u;
     if (count == 0u) st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_IDLE));
-    else start_path(st, cfg, slot, rs.x + k, rs.y, count - 1u);
+    else start_first_path(st, cfg, slot, rs.x + k, rs.y);      /* (owes count - 1 more: first_path_todo) */
 }
 
 /* all slots idle (state after allocation: nothing in flight) */

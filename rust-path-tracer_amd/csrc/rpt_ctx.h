@@ -101,6 +101,7 @@ struct rpt_ctx {
     DevState state{};
     DevQueues queues{};
     uint32_t samples = 0;
+    uint32_t call_samples = 0;  /* n_samples of the current / last rpt_render call (the shade stage of its first iteration derives what a slot owes) */
 
     /* scheduling: the traversal kernel reports each iteration's queue size into mapped pinned memory */
     unsigned long long *host_ring = nullptr;       /* host view, RING entries */

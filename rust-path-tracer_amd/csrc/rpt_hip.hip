@@ -307,11 +307,11 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     const uint32_t gspan = gstream_span(c, (uint32_t)RPT_GSTREAM_RAYS), gblocks = (q_positions + gspan - 1) / gspan;            /* any-hit walk */
     launch_nearest<STACK>(c, iteration);
     mark(true);
-    if (c->shade_compact) k_shade<NEE, TEXTURED, true><<<(c->n_slots + RPT_BLOCK * RPT_SHADE_ROUNDS - 1) / (RPT_BLOCK * RPT_SHADE_ROUNDS), RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
-    else k_shade<NEE, TEXTURED, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
+    if (c->shade_compact) k_shade<NEE, TEXTURED, true><<<(c->n_slots + RPT_BLOCK * RPT_SHADE_ROUNDS - 1) / (RPT_BLOCK * RPT_SHADE_ROUNDS), RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
+    else k_shade<NEE, TEXTURED, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
     /* generations are completed (and the next samples started) after every shade stage only where slots take more than one
      * sample in this call; a batch of known length completes them once, after its last iteration (render_impl) */
-    if (complete_each) k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, iteration, 0u);
+    if (complete_each) k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, iteration, 0u, c->dev_stats.p);
     mark();
     if (NEE != RPT_NEE_NONE) {
         if (STACK == 16 && c->scene.lds_scene && c->lds_stream && c->lds_shadow_stream) {
@@ -751,7 +751,8 @@ static int refresh_device_stats(rpt_ctx *c, const char *what) {
 int rpt_wait(rpt_ctx *c) {
     if (!c) return RPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->async_pending && c->has_state && c->n_slots)    /* the last asynchronous batch must have left every slot idle */
+    /* the last asynchronous batch must have left every slot idle (with several slots per pixel its k_complete has looked already) */
+    if (c->async_pending && c->has_state && c->n_slots && c->group_shift == 0)
         k_check_drained<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, c->stream>>>(c->hit.p, c->n_slots, c->dev_stats.p);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
@@ -810,6 +811,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     }
 
     if (!async) for (int k = 0; k < RING; ++k) __atomic_store_n(&c->host_ring[k], 0ull, __ATOMIC_RELAXED);
+    c->call_samples = n_samples;
     k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples, c->dev_stats.p);
     c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
 
@@ -860,7 +862,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         it += 1;
         if (it == known_iterations - short_batch) {             /* (no report needed: nothing can be left) */
             /* every path of the batch has ended (max_bounces iterations, side stages included): the one completion of the batch */
-            if (c->group_shift != 0) k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, (uint32_t)it, 1u);
+            if (c->group_shift != 0) k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, (uint32_t)it, 1u, c->dev_stats.p);
             break;
         }
         if (known_iterations == 0 && it >= (uint64_t)lag) {
@@ -896,7 +898,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         return RPT_OK;
     }
     /* a call that enqueued a fixed number of iterations must have left every slot idle: cross-check of that bound */
-    if (known_iterations != 0 && c->n_slots)
+    if (known_iterations != 0 && c->n_slots && c->group_shift == 0)     /* (several slots per pixel: k_complete's final pass has counted) */
         k_check_drained<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->hit.p, c->n_slots, c->dev_stats.p);
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
