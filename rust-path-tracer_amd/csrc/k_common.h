@@ -119,6 +119,7 @@ struct DevState {
     uint32_t n_slots;
     uint32_t n_pixels;
     uint32_t group_shift; /* log2 S, S = samples of one pixel in flight (slots per pixel) */
+    uint32_t q_shift;     /* log2 Q <= group_shift, Q = samples of one pixel in ONE wave (a wave = 64 / Q pixels x Q samples) */
 };
 
 /* flags word: bits 0-7 bounce, bit 8 last sampled lobe (1 = specular), bits 16-21 LDS dimension */
@@ -209,10 +210,30 @@ struct DevConfig {
  * 64 x S slots laid out sample-major: slot = chunk * 64 S + k * 64 + (pixel % 64).  A wave of 64 consecutive slots is 64
  * PIXELS at one sample index k (coherent primary rays), and the S samples of a pixel sit 64 slots apart — so the in-order sum of
  * a finished generation is a loop over k in ONE lane per pixel with coalesced loads (k_complete), not a chain across the lanes
- * of a wave.  Pixels are padded to a multiple of 64; the padding slots stay idle.  S = 1: slot == pixel. */
-__device__ __forceinline__ uint32_t slot_k(const DevState &st, uint32_t slot) { return (slot >> 6) & ((1u << st.group_shift) - 1u); }
-__device__ __forceinline__ uint32_t slot_pix(const DevState &st, uint32_t slot) { return ((slot >> (6u + st.group_shift)) << 6) | (slot & 63u); }
-__device__ __forceinline__ uint32_t pix_slot(const DevState &st, uint32_t pix, uint32_t k) { return ((pix >> 6) << (6u + st.group_shift)) | (k << 6) | (pix & 63u); }
+ * of a wave.  Pixels are padded to a multiple of 64; the padding slots stay idle.  S = 1: slot == pixel.
+ * General form (q_shift > 0): a wave holds 64 / Q pixels x Q consecutive samples of each (lane = pixel-in-wave * Q + k % Q; the
+ * waves of a chunk are ordered by pixel group, then k / Q).  Q = 1 is the layout above and what every shipped scene uses; rays
+ * of ONE pixel are the most coherent a wave can get, which only pays where a ray's walk is long: measured (profiles/
+ * r03_slot_layout.txt) the 2 M-node stand-in's traversal 605 -> 563 ms per 2 batches at Q = 32 (deep BVH stand-in 388 -> 377),
+ * VeachMIS / PBRTest +-0, DarkCornell's first launch 1.16 -> 1.12 ms but its later bounces 2.9 -> 3.0 — while k_complete's loads
+ * stop being coalesced (0.2 -> 1.4 ms per 33 M slots).  So Q = 32 for scenes of RPT_BIG_SCENE_TRIANGLES and more, where a batch
+ * takes hundreds of milliseconds, and 1 elsewhere; the image does not depend on it (tests: RPT_SLOT_Q_SHIFT). */
+#define RPT_BIG_SCENE_TRIANGLES (1u << 19)
+__device__ __forceinline__ uint32_t slot_k(const DevState &st, uint32_t slot) {
+    const uint32_t gs = st.group_shift, qs = st.q_shift;
+    const uint32_t wave = (slot >> 6) & ((1u << gs) - 1u);
+    return ((wave & ((1u << (gs - qs)) - 1u)) << qs) | (slot & ((1u << qs) - 1u));
+}
+__device__ __forceinline__ uint32_t slot_pix(const DevState &st, uint32_t slot) {
+    const uint32_t gs = st.group_shift, qs = st.q_shift;
+    const uint32_t wave = (slot >> 6) & ((1u << gs) - 1u);
+    return ((slot >> (6u + gs)) << 6) | ((wave >> (gs - qs)) << (6u - qs)) | ((slot & 63u) >> qs);
+}
+__device__ __forceinline__ uint32_t pix_slot(const DevState &st, uint32_t pix, uint32_t k) {
+    const uint32_t gs = st.group_shift, qs = st.q_shift;
+    const uint32_t p = pix & 63u, pg = p >> (6u - qs), pl = p & ((64u >> qs) - 1u);
+    return ((pix >> 6) << (6u + gs)) | ((((pg << (gs - qs)) | (k >> qs))) << 6) | (pl << qs) | (k & ((1u << qs) - 1u));
+}
 
 /* wave64 ballot + prefix compaction: every lane calls it (converged); lanes with
  * pred get a dense index in the queue, one atomic per wave. */

@@ -85,7 +85,7 @@ __device__ __forceinline__ void finish_in_side_stage(const DevState &st, const D
  * (HIT_IDLE) and at least one is finished, their radiances are added to the accumulator IN SLOT ORDER (= sample order,
  * kernels/src/lib.rs:225, src/trace.rs:295: the f32 sum order is part of the result), the pixel's rng.n advances by the number
  * of samples (lib.rs:226), and every finished slot starts its next sample (lib.rs:36-60) or goes idle.  The slots of a pixel
- * are 64 apart (k_common.h, slot_pix), so every load of the loop is a coalesced wave access.
+ * are 64 apart (k_common.h, slot_pix; q_shift = 0), so every load of the loop is a coalesced wave access.
  * Round 2 did this inside the shade stage with the S slots of a pixel in adjacent lanes: a dependent chain across the lanes of
  * every wave (ds_bpermute, then a DPP shift chain: 2 of 64 lanes useful), 0.45 ms of the last shade launch of a DarkCornell
  * batch + a 0.19 ms completion pass.  A batch of known length (no slot takes a second sample) runs this once, after its last
@@ -99,11 +99,10 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_complete(DevState st, DevQueues q
     const uint32_t S = 1u << st.group_shift;
     bool started = false;
     if (pix < st.n_pixels) {
-        const uint32_t base = pix_slot(st, pix, 0u);
         uint32_t done_mask = 0u;
         bool all = true;
         for (uint32_t k = 0; k < S; ++k) {
-            const uint32_t w = __float_as_uint(st.hit[base + (k << 6)].y);
+            const uint32_t w = __float_as_uint(st.hit[pix_slot(st, pix, k)].y);
             if (w == HIT_DONE) done_mask |= 1u << k;
             else if (w != HIT_IDLE) { all = false; break; }
         }
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_complete(DevState st, DevQueues q
             const uint32_t new_n = rs.x + (uint32_t)__popc(done_mask);
             for (uint32_t k = 0; k < S; ++k) {
                 if (((done_mask >> k) & 1u) == 0u) continue;
-                const uint32_t slot = base + (k << 6);
+                const uint32_t slot = pix_slot(st, pix, k);
                 const float4 r = st.rad[slot];
                 acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += 1.0f;
                 const uint32_t todo = __float_as_uint(r.w);
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_complete(DevState st, DevQueues q
             /* the one completion of a batch of known length found a sample still in flight: the bound on its iterations was
              * wrong (must never happen; rpt_wait / rpt_render report it).  Counted like k_check_drained would: slots not idle. */
             uint32_t bad = 0u;
-            for (uint32_t k = 0; k < S; ++k) bad += __float_as_uint(st.hit[base + (k << 6)].y) != HIT_IDLE ? 1u : 0u;
+            for (uint32_t k = 0; k < S; ++k) bad += __float_as_uint(st.hit[pix_slot(st, pix, k)].y) != HIT_IDLE ? 1u : 0u;
             atomicAdd(&stats->undrained, (unsigned long long)bad);
         }
     }

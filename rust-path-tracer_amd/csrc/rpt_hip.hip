@@ -166,7 +166,7 @@ int alloc_state(rpt_ctx *c) {
     s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.hit = c->hit.p; s.thr = c->thr.p; s.rad = c->rad.p;
     s.mis_a = c->mis_a.p; s.mis_b = c->mis_b.p;
     s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = (uint32_t)n;
-    s.n_pixels = (uint32_t)np; s.group_shift = c->group_shift;
+    s.n_pixels = (uint32_t)np; s.group_shift = c->group_shift; s.q_shift = 0;
     DevQueues &q = c->queues;
     q.sky = c->q_sky.p; q.ray_shards = c->ray_shards.p;
     q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p; q.count = c->q_count.p;
@@ -439,6 +439,7 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (const char *e9 = getenv("RPT_LDS_SHADOW_STREAM")) c->lds_shadow_stream = e9[0] != '0';
     if (const char *e7 = getenv("RPT_GSTREAM_MIN_WAVES")) c->gstream_min_waves = (uint32_t)std::max(1, atoi(e7));
     if (const char *e17 = getenv("RPT_STACK_BITS")) c->stack_bits_min = atoi(e17);      /* test aid: wider stack entries than the scene needs */
+    if (const char *e18 = getenv("RPT_SLOT_Q_SHIFT")) c->slot_q_shift_mode = std::max(0, std::min(5, atoi(e18)));   /* test aid: log2 of the samples of a pixel per wave */
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->stream_max_blocks = 2u * (uint32_t)prop.multiProcessorCount;
@@ -789,6 +790,9 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         c->group_shift = shift;
         c->n_slots = padded_pixels(c->n_pixels) << shift;
         c->state.group_shift = shift;
+        /* samples of one pixel per wave (k_common.h, slot_pix): 1 unless the scene is a large one */
+        const uint32_t qs = c->slot_q_shift_mode >= 0 ? (uint32_t)c->slot_q_shift_mode : (c->scene.n_triangles >= RPT_BIG_SCENE_TRIANGLES ? 5u : 0u);
+        c->state.q_shift = qs < shift ? qs : shift;
         c->state.n_slots = c->n_slots;
         c->queues.sky_wide_limit = std::min(c->n_slots / 16u, c->sky_wide_cfg);   /* the wide sky pass spends 16 threads of the grid per miss */
     }

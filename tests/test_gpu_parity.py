@@ -314,7 +314,7 @@ def test_baseline_configs_at_their_own_sample_counts(hipmod, oracle, rpt, world,
 @pytest.mark.parametrize("scene,nee,spp", [("DarkCornell", 0, 7), ("VeachMIS", 1, 5), ("PBRTest", 2, 3)])
 def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp):
     """Any number of samples of a pixel in flight gives the sequential sample-order sum, bit for bit
-    (k_path.h: complete_generations) — including sample counts that are not a multiple of it."""
+    (k_path.h: k_complete) — including sample counts that are not a multiple of it."""
     w = world(scene)
     W, H = 96, 80
     cfg = rpt.default_config(W, H, nee=nee)
@@ -329,6 +329,32 @@ def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp
         acc, n = r.read_accum()
         assert n == spp
         assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"samples in flight = {s_in_flight}"
+        g = r.stats()
+        assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays
+        assert np.array_equal(r.read_rng()["n"], rng_ref["n"])
+        r.close()
+
+
+@pytest.mark.parametrize("q_shift", [1, 2, 3, 5])
+def test_slot_layout_invisible(monkeypatch, hipmod, oracle, rpt, world, q_shift):
+    """The slot layout (k_common.h slot_pix: a wave = 64 / Q pixels x Q samples; Q = 1 for the shipped scenes, 32 for scenes of
+    half a million triangles and more) never reaches the image: every Q, sample counts that are not a multiple of the slots per
+    pixel, a second call that continues the first, an image whose pixel count is not a multiple of 64."""
+    monkeypatch.setenv("RPT_SLOT_Q_SHIFT", str(q_shift))
+    w = world("VeachMIS")
+    W, H, spp = 100, 70, 11
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+    ref, rng_ref, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    for s_in_flight in (0, 8, 2):
+        r = hipmod.Renderer(0)
+        r.set_samples_in_flight(s_in_flight)
+        r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+        r.render(spp - 3)
+        r.render(3)
+        acc, n = r.read_accum()
+        assert n == spp
+        assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"q_shift {q_shift}, samples in flight {s_in_flight}"
         g = r.stats()
         assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays
         assert np.array_equal(r.read_rng()["n"], rng_ref["n"])
