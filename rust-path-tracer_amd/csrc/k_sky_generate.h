@@ -137,7 +137,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_sky(DevScene sc, DevState st, Dev
                            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (drained != 0u) return;                                 /* surplus launch (grid-uniform) */
-    if (n < q.sky_threshold && alive != 0u) return;          /* not worth a pass yet (same test as k_traverse_nearest) */
+    if (q.sky_at_end == 0u && n < q.sky_threshold && alive != 0u) return;          /* not worth a pass yet (same test as k_traverse_nearest) */
     if (i == 0u && n) atomicAdd(&stats->sky_evals, (unsigned long long)n);
     /* STRIDED: a fixed grid of a few thousand workgroups walks the queue with a grid stride.  On a closed scene the queue
      * holds a few thousand misses, and a launch of n_slots / 256 workgroups that all just look at the counter costs 54 us per

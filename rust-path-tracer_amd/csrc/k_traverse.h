@@ -621,7 +621,7 @@ __device__ __forceinline__ void iteration_bookkeeping(const DevQueues &q, uint32
     uint32_t positions, waiting;
     q_extent(q.sky_cnt, positions, waiting);
     q_clear(q.shadow_cnt);
-    if (waiting >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u) q_clear(q.sky_cnt);
+    if (q.sky_at_end == 0u && (waiting >= q.sky_threshold || q.count[Q_ALIVE0 + prev * Q_LINE] == 0u)) q_clear(q.sky_cnt);
     q.count[Q_ALIVE0 + prev * Q_LINE] = 0u;
     q.count[Q_REGEN0 + prev * Q_LINE] = 0u;
 }

@@ -83,6 +83,7 @@ struct rpt_ctx {
     uint32_t n_pixels = 0;      /* pixels of this rank's tiles */
     uint32_t group_shift = 0;   /* log2 of the samples of one pixel kept in flight (of the current / last rpt_render call) */
     uint32_t max_group_shift = 0, max_slots = 0;   /* what the state arrays are sized for */
+    bool sky_at_end_ok = true;           /* batches of known length shade their misses once, after the last iteration (RPT_SKY_AT_END=0: in every iteration) */
     int slot_q_shift_mode = -1;          /* -1 automatic (by scene size, render_impl), else log2 of the samples of one pixel that share a wave (RPT_SLOT_Q_SHIFT) */
     uint32_t sky_wide_cfg = 32768;
     int samples_in_flight_request = 0;   /* 0 = automatic */

@@ -178,7 +178,7 @@ int alloc_state(rpt_ctx *c) {
     c->sky_wide_cfg = 32768u;
     if (const char *env = getenv("RPT_SKY_WIDE_LIMIT")) c->sky_wide_cfg = (uint32_t)std::max(0, atoi(env));
     q.sky_wide_limit = (uint32_t)std::min<size_t>(n / 16, c->sky_wide_cfg);     /* re-clamped per call to that call's slot count */
-    q.sky_threshold = 1u;
+    q.sky_threshold = 1u; q.sky_at_end = 0u;
     if (const char *env = getenv("RPT_SKY_THRESHOLD")) q.sky_threshold = (uint32_t)std::max(1, atoi(env));
     c->has_state = true;
     return RPT_OK;
@@ -292,7 +292,7 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration) {
 }
 
 template <int STACK, int NEE, bool TEXTURED>
-void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool complete_each) {
+void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool complete_each, bool sky_now) {
     hipStream_t s = c->stream;
     const bool only_traverse = c->timing_level == 2;
     auto mark = [&](bool traverse_edge = false) {
@@ -341,7 +341,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         }
     }
     mark();
-    {
+    if (c->queues.sky_at_end == 0u || sky_now) {
         if (c->sky_strided && blocks > c->sky_blocks) k_sky<true><<<c->sky_blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
         else k_sky<false><<<blocks_q, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
     }
@@ -349,20 +349,20 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
 }
 
 template <int STACK>
-void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool complete_each) {
+void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool complete_each, bool sky_now) {
     const bool tex = c->scene.textured != 0u;
     switch (c->cfg.nee_mode) {
         case RPT_NEE_MIS:
-            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, iteration, blocks, ev, ev_at, complete_each);
-            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, iteration, blocks, ev, ev_at, complete_each);
+            if (tex) launch_iteration<STACK, RPT_NEE_MIS, true>(c, iteration, blocks, ev, ev_at, complete_each, sky_now);
+            else launch_iteration<STACK, RPT_NEE_MIS, false>(c, iteration, blocks, ev, ev_at, complete_each, sky_now);
             break;
         case RPT_NEE_DIRECT:
-            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, iteration, blocks, ev, ev_at, complete_each);
-            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, iteration, blocks, ev, ev_at, complete_each);
+            if (tex) launch_iteration<STACK, RPT_NEE_DIRECT, true>(c, iteration, blocks, ev, ev_at, complete_each, sky_now);
+            else launch_iteration<STACK, RPT_NEE_DIRECT, false>(c, iteration, blocks, ev, ev_at, complete_each, sky_now);
             break;
         default:
-            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, iteration, blocks, ev, ev_at, complete_each);
-            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, iteration, blocks, ev, ev_at, complete_each);
+            if (tex) launch_iteration<STACK, RPT_NEE_NONE, true>(c, iteration, blocks, ev, ev_at, complete_each, sky_now);
+            else launch_iteration<STACK, RPT_NEE_NONE, false>(c, iteration, blocks, ev, ev_at, complete_each, sky_now);
             break;
     }
 }
@@ -439,6 +439,7 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (const char *e9 = getenv("RPT_LDS_SHADOW_STREAM")) c->lds_shadow_stream = e9[0] != '0';
     if (const char *e7 = getenv("RPT_GSTREAM_MIN_WAVES")) c->gstream_min_waves = (uint32_t)std::max(1, atoi(e7));
     if (const char *e17 = getenv("RPT_STACK_BITS")) c->stack_bits_min = atoi(e17);      /* test aid: wider stack entries than the scene needs */
+    if (const char *e19 = getenv("RPT_SKY_AT_END")) c->sky_at_end_ok = e19[0] != '0';
     if (const char *e18 = getenv("RPT_SLOT_Q_SHIFT")) c->slot_q_shift_mode = std::max(0, std::min(5, atoi(e18)));   /* test aid: log2 of the samples of a pixel per wave */
     {
         hipDeviceProp_t prop;
@@ -816,6 +817,9 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
 
     if (!async) for (int k = 0; k < RING; ++k) __atomic_store_n(&c->host_ring[k], 0ull, __ATOMIC_RELAXED);
     c->call_samples = n_samples;
+    /* A miss ends its path (lib.rs:79) and in a batch of known length nothing is started in its place: the misses of all iterations
+     * wait in the queue for ONE sky launch after the last iteration (three launches less per batch; RPT_SKY_AT_END=0: every iteration) */
+    c->queues.sky_at_end = (known_iterations != 0 && c->sky_at_end_ok) ? 1u : 0u;
     k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples, c->dev_stats.p);
     c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
 
@@ -857,10 +861,11 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
             for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
         }
         const bool complete_each = known_iterations == 0 && c->group_shift != 0;
+        const bool sky_now = it + 1 == known_iterations - short_batch;      /* (sky_at_end: the one sky launch of the batch) */
         switch (c->stack_cap) {
-            case 16: launch_iteration_stack<16>(c, (uint32_t)it, blocks, ev, ev_at, complete_each); break;
-            case 24: launch_iteration_stack<24>(c, (uint32_t)it, blocks, ev, ev_at, complete_each); break;
-            default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at, complete_each); break;
+            case 16: launch_iteration_stack<16>(c, (uint32_t)it, blocks, ev, ev_at, complete_each, sky_now); break;
+            case 24: launch_iteration_stack<24>(c, (uint32_t)it, blocks, ev, ev_at, complete_each, sky_now); break;
+            default: launch_iteration_stack<32>(c, (uint32_t)it, blocks, ev, ev_at, complete_each, sky_now); break;
         }
         full_iterations += 1u;
         it += 1;
@@ -894,7 +899,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += full_iterations;
         c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
         c->stats.kernel_launches[RPT_STAGE_SHADOW] += c->cfg.nee_mode != RPT_NEE_NONE ? full_iterations : 0;
-        c->stats.kernel_launches[RPT_STAGE_SKY] += full_iterations;
+        c->stats.kernel_launches[RPT_STAGE_SKY] += c->queues.sky_at_end ? 1u : full_iterations;
         if (ev) c->timing_pending.push_back(rpt_ctx::TimingBatch{async_events, it});
         c->samples += n_samples;
         c->stats.samples += (uint64_t)c->n_pixels * n_samples;
@@ -911,7 +916,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     c->stats.kernel_launches[RPT_STAGE_TRAVERSE] += full_iterations;
     c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
     c->stats.kernel_launches[RPT_STAGE_SHADOW] += nee ? full_iterations : 0;
-    c->stats.kernel_launches[RPT_STAGE_SKY] += full_iterations;
+    c->stats.kernel_launches[RPT_STAGE_SKY] += c->queues.sky_at_end ? 1u : full_iterations;
     if (ev) timing_accumulate(c, *ev, it);
     c->samples += n_samples;
     c->stats.samples += (uint64_t)c->n_pixels * n_samples;

@@ -335,6 +335,28 @@ def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp
         r.close()
 
 
+def test_sky_stage_per_iteration_or_once_per_batch(monkeypatch, hipmod, oracle, rpt, world):
+    """A batch of known length shades its misses in ONE sky launch after its last iteration (a miss only ends a path, lib.rs:79);
+    RPT_SKY_AT_END=0 shades them in the iteration that found them, as calls with several samples per slot always do.  Same image,
+    same ray and sky counts, on the scene where most paths end in the sky."""
+    w = world("PBRTest")
+    W, H, spp = 128, 96, 8
+    cfg = rpt.default_config(W, H, nee=1)
+    seeds = rpt.blue_noise_seeds(W, H)
+    ref, rng_ref, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    for at_end in ("1", "0"):
+        monkeypatch.setenv("RPT_SKY_AT_END", at_end)
+        r = hipmod.Renderer(0)
+        r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+        r.render_async(5); r.render_async(3); r.wait()
+        acc, n = r.read_accum()
+        g = r.stats()
+        assert n == spp and np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"RPT_SKY_AT_END={at_end}"
+        assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays and g["sky_evals"] == st.sky_evals
+        assert g["kernel_launches"]["sky"] == (2 if at_end == "1" else 2 * cfg.max_bounces)
+        r.close()
+
+
 @pytest.mark.parametrize("q_shift", [1, 2, 3, 5])
 def test_slot_layout_invisible(monkeypatch, hipmod, oracle, rpt, world, q_shift):
     """The slot layout (k_common.h slot_pix: a wave = 64 / Q pixels x Q samples; Q = 1 for the shipped scenes, 32 for scenes of
