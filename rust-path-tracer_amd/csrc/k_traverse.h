@@ -674,11 +674,15 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest(DevScene sc, DevSt
 #ifndef RPT_STREAM_RAYS
 #define RPT_STREAM_RAYS 8          /* most slots per lane of a workgroup (the host lowers it for small launches) */
 #endif
+/* a wave looks for new rays every RPT_STREAM_TRIPS loop trips, once RPT_STREAM_REFILL of its lanes are idle.  Re-measured with 64
+ * pixels per wave (round 3, three boxes, DarkCornell Mrays/s relative to 8 / 12): trips 4 / 12 / 16 / 24 / 32: -2.3 / +0.4 / +0.8 /
+ * +1.1 / -0.2 %; refill 8 / 16 / 24 at 8 trips: -1 / +-0 / +-0; 16 / 16: +1.1 ... +1.7 % (and +1.1 % with nee = MIS, +1.0 % on 1/8 of
+ * the image); 20 / 16 and 24 / 16 the same within noise, 16 / 20 less. */
 #ifndef RPT_STREAM_TRIPS
-#define RPT_STREAM_TRIPS 8
+#define RPT_STREAM_TRIPS 16
 #endif
 #ifndef RPT_STREAM_REFILL
-#define RPT_STREAM_REFILL 12
+#define RPT_STREAM_REFILL 16
 #endif
 /* The workgroup's pool is one 64-bit LDS word (next slot | end slot << 32): a wave takes slots with ONE 64-bit ds_add that
  * returns a consistent (next, end) pair.  When the span is used up the wave that notices fetches the next span of SPAN
@@ -958,7 +962,8 @@ __host__ __device__ constexpr int gstream_rays_nearest(int stack, int width) {
  * one or two pixels, so after a bounce their rays leave almost one point — 2 M-node stand-in + 2.4 %, PBRTest - 1.3 %, VeachMIS - 0.8 %,
  * the fat-leaf stand-in +- 0) */
 #ifndef RPT_GSTREAM_REFILL
-#define RPT_GSTREAM_REFILL 16
+#define RPT_GSTREAM_REFILL 24      /* (round 3, 64 pixels per wave: 8 / 16 / 24 idle lanes: PBRTest 7 390 / 7 390 / 7 445, VeachMIS 6 560 / 6 615 / 6 655 Mrays/s;
+                                      trips 4 / 8 / 12 / 16: 7 355 / 7 390 / 7 320 / 7 250 and 6 620 / 6 615 / 6 530 / 6 480) */
 #endif
 /* The global-memory walks wait on memory two thirds of their cycles (profiles/r02_*_pmc_sq.txt) and live on occupancy.  Left
  * alone the compiler settles at 68 / 77 VGPRs (7 / 6 waves per SIMD); asked for 8 it needs 57 / 58 and spills nothing:

@@ -264,10 +264,11 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration) {
     const uint32_t gspan_n = gstream_span(c, (uint32_t)gstream_rays_nearest(STACK, stack_width)), gblocks_n = (c->n_slots + gspan_n - 1) / gspan_n;
     if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
         /* persistent workgroups (as many as stay resident: 2 per CU) that fetch spans of slots from a launch-wide counter:
-         * a span = 1/16 of a workgroup's share, between 1 and 8 slots per lane (measured at 33 M slots: 8192 / 4096 / 2048
-         * slots per span: traverse 82.9 / 80.9 / 83.9 ms per 8 batches) */
+         * a span = 1/32 of a workgroup's share, between 1 and 8 slots per lane (measured at 33 M slots: 8192 / 4096 / 2048 / 1024
+         * slots per span: DarkCornell 9 995 / 10 160 / 10 255 / 10 200 Mrays/s with 64 pixels per wave; rounds 1-2, two pixels
+         * per wave, preferred 4096) */
         const uint32_t wgs = c->stream_max_blocks;
-        uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 16u);
+        uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 32u);
         span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
         span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
         const uint32_t n_spans = (c->n_slots + span - 1) / span;
@@ -316,7 +317,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     if (NEE != RPT_NEE_NONE) {
         if (STACK == 16 && c->scene.lds_scene && c->lds_stream && c->lds_shadow_stream) {
             const uint32_t wgs = c->stream_max_blocks;
-            uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 16u);
+            uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 32u);
             span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
             span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
             const uint32_t n_spans = (c->n_slots + span - 1) / span;
