@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void shadow_resolve(const DevState &st, const DevQueu
 }
 
 /* second half of the streamed LDS shadow stage: one dense pass over the shadow queue */
-__global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQueues q, DevConfig cfg) {
+static __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQueues q, DevConfig cfg) {
     if (q.count[Q_DRAINED] != 0u) return;
     const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
     uint32_t positions, n;

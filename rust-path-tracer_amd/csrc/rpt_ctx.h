@@ -131,6 +131,14 @@ struct rpt_ctx {
     uint32_t untile_n = 0;
 };
 
+/* workgroup size of the LDS-resident-scene traversal kernels: 2 x (32 KB of 16-bit stacks + up to 32 KB of scene = the 64 KB a
+ * workgroup may hold) per CU = 32 waves */
+#ifndef RPT_LDS_THREADS
+#define RPT_LDS_THREADS 1024
+#endif
+/* rpt_kernels_slp.hip: launches of the kernels that are built WITH the SLP vectorizer (the rest of the library is built without) */
+void rpt_launch_shadow_stream_lds(rpt_ctx *c, uint32_t workgroups, size_t lds_bytes, uint32_t span);
+
 /* rank-local slot order (rpt_hip.hip) */
 void rpt_build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, std::vector<uint32_t> &out);
 /* rpt_comm.hip: called by rpt_hip.hip when the context / its state goes away */

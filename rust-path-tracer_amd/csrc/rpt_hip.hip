@@ -232,11 +232,7 @@ bool build_lds_image(const rpt_bvh_node *nodes, size_t nn, const std::vector<flo
 #define RPT_GLOBAL_THREADS 64      /* one wave: no scene staging to share, and a finished wave frees its stack at once (PBRTest traverse -5 %) */
 #endif
 constexpr int GLOBAL_THREADS = RPT_GLOBAL_THREADS;   /* workgroup size of the global-memory traversal variants */
-#ifndef RPT_LDS_THREADS
-#define RPT_LDS_THREADS 1024
-#endif
-constexpr int LDS_THREADS = RPT_LDS_THREADS;     /* workgroup size of the LDS-resident-scene traversal variants: 2 x (32 KB of
-                                                    16-bit stacks + up to 32 KB of scene = the 64 KB a workgroup may hold) per CU = 32 waves */
+constexpr int LDS_THREADS = RPT_LDS_THREADS;     /* (rpt_ctx.h) */
 
 static uint32_t padded_pixels(uint32_t n_pixels) { return (n_pixels + 63u) & ~63u; }      /* whole chunks of 64 pixels (k_common.h, slot_pix) */
 
@@ -321,7 +317,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
             span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
             const uint32_t n_spans = (c->n_slots + span - 1) / span;
-            k_traverse_shadow_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
+            rpt_launch_shadow_stream_lds(c, n_spans < wgs ? n_spans : wgs, lds_bytes, span);      /* (built in rpt_kernels_slp.hip) */
             k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);

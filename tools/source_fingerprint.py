@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""sha256 over the device-side sources of librpt_hip.so (csrc/*.h, csrc/*.hip), in name order.
+"""sha256 over the device-side sources of librpt_hip.so (csrc/*.h, csrc/*.hip, in name order) and the Makefile (its compiler flags).
 
 The GPU box receives a snapshot without .git, so a commit id is not available where bench.py runs; this fingerprint
 identifies the kernel build instead.  PMC-derived figures kept under profiles/ carry it, and bench.py refuses to
@@ -18,6 +18,9 @@ def fingerprint():
             h.update(name.encode())
             with open(os.path.join(d, name), "rb") as f:
                 h.update(f.read())
+    with open(os.path.join(ROOT, "Makefile"), "rb") as f:
+        h.update(b"Makefile")
+        h.update(f.read())
     return h.hexdigest()[:16]
 
 
