@@ -1,0 +1,58 @@
+"""The occupancy the hot kernels were tuned for is a property of the BUILD: registers, scratch and LDS per kernel, read from the
+code objects inside librpt_hip.so (tools/kernel_resources.sh).  No GPU needed.
+
+Why these numbers: the streamed LDS walks run two 1 024-thread workgroups per CU = 8 waves per SIMD, which needs
+<= 64 VGPRs and 32 KB of static LDS (+ the scene image); the plain shade stage and the streamed global-memory walks of thin-leaf
+scenes ask the compiler for 8 waves per SIMD too; nothing on the hot path may spill."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "rust-path-tracer_amd", "lib", "librpt_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.fixture(scope="module")
+def resources():
+    if not (os.path.exists(LIB) and os.path.exists(OBJDUMP)):
+        pytest.skip("librpt_hip.so or the LLVM tools are not here")
+    out = subprocess.run([os.path.join(ROOT, "tools", "kernel_resources.sh"), LIB], capture_output=True, text=True, check=True).stdout
+    table = {}
+    for line in out.splitlines():
+        m = re.match(r"\s*(\d+) vgpr\s+(\d+) sgpr\s+(\d+) scratch\s+(\d+) lds\s+(.*)", line)
+        if m:
+            table.setdefault(m.group(5).strip(), []).append(tuple(int(m.group(k)) for k in (1, 2, 3, 4)))
+    assert len(table) > 50
+    return table
+
+
+def _find(table, prefix):
+    hits = [v for k, vs in table.items() if k.startswith(prefix) for v in vs]
+    assert hits, prefix
+    return hits
+
+
+@pytest.mark.parametrize("kernel", ["void k_traverse_nearest_stream<16, 1024>", "void k_traverse_shadow_stream<16, 1024>"])
+def test_streamed_lds_walks_fit_two_workgroups_per_cu(resources, kernel):
+    for vgpr, sgpr, scratch, lds in _find(resources, kernel):
+        assert vgpr <= 64 and scratch == 0
+        assert lds <= 32 * 1024 + 64          # 16-bit stacks of 16 waves + the pool; the scene image (<= 32 KB) is dynamic
+
+
+@pytest.mark.parametrize("kernel", ["void k_shade<0, false, false>", "void k_traverse_nearest_gstream<24, 16, false>",
+                                    "void k_traverse_shadow_gstream<24, 16, false>", "void k_traverse_nearest_gstream<16, 16, false>",
+                                    "void k_traverse_nearest_gstream<32, 21, false>", "void k_traverse_shadow_gstream<32, 21, false>"])
+def test_eight_waves_per_simd_where_asked(resources, kernel):
+    for vgpr, sgpr, scratch, lds in _find(resources, kernel):
+        assert vgpr <= 64 and scratch == 0
+
+
+def test_no_stage_kernel_of_the_shipped_scenes_spills(resources):
+    """every kernel a shipped scene (or the two stand-ins) launches: no scratch"""
+    for prefix in ("void k_shade<0, false, ", "void k_shade<1, false, ", "void k_shade<2, false, ", "void k_sky<", "k_generate_first", "k_complete",
+                   "k_shadow_resolve", "void k_traverse_nearest_gstream<32, 16, true>", "void k_traverse_shadow_gstream<32, 16, true>"):
+        for vgpr, sgpr, scratch, lds in _find(resources, prefix):
+            assert scratch == 0, prefix
