@@ -12,8 +12,7 @@ CXX      ?= g++
 
 HOST_SRCS := $(CSRC)/host/host_api.cpp $(CSRC)/host/glb_scene.cpp $(CSRC)/host/bvh_build.cpp \
              $(CSRC)/host/light_table.cpp $(CSRC)/host/bluenoise.cpp $(CSRC)/host/image_io.cpp $(CSRC)/host/textures.cpp $(CSRC)/host/obj_scene.cpp $(CSRC)/host/jpeg_decode.cpp
-HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_comm.hip     # built without the SLP vectorizer
-HIP_SRCS_SLP := $(CSRC)/rpt_kernels_slp.hip                # built with it (see that file)
+HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_comm.hip
 HIP_DEPS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hip) $(wildcard include/rpt/*.h)
 
 CXXFLAGS_COMMON := -std=c++20 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unknown-pragmas
@@ -22,9 +21,9 @@ CXXFLAGS_COMMON := -std=c++20 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -
 ORACLE_FLAGS := $(CXXFLAGS_COMMON) -mfma -msse4.1 -pthread
 HIPFLAGS := --offload-arch=gfx950 -std=c++20 -O3 -fPIC -ffp-contract=off -fno-fast-math \
             -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero \
-            -Wall -Wno-unused-function
-HIPFLAGS_NOSLP := $(HIPFLAGS) -fno-slp-vectorize
-OBJDIR := $(LIBDIR)/obj
+            -Wall -Wno-unused-function -fno-slp-vectorize
+# -fno-slp-vectorize: the packed f32 operations the SLP vectorizer forms issue in the time of two plain ones on gfx950 and cost v_mov
+# shuffles and registers (profiles/r03_slp.txt)
 
 all: host oracle hip fake_rccl
 
@@ -46,11 +45,7 @@ oracle/liboracle_libm.so: oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp $(CSRC)/rp
 # sources the LOADED library was built from, and says so when the library is older than the source tree
 $(LIBDIR)/librpt_hip.so: $(HIP_DEPS) tools/source_fingerprint.py Makefile
 	@mkdir -p $(LIBDIR)
-	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS_NOSLP) -DRPT_BUILD_FINGERPRINT=\"$$(python3 tools/source_fingerprint.py)\" -c -o $(OBJDIR)/rpt_hip.o $(CSRC)/rpt_hip.hip
-	$(HIPCC) $(HIPFLAGS_NOSLP) -c -o $(OBJDIR)/rpt_comm.o $(CSRC)/rpt_comm.hip
-	$(HIPCC) $(HIPFLAGS) -c -o $(OBJDIR)/rpt_kernels_slp.o $(HIP_SRCS_SLP)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJDIR)/rpt_hip.o $(OBJDIR)/rpt_comm.o $(OBJDIR)/rpt_kernels_slp.o -ldl
+	$(HIPCC) $(HIPFLAGS) -DRPT_BUILD_FINGERPRINT=\"$$(python3 tools/source_fingerprint.py)\" -shared -o $@ $(HIP_SRCS) -ldl
 
 # test infrastructure: a stand-in for RCCL's point-to-point calls over shared memory, so that N PROCESSES on a one-GPU test box run
 # the product's gather unchanged (tests/test_gpu_multiprocess.py; selected with RPT_RCCL_LIBRARY, never linked by the product)
@@ -59,6 +54,6 @@ tests/fake_rccl/librccl_fake.so: tests/fake_rccl/fake_rccl.cpp
 	$(HIPCC) -x c++ -std=c++17 -O2 -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -o $@ $< -L/opt/rocm/lib -lamdhip64 -lrt -pthread
 
 clean:
-	rm -rf $(LIBDIR)/*.so $(OBJDIR) oracle/*.so tests/fake_rccl/*.so
+	rm -f $(LIBDIR)/*.so oracle/*.so tests/fake_rccl/*.so
 
 .PHONY: all host oracle hip fake_rccl clean

@@ -282,7 +282,7 @@ __device__ __forceinline__ uint32_t block_push(uint32_t *counter, bool pred, uin
 }
 
 /* ---- stateless LDS sequence (kernels/src/rng.rs:20-32) --------------------- */
-static __device__ __constant__ uint32_t c_lds_primes[32] = {      /* (static: librpt_hip.so is built from several translation units) */
+__device__ __constant__ uint32_t c_lds_primes[32] = {
     0x6a09e667u, 0xbb67ae84u, 0x3c6ef372u, 0xa54ff539u, 0x510e527fu, 0x9b05688au, 0x1f83d9abu, 0x5be0cd18u,
     0xcbbb9d5cu, 0x629a2929u, 0x91590159u, 0x452fecd8u, 0x67332667u, 0x8eb44a86u, 0xdb0c2e0bu, 0x47b5481du,
     0xae5f9155u, 0xcf6c85d1u, 0x2f73477du, 0x6d1826cau, 0x8b43d455u, 0xe360b595u, 0x1c456002u, 0x6f196330u,

@@ -90,7 +90,7 @@ __device__ __forceinline__ void finish_in_side_stage(const DevState &st, const D
  * every wave (ds_bpermute, then a DPP shift chain: 2 of 64 lanes useful), 0.45 ms of the last shade launch of a DarkCornell
  * batch + a 0.19 ms completion pass.  A batch of known length (no slot takes a second sample) runs this once, after its last
  * iteration; otherwise it follows every shade stage. */
-static __global__ __launch_bounds__(RPT_BLOCK) void k_complete(DevState st, DevQueues q, DevConfig cfg, uint32_t iteration, uint32_t final_pass,
+__global__ __launch_bounds__(RPT_BLOCK) void k_complete(DevState st, DevQueues q, DevConfig cfg, uint32_t iteration, uint32_t final_pass,
                                                         DevStats *stats) {
     /* a surplus launch of the run-ahead returns at once (grid-uniform) — but not the one completion of a batch of known length:
      * "drained" there only says that no RAY was left in an earlier iteration, the finished samples still wait to be added */

@@ -722,7 +722,15 @@ __device__ __forceinline__ uint32_t wg_pool_take(WgPool *pool, uint32_t *global_
     return 0u;
 }
 
+/* The 1 024-thread workgroups of the streamed LDS walks come two to a CU = 8 waves per SIMD, and that is decided by SGPRs as
+ * much as by VGPRs and LDS: a SIMD has 800, a wave is given its count rounded up to 16 plus 16 more the runtime reserves (trap
+ * handler), so 8 waves fit only while the kernel needs <= 80.  At 82 the second workgroup no longer fits and the kernel runs at
+ * HALF occupancy — which hipModuleOccupancyMaxActiveBlocksPerMultiprocessor does not report (it answers 2) and only the counters
+ * show (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES 32 instead of 63).  Measured: the shadow walk 48.3 ms per four batches at 78 SGPRs, 61.2 at
+ * 82 (profiles/r03_slp.txt).  So the compiler is held to 80 (it spills nothing: the excess was address arithmetic it can redo). */
+#define RPT_LDS_WALK_SGPRS 80
 template <int STACK, int THREADS>
+__attribute__((amdgpu_num_sgpr(RPT_LDS_WALK_SGPRS)))
 __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
                                                                        uint32_t SPAN /* slots a workgroup fetches at a time */) {
     constexpr uint32_t NW = THREADS / RPT_WAVE;
@@ -860,6 +868,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
  * Lanes only record "occluded" in the unused .w of the entry's contribution record; k_shadow_resolve then adds the NEE
  * terms in one dense pass (all lanes busy, none of the walk's registers live). */
 template <int STACK, int THREADS>
+__attribute__((amdgpu_num_sgpr(RPT_LDS_WALK_SGPRS)))
 __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc, DevState st, DevQueues q, DevStats *stats, uint32_t SPAN) {
     constexpr uint32_t NW = THREADS / RPT_WAVE;
     __shared__ uint16_t lds_stack[NW][STACK][RPT_WAVE];
@@ -981,6 +990,9 @@ __host__ __device__ constexpr int gstream_waves(int stack, int width, bool coop)
     return (width <= 21 || (width == 24 && stack <= 24)) ? (coop ? (width == 21 ? 7 : RPT_GSTREAM_WAVES_COOP) : RPT_GSTREAM_WAVES) : 1;   /* (where LDS allows it at all;
                                                              fat leaves + 21-bit entries: 8 waves would spill 18 registers) */
 }
+/* (8 waves per SIMD also need <= 80 SGPRs, see RPT_LDS_WALK_SGPRS: the builds the shipped scenes and the stand-ins use have 78; some of the
+ * others — 21- and 32-bit stack entries — have 81 and run 7.  amdgpu_num_sgpr takes a literal, not a template expression, so it cannot follow
+ * gstream_waves.) */
 /* XCD-aware span mapping was measured on these kernels and rejected (profiles/r03_deepbvh_experiments.txt): workgroup id i runs on XCD
  * i % 8, so span = id spreads neighbouring pixels over all eight L2s.  Giving each XCD one contiguous eighth of the launch: 2 x
  * SLOWER on the 1 M-triangle stand-in (the XCD that owns the expensive part of the image finishes alone); runs of 64 consecutive
@@ -1082,7 +1094,7 @@ __device__ __forceinline__ void shadow_resolve(const DevState &st, const DevQueu
 }
 
 /* second half of the streamed LDS shadow stage: one dense pass over the shadow queue */
-static __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQueues q, DevConfig cfg) {
+__global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQueues q, DevConfig cfg) {
     if (q.count[Q_DRAINED] != 0u) return;
     const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
     uint32_t positions, n;

@@ -136,9 +136,6 @@ struct rpt_ctx {
 #ifndef RPT_LDS_THREADS
 #define RPT_LDS_THREADS 1024
 #endif
-/* rpt_kernels_slp.hip: launches of the kernels that are built WITH the SLP vectorizer (the rest of the library is built without) */
-void rpt_launch_shadow_stream_lds(rpt_ctx *c, uint32_t workgroups, size_t lds_bytes, uint32_t span);
-
 /* rank-local slot order (rpt_hip.hip) */
 void rpt_build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, std::vector<uint32_t> &out);
 /* rpt_comm.hip: called by rpt_hip.hip when the context / its state goes away */

@@ -317,7 +317,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
             span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
             const uint32_t n_spans = (c->n_slots + span - 1) / span;
-            rpt_launch_shadow_stream_lds(c, n_spans < wgs ? n_spans : wgs, lds_bytes, span);      /* (built in rpt_kernels_slp.hip) */
+            k_traverse_shadow_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
             k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);

@@ -39,6 +39,7 @@ def _find(table, prefix):
 def test_streamed_lds_walks_fit_two_workgroups_per_cu(resources, kernel):
     for vgpr, sgpr, scratch, lds in _find(resources, kernel):
         assert vgpr <= 64 and scratch == 0
+        assert sgpr <= 80                     # 82 halves the occupancy (k_traverse.h RPT_LDS_WALK_SGPRS): measured, not reported by the occupancy API
         assert lds <= 32 * 1024 + 64          # 16-bit stacks of 16 waves + the pool; the scene image (<= 32 KB) is dynamic
 
 
@@ -47,7 +48,7 @@ def test_streamed_lds_walks_fit_two_workgroups_per_cu(resources, kernel):
                                     "void k_traverse_nearest_gstream<32, 21, false>", "void k_traverse_shadow_gstream<32, 21, false>"])
 def test_eight_waves_per_simd_where_asked(resources, kernel):
     for vgpr, sgpr, scratch, lds in _find(resources, kernel):
-        assert vgpr <= 64 and scratch == 0
+        assert vgpr <= 64 and sgpr <= 80 and scratch == 0
 
 
 def test_no_stage_kernel_of_the_shipped_scenes_spills(resources):
