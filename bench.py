@@ -69,6 +69,215 @@ def usable_cores():
     return max(1, n)
 
 
+# algorithmic bytes per unit of each stage's OWN traffic and the unit it is counted in
+STAGE_MODEL = {
+    "traverse": ("extension_rays", TRAVERSE_BYTES_PER_RAY),          # hit word 8 + ray 24 read, hit record 8 written
+    "shade": ("extension_rays", 96),                                  # hit 8 + ray 24 + thr 16 read, ray 24 + hit 8 + thr 16 written
+    "shadow": ("shadow_rays", 80),                                    # entry 32 + contribution 16 read, radiance 16 + 16 RMW
+    "sky": ("sky_evals", 76),                                         # slot id 4 + ray 24 + thr 16 + rad 16 read, rad 16 written
+    "generate": ("samples", 80),
+    "complete": ("samples", 72),                                      # per slot hit 8 + rad 16 read, hit 8 written; per pixel accum 32 + rng 16 (amortised)
+}
+VALU_ISSUE_CYCLES_FLOOR = 2.1   # SIMD cycles a wave64 v_fma_f32 occupies the issue port (tools/microbench/valu_rates.hip)
+
+
+def build_world(rpt, scene):
+    if scene.startswith("procedural:"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from scenes import deep_bvh_scene, scatter_scene
+        return deep_bvh_scene(1_000_000) if scene.endswith("deep_bvh_1M") else scatter_scene(1_000_000)
+    return rpt.World.from_path(rpt.fixture(scene + ".glb"))
+
+
+def load_traffic(hip, workload):
+    """profiles/traffic_<workload>.json, but only when it was measured on exactly the kernel sources of the LOADED library
+    (tools/source_fingerprint.py; PMC counters cannot be collected from inside this process) -> (json or None, note)"""
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    if not os.path.exists(tpath):
+        return None, None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from source_fingerprint import fingerprint
+        with open(tpath) as f:
+            tj = json.load(f)
+        fp = hip.build_fingerprint()             # of the LOADED library, not of whatever the source tree holds now
+        if fp != fingerprint():
+            print(f"bench: librpt_hip.so was built from other sources ({fp}) than the tree holds ({fingerprint()}): run make", file=sys.stderr)
+        if tj.get("workload") == workload and tj.get("source_fingerprint") == fp:
+            return tj, f"profiles/traffic_{workload}.json@{fp}"
+        return None, f"profiles/traffic_{workload}.json is from other kernel sources ({tj.get('source_fingerprint')} != {fp}): not reported"
+    except Exception as e:                       # noqa: BLE001
+        return None, f"profiles/traffic_{workload}.json unreadable: {e}"
+
+
+def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipeline_bytes):
+    """(roofline of the dominant kernel, whole-batch traffic / VALU figures) from the HIP events recorded in this run and the kept
+    PMC passes of the same kernel sources"""
+    kms = {k: s1["kernel_ms"][k] - s0["kernel_ms"][k] for k in s1["kernel_ms"]}
+    klaunch = {k: s1["kernel_launches"][k] - s0["kernel_launches"][k] for k in s1["kernel_launches"]}
+    dominant = max(kms, key=lambda k: kms[k])
+    if kms[dominant] <= 0:
+        return None, None
+    avg_ms = kms[dominant] / max(klaunch[dominant], 1)
+    unit_key, bytes_per_unit = STAGE_MODEL[dominant]
+    units = (s1["first_" + unit_key] - s0["first_" + unit_key]) / max(klaunch[dominant], 1)   # (of the pipeline whose launches were timed)
+    achieved = bytes_per_unit * units / (avg_ms * 1e-3) / 1e9
+    tj, traffic_source = load_traffic(hip, workload)
+    traffic = valu = None
+    if tj and dominant in tj.get("stages", {}):
+        traffic = tj["stages"][dominant]["hbm_bytes_per_launch"]
+        valu = tj["stages"][dominant].get("valu")       # SQ pass of the same profiling run: what actually bounds the kernel
+    roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[dominant]),
+                "units_per_launch": round(units, 1), "units_are": unit_key, "algorithmic_bytes_per_unit": bytes_per_unit,
+                "stage_ms": {k: round(v, 3) for k, v in kms.items()},
+                "stage_launches": {k: int(v) for k, v in klaunch.items()}}
+    simds = cus * 4
+    if valu:
+        # not an HBM kernel: the VALU issue figures of the kept SQ pass (same fingerprint rule as `traffic`), and from them
+        # and THIS run's launch time the SIMD time per wave-instruction
+        roofline["valu"] = {"lane_utilisation": valu["lane_utilisation"],
+                            "wave_instructions_per_launch": valu["wave_instructions_per_launch"],
+                            "simd_ns_per_wave_instruction": round(avg_ms * 1e6 * simds / valu["wave_instructions_per_launch"], 4),
+                            "simd_cycles_per_wave_instruction": round(avg_ms * 1e3 * clock_mhz * simds / valu["wave_instructions_per_launch"], 3),
+                            "simds": simds, "clock_mhz": clock_mhz,
+                            "note": "the traversal mix issues in ~2.7 SIMD cycles per wave64 instruction (DESIGN.md 4)"}
+    # whole batch: measured HBM bytes of ALL kernels (FETCH x 2 + WRITE per launch x this run's launches) against SURVEY.md 8d's
+    # algorithmic bytes, and the share of the SIMD issue cycles of the timed region the VALU instructions of all kernels need
+    whole = None
+    if tj:
+        launches_of = dict(klaunch)
+        launches_of["shadow_resolve"] = klaunch.get("shadow", 0)
+        tot_bytes, tot_insts, covered, missing = 0.0, 0.0, [], []
+        for st, rec in tj.get("stages", {}).items():
+            n = launches_of.get(st, 0)
+            if n <= 0:
+                continue
+            tot_bytes += rec["hbm_bytes_per_launch"] * n
+            if "valu" in rec:
+                tot_insts += rec["valu"]["wave_instructions_per_launch"] * n
+            covered.append(st)
+        for st, n in klaunch.items():
+            if n > 0 and st not in tj.get("stages", {}):
+                missing.append(st)
+        avail = simds * clock_mhz * 1e6 * elapsed_s
+        whole = {"traffic": int(tot_bytes / max(steps, 1)), "traffic_over_algorithmic": round(tot_bytes / max(pipeline_bytes, 1), 4),
+                 "traffic_is": "HBM bytes per batch, all kernels: (2 x FETCH_SIZE + WRITE_SIZE) per launch of the kept PMC passes x the launches of this run",
+                 "stages_covered": covered, "stages_without_counters": missing,
+                 "valu": {"wave_instructions_per_batch": int(tot_insts / max(steps, 1)),
+                          "simd_cycles_per_wave_instruction": round(avail / tot_insts, 3) if tot_insts else None,
+                          "issue_frac": round(tot_insts * VALU_ISSUE_CYCLES_FLOOR / avail, 4) if tot_insts else None,
+                          "issue_frac_is": f"all kernels' VALU wave-instructions x {VALU_ISSUE_CYCLES_FLOOR} cycles (the fastest class, v_fma_f32; "
+                                           "compares / min / max / integer take ~4) / (SIMDs x clock x timed seconds)"}}
+    return roofline, whole
+
+
+def parity_windows(world, cfg, seeds, image, image_spp, want_spp, W, H, budget_s=40.0):
+    """windows of an image the GPU has just rendered vs the CPU oracle at the same sample count (same scene buffers, config, seeds):
+    accumulators must be equal BIT FOR BIT (the sum order over all samples is part of the result, kernels/src/lib.rs:225-226)"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle_ffi import Oracle
+    orc = Oracle("rpt_math")
+    osc = orc.scene(world)
+    ww, wh = min(48, W), min(40, H)
+    # centre, across a 64 x 64 tile seam (x = 64 k: two ranks' tiles when N > 1), bottom-right corner
+    seam_x, seam_y = 64 * max(1, W // 192), 64 * max(1, H // 320)         # a tile corner away from the centre (1024^2: 320, 192)
+    clampx, clampy = (lambda v: max(0, min(W - ww, v))), (lambda v: max(0, min(H - wh, v)))
+    rects = [(clampx((W - ww) // 2), clampy((H - wh) // 2)), (clampx(seam_x - ww // 2), clampy(seam_y - wh // 2)), (W - ww, H - wh)]
+    t_par = time.perf_counter()
+    n_win, bitwise, num, den, worst = 0, True, 0.0, 0.0, 0
+    for (x0, y0) in rects:
+        if n_win >= 2 and time.perf_counter() - t_par > budget_s:
+            break
+        ref, _, _ = orc.trace_cpu(cfg, osc, seeds, want_spp, rect=(x0, y0, x0 + ww, y0 + wh), threads=usable_cores())
+        a = image[y0:y0 + wh, x0:x0 + ww]
+        b = ref[y0:y0 + wh, x0:x0 + ww]
+        same = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+        bitwise = bitwise and same
+        worst = max(worst, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
+        num += float(((a[..., :3].astype(np.float64) - b[..., :3]) ** 2).sum())
+        den += float((b[..., :3].astype(np.float64) ** 2).sum())
+        n_win += 1
+    parity = {"windows": n_win, "window_px": [ww, wh], "spp": int(want_spp), "image_spp": int(image_spp), "bitwise": bitwise,
+              "rel_l2": (num / den) ** 0.5 if den > 0 else 0.0, "differing_words": worst,
+              "against": "oracle/rpt_oracle.cpp trace_cpu(rect) at the same spp, config, seeds", "seconds": round(time.perf_counter() - t_par, 2)}
+    if image_spp != want_spp:
+        parity["bitwise"] = False
+        parity["error"] = f"image carries {image_spp} spp, expected {want_spp}"
+    return parity
+
+
+def parity_ok(parity):
+    return parity is None or (parity["bitwise"] and parity["rel_l2"] <= 1e-4)
+
+
+def workload_label(scene, W, H, steps, spp_per_step, total_spp, cfg):
+    return (f"{scene}.glb {W}x{H}, {steps}x{spp_per_step} spp (config total {total_spp}), "
+            f"nee={cfg.nee}, bounces {cfg.min_bounces}/{cfg.max_bounces}")
+
+
+def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, device_index, cus, clock_mhz, parity=True):
+    """One more BASELINE workload on ONE GPU, on a fresh context, after (never inside) the headline's timed loop: the same step
+    (rpt_render_async of one batch), the same bracketing, the same roofline / parity objects as the headline line."""
+    import torch
+    scene, W, H, total_spp, over = WORKLOADS[name]
+    world = build_world(rpt, scene)
+    cfg = rpt.default_config(W, H, **over)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hip.Renderer(device_index)
+    try:
+        r.upload_scene(world)
+        r.set_config(cfg)
+        r.reset(seeds)
+        for _ in range(2):                                           # set-up: touch every page of the path state, clocks up
+            r.render(spp_per_step)
+        r.reset(seeds)
+
+        def stats():
+            st = r.stats()
+            for k in ("extension_rays", "shadow_rays", "samples", "sky_evals"):
+                st["first_" + k] = st[k]
+            return st
+        for _ in range(warmup):
+            r.render_async(spp_per_step)
+        r.wait()
+        torch.cuda.synchronize()
+        s0 = stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.render_async(spp_per_step)
+        r.wait()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        s1 = stats()
+        n_ext, n_shadow = s1["extension_rays"] - s0["extension_rays"], s1["shadow_rays"] - s0["shadow_rays"]
+        n_samples, n_sky = s1["samples"] - s0["samples"], s1["sky_evals"] - s0["sky_evals"]
+        n_mis = n_shadow if cfg.nee == 1 else 0
+        pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
+        roofline, whole = stage_roofline(hip, name, s0, s1, steps, elapsed, cus, clock_mhz, pipeline_bytes)
+        pgbs = pipeline_bytes / elapsed / 1e9
+        par = None
+        if parity:
+            image, image_spp = r.read_accum()
+            par = parity_windows(world, cfg, seeds, image, image_spp, spp_per_step * (warmup + steps), W, H, budget_s=15.0)
+    finally:
+        r.close()
+    pipeline = {"bound": "hbm", "achieved": round(pgbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pgbs / HBM_PEAK_GBS, 6)}
+    if whole:
+        pipeline.update({k: whole[k] for k in ("traffic", "traffic_over_algorithmic", "stages_without_counters")})
+        pipeline["valu"] = whole["valu"]
+    return {"value": round((n_ext + n_shadow) / elapsed / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "steps": steps, "warmup": warmup, "samples_per_s": round(n_samples / elapsed, 1),
+            "data": ("fixtures/" + scene + ".glb (reference scene file)" if not scene.startswith("procedural:")
+                     else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
+            "config": {"workload": workload_label(scene, W, H, steps, spp_per_step, total_spp, cfg), "spp_per_step": spp_per_step},
+            "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
+                     "per_sample": round((n_ext + n_shadow) / max(n_samples, 1), 4)},
+            "roofline": roofline, "pipeline_roofline": pipeline, "parity_check": par}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +302,12 @@ def main():
                          "library's gather over the test stand-in for RCCL (RPT_RCCL_LIBRARY).  Exercises every line the scaling run executes; "
                          "the JSON line is marked and its value is not a measurement")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed comparison of windows of the rendered image with the CPU oracle")
+    ap.add_argument("--extra-workloads", default="darkcornell_mis,veachmis,pbrtest,deepbvh",
+                    help="N = 1, headline workload only: the other single-GPU BASELINE workloads, measured AFTER the headline's timed loop on fresh "
+                         "contexts and reported under \"workloads\" (value, roofline, pipeline_roofline, parity_check each); a failed parity check fails the bench")
+    ap.add_argument("--no-extra-workloads", action="store_true")
+    ap.add_argument("--extra-steps", type=int, default=4)
+    ap.add_argument("--extra-warmup", type=int, default=1)
     ap.add_argument("--no-readback", action="store_true", help="skip the extra render -> read_accum loop (reference loop shape, src/trace.rs:182-204)")
     args = ap.parse_args()
 
@@ -143,12 +358,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world_size)
 
     scene, W, H, total_spp, over = WORKLOADS[args.workload]
-    if scene.startswith("procedural:"):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from scenes import deep_bvh_scene, scatter_scene
-        world = deep_bvh_scene(1_000_000) if scene.endswith("deep_bvh_1M") else scatter_scene(1_000_000)
-    else:
-        world = rpt.World.from_path(rpt.fixture(scene + ".glb"))
+    world = build_world(rpt, scene)
     cfg = rpt.default_config(W, H, **over)
     seeds = rpt.blue_noise_seeds(W, H)
 
@@ -365,60 +575,11 @@ def main():
     n_mis = n_shadow if cfg.nee == 1 else 0.0
 
     # --- roofline of the dominant kernel, from the HIP events recorded in this run (rank 0's stream)
-    kms = {k: s1["kernel_ms"][k] - s0["kernel_ms"][k] for k in s1["kernel_ms"]}
-    klaunch = {k: s1["kernel_launches"][k] - s0["kernel_launches"][k] for k in s1["kernel_launches"]}
-    dominant = max(kms, key=lambda k: kms[k])
-    roofline = None
-    if kms[dominant] > 0:
-        avg_ms = kms[dominant] / max(klaunch[dominant], 1)
-        # algorithmic bytes per unit of the stage's OWN traffic and the unit it is counted in
-        stage_model = {
-            "traverse": ("extension_rays", TRAVERSE_BYTES_PER_RAY),          # hit word 8 + ray 24 read, hit record 8 written
-            "shade": ("extension_rays", 96),                                  # hit 8 + ray 24 + thr 16 read, ray 24 + hit 8 + thr 16 written
-            "shadow": ("shadow_rays", 80),                                    # entry 32 + contribution 16 read, radiance 16 + 16 RMW
-            "sky": ("sky_evals", 76),                                         # slot id 4 + ray 24 + thr 16 + rad 16 read, rad 16 written
-            "generate": ("samples", 80),
-        }
-        unit_key, bytes_per_unit = stage_model[dominant]
-        units = delta("first_" + unit_key) / max(klaunch[dominant], 1)       # (of the pipeline whose launches were timed)
-        achieved = bytes_per_unit * units / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes kept under profiles/ (tools/profile_workload.sh).
-        # PMC counters cannot be collected from inside this process, so the figure is only reported when it was measured
-        # on exactly these kernel sources (tools/source_fingerprint.py); otherwise null, never a stale number.
-        traffic, traffic_source, valu = None, None, None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(tpath):
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                from source_fingerprint import fingerprint
-                with open(tpath) as f:
-                    tj = json.load(f)
-                fp = hip.build_fingerprint()             # of the LOADED library, not of whatever the source tree holds now
-                if fp != fingerprint():
-                    print(f"bench: librpt_hip.so was built from other sources ({fp}) than the tree holds ({fingerprint()}): run make", file=sys.stderr)
-                if tj.get("workload") == args.workload and tj.get("source_fingerprint") == fp and dominant in tj.get("stages", {}):
-                    traffic = tj["stages"][dominant]["hbm_bytes_per_launch"]
-                    valu = tj["stages"][dominant].get("valu")       # SQ pass of the same profiling run: what actually bounds the kernel
-                    traffic_source = f"profiles/traffic_{args.workload}.json@{fp}"
-                else:
-                    traffic_source = f"profiles/traffic_{args.workload}.json is from other kernel sources ({tj.get('source_fingerprint')} != {fp}): not reported"
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                    "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[dominant]),
-                    "units_per_launch": round(units, 1), "units_are": unit_key, "algorithmic_bytes_per_unit": bytes_per_unit,
-                    "stage_ms": {k: round(v, 3) for k, v in kms.items()}}
-        if valu:
-            # not an HBM kernel: the VALU issue figures of the kept SQ pass (same fingerprint rule as `traffic`), and from them
-            # and THIS run's launch time the SIMD time per wave-instruction
-            cus = torch.cuda.get_device_properties(device).multi_processor_count
-            roofline["valu"] = {"lane_utilisation": valu["lane_utilisation"],
-                                "wave_instructions_per_launch": valu["wave_instructions_per_launch"],
-                                "simd_ns_per_wave_instruction": round(avg_ms * 1e6 * cus * 4 / valu["wave_instructions_per_launch"], 4),
-                                "simds": cus * 4, "note": "x 2.4 GHz = SIMD cycles per wave64 instruction; the traversal mix issues in ~2.8 (DESIGN.md 4)"}
+    props = torch.cuda.get_device_properties(device)
+    cus, clock_mhz = props.multi_processor_count, props.clock_rate / 1e3
     pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
     pipeline_gbs = pipeline_bytes / elapsed_max / 1e9
+    roofline, whole = stage_roofline(hip, args.workload, s0, s1, args.steps, elapsed_max, cus, clock_mhz, pipeline_bytes / world_size)
 
     # --- CPU baseline: the oracle (a port of trace_cpu) on this host's cores, bounded sample of the same workload
     cpu = None
@@ -442,41 +603,24 @@ def main():
                "samples_per_s": round(st.samples / st.seconds, 1)}
 
     # --- parity inside the benchmark run: windows of the image the timed loop rendered vs the CPU oracle at the same sample
-    # count (same scene buffers, config, seeds) — accumulators must be equal BIT FOR BIT (sum order over all samples is part of
-    # the result, kernels/src/lib.rs:225-226); a mismatch fails the bench.
+    # count; a mismatch fails the bench.
     parity = None
     if bench_image is not None:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        from oracle_ffi import Oracle
-        orc = Oracle("rpt_math")
-        osc = orc.scene(world)
-        want_spp = args.spp_per_step * (args.warmup + args.steps)
-        ww, wh = min(48, W), min(40, H)
-        # centre, across a 64 x 64 tile seam (x = 64 k: two ranks' tiles when N > 1), bottom-right corner
-        seam_x, seam_y = 64 * max(1, W // 192), 64 * max(1, H // 320)         # a tile corner away from the centre (1024^2: 320, 192)
-        clampx, clampy = (lambda v: max(0, min(W - ww, v))), (lambda v: max(0, min(H - wh, v)))
-        rects = [(clampx((W - ww) // 2), clampy((H - wh) // 2)), (clampx(seam_x - ww // 2), clampy(seam_y - wh // 2)), (W - ww, H - wh)]
-        budget_s = 40.0
-        t_par = time.perf_counter()
-        n_win, bitwise, num, den, worst = 0, True, 0.0, 0.0, 0
-        for (x0, y0) in rects:
-            if n_win >= 2 and time.perf_counter() - t_par > budget_s:
-                break
-            ref, _, _ = orc.trace_cpu(cfg, osc, seeds, want_spp, rect=(x0, y0, x0 + ww, y0 + wh), threads=usable_cores())
-            a = bench_image[y0:y0 + wh, x0:x0 + ww]
-            b = ref[y0:y0 + wh, x0:x0 + ww]
-            same = bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
-            bitwise = bitwise and same
-            worst = max(worst, int((a.view(np.uint32) != b.view(np.uint32)).sum()))
-            num += float(((a[..., :3].astype(np.float64) - b[..., :3]) ** 2).sum())
-            den += float((b[..., :3].astype(np.float64) ** 2).sum())
-            n_win += 1
-        parity = {"windows": n_win, "window_px": [ww, wh], "spp": int(want_spp), "image_spp": int(bench_image_spp), "bitwise": bitwise,
-                  "rel_l2": (num / den) ** 0.5 if den > 0 else 0.0, "differing_words": worst,
-                  "against": "oracle/rpt_oracle.cpp trace_cpu(rect) at the same spp, config, seeds", "seconds": round(time.perf_counter() - t_par, 2)}
-        if bench_image_spp != want_spp:
-            parity["bitwise"] = False
-            parity["error"] = f"image carries {bench_image_spp} spp, expected {want_spp}"
+        parity = parity_windows(world, cfg, seeds, bench_image, bench_image_spp, args.spp_per_step * (args.warmup + args.steps), W, H)
+
+    # --- the other single-GPU BASELINE workloads (C2 with MIS, C3, C4 as one GPU sees it, the C5 stand-in): after the headline, never
+    # inside its timed region, each on a fresh context
+    workloads = None
+    if world_size == 1 and args.workload == "darkcornell" and not args.no_extra_workloads and not args.with_gather and pipelines == 1:
+        r.close()
+        workloads = {}
+        for name in [w for w in args.extra_workloads.split(",") if w]:
+            if name not in WORKLOADS:
+                raise SystemExit(f"--extra-workloads: unknown workload {name}")
+            t_w = time.perf_counter()
+            workloads[name] = measure_single_gpu_workload(rpt, hip, name, args.extra_steps, args.extra_warmup, args.spp_per_step,
+                                                          local_rank, cus, clock_mhz, parity=not args.no_parity_check)
+            workloads[name]["wall_s"] = round(time.perf_counter() - t_w, 1)
 
     out = {}
     if args.rehearsal:
@@ -487,8 +631,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": (f"fixtures/{scene}.glb (reference scene file) + blue-noise seeds; no synthetic geometry"
                  if not scene.startswith("procedural:") else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
-        "config": {"workload": f"{scene}.glb {W}x{H}, {args.steps}x{args.spp_per_step} spp (config total {total_spp}), "
-                               f"nee={cfg.nee}, bounces {cfg.min_bounces}/{cfg.max_bounces}",
+        "config": {"workload": workload_label(scene, W, H, args.steps, args.spp_per_step, total_spp, cfg),
                    "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU",
                    "kernel_sources": hip.build_fingerprint(), "gather": gather_impl, "collective_library": hip.comm_library() or None, "pipelines_per_rank": pipelines},
         "samples_per_s": round(n_samples / elapsed_max, 1),
@@ -502,14 +645,25 @@ def main():
         "parity_check": parity,
         "readback": readback,
     })
+    if whole:                       # (rank 0's kernels; at N > 1 the per-rank share of the algorithmic bytes is what they are compared with)
+        out["pipeline_roofline"].update({k: whole[k] for k in ("traffic", "traffic_over_algorithmic", "traffic_is", "stages_without_counters")})
+        if roofline and "valu" in roofline:
+            roofline["valu"].update({"issue_frac": whole["valu"]["issue_frac"], "issue_frac_is": whole["valu"]["issue_frac_is"],
+                                     "batch_wave_instructions": whole["valu"]["wave_instructions_per_batch"],
+                                     "batch_simd_cycles_per_wave_instruction": whole["valu"]["simd_cycles_per_wave_instruction"]})
+    if workloads is not None:
+        out["workloads"] = workloads
     import ctypes
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world_size > 1:
         dist.destroy_process_group()
-    if parity is not None and not (parity["bitwise"] and parity["rel_l2"] <= 1e-4):
-        print("bench: PARITY CHECK FAILED: " + json.dumps(parity), file=sys.stderr)
+    failed = [] if parity_ok(parity) else [(args.workload, parity)]
+    failed += [(n, w["parity_check"]) for n, w in (workloads or {}).items() if not parity_ok(w["parity_check"])]
+    for n, pc in failed:
+        print(f"bench: PARITY CHECK FAILED ({n}): " + json.dumps(pc), file=sys.stderr)
+    if failed:
         raise SystemExit(4)
 
 

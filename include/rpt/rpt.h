@@ -62,7 +62,8 @@ enum {
     RPT_STAGE_SHADE = 2,       /* material, BSDF sample, NEE setup    */
     RPT_STAGE_SHADOW = 3,      /* any-hit traversal + NEE resolve     */
     RPT_STAGE_SKY = 4,         /* miss shading                        */
-    RPT_STAGE_COUNT = 5
+    RPT_STAGE_COMPLETE = 5,    /* a batch's one completion pass: radiances of a generation added to the accumulator in sample order */
+    RPT_STAGE_COUNT = 6
 };
 
 /* Replaces the lazy wgpu framework/adaptor creation, src/trace.rs:3-6,25-38.
@@ -200,8 +201,10 @@ int rpt_comm_init_local(rpt_ctx *ctx);
  * its own stream.  The K local contexts become sub-ranks rank*K .. rank*K + K-1 of world*K of the tile partition (set by this call
  * on all of them: rpt_reset each afterwards); EVERY rank must add the same number.  The caller drives each context (scene,
  * configuration, reset, rpt_render_async); rpt_gather_async on the OWNER covers all K blocks, each snapshotted on its own
- * stream after that pipeline's batch, so the pipelines never wait for each other.  Pays where a rank's launches are small
- * (1/8 of a 1024^2 image: + 3.5 % per GPU), not on a whole image.  Destroy extras before, or together with, the owner. */
+ * stream after that pipeline's batch, so the pipelines never wait for each other.  EXPERIMENTAL: measured with the per-batch
+ * gather in the loop it pays + 1.1 % per GPU at 1/8 of a 1024^2 image, nothing or a loss elsewhere (profiles/r03_pipeline_probe.txt);
+ * one pipeline per rank is the default everywhere.  All or nothing: on failure every context keeps the partition it had.  An
+ * extra that is destroyed hands its pixels back to the remaining contexts (rpt_reset them before rendering on). */
 int rpt_comm_add_pipeline(rpt_ctx *owner, rpt_ctx *extra);
 int rpt_comm_world(rpt_ctx *ctx, uint32_t *rank_out, uint32_t *world_size_out);   /* as RCCL reports it (ncclCommCount) */
 /* Which collective library the process resolved (dlopen): "librccl.so.1" ..., "" before the first communicator, or the path
@@ -292,6 +295,11 @@ int rpt_debug_trace_rays_production(rpt_ctx *ctx, size_t n, const float *origins
  * pad(2); 8 floats out: pdf, lobe (u32 bits), spectrum(3), direction(3).  kind 0 Lambertian::sample, 1 Glass::sample,
  * 2 Lambertian::{evaluate, pdf} (sample_direction = r), 3 Glass::{evaluate, pdf} (lobe = (u32) r.x). */
 int rpt_debug_bsdf(rpt_ctx *ctx, int kind, size_t n, const float *in, float *out);
+/* The gather's point-to-point calls against the collective library the process resolved (rpt_comm_library), without a second GPU:
+ * inside one ncclGroupStart / ncclGroupEnd this rank posts ncclRecv from rank - 1 and ncclSend to rank + 1 (one rank: to and from
+ * itself) on the communicator's second stream, ordered by the same events as rpt_gather_async; n_floats of a known pattern travel
+ * as ncclFloat and are compared on the host.  Needs rpt_comm_init; collective (every rank calls it). */
+int rpt_debug_comm_selftest(rpt_ctx *ctx, uint32_t n_floats, uint64_t *mismatches_out);
 
 #ifdef __cplusplus
 }

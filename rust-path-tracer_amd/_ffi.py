@@ -74,7 +74,7 @@ class Stats(C.Structure):
     ]
 
 
-STAGE_NAMES = ["generate", "traverse", "shade", "shadow", "sky"]
+STAGE_NAMES = ["generate", "traverse", "shade", "shadow", "sky", "complete"]
 
 
 def ptr(arr):

@@ -470,7 +470,9 @@ bool load_gltf_texture(const Glb &g, const JValue *texinfo, Image8 &img, bool &p
     double off = views->arr[bv]->number_or("byteOffset", 0), len = views->arr[bv]->number_or("byteLength", 0);
     if (!(off >= 0) || !(len >= 8) || off + len > (double)g.bin.size()) { set_error("GLB image bufferView out of range"); return false; }
     const uint8_t *p = g.bin.data() + (size_t)off;
-    if (!decode_image(p, (size_t)len, img)) return false;      /* PNG or JPEG (the two formats glTF allows) */
+    /* PNG or JPEG (the two formats glTF allows).  An image that does not decode (here: arithmetic-coded, 12-bit, CMYK ... JPEG) is an
+     * ABSENT texture, as the reference's `.decode().ok()?` makes it (src/asset.rs:35) — not a failed scene load */
+    if (!decode_image(p, (size_t)len, img)) return true;
     present = true;
     return true;
 }

@@ -439,9 +439,11 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
     /* Overlapped form (the default): batch k+1 is enqueued before the image after batch k is read — the
      * read-back (device un-tile, DMA, host copy) hides behind the rendering; the framebuffer and `samples` the UI sees are
      * those of the image just read, one batch behind the device.  Same images, same flush semantics: an iteration that
-     * flushes (`interacting | dirty`) reads and publishes the batch it has just enqueued before the reset, exactly as the
-     * reference publishes on every iteration (trace.rs:198-213 run before 216-222) — so a camera drag, which holds
-     * `interacting` for many batches, keeps updating the framebuffer.  rpt_tracing_state_set_overlap(state, 0) selects the
+     * flushes (`interacting | dirty`) reads and publishes what it has just enqueued before the reset, as the reference
+     * publishes on every iteration (trace.rs:198-213 run before 216-222) — so a camera drag, which holds `interacting` for many
+     * iterations, keeps updating the framebuffer, with 1-sample images as in the reference (the flag is seen at the top of the
+     * iteration here, after the first sample there; a flag raised DURING a batch takes effect after that batch, up to sync_rate - 1
+     * samples later than in the reference, whose loop polls it per sample).  rpt_tracing_state_set_overlap(state, 0) selects the
      * blocking loop (rpt_render ; rpt_read_accum), the reference's literal shape. */
     const bool overlap = state->overlap.load(std::memory_order_relaxed);
     if (overlap && (rc = api.comm_init_local(ctx))) return fail(rc);
@@ -467,6 +469,9 @@ int rpt_trace_gpu(const char *scene_path, const char *skybox_path, rpt_tracing_s
          * (trace.rs:187); one rpt_render call covers the whole batch, so the
          * poll happens once per batch */
         bool flush = state->interacting.load(std::memory_order_relaxed) || state->dirty.load(std::memory_order_relaxed);
+        /* a flag that is ALREADY up ends the reference's inner loop after its first sample (trace.rs:181-189): while a camera drag
+         * holds `interacting`, every published frame is a 1-sample image — not a whole sync_rate batch that the reset then discards */
+        if (flush && n > 1u) n = 1u;
         if (!overlap) {
             if (n) {
                 if ((rc = api.render(ctx, n))) return fail(rc);

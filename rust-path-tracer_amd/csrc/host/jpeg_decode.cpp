@@ -278,7 +278,7 @@ struct Decoder {
         const int t = decode_symbol(br, dc);
         if (t < 0 || t > 15) return false;
         const int diff = t ? extend(br.get_bits(t), t) : 0;
-        c.dc_pred += diff;
+        c.dc_pred = (int)((uint32_t)c.dc_pred + (uint32_t)diff);      /* wraps, as jpeg-decoder's wrapping_add: a hostile file must not be UB */
         b[0] = (int16_t)c.dc_pred;
         for (int k = 1; k < 64;) {
             const int rs = decode_symbol(br, ac);
@@ -300,8 +300,8 @@ struct Decoder {
         const int t = decode_symbol(br, hdc[c.td]);
         if (t < 0 || t > 15) return false;
         const int diff = t ? extend(br.get_bits(t), t) : 0;
-        c.dc_pred += diff;
-        b[0] = (int16_t)(c.dc_pred * (1 << al));
+        c.dc_pred = (int)((uint32_t)c.dc_pred + (uint32_t)diff);
+        b[0] = (int16_t)((uint32_t)c.dc_pred << al);
         return true;
     }
     static void block_dc_refine(BitReader &br, int16_t *b, int al) {

@@ -141,6 +141,8 @@ void rpt_image_release(rpt_ctx *c) {
     c->untile_key = 0;
 }
 
+namespace { int comm_repartition(rpt_ctx *c); }
+
 void rpt_comm_release(rpt_ctx *c) {
     if (c->pipeline_of && c->pipeline_of->comm) {
         /* an extra pipeline leaves its owner's communicator: the owner's gathers no longer cover this context's pixels */
@@ -155,6 +157,7 @@ void rpt_comm_release(rpt_ctx *c) {
             }
         ocm->conf_w = ocm->conf_h = 0;
         ocm->started = false;
+        (void)comm_repartition(c->pipeline_of);      /* the remaining contexts cover the rank's pixels again (rpt_reset each before rendering on) */
     }
     c->pipeline_of = nullptr;
     rpt_comm *cm = c->comm;
@@ -266,6 +269,18 @@ int comm_check_partitions(rpt_ctx *c) {
             c->error = "gather: a pipeline context has no configuration of the owner's size";
             return RPT_EINVAL;
         }
+    }
+    return RPT_OK;
+}
+
+/* the K local contexts of a communicator (owner first) are sub-ranks rank K .. rank K + K - 1 of world K of the tile partition */
+int comm_repartition(rpt_ctx *c) {
+    rpt_comm *cm = c->comm;
+    const uint32_t K = 1u + (uint32_t)cm->pipes.size();
+    for (uint32_t j = 0; j < K; ++j) {
+        rpt_ctx *p = j ? cm->pipes[j - 1] : c;
+        int rc = rpt_set_partition(p, cm->rank * K + j, cm->world * K);
+        if (rc) { if (p != c) c->error = p->error; return rc; }
     }
     return RPT_OK;
 }
@@ -452,8 +467,10 @@ int rpt_comm_init_local(rpt_ctx *c) {
  * same number of pipelines), the caller drives each (scene, configuration, reset, rpt_render_async), and rpt_gather_async on
  * the OWNER snapshots all K blocks — each on its own stream, after that pipeline's batch, none waiting for another — before
  * the one exchange.  Why: a rank that owns 1/8 of an image launches kernels over 4 M slots whose drain tails a 33 M-slot
- * launch amortises; two pipelines whose batches are not fenced against each other hide them (tools/overlap_probe.py:
- * + 3.5 % per GPU at 1/8 of DarkCornell 1024^2, nothing on a whole image). */
+ * launch amortises; two pipelines whose batches are not fenced against each other hide them.  MEASURED with the per-batch gather in
+ * the loop (tools/pipeline_probe.py, profiles/r03_pipeline_probe.txt): + 1.1 % per GPU at 1/8 of DarkCornell 1024^2, - 0.3 % at 1/4, three
+ * pipelines lose everywhere — experimental, opt-in, one pipeline per rank is the default everywhere.  Every rank must add the same
+ * number: the root posts its receives from its OWN K (block sizes are not exchanged). */
 int rpt_comm_add_pipeline(rpt_ctx *c, rpt_ctx *extra) {
     if (!c || !extra) return RPT_EINVAL;
     rpt_comm *cm = c->comm;
@@ -470,13 +487,19 @@ int rpt_comm_add_pipeline(rpt_ctx *c, rpt_ctx *extra) {
     extra->pipeline_of = c;
     cm->conf_w = cm->conf_h = 0;         /* sizes, offsets and the root's map are rebuilt at the next gather */
     cm->started = false;
-    const uint32_t K = 1u + (uint32_t)cm->pipes.size();
-    for (uint32_t j = 0; j < K; ++j) {
-        rpt_ctx *p = j ? cm->pipes[j - 1] : c;
-        int rc = rpt_set_partition(p, cm->rank * K + j, cm->world * K);
-        if (rc) { if (p != c) c->error = p->error; return rc; }
+    int rc = comm_repartition(c);
+    if (rc) {
+        /* all or nothing: the extra context leaves again and everybody gets the partition back that held before the call */
+        const std::string why = c->error;
+        cm->pipes.pop_back();
+        cm->pipe_staged.pop_back();
+        (void)hipEventDestroy(ev);
+        extra->pipeline_of = nullptr;
+        (void)rpt_set_partition(extra, 0u, 1u);
+        (void)comm_repartition(c);
+        c->error = why;
     }
-    return RPT_OK;
+    return rc;
 }
 
 int rpt_comm_world(rpt_ctx *c, uint32_t *rank, uint32_t *world_size) {
@@ -505,6 +528,58 @@ int rpt_gather_async(rpt_ctx *c) {
         NCCL_TRY(c, ge);
     }
     return gather_finish(c);
+}
+
+/* The library's own point-to-point calls, executed: through the RcclApi function table, on the communicator's comm stream, ordered by the
+ * `staged` / `sent` events exactly as a gather orders them, inside ONE ncclGroupStart / ncclGroupEnd — this rank posts ncclRecv from
+ * rank - 1 and ncclSend to rank + 1 (a ring; with one rank: a send to itself and a receive from itself, which RCCL accepts inside a
+ * group).  n_floats of a known pattern travel as ncclFloat and are compared word for word on the host.  A wrong argument order, count
+ * unit or dtype enum in gather_exchange's calls shows here, on one GPU, before an 8-GPU run. */
+int rpt_debug_comm_selftest(rpt_ctx *c, uint32_t n_floats, uint64_t *mismatches_out) {
+    if (!c || !mismatches_out || n_floats == 0) return RPT_EINVAL;
+    rpt_comm *cm = c->comm;
+    if (!cm || !cm->comm) { c->error = "rpt_debug_comm_selftest: needs an RCCL communicator (rpt_comm_init)"; return RPT_EINVAL; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int next = (int)((cm->rank + 1u) % cm->world), prev = (int)((cm->rank + cm->world - 1u) % cm->world);
+    std::vector<float> host(n_floats), back(n_floats, -1.0f);
+    /* what `prev` sends is a function of ITS rank: every rank can check what it received */
+    auto pattern = [](uint32_t rank, uint32_t i) { return (float)(int32_t)((i * 2654435761u) ^ (rank * 0x9e3779b9u)) * (1.0f / 65536.0f); };
+    for (uint32_t i = 0; i < n_floats; ++i) host[i] = pattern(cm->rank, i);
+    DevBuf<float> src, dst;
+    HIP_TRY(c, src.alloc(n_floats));
+    if (dst.alloc(n_floats) != hipSuccess) { src.release(); c->error = "rpt_debug_comm_selftest: out of device memory"; return RPT_ENOMEM; }
+    int rc = RPT_OK;
+    auto body = [&]() -> int {
+        /* render stream: the payload is staged (as gather_stage's snapshot is), the comm stream waits for it */
+        if (cm->started) HIP_TRY(c, hipStreamWaitEvent(c->stream, cm->sent, 0));
+        HIP_TRY(c, hipMemcpyAsync(src.p, host.data(), (size_t)n_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(dst.p, 0xff, (size_t)n_floats * sizeof(float), c->stream));
+        HIP_TRY(c, hipEventRecord(cm->staged, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(cm->stream, cm->staged, 0));
+        NCCL_TRY(c, rccl().GroupStart());
+        ncclResult_t r1 = rccl().Send(src.p, n_floats, ncclFloat, next, cm->comm, cm->stream);
+        ncclResult_t r2 = rccl().Recv(dst.p, n_floats, ncclFloat, prev, cm->comm, cm->stream);
+        ncclResult_t ge = rccl().GroupEnd();
+        NCCL_TRY(c, r1);
+        NCCL_TRY(c, r2);
+        NCCL_TRY(c, ge);
+        HIP_TRY(c, hipEventRecord(cm->sent, cm->stream));
+        HIP_TRY(c, hipMemcpyAsync(back.data(), dst.p, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost, cm->stream));
+        HIP_TRY(c, hipStreamSynchronize(cm->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return RPT_OK;
+    };
+    rc = body();
+    src.release();
+    dst.release();
+    if (rc) return rc;
+    uint64_t bad = 0;
+    for (uint32_t i = 0; i < n_floats; ++i) {
+        const float want = pattern((uint32_t)prev, i);
+        bad += memcmp(&want, &back[i], sizeof(float)) != 0;
+    }
+    *mismatches_out = bad;
+    return RPT_OK;
 }
 
 int rpt_gather_wait(rpt_ctx *c) {

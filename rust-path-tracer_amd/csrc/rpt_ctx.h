@@ -115,7 +115,7 @@ struct rpt_ctx {
     int timing_level = 0;           /* RPT_STAGE_TIMING: 1 = an event after every stage kernel, 2 = only around the traversal kernel */
     std::vector<hipEvent_t> timing_events;
     /* batches enqueued by rpt_render_async whose stage timing has not been read back yet */
-    struct TimingBatch { std::vector<hipEvent_t> ev; uint64_t iterations; };
+    struct TimingBatch { std::vector<hipEvent_t> ev; uint64_t iterations; bool complete_timed; };
     std::vector<TimingBatch> timing_pending;
     std::vector<hipEvent_t> timing_pool;
     bool async_pending = false;

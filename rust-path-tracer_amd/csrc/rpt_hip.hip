@@ -364,26 +364,30 @@ void launch_iteration_stack(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std
     }
 }
 
-constexpr int EVENTS_PER_ITER = 4;   /* timing level 1: after traverse, shade, shadow, sky (+ one leading event per call);
+constexpr int EVENTS_PER_ITER = 4;   /* timing level 1: after traverse, shade, shadow, sky; per call two leading events (before and
+                                        after k_generate_first) and one after the batch's k_complete;
                                         level 2: before and after the traversal kernel only */
+constexpr int EVENTS_LEAD = 2, EVENTS_TAIL = 1;
 
 static size_t timing_events_needed(const rpt_ctx *c, uint64_t iterations) {
-    return c->timing_level == 2 ? (size_t)iterations * 2 : 1 + (size_t)iterations * EVENTS_PER_ITER;
+    return c->timing_level == 2 ? (size_t)iterations * 2 : EVENTS_LEAD + (size_t)iterations * EVENTS_PER_ITER + EVENTS_TAIL;
 }
-static void timing_accumulate(rpt_ctx *c, const std::vector<hipEvent_t> &ev, uint64_t iterations) {
+static void timing_accumulate(rpt_ctx *c, const std::vector<hipEvent_t> &ev, uint64_t iterations, bool complete_timed) {
     float ms;
     if (c->timing_level == 2) {
         for (uint64_t k = 0; k < iterations; ++k)
             if (hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) == hipSuccess) c->stats.kernel_ms[RPT_STAGE_TRAVERSE] += ms;
         return;
     }
+    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.kernel_ms[RPT_STAGE_GENERATE] += ms;
     const int stage_of[EVENTS_PER_ITER] = {RPT_STAGE_TRAVERSE, RPT_STAGE_SHADE, RPT_STAGE_SHADOW, RPT_STAGE_SKY};
-    size_t at = 1;
+    size_t at = EVENTS_LEAD;
     for (uint64_t k = 0; k < iterations; ++k)
         for (int e = 0; e < EVENTS_PER_ITER; ++e) {
             if (hipEventElapsedTime(&ms, ev[at - 1], ev[at]) == hipSuccess) c->stats.kernel_ms[stage_of[e]] += ms;
             at += 1;
         }
+    if (complete_timed && hipEventElapsedTime(&ms, ev[at - 1], ev[at]) == hipSuccess) c->stats.kernel_ms[RPT_STAGE_COMPLETE] += ms;
 }
 
 }  // namespace
@@ -750,9 +754,13 @@ static int refresh_device_stats(rpt_ctx *c, const char *what) {
 int rpt_wait(rpt_ctx *c) {
     if (!c) return RPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    /* the last asynchronous batch must have left every slot idle (with several slots per pixel its k_complete has looked already) */
-    if (c->async_pending && c->has_state && c->n_slots && c->group_shift == 0)
-        k_check_drained<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, c->stream>>>(c->hit.p, c->n_slots, c->dev_stats.p);
+    /* the last asynchronous batch must have left every slot idle — ALL the context's slots, not only the ones this call used: k_complete's
+     * final pass looks at the slots of pixels it could not complete, and a slot beyond this call's n_slots (left by an earlier call with
+     * more samples in flight) is outside its view.  One 8-byte read per slot, once per rpt_wait. */
+    if (c->async_pending && c->has_state && c->hit.n) {
+        const uint32_t all = (uint32_t)c->hit.n;
+        k_check_drained<<<(all + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, c->stream>>>(c->hit.p, all, c->dev_stats.p);
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     if (c->async_pending) {
@@ -763,7 +771,7 @@ int rpt_wait(rpt_ctx *c) {
         if (rc) return rc;
     }
     for (auto &b : c->timing_pending) {
-        timing_accumulate(c, b.ev, b.iterations);
+        timing_accumulate(c, b.ev, b.iterations, b.complete_timed);
         c->timing_pool.insert(c->timing_pool.end(), b.ev.begin(), b.ev.end());
     }
     c->timing_pending.clear();
@@ -817,9 +825,6 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     /* A miss ends its path (lib.rs:79) and in a batch of known length nothing is started in its place: the misses of all iterations
      * wait in the queue for ONE sky launch after the last iteration (three launches less per batch; RPT_SKY_AT_END=0: every iteration) */
     c->queues.sky_at_end = (known_iterations != 0 && c->sky_at_end_ok) ? 1u : 0u;
-    k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples, c->dev_stats.p);
-    c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
-
     std::vector<hipEvent_t> async_events;
     std::vector<hipEvent_t> *ev = c->stage_timing ? (async ? &async_events : &c->timing_events) : nullptr;
     size_t ev_at = 0;
@@ -834,10 +839,15 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         async_events.assign(c->timing_pool.end() - (long)need, c->timing_pool.end());
         c->timing_pool.resize(c->timing_pool.size() - need);
     }
-    if (ev && c->timing_level == 1) {
-        if (ev->empty()) { ev->resize(1); HIP_TRY(c, hipEventCreate(&(*ev)[0])); }
+    const bool time_stages = ev && c->timing_level == 1;
+    if (time_stages) {
+        while (ev->size() < (size_t)EVENTS_LEAD) { hipEvent_t e; HIP_TRY(c, hipEventCreate(&e)); ev->push_back(e); }
         HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s));
     }
+    k_generate_first<<<blocks, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, n_samples, c->dev_stats.p);
+    c->stats.kernel_launches[RPT_STAGE_GENERATE] += 1;
+    if (time_stages) HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s));
+    bool complete_timed = false;
 
     uint64_t it = 0, full_iterations = 0;
     bool drained = c->cfg.c.max_bounces == 0u;
@@ -852,9 +862,9 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     /* safety net against a stuck pipeline (a bug), far above what deferral of sky work can cost */
     const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces + 2u) * 16u + 4096u;
     while (!drained) {
-        if (ev && ev->size() < ev_at + EVENTS_PER_ITER) {
+        if (ev && ev->size() < ev_at + EVENTS_PER_ITER + EVENTS_TAIL) {
             size_t old = ev->size();
-            ev->resize(ev_at + EVENTS_PER_ITER * 64);
+            ev->resize(ev_at + EVENTS_PER_ITER * 64 + EVENTS_TAIL);
             for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
         }
         const bool complete_each = known_iterations == 0 && c->group_shift != 0;
@@ -868,7 +878,11 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         it += 1;
         if (it == known_iterations - short_batch) {             /* (no report needed: nothing can be left) */
             /* every path of the batch has ended (max_bounces iterations, side stages included): the one completion of the batch */
-            if (c->group_shift != 0) k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, (uint32_t)it, 1u, c->dev_stats.p);
+            if (c->group_shift != 0) {
+                k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, (uint32_t)it, 1u, c->dev_stats.p);
+                c->stats.kernel_launches[RPT_STAGE_COMPLETE] += 1;
+                if (time_stages) { HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s)); complete_timed = true; }
+            }
             break;
         }
         if (known_iterations == 0 && it >= (uint64_t)lag) {
@@ -897,7 +911,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
         c->stats.kernel_launches[RPT_STAGE_SHADOW] += c->cfg.nee_mode != RPT_NEE_NONE ? full_iterations : 0;
         c->stats.kernel_launches[RPT_STAGE_SKY] += c->queues.sky_at_end ? 1u : full_iterations;
-        if (ev) c->timing_pending.push_back(rpt_ctx::TimingBatch{async_events, it});
+        if (ev) c->timing_pending.push_back(rpt_ctx::TimingBatch{async_events, it, complete_timed});
         c->samples += n_samples;
         c->stats.samples += (uint64_t)c->n_pixels * n_samples;
         c->stats.render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -914,7 +928,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     c->stats.kernel_launches[RPT_STAGE_SHADE] += it;
     c->stats.kernel_launches[RPT_STAGE_SHADOW] += nee ? full_iterations : 0;
     c->stats.kernel_launches[RPT_STAGE_SKY] += c->queues.sky_at_end ? 1u : full_iterations;
-    if (ev) timing_accumulate(c, *ev, it);
+    if (ev) timing_accumulate(c, *ev, it, complete_timed);
     c->samples += n_samples;
     c->stats.samples += (uint64_t)c->n_pixels * n_samples;
     c->stats.render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -45,6 +45,7 @@ def main():
     r = hip.Renderer(0, rank=args.rank, world_size=args.world)
     r.comm_init(bytes.fromhex(args.uid), args.rank, args.world)
     seen_rank, seen_world = r.comm_world()
+    ring_bad = r.comm_selftest(70001) if args.world > 1 else 0     # rpt_debug_comm_selftest: a ring of grouped send / receive over all ranks
     extras = [hip.Renderer(0) for _ in range(args.pipelines - 1)]
     for e in extras:
         r.comm_add_pipeline(e)                               # re-partitions r and every extra: sub-ranks of world * pipelines
@@ -63,7 +64,7 @@ def main():
         p.wait()
     sts = [p.stats() for p in [r] + extras]
     st = {k: sum(s[k] for s in sts) for k in ("extension_rays", "shadow_rays", "samples")}
-    info = {"rank": seen_rank, "world": seen_world, "library": hip.comm_library(), "pixels": int(sum(p.local_pixels() for p in [r] + extras)),
+    info = {"ring_mismatches": int(ring_bad), "rank": seen_rank, "world": seen_world, "library": hip.comm_library(), "pixels": int(sum(p.local_pixels() for p in [r] + extras)),
             "extension_rays": int(st["extension_rays"]), "shadow_rays": int(st["shadow_rays"]), "samples": int(st["samples"])}
     if args.rank == 0:
         img, s = r.read_gathered()

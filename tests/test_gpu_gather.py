@@ -67,6 +67,23 @@ def test_rccl_gather_one_rank_through_the_c_abi(hipmod, rpt, world):
     r.close()
 
 
+def test_real_rccl_point_to_point_through_the_librarys_function_table(hipmod):
+    """The gather's ncclSend / ncclRecv have only ever met a test stand-in (tests/fake_rccl) — a 1-rank communicator exchanges nothing.
+    rpt_debug_comm_selftest runs exactly those two entry points of the REAL library (resolved by dlsym as the gather resolves them),
+    inside one ncclGroupStart / ncclGroupEnd, on the communicator's second stream behind the `staged` event: a send to itself and a
+    receive from itself, ncclFloat, 1 M and 3 floats — every word must arrive."""
+    import os
+    assert not os.environ.get("RPT_RCCL_LIBRARY"), "this test is about the real RCCL"
+    r = hipmod.Renderer(0)
+    r.comm_init(hipmod.comm_unique_id(), 0, 1)
+    lib = hipmod.comm_library()
+    assert "rccl" in lib and "fake" not in lib, lib
+    assert r.comm_world() == (0, 1)
+    for n in (1 << 20, 3, 1 << 20):
+        assert r.comm_selftest(n) == 0
+    r.close()
+
+
 def test_local_communicator_reads_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, world):
     """rpt_comm_init_local (one rank, no RCCL): render_async(k) ; gather_async ; render_async(k+1) ; read_gathered returns the
     image AFTER BATCH k — the snapshot was taken before batch k+1 touched the accumulators — with k's sample count."""

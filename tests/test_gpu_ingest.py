@@ -136,10 +136,10 @@ def test_host_dispatch_flush_from_another_thread(oracle, rpt, world, overlap):
 
 @pytest.mark.parametrize("overlap", [False, True])
 def test_host_dispatch_keeps_publishing_while_interacting(oracle, rpt, world, overlap):
-    """A camera drag holds `interacting` for many batches (src/app.rs): every iteration renders sync_rate samples from zero,
-    PUBLISHES them (src/trace.rs:198-213 run before the flush of 216-222) and discards them.  The framebuffer therefore
-    follows the camera while the drag lasts — in the overlapped loop too, where a flushing iteration must read the batch it
-    has just enqueued before the reset throws it away."""
+    """A camera drag holds `interacting` for many iterations (src/app.rs): with the flag already up the reference's inner loop ends after
+    its FIRST sample (src/trace.rs:181-189), the 1-sample image is PUBLISHED (198-213 run before the flush of 216-222) and discarded.
+    The framebuffer therefore follows the camera while the drag lasts, one sample per frame whatever sync_rate is — in the overlapped
+    loop too, where a flushing iteration must read what it has just enqueued before the reset throws it away."""
     import threading
     import time
     W, H, rate = 96, 64, 3
@@ -169,11 +169,11 @@ def test_host_dispatch_keeps_publishing_while_interacting(oracle, rpt, world, ov
     for k, view in enumerate(views):
         if k:
             state.set_config(view)                              # (picked up by the very next iteration: interacting flushes each one)
-        ref, _, _ = oracle.trace_cpu(view, sc, seeds, rate)
-        want = (ref[..., :3] / np.float32(rate)).view(np.uint32)
+        ref, _, _ = oracle.trace_cpu(view, sc, seeds, 1)
+        want = ref[..., :3].view(np.uint32)                       # (sum of one sample / 1.0)
         ok = False
         while time.time() < deadline and t.is_alive() and not ok:
-            ok = np.array_equal(state.framebuffer().view(np.uint32), want)     # the drag's current view, `rate` samples, from zero
+            ok = np.array_equal(state.framebuffer().view(np.uint32), want)     # the drag's current view, ONE sample, from zero
             time.sleep(0.001)
         shown.append(ok)
     state.set_interacting(False)

@@ -84,6 +84,7 @@ def test_n_processes_gather_the_one_rank_image(hipmod, rpt, world, tmp_path, ran
     infos = _run_ranks(tmp_path, ranks, ["--width", str(W), "--height", str(H), "--nee", "1", "--batches", ",".join(map(str, batches)), "--second-image"])
     for r, info in enumerate(infos):
         assert (info["rank"], info["world"]) == (r, ranks) and info["library"] == FAKE
+        assert info["ring_mismatches"] == 0                # rpt_debug_comm_selftest as a ring over the N ranks (one rank on real RCCL: test_gpu_gather.py)
     assert sum(i["pixels"] for i in infos) == W * H
     assert infos[0]["gathered_samples"] == sum(batches)
     img = np.load(tmp_path / "image.npy")

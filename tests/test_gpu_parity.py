@@ -147,6 +147,8 @@ CASES = [
     ("FurnaceTest", 128, 128, 8, 0, {}),
     ("FurnaceTest", 128, 128, 8, 1, {}),
     ("FurnaceTest", 96, 64, 4, 2, {}),
+    ("FurnaceTest", 256, 256, 16, 0, {}),                      # BASELINE config[0] at its own size and sample count
+    ("FurnaceTest", 256, 256, 16, 1, {}),
     ("DarkCornell", 256, 256, 8, 0, {}),
     ("DarkCornell", 200, 120, 6, 1, {}),                       # ragged: not a multiple of the 64-pixel tile
     ("DarkCornell", 128, 128, 4, 2, {"min_bounces": 1, "max_bounces": 3}),   # roulette active

@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 WL=$1; shift
 for envs in "$@"; do
-  out=$(env $envs python3 "$ROOT/bench.py" --no-cpu-baseline --no-readback $WL 2>/dev/null | tail -1)
+  out=$(env $envs python3 "$ROOT/bench.py" --no-cpu-baseline --no-extra-workloads --no-readback $WL 2>/dev/null | tail -1)
   python3 - "$envs" "$WL" "$out" <<'PY'
 import json, sys
 envs, wl, out = sys.argv[1:4]

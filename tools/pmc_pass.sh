@@ -12,7 +12,7 @@ for group in "$@"; do
   i=$((i+1))
   d=$OUT/pass$i
   rm -rf "$d"
-  rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$d" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline ${BENCH_ARGS:-} > "$d.log" 2>&1
+  rocprofv3 --pmc $group --kernel-trace --output-format csv -d "$d" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extra-workloads ${BENCH_ARGS:-} > "$d.log" 2>&1
   f=$(find "$d" -name '*counter_collection.csv' | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections

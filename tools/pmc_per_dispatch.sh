@@ -4,7 +4,7 @@ K=$1; C=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/prof_pd
-rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_pd -- python3 $ROOT/bench.py --no-cpu-baseline --no-readback --no-parity-check "$@" > /tmp/pd.log 2>&1
+rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_pd -- python3 $ROOT/bench.py --no-cpu-baseline --no-extra-workloads --no-readback --no-parity-check "$@" > /tmp/pd.log 2>&1
 python3 - "$K" "$(find /tmp/prof_pd -name '*counter_collection.csv' | head -1)" <<'PY'
 import csv, sys, collections
 k, path = sys.argv[1], sys.argv[2]

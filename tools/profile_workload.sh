@@ -14,7 +14,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profile
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --workload $WL"
+B="$ROOT/bench.py --workload $WL --no-extra-workloads"
 rm -rf /tmp/prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $B --no-cpu-baseline "$@" > "$OUT/${TAG}_${WL}_stats_run.log" 2>&1
 cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_${WL}_kernel_stats.csv"

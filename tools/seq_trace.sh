@@ -3,5 +3,5 @@
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/prof_seq
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_seq -- python3 $ROOT/bench.py --no-cpu-baseline --no-readback --no-parity-check "$@" > /tmp/seq.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_seq -- python3 $ROOT/bench.py --no-cpu-baseline --no-extra-workloads --no-readback --no-parity-check "$@" > /tmp/seq.log 2>&1
 python3 $ROOT/tools/trace_sequence.py "$(find /tmp/prof_seq -name '*kernel_trace.csv' | head -1)"

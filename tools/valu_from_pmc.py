@@ -8,7 +8,7 @@ import re
 import sys
 
 STAGES = (("k_traverse_nearest", "traverse"), ("k_shade", "shade"), ("k_traverse_shadow", "shadow"), ("k_sky", "sky"),
-          ("k_generate_first", "generate"))
+          ("k_generate_first", "generate"), ("k_complete", "complete"), ("k_shadow_resolve", "shadow_resolve"))
 sq, out = sys.argv[1:3]
 acc = {}
 for line in open(sq):
