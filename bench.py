@@ -575,8 +575,7 @@ def main():
     n_mis = n_shadow if cfg.nee == 1 else 0.0
 
     # --- roofline of the dominant kernel, from the HIP events recorded in this run (rank 0's stream)
-    props = torch.cuda.get_device_properties(device)
-    cus, clock_mhz = props.multi_processor_count, props.clock_rate / 1e3
+    cus, clock_mhz = hip.device_info(local_rank)
     pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
     pipeline_gbs = pipeline_bytes / elapsed_max / 1e9
     roofline, whole = stage_roofline(hip, args.workload, s0, s1, args.steps, elapsed_max, cus, clock_mhz, pipeline_bytes / world_size)

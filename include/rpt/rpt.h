@@ -252,6 +252,8 @@ int rpt_abi_version(void);
 /* tools/source_fingerprint.py of the device-side sources this library was built from ("unknown" for a build outside the Makefile):
  * profiles/traffic_*.json carry the same value, and bench.py reports counter-derived figures only when they match. */
 const char *rpt_build_fingerprint(void);
+/* compute units and peak engine clock of a HIP device, as the runtime reports them (bench.py: SIMD issue cycles available) */
+int rpt_device_info(int device_id, uint32_t *compute_units_out, uint32_t *clock_khz_out);
 
 /* --- scene preparation on the device ---------------------- */
 /* BVHBuilder::new(vertices, indices).sah_samples(n).build()  (reference src/bvh.rs:59-324, the call at

@@ -401,6 +401,18 @@ int rpt_abi_version(void) { return RPT_ABI_VERSION; }
 #endif
 const char *rpt_build_fingerprint(void) { return RPT_BUILD_FINGERPRINT; }
 
+int rpt_device_info(int device_id, uint32_t *compute_units_out, uint32_t *clock_khz_out) {
+    int cus = 0, khz = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess ||
+        hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, device_id) != hipSuccess) {
+        g_create_error = "rpt_device_info: no such HIP device";
+        return RPT_ENODEV;
+    }
+    if (compute_units_out) *compute_units_out = (uint32_t)cus;
+    if (clock_khz_out) *clock_khz_out = (uint32_t)khz;
+    return RPT_OK;
+}
+
 const char *rpt_last_error(rpt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 int rpt_create(int device_id, rpt_ctx **out) {

@@ -160,3 +160,32 @@ def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks, pipelines):
     cmd_real = [c for c in cmd if c != "--rehearsal"]
     p2 = subprocess.run(cmd_real, env=_env(), capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert p2.returncode != 0 and "RPT_RCCL_LIBRARY" in (p2.stderr + p2.stdout)
+
+
+def test_bench_line_carries_the_other_single_gpu_workloads(tmp_path):
+    """`bench.py --gpus 1` as the driver runs it: after the headline's timed loop the other single-GPU BASELINE workloads run on fresh
+    contexts and appear under "workloads", each with its own value, roofline (dominant kernel, HIP-event timed), pipeline_roofline and a
+    bitwise parity_check; the headline keeps its contract and attributes k_generate_first / k_complete in stage_ms.  (Two of the four
+    extra workloads and short loops here; the driver's run takes all four.)"""
+    env = dict(os.environ)
+    env.pop("RPT_RCCL_LIBRARY", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-readback",
+           "--extra-workloads", "darkcornell_mis,veachmis", "--extra-steps", "1", "--extra-warmup", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["metric"] == "Mrays/s" and out["n_gpus"] == 1 and out["parity_check"]["bitwise"] is True
+    sm = out["roofline"]["stage_ms"]
+    assert sm["generate"] > 0 and sm["complete"] > 0 and sm["traverse"] > sm["shade"] > 0
+    assert set(out["workloads"]) == {"darkcornell_mis", "veachmis"}
+    for name, w in out["workloads"].items():
+        assert w["value"] > 100 and w["unit"] == "Mrays/s" and w["steps"] == 1 and w["ms_per_step"] > 0
+        assert w["rays"]["shadow"] > 0 and w["config"]["workload"].startswith(("DarkCornell.glb 1024x1024", "VeachMIS.glb 1920x1080"))
+        r = w["roofline"]
+        assert r["bound"] == "hbm" and r["kernel"].startswith("k_") and 0 < r["frac"] < 1 and r["avg_launch_ms"] > 0
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_unit"] * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-2 * r["achieved"]
+        assert 0 < w["pipeline_roofline"]["frac"] < 1
+        pc = w["parity_check"]
+        assert pc["bitwise"] is True and pc["windows"] >= 2 and pc["image_spp"] == pc["spp"] == 32
