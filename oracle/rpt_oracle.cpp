@@ -202,6 +202,7 @@ struct Counters {
     uint32_t error_flags = 0;   /* bit0 stack overflow, bit1 rng dimension overflow */
     uint8_t *event_log = nullptr;   /* analysis hook, see log_event */
     uint32_t event_cap = 0, event_len = 0;
+    uint64_t *hist_nearest = nullptr, *hist_any = nullptr;   /* analysis hook: node pops per node (oracle_node_histogram) */
 };
 
 /* ------------------------------------------------------------------------ */
@@ -296,6 +297,7 @@ TraceResult intersect_front_to_back(const Scene &sc, V3 ro, V3 rd, float max_t, 
         const rpt_bvh_node &node = sc.nodes[node_index];
         cnt.node_pops++;
         log_event(cnt, node.triangle_count > 0 ? 1 : 0);
+        if (uint64_t *h = NEAREST_HIT ? cnt.hist_nearest : cnt.hist_any) h[node_index] += 1;
         if (node.triangle_count > 0) {
             for (uint32_t i = 0; i < node.triangle_count; ++i) {
                 uint32_t triangle_index = node.left_or_first + i;
@@ -984,6 +986,25 @@ int oracle_trace_events(const oracle_scene *scene, size_t n, const float *origin
         lengths[i] = cnt.event_len;
     }
     return 0;
+}
+
+/* Analysis hook (tools/node_visit_share.py): how often each BVH node is popped by the nearest-hit and by the any-hit walks of
+ * n_samples samples of every pixel — which part of a tree a top-of-tree cache would have to hold. */
+int oracle_node_histogram(const rpt_tracing_config *config, const oracle_scene *scene, const rpt_rng_state *rng, uint32_t n_samples,
+                          uint64_t *hist_nearest, uint64_t *hist_any) {
+    Scene sc = make_scene(scene);
+    Counters cnt;
+    cnt.hist_nearest = hist_nearest;
+    cnt.hist_any = hist_any;
+    for (uint32_t y = 0; y < config->height; ++y)
+        for (uint32_t x = 0; x < config->width; ++x) {
+            rpt_rng_state r = rng[(size_t)y * config->width + x];
+            for (uint32_t s = 0; s < n_samples; ++s) {
+                trace_pixel(x, y, *config, r, sc, cnt);
+                r.n += 1;
+            }
+        }
+    return (int)cnt.error_flags;
 }
 
 /* rays[(y*W + x)*6..] = extension ray of bounce `bounce` of sample rng[i] of every pixel; valid[i] = 0 if the path ended earlier */
