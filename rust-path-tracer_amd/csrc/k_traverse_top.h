@@ -50,6 +50,7 @@ struct SceneViewTop {
     uint32_t K, K2;               /* ids < K: pair in the image; < K2: pair in `gpairs`; else leaf */
     const float4 *gpairs;         /* global: 4 x float4 per inner node K <= id < K2: (L.lo | id L) (L.hi | -) (R.lo | id R) (R.hi | -) */
     const uint32_t *leaves;       /* global: first triangle | count << 24 per leaf id - K2 */
+    uint32_t leaf_lds_vecs;       /* != 0: the table is also in LDS, that many float4 behind `img` (a dependent global load less per leaf step) */
     const float *tri_isect;
     __device__ __forceinline__ void edges(uint32_t ti, F3 &e1, F3 &e2) const {
         const float *p = tri_isect + 9u * (size_t)ti;
@@ -74,7 +75,7 @@ __device__ __forceinline__ void top_walk_begin(TopWalk &w) {
 }
 
 /* At most `budget` trips for the lanes of this wave; rays inside the exact-division guard only (the caller walks the others alone). */
-template <int STACK, bool ANY_HIT>
+template <int STACK, bool ANY_HIT, bool LEAF_LDS>
 __device__ __forceinline__ void top_walk_run(const SceneViewTop &view, TopWalk &w, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack, int budget) {
     const uint32_t K = view.K, K2 = view.K2;
     const float4 *px = view.img + (rd.x < 0.0f ? K : 0u);
@@ -140,13 +141,18 @@ __device__ __forceinline__ void top_walk_run(const SceneViewTop &view, TopWalk &
             }
         } else if (at_leaf) {
             bool accepted = false;
-            const uint32_t rec = view.leaves[cur - K2];
+            /* (a template parameter, not a run-time choice: a select between an LDS and a global address becomes a FLAT load) */
+            const uint32_t rec = LEAF_LDS ? reinterpret_cast<const uint32_t *>(view.img + view.leaf_lds_vecs)[cur - K2] : view.leaves[cur - K2];
             const uint32_t count = rec >> 24, first = rec & 0xffffffu;
             for (uint32_t i = 0; i < count; ++i) {
                 uint32_t ti = first + i;
                 float t = 0.0f;
                 bool bf = false;
-                if (moller_trumbore_view(view, ti, ro, rd, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
+                /* the whole 36-byte record at once: with 4 waves per SIMD a second dependent load (the corner, which the LDS walk fetches
+                 * only past the determinant test) is a memory round trip nobody hides */
+                const float *p = view.tri_isect + 9u * (size_t)ti;
+                const F3 e1 = f3(p[0], p[1], p[2]), e2 = f3(p[3], p[4], p[5]), a = f3(p[6], p[7], p[8]);
+                if (moller_trumbore_regs(e1, e2, a, ro, rd, t, bf) && t > 0.001f && t < res.t && (!ANY_HIT || t <= max_t)) {
                     asm volatile("" ::: "memory");          /* (a real branch: see lds_walk_run) */
                     res.t = t;
                     res.tri = ti | (bf ? 0x80000000u : 0u);
@@ -166,15 +172,23 @@ __device__ __forceinline__ void top_walk_run(const SceneViewTop &view, TopWalk &
     w.res = res;
 }
 
-/* all LDS of these kernels is dynamic: [ image (top_vecs float4) | stacks NW x STACK x 64 x u16 | pool ] — together up to 160 KB */
-template <int STACK, int THREADS>
-__device__ __forceinline__ SceneViewTop stage_scene_top(const DevScene &sc, float4 *lds, uint16_t *&stacks, WgPool *&pool) {
-    stacks = reinterpret_cast<uint16_t *>(lds + sc.top_vecs);
-    pool = reinterpret_cast<WgPool *>(stacks + (size_t)(THREADS / RPT_WAVE) * STACK * RPT_WAVE);
-    return SceneViewTop{lds, sc.top_pairs, sc.top_k2, sc.top_gpairs, sc.top_leaves, sc.tri_isect};
+/* all LDS of these kernels is dynamic: [ image (top_vecs float4) | leaf table (if it fits) | stacks NW x entries x 64 x u16 | per-wave refill
+ * scratch NW x 64 x u32 | pool ] — together up to 160 KB.  `entries` = the tree's depth + 1 (<= STACK), not the template's cap: 16 waves
+ * pay 2 KB per stack level. */
+template <int THREADS>
+__device__ __forceinline__ SceneViewTop stage_scene_top(const DevScene &sc, float4 *lds, uint16_t *&stacks, uint32_t *&scratch, WgPool *&pool) {
+    uint32_t *leaf_lds = reinterpret_cast<uint32_t *>(lds + sc.top_vecs);
+    stacks = reinterpret_cast<uint16_t *>(leaf_lds + sc.top_leaf_words);
+    scratch = reinterpret_cast<uint32_t *>(stacks + (size_t)(THREADS / RPT_WAVE) * sc.top_stack * RPT_WAVE);
+    pool = reinterpret_cast<WgPool *>(scratch + (size_t)(THREADS / RPT_WAVE) * RPT_WAVE);
+    return SceneViewTop{lds, sc.top_pairs, sc.top_k2, sc.top_gpairs, sc.top_leaves, sc.top_leaf_words ? sc.top_vecs : 0u, sc.tri_isect};
 }
-template <int STACK, int THREADS> constexpr size_t top_lds_bytes(size_t top_vecs) {
-    return top_vecs * sizeof(float4) + (size_t)(THREADS / RPT_WAVE) * STACK * RPT_WAVE * sizeof(uint16_t) + 16u;
+/* copy the image (and the leaf table) in; the caller synchronises */
+template <int THREADS>
+__device__ __forceinline__ void copy_scene_top(const DevScene &sc, float4 *lds) {
+    for (uint32_t k = threadIdx.x; k < sc.top_vecs; k += THREADS) lds[k] = sc.top_image[k];
+    uint32_t *leaf_lds = reinterpret_cast<uint32_t *>(lds + sc.top_vecs);
+    for (uint32_t k = threadIdx.x; k < sc.top_leaf_words; k += THREADS) leaf_lds[k] = sc.top_leaves[k];
 }
 
 /* a ray outside the exact-division guard (a zero / denormal-small direction component): walked alone through the reference's own node
@@ -185,13 +199,14 @@ __device__ __forceinline__ HitRecord top_walk_slow(const DevScene &sc, F3 ro, F3
     return traverse_loop<STACK, ANY_HIT, false>(g, ro, rd, rd, max_t, stack);
 }
 
-template <int STACK, int THREADS>
+template <int STACK, int THREADS, bool LEAF_LDS>
 __global__ __launch_bounds__(THREADS) void k_traverse_nearest_tstream(DevScene sc, DevState st, DevQueues q, uint32_t iteration, uint32_t SPAN) {
     float4 *lds = rpt_lds_dyn;
     uint16_t *stacks;
+    uint32_t *scratch_all;
     WgPool *poolp;
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
-    SceneViewTop view = stage_scene_top<STACK, THREADS>(sc, lds, stacks, poolp);
+    SceneViewTop view = stage_scene_top<THREADS>(sc, lds, stacks, scratch_all, poolp);
     WgPool &pool = *poolp;
     uint32_t *global_next = &q.count[Q_POOL0 + (iteration & 1u) * Q_LINE];
     if (blockIdx.x == 0u && threadIdx.x == 0u) {
@@ -206,9 +221,10 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_tstream(DevScene s
     }
     __syncthreads();
     if ((uint32_t)(pool.word >> 32) == 0u) return;             /* block-uniform: a late workgroup, nothing left */
-    for (uint32_t k = threadIdx.x; k < sc.top_vecs; k += THREADS) lds[k] = sc.top_image[k];
+    copy_scene_top<THREADS>(sc, lds);
     __syncthreads();
-    uint16_t *stack = stacks + (size_t)wave * STACK * RPT_WAVE + lane;
+    uint16_t *stack = stacks + (size_t)wave * sc.top_stack * RPT_WAVE + lane;
+    volatile uint32_t *scratch = scratch_all + wave * RPT_WAVE;
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     TopWalk w;
     top_walk_begin(w);
@@ -217,51 +233,69 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_tstream(DevScene s
     bool have = false;                                         /* this lane holds a ray whose result is not written yet */
     bool pool_open = true;                                     /* wave-uniform: the launch may still have slots */
     uint32_t traced = 0u;                                      /* wave-uniform */
+    /* An open scene leaves most slots without a pending ray after the first bounce: the wave LOOKS at 64 consecutive slots at a time
+     * (one coalesced load of their stage words) and keeps the pending ones of that chunk as a mask; idle lanes take them in order. */
+    unsigned long long left_m = 0ull;                          /* wave-uniform: pending, not yet taken slots of the chunk at scan_base */
+    uint32_t scan_base = 0u;
     for (;;) {
         const unsigned long long idle_m = rpt_ballot(w.cur == TOP_DEAD);
         const uint32_t n_idle = (uint32_t)__popcll(idle_m);
-        if (pool_open && n_idle >= (uint32_t)RPT_TOP_REFILL) {
-            uint32_t base = 0u, got = 0u;
-            bool finished = false;
-            if (lane == 0u) base = wg_pool_take(&pool, global_next, st.n_slots, SPAN, n_idle, got, finished);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            pool_open = __builtin_amdgcn_readfirstlane((int)finished) == 0;
-            bool took = false;
-            if (w.cur == TOP_DEAD) {
-                if (have) {
-                    st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
-                    have = false;
-                }
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
-                if (rank < got) {
-                    const uint32_t cand = base + rank;
-                    if (__float_as_uint(st.hit[cand].y) == HIT_PENDING) {
-                        const float4 ra = st.ray_a[cand];
-                        const float2 rb = st.ray_b[cand];
-                        ro = f3(ra.x, ra.y, ra.z); rd = f3(ra.w, rb.x, rb.y);
-                        slot = cand;
-                        took = true;
-                        if (fastdiv_ray_ok(sc.fastdiv_ok, ro, rd)) {
-                            ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                            top_walk_begin(w);
-                            have = true;
-                        } else {
-                            HitRecord h = top_walk_slow<STACK, false>(sc, ro, rd, 0.0f, stack);
-                            st.hit[cand] = make_float2(h.t, __uint_as_float(h.tri));
-                        }
-                    }
+        if ((pool_open || left_m != 0ull) && n_idle >= (uint32_t)RPT_TOP_REFILL) {
+            if (w.cur == TOP_DEAD && have) {
+                st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
+                have = false;
+            }
+            if (left_m == 0ull) {
+                uint32_t base = 0u, got = 0u;
+                bool finished = false;
+                if (lane == 0u) base = wg_pool_take(&pool, global_next, st.n_slots, SPAN, RPT_WAVE, got, finished);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                pool_open = __builtin_amdgcn_readfirstlane((int)finished) == 0;
+                if (got == 0u) {
+                    if (pool_open && idle_m == ~0ull) __builtin_amdgcn_s_sleep(8);   /* another wave is fetching the next span */
+                    if (!pool_open && idle_m == ~0ull) break;
+                    if (idle_m == ~0ull) continue;
+                } else {
+                    left_m = rpt_ballot(lane < got && __float_as_uint(st.hit[base + lane].y) == HIT_PENDING);
+                    scan_base = base;
                 }
             }
-            traced += (uint32_t)__popcll(rpt_ballot(took));
-            if (got != 0u || !pool_open) continue;             /* slots that were not pending leave lanes idle: look again */
-            if (idle_m == ~0ull) { __builtin_amdgcn_s_sleep(8); continue; }   /* another wave is fetching the next span */
+            if (left_m != 0ull) {
+                const bool mine = ((left_m >> lane) & 1ull) != 0ull;
+                const uint32_t rank_p = __builtin_amdgcn_mbcnt_hi((uint32_t)(left_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)left_m, 0u));
+                const uint32_t n_p = (uint32_t)__popcll(left_m), n_take = n_p < n_idle ? n_p : n_idle;
+                if (mine) scratch[rank_p] = scan_base + lane;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rank_i = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+                bool took = false;
+                if (w.cur == TOP_DEAD && rank_i < n_take) {
+                    const uint32_t cand = scratch[rank_i];
+                    const float4 ra = st.ray_a[cand];
+                    const float2 rb = st.ray_b[cand];
+                    ro = f3(ra.x, ra.y, ra.z); rd = f3(ra.w, rb.x, rb.y);
+                    slot = cand;
+                    took = true;
+                    if (fastdiv_ray_ok(sc.fastdiv_ok, ro, rd)) {
+                        ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        top_walk_begin(w);
+                        have = true;
+                    } else {
+                        HitRecord h = top_walk_slow<STACK, false>(sc, ro, rd, 0.0f, stack);
+                        st.hit[cand] = make_float2(h.t, __uint_as_float(h.tri));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                traced += (uint32_t)__popcll(rpt_ballot(took));
+                left_m &= ~rpt_ballot(mine && rank_p < n_take);
+                continue;                                      /* look again: lanes may still be idle, the chunk or the pool may hold more */
+            }
         }
         if (idle_m == ~0ull) {
-            if (!pool_open) break;                             /* nothing in flight and nothing left to hand out */
+            if (!pool_open && left_m == 0ull) break;           /* nothing in flight and nothing left to hand out */
             continue;
         }
-        top_walk_run<STACK, false>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_TOP_TRIPS : 0x7fffffff);
+        top_walk_run<STACK, false, LEAF_LDS>(view, w, ro, rd, ird, 0.0f, stack, (pool_open || left_m != 0ull) ? RPT_TOP_TRIPS : 0x7fffffff);
     }
     if (have) st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
     if (lane == 0u && traced != 0u) {
@@ -271,13 +305,14 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_tstream(DevScene s
 }
 
 /* shadow rays, as k_traverse_shadow_stream: lanes note "occluded" in the entry's contribution record, k_shadow_resolve adds the NEE terms */
-template <int STACK, int THREADS>
+template <int STACK, int THREADS, bool LEAF_LDS>
 __global__ __launch_bounds__(THREADS) void k_traverse_shadow_tstream(DevScene sc, DevState st, DevQueues q, DevStats *stats, uint32_t SPAN) {
     float4 *lds = rpt_lds_dyn;
     uint16_t *stacks;
+    uint32_t *scratch_all;
     WgPool *poolp;
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
-    SceneViewTop view = stage_scene_top<STACK, THREADS>(sc, lds, stacks, poolp);
+    SceneViewTop view = stage_scene_top<THREADS>(sc, lds, stacks, scratch_all, poolp);
     WgPool &pool = *poolp;
     uint32_t n, n_entries;                                     /* n: queue positions to hand out */
     q_extent(q.shadow_cnt, n, n_entries);
@@ -291,9 +326,9 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_tstream(DevScene sc
     }
     __syncthreads();
     if ((uint32_t)(pool.word >> 32) == 0u) return;             /* block-uniform: nothing (left) to trace */
-    for (uint32_t k = threadIdx.x; k < sc.top_vecs; k += THREADS) lds[k] = sc.top_image[k];
+    copy_scene_top<THREADS>(sc, lds);
     __syncthreads();
-    uint16_t *stack = stacks + (size_t)wave * STACK * RPT_WAVE + lane;
+    uint16_t *stack = stacks + (size_t)wave * sc.top_stack * RPT_WAVE + lane;
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     float max_t = 0.0f;
     TopWalk w;
@@ -339,7 +374,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_tstream(DevScene sc
             if (!pool_open) break;                             /* nothing in flight and nothing left to hand out */
             continue;
         }
-        top_walk_run<STACK, true>(view, w, ro, rd, ird, max_t, stack, pool_open ? RPT_TOP_TRIPS : 0x7fffffff);
+        top_walk_run<STACK, true, LEAF_LDS>(view, w, ro, rd, ird, max_t, stack, pool_open ? RPT_TOP_TRIPS : 0x7fffffff);
     }
     if (have) q.sh_c[entry].w = w.res.tri == HIT_MISS ? 0.0f : 1.0f;
 }

@@ -339,13 +339,18 @@ static uint32_t gstream_span(const rpt_ctx *c, uint32_t most) {
 
 constexpr int TOP_THREADS = RPT_TOP_THREADS;
 constexpr size_t RPT_LDS_PER_CU = 160u * 1024u;      /* gfx950: a single workgroup may hold all of it */
-static size_t top_lds_bytes_rt(int stack_cap, size_t top_vecs) {
-    return top_vecs * sizeof(float4) + (size_t)(TOP_THREADS / RPT_WAVE) * (size_t)stack_cap * RPT_WAVE * sizeof(uint16_t) + 16u;
+#ifndef RPT_TOP_LEAF_TABLE_BYTES
+#define RPT_TOP_LEAF_TABLE_BYTES 24576     /* the leaf table goes into LDS when it is at most this large (a dependent global load less per leaf step) */
+#endif
+static size_t top_lds_bytes_rt(uint32_t stack_entries, size_t top_vecs, size_t leaf_words) {
+    return top_vecs * sizeof(float4) + leaf_words * 4u + (size_t)(TOP_THREADS / RPT_WAVE) * ((size_t)stack_entries * RPT_WAVE * sizeof(uint16_t) + RPT_WAVE * 4u) + 16u;
 }
 /* more than 64 KB of dynamic LDS has to be asked for, per kernel */
 template <int STACK> static hipError_t top_allow_big_lds_for() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_nearest_tstream<STACK, TOP_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RPT_LDS_PER_CU);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_shadow_tstream<STACK, TOP_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RPT_LDS_PER_CU);
+    hipError_t e = hipSuccess;
+    for (const void *f : {reinterpret_cast<const void *>(&k_traverse_nearest_tstream<STACK, TOP_THREADS, false>), reinterpret_cast<const void *>(&k_traverse_nearest_tstream<STACK, TOP_THREADS, true>),
+                          reinterpret_cast<const void *>(&k_traverse_shadow_tstream<STACK, TOP_THREADS, false>), reinterpret_cast<const void *>(&k_traverse_shadow_tstream<STACK, TOP_THREADS, true>)})
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RPT_LDS_PER_CU);
     return e;
 }
 static int top_allow_big_lds(rpt_ctx *c) {
@@ -384,8 +389,10 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration) {
     else if (c->scene.top_tree) {
         /* one persistent 1 024-thread workgroup per CU: the top of the tree + 16 stacks fill its LDS */
         const uint32_t span = top_span(c, c->n_slots), n_spans = (c->n_slots + span - 1) / span;
-        k_traverse_nearest_tstream<STACK, TOP_THREADS><<<n_spans < c->top_blocks ? n_spans : c->top_blocks, TOP_THREADS, top_lds_bytes_rt(STACK, c->scene.top_vecs), s>>>(
-            c->scene, c->state, c->queues, iteration, span);
+        const uint32_t grid = n_spans < c->top_blocks ? n_spans : c->top_blocks;
+        const size_t lds = top_lds_bytes_rt(c->scene.top_stack, c->scene.top_vecs, c->scene.top_leaf_words);
+        if (c->scene.top_leaf_words) k_traverse_nearest_tstream<STACK, TOP_THREADS, true><<<grid, TOP_THREADS, lds, s>>>(c->scene, c->state, c->queues, iteration, span);
+        else k_traverse_nearest_tstream<STACK, TOP_THREADS, false><<<grid, TOP_THREADS, lds, s>>>(c->scene, c->state, c->queues, iteration, span);
     } else if (c->gstream) {
 #define RPT_LAUNCH_NEAREST(W, COOP) k_traverse_nearest_gstream<STACK, W, COOP><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n)
         if (c->fat_leaves) {
@@ -438,8 +445,10 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else if (c->scene.top_tree) {
             const uint32_t span = top_span(c, q_positions), n_spans = (q_positions + span - 1) / span;
-            k_traverse_shadow_tstream<STACK, TOP_THREADS><<<n_spans < c->top_blocks ? n_spans : c->top_blocks, TOP_THREADS, top_lds_bytes_rt(STACK, c->scene.top_vecs), s>>>(
-                c->scene, c->state, c->queues, c->dev_stats.p, span);
+            const uint32_t grid = n_spans < c->top_blocks ? n_spans : c->top_blocks;
+            const size_t lds = top_lds_bytes_rt(c->scene.top_stack, c->scene.top_vecs, c->scene.top_leaf_words);
+            if (c->scene.top_leaf_words) k_traverse_shadow_tstream<STACK, TOP_THREADS, true><<<grid, TOP_THREADS, lds, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
+            else k_traverse_shadow_tstream<STACK, TOP_THREADS, false><<<grid, TOP_THREADS, lds, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
             k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
         } else if (c->gstream) {
 #define RPT_LAUNCH_SHADOW(W, COOP) k_traverse_shadow_gstream<STACK, W, COOP><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan)
@@ -766,25 +775,33 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     c->bvh_depth = depth;
     c->stack_cap = depth <= 15 ? 16 : (depth <= 23 ? 24 : 32);
     /* mid-size scenes: the top of the tree in LDS (k_traverse_top.h).  What one 1 024-thread workgroup per CU can hold beside its 16 stacks. */
-    s.top_tree = 0u; s.top_pairs = s.top_vecs = s.top_k2 = 0u; s.top_image = nullptr; s.top_gpairs = nullptr; s.top_leaves = nullptr;
+    s.top_tree = 0u; s.top_pairs = s.top_vecs = s.top_k2 = s.top_stack = s.top_leaf_words = 0u; s.top_image = nullptr; s.top_gpairs = nullptr; s.top_leaves = nullptr;
     c->top_coverage = 0.0;
     if (!s.lds_scene && !c->fat_leaves && s.fastdiv_ok && c->top_tree_mode != 0 && nn < (size_t)TOP_DEAD) {
-        const size_t stacks = (size_t)(TOP_THREADS / RPT_WAVE) * (size_t)c->stack_cap * RPT_WAVE * sizeof(uint16_t);
-        const size_t budget = RPT_LDS_PER_CU - stacks - 64u;
+        /* LDS of the one workgroup of a CU: stacks (depth + 1 entries per lane), refill scratch, pool, the leaf table if small, the image */
+        size_t n_leaves = 0;
+        for (size_t i = 0; i < nn; ++i) n_leaves += nodes[i].triangle_count != 0u;
+        const uint32_t stack_entries = std::min<uint32_t>(depth + 1u, (uint32_t)c->stack_cap);
+        const size_t leaf_words = n_leaves * 4u <= (size_t)RPT_TOP_LEAF_TABLE_BYTES ? ((n_leaves + 3u) & ~(size_t)3u) : 0u;
+        const size_t fixed = top_lds_bytes_rt(stack_entries, 0, leaf_words);
+        const size_t budget = RPT_LDS_PER_CU - fixed;
         uint32_t k_max = (uint32_t)(budget / 100u);
+        while (k_max > 1u && top_lds_bytes_rt(stack_entries, 6u * (size_t)k_max + (k_max + 3u) / 4u, leaf_words) > RPT_LDS_PER_CU) k_max -= 1u;
         if (c->top_pairs_cap && c->top_pairs_cap < k_max) k_max = c->top_pairs_cap;
         std::vector<float4> image, gpairs;
         std::vector<uint32_t> leaves;
         uint32_t K = 0, K2 = 0;
         if (build_top_image(nodes, nn, nt, k_max, c->top_order, image, gpairs, leaves, K, K2) &&
-            top_lds_bytes_rt(c->stack_cap, image.size()) <= RPT_LDS_PER_CU) {
+            top_lds_bytes_rt(stack_entries, image.size(), leaf_words) <= RPT_LDS_PER_CU) {
             HIP_TRY(c, c->top_image.alloc(std::max<size_t>(1, image.size())));
             HIP_TRY(c, c->top_gpairs.alloc(std::max<size_t>(1, gpairs.size())));
+            leaves.resize(std::max(leaves.size(), leaf_words), 0u);
             HIP_TRY(c, c->top_leaves.alloc(std::max<size_t>(1, leaves.size())));
             HIP_TRY(c, hipMemcpy(c->top_image.p, image.data(), image.size() * sizeof(float4), hipMemcpyHostToDevice));
             if (!gpairs.empty()) HIP_TRY(c, hipMemcpy(c->top_gpairs.p, gpairs.data(), gpairs.size() * sizeof(float4), hipMemcpyHostToDevice));
             if (!leaves.empty()) HIP_TRY(c, hipMemcpy(c->top_leaves.p, leaves.data(), leaves.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             s.top_tree = 1u; s.top_pairs = K; s.top_vecs = (uint32_t)image.size(); s.top_k2 = K2;
+            s.top_stack = stack_entries; s.top_leaf_words = (uint32_t)leaf_words;
             s.top_image = c->top_image.p; s.top_gpairs = c->top_gpairs.p; s.top_leaves = c->top_leaves.p;
             c->top_coverage = (double)K / (double)K2;
             int rc_attr = top_allow_big_lds(c);
