@@ -94,14 +94,6 @@ struct DevScene {
     uint32_t lds_scene;            /* the traversal image fits in RPT_LDS_SCENE_BYTES: traverse out of LDS */
     const float4 *lds_image;       /* LDS-resident traversal image (k_traverse.h SceneViewLds), lds_vecs float4 */
     uint32_t lds_pairs, lds_vecs, lds_root;
-    /* mid-size scenes: the top of the tree as an LDS image, the rest behind global bodies (k_traverse_top.h) */
-    uint32_t top_tree;             /* 0: not built / not used */
-    uint32_t top_pairs, top_vecs, top_k2;
-    uint32_t top_stack;            /* entries per lane of its stacks: the tree's depth + 1 */
-    uint32_t top_leaf_words;       /* > 0: the leaf table (that many words) is copied into LDS behind the image */
-    const float4 *top_image;       /* global copy of the image: 6 K plane records + K child-id words, top_vecs float4 */
-    const float4 *top_gpairs;      /* 4 x float4 per inner node below the image */
-    const uint32_t *top_leaves;    /* first | count << 24 per leaf */
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */
     uint32_t fastdiv_ok;           /* every node bound is 0 or in [2^-60, 2^40): exact fast division allowed */
     uint32_t textured;             /* some material has a texture flag set */

@@ -69,13 +69,6 @@ struct rpt_ctx {
     DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials, lds_image, light_rec;
     DevBuf<uint4> indices;
     DevBuf<float> tri_isect;
-    DevBuf<float4> top_image, top_gpairs;      /* top-of-tree walk of mid-size scenes (k_traverse_top.h) */
-    DevBuf<uint32_t> top_leaves;
-    int top_tree_mode = -1;                    /* RPT_TOP_TREE: -1 automatic, 0 never, 1 whenever the scene can be represented */
-    uint32_t top_pairs_cap = 0;                /* RPT_TOP_PAIRS: at most this many pairs in the image (0: what the LDS holds) */
-    int top_order = 0;                         /* RPT_TOP_ORDER: 0 best-first by parent box area, 1 breadth first */
-    uint32_t top_blocks = 256;                 /* persistent workgroups of the top-of-tree walks: one per CU */
-    double top_coverage = 0.0;                 /* share of the inner nodes the image holds */
     DevBuf<rpt_light_pick_entry> light_pick;
     DevBuf<uchar4> atlas;
     DevBuf<float4> skybox;

@@ -17,12 +17,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <queue>
 #include <vector>
 
 #include "rpt_ctx.h"
 #include "k_traverse.h"
-#include "k_traverse_top.h"
 #include "k_bvh_build.h"
 #include "k_shade.h"
 #include "k_sky_generate.h"
@@ -230,92 +228,6 @@ bool build_lds_image(const rpt_bvh_node *nodes, size_t nn, const std::vector<flo
     return true;
 }
 
-/* The top-of-tree image of a mid-size scene (k_traverse_top.h): nodes renumbered — parents of the K image pairs first, then the other
- * inner nodes, then the leaves — the image in the LDS walk's format (sign-selected plane records + child ids), a pair array for the
- * inner nodes below it and a (first | count << 24) word per leaf.  The K image pairs are chosen by a best-first descent from the root on
- * the surface area of the parent's box (order 0; camera independent, closed under "parent of") or breadth first (order 1).  Returns
- * false when the scene cannot be represented: 65 535 nodes or more (ids are 16 bits), a leaf as root, a leaf of 256+ triangles, a
- * triangle index of 2^24 or more, a box with lo > hi or a NaN bound. */
-bool build_top_image(const rpt_bvh_node *nodes, size_t nn, size_t nt, uint32_t k_max, int order, std::vector<float4> &image,
-                     std::vector<float4> &gpairs, std::vector<uint32_t> &leaves, uint32_t &K, uint32_t &K2) {
-    if (nn < 3 || nn >= (size_t)TOP_DEAD || nodes[0].triangle_count != 0u || k_max == 0u) return false;
-    std::vector<uint32_t> parent_area_rank;
-    for (size_t i = 0; i < nn; ++i) {
-        const rpt_bvh_node &n = nodes[i];
-        for (int k = 0; k < 3; ++k)
-            if (!(n.aabb_min[k] <= n.aabb_max[k])) return false;
-        if (n.triangle_count != 0u) {
-            if (n.triangle_count >= 256u || n.left_or_first >= (1u << 24) || (size_t)n.left_or_first + n.triangle_count > nt) return false;
-        } else if ((size_t)n.left_or_first + 1 >= nn || n.left_or_first == 0u) return false;
-    }
-    auto area = [&](uint32_t i) {
-        const rpt_bvh_node &n = nodes[i];
-        const double ex = (double)n.aabb_max[0] - n.aabb_min[0], ey = (double)n.aabb_max[1] - n.aabb_min[1], ez = (double)n.aabb_max[2] - n.aabb_min[2];
-        return ex * ey + ey * ez + ez * ex;
-    };
-    std::vector<uint32_t> tid(nn, TOP_DEAD);
-    std::vector<uint32_t> img_nodes;
-    if (order == 1) {
-        std::queue<uint32_t> fifo;
-        fifo.push(0u);
-        while (!fifo.empty() && img_nodes.size() < k_max) {
-            const uint32_t p = fifo.front(); fifo.pop();
-            tid[p] = (uint32_t)img_nodes.size();
-            img_nodes.push_back(p);
-            for (uint32_t c = nodes[p].left_or_first; c < nodes[p].left_or_first + 2u; ++c)
-                if (nodes[c].triangle_count == 0u) fifo.push(c);
-        }
-    } else {
-        typedef std::pair<double, uint32_t> Item;                /* largest area first; ties: the smaller node index */
-        auto worse = [](const Item &a, const Item &b) { return a.first < b.first || (a.first == b.first && a.second > b.second); };
-        std::priority_queue<Item, std::vector<Item>, decltype(worse)> heap(worse);
-        heap.push(Item(area(0u), 0u));
-        while (!heap.empty() && img_nodes.size() < k_max) {
-            const uint32_t p = heap.top().second; heap.pop();
-            tid[p] = (uint32_t)img_nodes.size();
-            img_nodes.push_back(p);
-            for (uint32_t c = nodes[p].left_or_first; c < nodes[p].left_or_first + 2u; ++c)
-                if (nodes[c].triangle_count == 0u) heap.push(Item(area(c), c));
-        }
-    }
-    K = (uint32_t)img_nodes.size();
-    uint32_t next = K;
-    std::vector<uint32_t> glb_nodes, leaf_nodes;
-    for (size_t i = 0; i < nn; ++i)
-        if (nodes[i].triangle_count == 0u && tid[i] == TOP_DEAD) { tid[i] = next++; glb_nodes.push_back((uint32_t)i); }
-    K2 = next;
-    for (size_t i = 0; i < nn; ++i)
-        if (nodes[i].triangle_count != 0u) { tid[i] = next++; leaf_nodes.push_back((uint32_t)i); }
-    if (next >= TOP_DEAD) return false;
-    const size_t id_vecs = ((size_t)K + 3) / 4;
-    image.assign(6 * (size_t)K + id_vecs, make_float4(0, 0, 0, 0));
-    uint32_t *ids = reinterpret_cast<uint32_t *>(image.data() + 6 * (size_t)K);
-    for (uint32_t q = 0; q < K; ++q) {
-        const uint32_t l = nodes[img_nodes[q]].left_or_first;
-        const rpt_bvh_node &L = nodes[l], &R = nodes[l + 1];
-        ids[q] = tid[l] | (tid[l + 1] << 16);
-        for (int k = 0; k < 3; ++k) {
-            image[(2 * k) * (size_t)K + q] = make_float4(L.aabb_min[k], R.aabb_min[k], L.aabb_max[k], R.aabb_max[k]);
-            image[(2 * k + 1) * (size_t)K + q] = make_float4(L.aabb_max[k], R.aabb_max[k], L.aabb_min[k], R.aabb_min[k]);
-        }
-    }
-    gpairs.assign(4 * glb_nodes.size(), make_float4(0, 0, 0, 0));
-    for (size_t g = 0; g < glb_nodes.size(); ++g) {
-        const uint32_t l = nodes[glb_nodes[g]].left_or_first;
-        const rpt_bvh_node &L = nodes[l], &R = nodes[l + 1];
-        uint32_t il = tid[l], ir = tid[l + 1];
-        float fl, fr;
-        memcpy(&fl, &il, 4); memcpy(&fr, &ir, 4);
-        gpairs[4 * g + 0] = make_float4(L.aabb_min[0], L.aabb_min[1], L.aabb_min[2], fl);
-        gpairs[4 * g + 1] = make_float4(L.aabb_max[0], L.aabb_max[1], L.aabb_max[2], 0.0f);
-        gpairs[4 * g + 2] = make_float4(R.aabb_min[0], R.aabb_min[1], R.aabb_min[2], fr);
-        gpairs[4 * g + 3] = make_float4(R.aabb_max[0], R.aabb_max[1], R.aabb_max[2], 0.0f);
-    }
-    leaves.resize(leaf_nodes.size());
-    for (size_t g = 0; g < leaf_nodes.size(); ++g) leaves[g] = nodes[leaf_nodes[g]].left_or_first | (nodes[leaf_nodes[g]].triangle_count << 24);
-    return true;
-}
-
 #ifndef RPT_GLOBAL_THREADS
 #define RPT_GLOBAL_THREADS 64      /* one wave: no scene staging to share, and a finished wave frees its stack at once (PBRTest traverse -5 %) */
 #endif
@@ -335,33 +247,6 @@ static uint32_t gstream_span(const rpt_ctx *c, uint32_t most) {
     const uint32_t wanted = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
     const uint32_t g = wanted < 1u ? 1u : (wanted > most ? most : wanted);
     return g * RPT_WAVE;
-}
-
-constexpr int TOP_THREADS = RPT_TOP_THREADS;
-constexpr size_t RPT_LDS_PER_CU = 160u * 1024u;      /* gfx950: a single workgroup may hold all of it */
-#ifndef RPT_TOP_LEAF_TABLE_BYTES
-#define RPT_TOP_LEAF_TABLE_BYTES 24576     /* the leaf table goes into LDS when it is at most this large (a dependent global load less per leaf step) */
-#endif
-static size_t top_lds_bytes_rt(uint32_t stack_entries, size_t top_vecs, size_t leaf_words) {
-    return top_vecs * sizeof(float4) + leaf_words * 4u + (size_t)(TOP_THREADS / RPT_WAVE) * ((size_t)stack_entries * RPT_WAVE * sizeof(uint16_t) + RPT_WAVE * 4u) + 16u;
-}
-/* more than 64 KB of dynamic LDS has to be asked for, per kernel */
-template <int STACK> static hipError_t top_allow_big_lds_for() {
-    hipError_t e = hipSuccess;
-    for (const void *f : {reinterpret_cast<const void *>(&k_traverse_nearest_tstream<STACK, TOP_THREADS, false>), reinterpret_cast<const void *>(&k_traverse_nearest_tstream<STACK, TOP_THREADS, true>),
-                          reinterpret_cast<const void *>(&k_traverse_shadow_tstream<STACK, TOP_THREADS, false>), reinterpret_cast<const void *>(&k_traverse_shadow_tstream<STACK, TOP_THREADS, true>)})
-        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RPT_LDS_PER_CU);
-    return e;
-}
-static int top_allow_big_lds(rpt_ctx *c) {
-    hipError_t e = c->stack_cap == 16 ? top_allow_big_lds_for<16>() : (c->stack_cap == 24 ? top_allow_big_lds_for<24>() : top_allow_big_lds_for<32>());
-    if (e != hipSuccess) { c->error = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e); return RPT_EHIP; }
-    return RPT_OK;
-}
-static uint32_t top_span(const rpt_ctx *c, uint32_t n) {
-    uint32_t span = c->stream_span ? c->stream_span : n / (c->top_blocks * 32u);
-    span = span < (uint32_t)TOP_THREADS ? (uint32_t)TOP_THREADS : (span > 8u * TOP_THREADS ? 8u * TOP_THREADS : span);
-    return (span + TOP_THREADS - 1) / TOP_THREADS * TOP_THREADS;
 }
 
 /* The nearest-hit traversal stage for the context's scene and state: which kernel, which grid.  Used by every iteration of a
@@ -386,14 +271,7 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration) {
         k_traverse_nearest_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span);
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
-    else if (c->scene.top_tree) {
-        /* one persistent 1 024-thread workgroup per CU: the top of the tree + 16 stacks fill its LDS */
-        const uint32_t span = top_span(c, c->n_slots), n_spans = (c->n_slots + span - 1) / span;
-        const uint32_t grid = n_spans < c->top_blocks ? n_spans : c->top_blocks;
-        const size_t lds = top_lds_bytes_rt(c->scene.top_stack, c->scene.top_vecs, c->scene.top_leaf_words);
-        if (c->scene.top_leaf_words) k_traverse_nearest_tstream<STACK, TOP_THREADS, true><<<grid, TOP_THREADS, lds, s>>>(c->scene, c->state, c->queues, iteration, span);
-        else k_traverse_nearest_tstream<STACK, TOP_THREADS, false><<<grid, TOP_THREADS, lds, s>>>(c->scene, c->state, c->queues, iteration, span);
-    } else if (c->gstream) {
+    else if (c->gstream) {
 #define RPT_LAUNCH_NEAREST(W, COOP) k_traverse_nearest_gstream<STACK, W, COOP><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n)
         if (c->fat_leaves) {
             if (stack_width == 16) RPT_LAUNCH_NEAREST(16, true); else if (stack_width == 21) RPT_LAUNCH_NEAREST(21, true);
@@ -443,14 +321,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
-        else if (c->scene.top_tree) {
-            const uint32_t span = top_span(c, q_positions), n_spans = (q_positions + span - 1) / span;
-            const uint32_t grid = n_spans < c->top_blocks ? n_spans : c->top_blocks;
-            const size_t lds = top_lds_bytes_rt(c->scene.top_stack, c->scene.top_vecs, c->scene.top_leaf_words);
-            if (c->scene.top_leaf_words) k_traverse_shadow_tstream<STACK, TOP_THREADS, true><<<grid, TOP_THREADS, lds, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
-            else k_traverse_shadow_tstream<STACK, TOP_THREADS, false><<<grid, TOP_THREADS, lds, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
-            k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
-        } else if (c->gstream) {
+        else if (c->gstream) {
 #define RPT_LAUNCH_SHADOW(W, COOP) k_traverse_shadow_gstream<STACK, W, COOP><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan)
             if (c->fat_leaves) {
                 if (stack_width == 16) RPT_LAUNCH_SHADOW(16, true); else if (stack_width == 21) RPT_LAUNCH_SHADOW(21, true);
@@ -576,10 +447,6 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (const char *e2 = getenv("RPT_LDS_STREAM")) c->lds_stream = e2[0] != '0';
     if (const char *e10 = getenv("RPT_MAX_SLOTS")) c->max_slots_budget = (uint64_t)std::max(1ll, atoll(e10));
     if (const char *e6 = getenv("RPT_GSTREAM")) c->gstream = e6[0] != '0';
-    if (const char *e = getenv("RPT_TOP_TREE")) c->top_tree_mode = atoi(e);
-    if (const char *e = getenv("RPT_TOP_PAIRS")) c->top_pairs_cap = (uint32_t)std::max(0, atoi(e));
-    if (const char *e = getenv("RPT_TOP_ORDER")) c->top_order = atoi(e);
-    if (const char *e = getenv("RPT_TOP_BLOCKS")) c->top_blocks = (uint32_t)std::max(1, atoi(e));
     if (const char *e11 = getenv("RPT_SHADE_COMPACT")) { c->shade_compact_mode = e11[0] != '0' ? 1 : 0; c->shade_compact = c->shade_compact_mode == 1; }
     if (const char *e12 = getenv("RPT_SHADE_COMPACT_AT")) c->shade_compact_at = atof(e12);
     if (const char *e9 = getenv("RPT_LDS_SHADOW_STREAM")) c->lds_shadow_stream = e9[0] != '0';
@@ -607,7 +474,6 @@ void rpt_destroy(rpt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rpt_comm_release(c);
     release_state(c);
-    c->top_image.release(); c->top_gpairs.release(); c->top_leaves.release();
     c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_isect.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->light_rec.release(); c->atlas.release(); c->skybox.release();
@@ -774,40 +640,6 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     s.skybox = DevImage{c->skybox.p, sw, sh};
     c->bvh_depth = depth;
     c->stack_cap = depth <= 15 ? 16 : (depth <= 23 ? 24 : 32);
-    /* mid-size scenes: the top of the tree in LDS (k_traverse_top.h).  What one 1 024-thread workgroup per CU can hold beside its 16 stacks. */
-    s.top_tree = 0u; s.top_pairs = s.top_vecs = s.top_k2 = s.top_stack = s.top_leaf_words = 0u; s.top_image = nullptr; s.top_gpairs = nullptr; s.top_leaves = nullptr;
-    c->top_coverage = 0.0;
-    if (!s.lds_scene && !c->fat_leaves && s.fastdiv_ok && c->top_tree_mode != 0 && nn < (size_t)TOP_DEAD) {
-        /* LDS of the one workgroup of a CU: stacks (depth + 1 entries per lane), refill scratch, pool, the leaf table if small, the image */
-        size_t n_leaves = 0;
-        for (size_t i = 0; i < nn; ++i) n_leaves += nodes[i].triangle_count != 0u;
-        const uint32_t stack_entries = std::min<uint32_t>(depth + 1u, (uint32_t)c->stack_cap);
-        const size_t leaf_words = n_leaves * 4u <= (size_t)RPT_TOP_LEAF_TABLE_BYTES ? ((n_leaves + 3u) & ~(size_t)3u) : 0u;
-        const size_t fixed = top_lds_bytes_rt(stack_entries, 0, leaf_words);
-        const size_t budget = RPT_LDS_PER_CU - fixed;
-        uint32_t k_max = (uint32_t)(budget / 100u);
-        while (k_max > 1u && top_lds_bytes_rt(stack_entries, 6u * (size_t)k_max + (k_max + 3u) / 4u, leaf_words) > RPT_LDS_PER_CU) k_max -= 1u;
-        if (c->top_pairs_cap && c->top_pairs_cap < k_max) k_max = c->top_pairs_cap;
-        std::vector<float4> image, gpairs;
-        std::vector<uint32_t> leaves;
-        uint32_t K = 0, K2 = 0;
-        if (build_top_image(nodes, nn, nt, k_max, c->top_order, image, gpairs, leaves, K, K2) &&
-            top_lds_bytes_rt(stack_entries, image.size(), leaf_words) <= RPT_LDS_PER_CU) {
-            HIP_TRY(c, c->top_image.alloc(std::max<size_t>(1, image.size())));
-            HIP_TRY(c, c->top_gpairs.alloc(std::max<size_t>(1, gpairs.size())));
-            leaves.resize(std::max(leaves.size(), leaf_words), 0u);
-            HIP_TRY(c, c->top_leaves.alloc(std::max<size_t>(1, leaves.size())));
-            HIP_TRY(c, hipMemcpy(c->top_image.p, image.data(), image.size() * sizeof(float4), hipMemcpyHostToDevice));
-            if (!gpairs.empty()) HIP_TRY(c, hipMemcpy(c->top_gpairs.p, gpairs.data(), gpairs.size() * sizeof(float4), hipMemcpyHostToDevice));
-            if (!leaves.empty()) HIP_TRY(c, hipMemcpy(c->top_leaves.p, leaves.data(), leaves.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            s.top_tree = 1u; s.top_pairs = K; s.top_vecs = (uint32_t)image.size(); s.top_k2 = K2;
-            s.top_stack = stack_entries; s.top_leaf_words = (uint32_t)leaf_words;
-            s.top_image = c->top_image.p; s.top_gpairs = c->top_gpairs.p; s.top_leaves = c->top_leaves.p;
-            c->top_coverage = (double)K / (double)K2;
-            int rc_attr = top_allow_big_lds(c);
-            if (rc_attr) return rc_attr;
-        }
-    }
     c->has_scene = true;
     return RPT_OK;
 }

@@ -94,20 +94,17 @@ def test_ray_parity_nearest_and_any(renderer, oracle, world, scene):
 
 @pytest.mark.parametrize("scene,knob", [("DarkCornell", None), ("DarkCornell", "RPT_LDS_STREAM=0"), ("DarkCornell", "RPT_NO_LDS_SCENE=1"),
                                         ("VeachMIS", None), ("VeachMIS", "RPT_GSTREAM=0"), ("FurnaceTest", None), ("PBRTest", None),
-                                        ("VeachMIS", "RPT_TOP_TREE=0"), ("VeachMIS", "RPT_TOP_TREE=1,RPT_TOP_PAIRS=37"), ("VeachMIS", "RPT_TOP_TREE=1,RPT_TOP_ORDER=1"),
-                                        ("PBRTest", "RPT_TOP_TREE=0"), ("FurnaceTest", "RPT_TOP_TREE=1,RPT_TOP_PAIRS=1"),
                                         ("PBRTest", "RPT_COOP_LEAVES=1"), ("deep_bvh", None), ("deep_bvh", "RPT_COOP_LEAVES=0"),
                                         ("deep_bvh", "RPT_STACK_BITS=21"), ("scatter", None)])
 def test_ray_parity_through_the_production_traversal_stage(monkeypatch, hipmod, oracle, rpt, world, scene, knob):
     """intersect_front_to_back (intersection.rs:177-234) per ray — t, triangle, backface bit for bit against the oracle — through
     the kernels rpt_render itself launches (rpt_debug_trace_rays_production): the persistent LDS-pool stream for DarkCornell, the
     streamed global-memory walks for the others (without the cooperative leaf code for thin-leaf scenes, with it for the fat-leaf
-    stand-in, and each forced the other way), the one-shot kernels behind their knobs, 21-bit stack entries; the top-of-tree walks of
-    mid-size scenes (k_traverse_top.h: VeachMIS, FurnaceTest, PBRTest by default) with full, 37-pair, one-pair and breadth-first images.  The rays are
+    stand-in, and each forced the other way), the one-shot kernels behind their knobs, 21-bit stack entries.  The rays are
     incoherent (random origins inside the scene, random directions) and include axis-parallel directions with exact zeros,
     which leave the exact-division fast path."""
-    for one in (knob.split(",") if knob else ()):
-        k, v = one.split("=")
+    if knob:
+        k, v = knob.split("=")
         monkeypatch.setenv(k, v)
     if scene == "deep_bvh":
         from scenes import deep_bvh_scene
@@ -619,8 +616,7 @@ def test_host_dispatch_trace_gpu_furnace(rpt):
                                   "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MAX_BLOCKS=7", "RPT_STREAM_SPAN=1024", "RPT_GSTREAM=0",
                                   "RPT_SHADE_COMPACT=1", "RPT_LDS_SHADOW_STREAM=0", "RPT_MAX_SLOTS=65536",
                                   "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=3",
-                                  "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=5,RPT_SKY_WIDE_LIMIT=1000000", "RPT_SKY_STRIDED=0", "RPT_GSTREAM=1,RPT_STACK_BITS=21", "RPT_GSTREAM=1,RPT_STACK_BITS=24", "RPT_GSTREAM=1,RPT_STACK_BITS=32",
-                                  "RPT_TOP_TREE=0", "RPT_TOP_TREE=1,RPT_TOP_PAIRS=100", "RPT_TOP_TREE=1,RPT_TOP_PAIRS=3,RPT_TOP_ORDER=1", "RPT_TOP_TREE=1,RPT_TOP_BLOCKS=3"])
+                                  "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=5,RPT_SKY_WIDE_LIMIT=1000000", "RPT_SKY_STRIDED=0", "RPT_GSTREAM=1,RPT_STACK_BITS=21", "RPT_GSTREAM=1,RPT_STACK_BITS=24", "RPT_GSTREAM=1,RPT_STACK_BITS=32"])
 def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world, knob):
     """README: every tuning knob leaves the image bit-identical (they select kernels / schedules, never arithmetic)."""
     W, H, spp = 160, 96, 6
@@ -628,7 +624,7 @@ def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world
     seeds = rpt.blue_noise_seeds(W, H)
 
     # (the global-memory walk / a scene open to the sky / the LDS walk)
-    scene = "VeachMIS" if knob.startswith(("RPT_GSTREAM", "RPT_TOP_TREE")) else "PBRTest" if knob.startswith("RPT_SKY_STRIDED") else "DarkCornell"
+    scene = "VeachMIS" if knob.startswith("RPT_GSTREAM") else "PBRTest" if knob.startswith("RPT_SKY_STRIDED") else "DarkCornell"
 
     def render():
         r = hipmod.Renderer(0)
