@@ -987,8 +987,8 @@ __host__ __device__ constexpr int gstream_rays_nearest(int stack, int width) {
                                       stand-in 2 343 Mrays/s without, 2 008 / 2 164 / 2 099 with it at 8 (spilling) / 7 / 6 waves per SIMD */
 #endif
 __host__ __device__ constexpr int gstream_waves(int stack, int width, bool coop) {
-    return (width <= 21 || (width == 24 && stack <= 24)) ? (coop ? (width == 21 ? 7 : RPT_GSTREAM_WAVES_COOP) : RPT_GSTREAM_WAVES) : 1;   /* (where LDS allows it at all;
-                                                             fat leaves + 21-bit entries: 8 waves would spill 18 registers) */
+    return (width <= 21 || (width == 24 && stack <= 24)) ? (coop ? (width >= 21 ? 7 : RPT_GSTREAM_WAVES_COOP) : RPT_GSTREAM_WAVES) : 1;   /* (where LDS allows it at all;
+                                                             fat leaves + 21-bit entries: 8 waves would spill 18 registers, + 24-bit entries: 3) */
 }
 /* (8 waves per SIMD also need <= 80 SGPRs, see RPT_LDS_WALK_SGPRS: the builds the shipped scenes and the stand-ins use have 78; some of the
  * others — 21- and 32-bit stack entries — have 81 and run 7.  amdgpu_num_sgpr takes a literal, not a template expression, so it cannot follow
