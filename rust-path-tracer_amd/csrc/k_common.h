@@ -61,7 +61,13 @@ __device__ __forceinline__ float len3(F3 a) { return rptm::sqrtr(dot3(a, a)); }
 __device__ __forceinline__ F3 norm3(F3 a) { return a * (1.0f / len3(a)); }
 __device__ __forceinline__ F3 lerp3(F3 a, F3 b, float s) { return a + ((b - a) * s); }
 __device__ __forceinline__ bool finite3(F3 a) { return rptm::finiter(a.x) && rptm::finiter(a.y) && rptm::finiter(a.z); }
-__device__ __forceinline__ F3 mask_nan3(F3 a) { return finite3(a) ? a : f3s(0.0f); }   /* util.rs:271-277 */
+/* util.rs:271-277: v if finite, else zero — as ONE select of a bit mask and three ands: three selects on one condition compile to
+ * back-to-back VOP2 v_cndmask on vcc, which gfx950 issues at ~30 cycles each (tools/microbench/valu_rates.hip) */
+__device__ __forceinline__ F3 mask_nan3(F3 a) {
+    uint32_t m = finite3(a) ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));          /* opaque: the optimiser would fold "x & (c ? ~0 : 0)" back into three selects */
+    return F3{rptm::u2f(rptm::f2u(a.x) & m), rptm::u2f(rptm::f2u(a.y) & m), rptm::u2f(rptm::f2u(a.z) & m)};
+}
 __device__ __forceinline__ F3 xyz4(float4 v) { return F3{v.x, v.y, v.z}; }
 
 /* ---- scene (read-only) ---------------------------------------------------- */

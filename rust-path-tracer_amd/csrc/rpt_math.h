@@ -210,12 +210,14 @@ RPT_HD void sincosr(float xf, float &s, float &c) {
     int q;
     double r = reduce_pio2((double)xf, q);
     double sr = sin_poly(r), cr = cos_poly(r);
-    double sv = (q & 1) ? cr : sr;
-    double cv = (q & 1) ? sr : cr;
-    if (q & 2) sv = -sv;
-    if ((q + 1) & 2) cv = -cv;
-    s = (float)sv;
-    c = (float)cv;
+    /* The quadrant fix-up on the ROUNDED floats, as integer logic: rounding to nearest commutes with negation and with picking one of the
+     * two values, so the result is the same float as selecting / negating the doubles first — and the four back-to-back VOP2 v_cndmask (vcc)
+     * a select of two doubles compiles to issue at ~30 cycles each on gfx950 (tools/microbench/valu_rates.hip: "cmp; 32 cnd vcc"), xor / and
+     * at 2.  swap: (a, b) -> (a ^ d, b ^ d) with d = (a ^ b) & mask. */
+    const uint32_t sb = f2u((float)sr), cb = f2u((float)cr);
+    const uint32_t d = (sb ^ cb) & (0u - ((uint32_t)q & 1u));
+    s = u2f((sb ^ d) ^ (((uint32_t)q & 2u) << 30));
+    c = u2f((cb ^ d) ^ ((((uint32_t)q + 1u) & 2u) << 30));
 }
 RPT_HD float sinr(float x) { float s, c; sincosr(x, s, c); return s; }
 RPT_HD float cosr(float x) { float s, c; sincosr(x, s, c); return c; }

@@ -159,7 +159,36 @@ DEFINE_MASKED(k_f64_lo16, "0xffff", "0", P32("v_fma_f64 v", ", v[56:57], v[58:59
 DEFINE_MASKED(k_rcp_lo32, "-1", "0", R32("v_rcp_f32 v", ", %0"))
 DEFINE_MASKED(k_rcp_lo16, "0xffff", "0", R32("v_rcp_f32 v", ", %0"))
 
-struct Case { const char *name; void (*fn)(float *); };
+
+// ---- round 4: do the fma-class pipe (fma / mul / add / mov: ~2 cycles per wave64 instruction) and the "other" pipe (min / max3 / cmp /
+// cndmask / integer: ~4) overlap ACROSS waves, or only between ADJACENT instructions of one wave?  The traversal's inner step is 48
+// fma-class instructions in two runs of 24 followed by runs of max3 / min3 / cmp: if a run of one class blocks its pipe for every wave,
+// re-ordering the body (sched_group_barrier) would pay.  Same 72 instructions, blocked (48 fma, then 24 min) vs interleaved (2 fma, 1 min).
+#define F(n) "v_fma_f32 v" #n ", %0, %1, %2\n"
+#define M(n) "v_min_f32 v" #n ", %0, %1\n"
+#define F8 F(40) F(41) F(42) F(43) F(44) F(45) F(46) F(47)
+#define M8 M(48) M(49) M(50) M(51) M(52) M(53) M(54) M(55)
+DEFINE_KERNEL(k_blocked_48_24, F8 F8 F8 F8 F8 F8 M8 M8 M8, CL)
+#define FFM(a, b, c) F(a) F(b) M(c)
+DEFINE_KERNEL(k_inter_2_1, FFM(40, 41, 48) FFM(42, 43, 49) FFM(44, 45, 50) FFM(46, 47, 51) FFM(40, 41, 52) FFM(42, 43, 53) FFM(44, 45, 54) FFM(46, 47, 55)
+                           FFM(40, 41, 48) FFM(42, 43, 49) FFM(44, 45, 50) FFM(46, 47, 51) FFM(40, 41, 52) FFM(42, 43, 53) FFM(44, 45, 54) FFM(46, 47, 55)
+                           FFM(40, 41, 48) FFM(42, 43, 49) FFM(44, 45, 50) FFM(46, 47, 51) FFM(40, 41, 52) FFM(42, 43, 53) FFM(44, 45, 54) FFM(46, 47, 55), CL)
+// the same with the dependences of a slab test: each min consumes the two fma results before it (interleaved), or all at the end (blocked)
+#define MD(d, a, b) "v_min_f32 v" #d ", v" #a ", v" #b "\n"
+DEFINE_KERNEL(k_blocked_dep, F8 F8 F8 F8 F8 F8 MD(48, 40, 41) MD(49, 42, 43) MD(50, 44, 45) MD(51, 46, 47) MD(52, 40, 41) MD(53, 42, 43) MD(54, 44, 45) MD(55, 46, 47)
+                             MD(48, 40, 41) MD(49, 42, 43) MD(50, 44, 45) MD(51, 46, 47) MD(52, 40, 41) MD(53, 42, 43) MD(54, 44, 45) MD(55, 46, 47)
+                             MD(48, 40, 41) MD(49, 42, 43) MD(50, 44, 45) MD(51, 46, 47) MD(52, 40, 41) MD(53, 42, 43) MD(54, 44, 45) MD(55, 46, 47), CL)
+#define FFMD(a, b, c) F(a) F(b) MD(c, a, b)
+DEFINE_KERNEL(k_inter_dep, FFMD(40, 41, 48) FFMD(42, 43, 49) FFMD(44, 45, 50) FFMD(46, 47, 51) FFMD(40, 41, 52) FFMD(42, 43, 53) FFMD(44, 45, 54) FFMD(46, 47, 55)
+                           FFMD(40, 41, 48) FFMD(42, 43, 49) FFMD(44, 45, 50) FFMD(46, 47, 51) FFMD(40, 41, 52) FFMD(42, 43, 53) FFMD(44, 45, 54) FFMD(46, 47, 55)
+                           FFMD(40, 41, 48) FFMD(42, 43, 49) FFMD(44, 45, 50) FFMD(46, 47, 51) FFMD(40, 41, 52) FFMD(42, 43, 53) FFMD(44, 45, 54) FFMD(46, 47, 55), CL)
+// software-pipelined: the min of pair k issued after the fmas of pair k + 1 (what a scheduler would emit)
+#define FFMP(a, b, c, pa, pb) F(a) F(b) MD(c, pa, pb)
+DEFINE_KERNEL(k_inter_dep_lag, FFMP(40, 41, 48, 46, 47) FFMP(42, 43, 49, 40, 41) FFMP(44, 45, 50, 42, 43) FFMP(46, 47, 51, 44, 45) FFMP(40, 41, 52, 46, 47) FFMP(42, 43, 53, 40, 41) FFMP(44, 45, 54, 42, 43) FFMP(46, 47, 55, 44, 45)
+                               FFMP(40, 41, 48, 46, 47) FFMP(42, 43, 49, 40, 41) FFMP(44, 45, 50, 42, 43) FFMP(46, 47, 51, 44, 45) FFMP(40, 41, 52, 46, 47) FFMP(42, 43, 53, 40, 41) FFMP(44, 45, 54, 42, 43) FFMP(46, 47, 55, 44, 45)
+                               FFMP(40, 41, 48, 46, 47) FFMP(42, 43, 49, 40, 41) FFMP(44, 45, 50, 42, 43) FFMP(46, 47, 51, 44, 45) FFMP(40, 41, 52, 46, 47) FFMP(42, 43, 53, 40, 41) FFMP(44, 45, 54, 42, 43) FFMP(46, 47, 55, 44, 45), CL)
+
+struct Case { const char *name; void (*fn)(float *); int n_instr = 32; };
 
 int main(int argc, char **argv) {
     int wps = argc > 1 ? atoi(argv[1]) : 2;           // waves per SIMD
@@ -180,6 +209,8 @@ int main(int argc, char **argv) {
         {"v_fma_f32 exec=lo32", k_fma_lo32}, {"v_fma_f32 exec=lo16", k_fma_lo16}, {"v_fma_f32 exec=hi32", k_fma_hi32}, {"v_fma_f32 exec=0x5555..", k_fma_alt}, {"v_fma_f32 exec=1", k_fma_one},
         {"v_min_f32 exec=lo32", k_min_lo32}, {"v_min_f32 exec=lo16", k_min_lo16}, {"v_min_f32 exec=0x5555..", k_min_alt},
         {"v_fma_f64 exec=lo32", k_f64_lo32}, {"v_fma_f64 exec=lo16", k_f64_lo16}, {"v_rcp_f32 exec=lo32", k_rcp_lo32}, {"v_rcp_f32 exec=lo16", k_rcp_lo16},
+        {"72: 48 fma then 24 min (independent)", k_blocked_48_24, 72}, {"72: 24 x (2 fma, 1 min) (independent)", k_inter_2_1, 72},
+        {"72: 48 fma then 24 min of their results", k_blocked_dep, 72}, {"72: 24 x (2 fma, min of the two)", k_inter_dep, 72}, {"72: 24 x (2 fma, min of the previous two)", k_inter_dep_lag, 72},
         {"Horner step f64 (1 v_fma_f64)", k_horner_f64}, {"Horner step double-float (16 f32)", k_horner_df32},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -198,7 +229,7 @@ int main(int argc, char **argv) {
         float base = time_of(k_fma_f32);
         float t = time_of(c.fn);
         float base2 = time_of(k_fma_f32);
-        double rel = t / (0.5 * (base + base2)) * 4.0;
+        double rel = t / (0.5 * (base + base2)) * 4.0 * 32.0 / c.n_instr;
         printf("%-34s %8.3f ms (fma %.3f/%.3f)  %6.2f cycles/wave-instr (v_fma_f32 := 4)\n", c.name, t, base, base2, rel);
     }
     return 0;
