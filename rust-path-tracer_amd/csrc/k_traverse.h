@@ -152,6 +152,63 @@ struct SceneViewGlobalT {
 };
 typedef SceneViewGlobalT<true> SceneViewGlobal;
 
+/* The streamed global-memory walks read a PAIR array instead (round 4).  Counters first (profiles/r04_*_pmc_ta.txt): these walks keep the CU's
+ * texture-address unit busy 83-92 % of the time (TA_TA_BUSY / TCP_GATE_EN1: VeachMIS shadow 92 %, PBRTest nearest 91 %; the LDS walk 12 %) at
+ * ~20 TA cycles per 16-byte wave load — that unit, 64 bytes per clock and CU, is what bounds them, and a visit costs it 4 x 16 bytes per lane: the
+ * two 32-byte nodes as uploaded, 48 bytes of boxes and 16 of (count, child / first) words.  Here a child pair is ONE 64-byte-aligned record
+ *     q0 = (L.lo.xyz, L.hi.x)  q1 = (L.hi.yz, R.lo.xy)  q2 = (R.lo.z, R.hi.xyz)  [8 bytes unused]  (link L, link R)
+ * with link = triangle_count << 24 | left child / first triangle: three 16-byte loads and one 8-byte load,
+ * 56 instead of 64 bytes per lane and visit through the TA, and a popped node index costs one 4-byte load from `links[]` instead of two.  Pair p = the children (2p + 1, 2p + 2) of the
+ * reference's node pool (its builder allocates children in pairs after the root); a scene whose pool is not pair-shaped, or with a leaf of 255+
+ * triangles or 2^24+ triangles, keeps the one-shot generic walks.  The node is one register: an inner node is its left child's index (< 2^24). */
+template <bool COOP>
+struct SceneViewPairsT {
+    static constexpr bool kCoopLeaves = COOP;
+    const float4 *pairs;          /* 64 bytes per pair: 3 x float4 of boxes, 8 bytes unused, (link L, link R) in the LAST 8 bytes — at offset 48, 16-byte aligned,
+                                     the compiler widens the 8-byte load to a 16-byte one and the record costs the TA 64 bytes again */
+    const uint2 *plinks;          /* (unused) */
+    const uint32_t *links;
+    const float *tri_isect;
+    typedef uint32_t Cur;
+    __device__ __forceinline__ Cur root() const { return links[0]; }
+    __device__ __forceinline__ static bool is_inner(Cur c) { return c < (1u << 24); }
+    __device__ __forceinline__ static bool is_leaf(Cur c) { return c + 1u > (1u << 24); }          /* (the dead word wraps to 0) */
+    __device__ __forceinline__ static Cur dead() { return 0xffffffffu; }
+    __device__ __forceinline__ static uint32_t leaf_count(Cur c) { return c >> 24; }
+    __device__ __forceinline__ static uint32_t leaf_first(Cur c) { return c & 0xffffffu; }
+    __device__ __forceinline__ void children(Cur c, float4 &lmin, float4 &lmax, float4 &rmin, float4 &rmax) const {
+        const float4 *p = pairs + 4u * (c >> 1);
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2];
+        uint2 lk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(p) + 56);
+        asm volatile("" : "+v"(lk.x), "+v"(lk.y));      /* issued WITH the boxes: left alone the compiler sinks this load behind the slab tests, a second round trip */
+        lmin = make_float4(q0.x, q0.y, q0.z, __uint_as_float(lk.x));
+        lmax = make_float4(q0.w, q1.x, q1.y, 0.0f);
+        rmin = make_float4(q1.z, q1.w, q2.x, __uint_as_float(lk.y));
+        rmax = make_float4(q2.y, q2.z, q2.w, 0.0f);
+    }
+    __device__ __forceinline__ static Cur enter(bool right, float4 lmin, float4, float4 rmin, float4) { return __float_as_uint(right ? rmin.w : lmin.w); }
+    __device__ __forceinline__ uint32_t far_entry(Cur c, bool far_is_left) const { return far_is_left ? c : c + 1u; }
+    __device__ __forceinline__ Cur from_entry(uint32_t e) const { return links[e]; }
+    __device__ __forceinline__ void edges(uint32_t ti, F3 &e1, F3 &e2) const {
+        const float *p = tri_isect + 9u * (size_t)ti;
+        e1 = f3(p[0], p[1], p[2]); e2 = f3(p[3], p[4], p[5]);
+    }
+    __device__ __forceinline__ F3 corner(uint32_t ti) const {
+        const float *p = tri_isect + 9u * (size_t)ti + 6u;
+        return f3(p[0], p[1], p[2]);
+    }
+};
+#ifndef RPT_GSTREAM_PAIRS
+#define RPT_GSTREAM_PAIRS 1
+#endif
+#if RPT_GSTREAM_PAIRS
+#define RPT_GSTREAM_VIEW(COOP, sc) SceneViewPairsT<COOP>{(sc).gpairs, (sc).gplinks, (sc).glinks, (sc).tri_isect}
+template <bool COOP> struct GstreamView { typedef SceneViewPairsT<COOP> type; };
+#else
+#define RPT_GSTREAM_VIEW(COOP, sc) SceneViewGlobalT<COOP>{(sc).nodes, (sc).tri_isect}
+template <bool COOP> struct GstreamView { typedef SceneViewGlobalT<COOP> type; };
+#endif
+
 /* The LDS-resident image of a small scene, built once at upload (rpt_hip.hip, build_lds_image) and copied into
  * LDS by every workgroup.  Measured on MI355X (tools/microbench/valu_rates.hip, SQ counters in profiles/): the
  * traversal kernel is VALU-ISSUE bound — fma/mul/add issue in ~2 cycles per wave64 instruction, everything else
@@ -1028,8 +1085,8 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
         raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
         atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE], (unsigned long long)count);
     }
-    typedef SceneViewGlobalT<COOP> View;
-    const View view{sc.nodes, sc.tri_isect};
+    typedef typename GstreamView<COOP>::type View;
+    const View view = RPT_GSTREAM_VIEW(COOP, sc);
     auto stack = lds_stack.column(lane);
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     Walk<View> w;
@@ -1122,8 +1179,8 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
     if (begin >= n) return;
     const uint32_t end = begin + SPAN < n ? begin + SPAN : n;
     {
-        typedef SceneViewGlobalT<COOP> View;
-        const View view{sc.nodes, sc.tri_isect};
+        typedef typename GstreamView<COOP>::type View;
+        const View view = RPT_GSTREAM_VIEW(COOP, sc);
         auto stack = lds_stack.column(lane);
         F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
         float max_t = 0.0f;

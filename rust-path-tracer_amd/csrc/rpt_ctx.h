@@ -69,6 +69,9 @@ struct rpt_ctx {
     DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials, lds_image, light_rec;
     DevBuf<uint4> indices;
     DevBuf<float> tri_isect;
+    DevBuf<float4> gpairs;                     /* pair records + links of the streamed global-memory walks (k_traverse.h SceneViewPairsT) */
+    DevBuf<uint32_t> glinks;
+    DevBuf<uint2> gplinks;
     DevBuf<rpt_light_pick_entry> light_pick;
     DevBuf<uchar4> atlas;
     DevBuf<float4> skybox;

@@ -271,7 +271,7 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration) {
         k_traverse_nearest_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span);
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
-    else if (c->gstream) {
+    else if (c->gstream && (!RPT_GSTREAM_PAIRS || c->scene.gpairs)) {
 #define RPT_LAUNCH_NEAREST(W, COOP) k_traverse_nearest_gstream<STACK, W, COOP><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n)
         if (c->fat_leaves) {
             if (stack_width == 16) RPT_LAUNCH_NEAREST(16, true); else if (stack_width == 21) RPT_LAUNCH_NEAREST(21, true);
@@ -321,7 +321,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
-        else if (c->gstream) {
+        else if (c->gstream && (!RPT_GSTREAM_PAIRS || c->scene.gpairs)) {
 #define RPT_LAUNCH_SHADOW(W, COOP) k_traverse_shadow_gstream<STACK, W, COOP><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan)
             if (c->fat_leaves) {
                 if (stack_width == 16) RPT_LAUNCH_SHADOW(16, true); else if (stack_width == 21) RPT_LAUNCH_SHADOW(21, true);
@@ -474,6 +474,7 @@ void rpt_destroy(rpt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rpt_comm_release(c);
     release_state(c);
+    c->gpairs.release(); c->glinks.release(); c->gplinks.release();
     c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_isect.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->light_rec.release(); c->atlas.release(); c->skybox.release();
@@ -630,6 +631,39 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         }
     }
     if (const char *env = getenv("RPT_NO_LDS_SCENE"); env && env[0] == '1') s.lds_scene = 0u;
+    /* pair records for the streamed global-memory walks (k_traverse.h SceneViewPairsT); a pool they cannot express keeps the one-shot walks */
+    s.gpairs = nullptr; s.glinks = nullptr; s.gplinks = nullptr;
+    {
+        bool ok = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
+        std::vector<uint32_t> links(nn);
+        for (size_t i = 0; i < nn && ok; ++i) {
+            const rpt_bvh_node &n = nodes[i];
+            if (n.triangle_count >= 255u || n.left_or_first >= (1u << 24)) ok = false;
+            else if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) ok = false;
+            links[i] = (n.triangle_count << 24) | n.left_or_first;
+        }
+        if (ok) {
+            const size_t P = (nn - 1) / 2;
+            std::vector<float4> pairs(4 * P, make_float4(0, 0, 0, 0));
+            std::vector<uint2> plinks(1);
+            for (size_t p = 0; p < P; ++p) {
+                const rpt_bvh_node &L = nodes[2 * p + 1], &R = nodes[2 * p + 2];
+                float fl, fr;
+                memcpy(&fl, &links[2 * p + 1], 4); memcpy(&fr, &links[2 * p + 2], 4);
+                pairs[4 * p + 0] = make_float4(L.aabb_min[0], L.aabb_min[1], L.aabb_min[2], L.aabb_max[0]);
+                pairs[4 * p + 1] = make_float4(L.aabb_max[1], L.aabb_max[2], R.aabb_min[0], R.aabb_min[1]);
+                pairs[4 * p + 2] = make_float4(R.aabb_min[2], R.aabb_max[0], R.aabb_max[1], R.aabb_max[2]);
+                pairs[4 * p + 3] = make_float4(0.0f, 0.0f, fl, fr);
+            }
+            HIP_TRY(c, c->gpairs.alloc(std::max<size_t>(1, pairs.size())));
+            HIP_TRY(c, c->gplinks.alloc(std::max<size_t>(1, plinks.size())));
+            HIP_TRY(c, c->glinks.alloc(nn));
+            HIP_TRY(c, hipMemcpy(c->gpairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->gplinks.p, plinks.data(), plinks.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->glinks.p, links.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice));
+            s.gpairs = c->gpairs.p; s.glinks = c->glinks.p; s.gplinks = c->gplinks.p;
+        }
+    }
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
     s.fastdiv_ok = 1u;
     for (size_t i = 0; i < nn && s.fastdiv_ok; ++i)

@@ -699,14 +699,15 @@ def test_randomised_configurations_equal_the_oracle(seed):
     assert fuzz.main(n_cases=14, seed=seed) == 0
 
 
-@pytest.mark.parametrize("nee", [0, 1])
-def test_unsplittable_fat_leaf_parity(renderer, oracle, rpt, nee):
-    """300 triangles with one centroid stay ONE leaf (tests/scenes.py fat_leaf_scene): too fat for the LDS image, so the
-    global-memory walk with the wave-cooperative leaf test over several rounds of 64 lanes — image, rng and ray counts
-    equal the oracle's, and so does every single ray."""
+@pytest.mark.parametrize("nee,n_stack", [(0, 220), (1, 220), (1, 300)])
+def test_unsplittable_fat_leaf_parity(renderer, oracle, rpt, nee, n_stack):
+    """n_stack triangles with one centroid stay ONE leaf (tests/scenes.py fat_leaf_scene): too fat for the LDS image.  220: the streamed
+    global-memory walk with the wave-cooperative leaf test over several rounds of 64 lanes; 300: more than the 254 triangles a link of the
+    walk's pair records can count (k_traverse.h SceneViewPairsT), so the scene keeps the one-shot generic walks over the reference's own node
+    array — image, rng and ray counts equal the oracle's, and so does every single ray."""
     from scenes import fat_leaf_scene
-    w = fat_leaf_scene()
-    assert w.nodes["triangle_count"].max() >= 128
+    w = fat_leaf_scene(n_stack)
+    assert w.nodes["triangle_count"].max() == n_stack
     W, H, spp = 96, 80, 4
     cfg = rpt.default_config(W, H, nee=nee, cam_position=(0.0, 1.4, -0.8, 0.0))
     seeds = rpt.blue_noise_seeds(W, H)
