@@ -133,6 +133,9 @@ def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipe
                 "units_per_launch": round(units, 1), "units_are": unit_key, "algorithmic_bytes_per_unit": bytes_per_unit,
                 "stage_ms": {k: round(v, 3) for k, v in kms.items()},
                 "stage_launches": {k: int(v) for k, v in klaunch.items()}}
+    if tj and dominant in tj.get("stages", {}) and tj["stages"][dominant].get("ta"):
+        # the streamed global-memory walks are bound by the CU's texture-address unit, not by HBM: its busy share from the kept TA pass
+        roofline["ta"] = tj["stages"][dominant]["ta"]
     simds = cus * 4
     if valu:
         # not an HBM kernel: the VALU issue figures of the kept SQ pass (same fingerprint rule as `traffic`), and from them
