@@ -203,6 +203,8 @@ struct Counters {
     uint8_t *event_log = nullptr;   /* analysis hook, see log_event */
     uint32_t event_cap = 0, event_len = 0;
     uint64_t *hist_nearest = nullptr, *hist_any = nullptr;   /* analysis hook: node pops per node (oracle_node_histogram) */
+    uint32_t *node_log = nullptr;                            /* analysis hook: the popped node indices of one walk (oracle_trace_nodes) */
+    uint32_t node_cap = 0, node_len = 0;
 };
 
 /* ------------------------------------------------------------------------ */
@@ -298,6 +300,7 @@ TraceResult intersect_front_to_back(const Scene &sc, V3 ro, V3 rd, float max_t, 
         cnt.node_pops++;
         log_event(cnt, node.triangle_count > 0 ? 1 : 0);
         if (uint64_t *h = NEAREST_HIT ? cnt.hist_nearest : cnt.hist_any) h[node_index] += 1;
+        if (cnt.node_log) { if (cnt.node_len < cnt.node_cap) cnt.node_log[cnt.node_len] = node_index; cnt.node_len += 1; }
         if (node.triangle_count > 0) {
             for (uint32_t i = 0; i < node.triangle_count; ++i) {
                 uint32_t triangle_index = node.left_or_first + i;
@@ -984,6 +987,21 @@ int oracle_trace_events(const oracle_scene *scene, size_t n, const float *origin
         cnt.event_len = 0;
         intersect_front_to_back<true>(sc, xyz(origins + 3 * i), xyz(dirs + 3 * i), 0.0f, cnt);
         lengths[i] = cnt.event_len;
+    }
+    return 0;
+}
+
+/* Analysis hook (tools/uniform_visit_share.py): per ray the sequence of popped node indices of the nearest-hit walk. */
+int oracle_trace_nodes(const oracle_scene *scene, size_t n, const float *origins, const float *dirs, uint32_t *nodes_out, uint32_t max_nodes,
+                       uint32_t *lengths) {
+    Scene sc = make_scene(scene);
+    Counters cnt;
+    for (size_t i = 0; i < n; ++i) {
+        cnt.node_log = nodes_out + i * (size_t)max_nodes;
+        cnt.node_cap = max_nodes;
+        cnt.node_len = 0;
+        intersect_front_to_back<true>(sc, xyz(origins + 3 * i), xyz(dirs + 3 * i), 0.0f, cnt);
+        lengths[i] = cnt.node_len;
     }
     return 0;
 }
