@@ -121,6 +121,7 @@ struct SceneViewGlobalT {
     static constexpr bool kCoopLeaves = COOP;               /* leaves may hold dozens of triangles: see walk_run.  The streamed walks are
                                                                built both ways and the host picks by the scene's largest leaf: the cooperative
                                                                leaf code costs registers the walk of a thin-leaf scene (every shipped one) needs */
+    static constexpr bool kUniformScalar = false;
     const float4 *nodes;
     const float *tri_isect;
     typedef uint2 Cur;                                      /* x = triangle_count, y = left child / first triangle */
@@ -161,6 +162,9 @@ typedef SceneViewGlobalT<true> SceneViewGlobal;
  * 56 instead of 64 bytes per lane and visit through the TA, and a popped node index costs one 4-byte load from `links[]` instead of two.  Pair p = the children (2p + 1, 2p + 2) of the
  * reference's node pool (its builder allocates children in pairs after the root); a scene whose pool is not pair-shaped, or with a leaf of 255+
  * triangles or 2^24+ triangles, keeps the one-shot generic walks.  The node is one register: an inner node is its left child's index (< 2^24). */
+#ifndef RPT_GSTREAM_UNIFORM_SCALAR
+#define RPT_GSTREAM_UNIFORM_SCALAR 1
+#endif
 template <bool COOP>
 struct SceneViewPairsT {
     static constexpr bool kCoopLeaves = COOP;
@@ -185,6 +189,22 @@ struct SceneViewPairsT {
         lmax = make_float4(q0.w, q1.x, q1.y, 0.0f);
         rmin = make_float4(q1.z, q1.w, q2.x, __uint_as_float(lk.y));
         rmax = make_float4(q2.y, q2.z, q2.w, 0.0f);
+    }
+    /* The same record through the SCALAR cache, for a node every participating lane stands on (c is wave-uniform): one s_load_dwordx16 instead
+     * of four vector loads — no texture-address cycles at all.  A wave of the first iteration is an 8 x 8 pixel block at one sample index, and at
+     * the BASELINE resolutions its 64 camera rays walk the same nodes: 98 % of the inner steps of primary-ray waves are wave-uniform on PBRTest
+     * 2048^2 and VeachMIS 1080p (tools/uniform_visit_share.py, profiles/r04_uniform_visit_share.txt).  The wait is inside the asm statement: the
+     * compiler's s_waitcnt insertion does not see a load it did not emit. */
+    static constexpr bool kUniformScalar = RPT_GSTREAM_UNIFORM_SCALAR != 0;
+    __device__ __forceinline__ void children_uniform(uint32_t c, float4 &lmin, float4 &lmax, float4 &rmin, float4 &rmax) const {
+        typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+        const float4 *p = pairs + 4u * (c >> 1);
+        u32x16 r;
+        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+        lmin = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[14]));
+        lmax = make_float4(__uint_as_float(r[3]), __uint_as_float(r[4]), __uint_as_float(r[5]), 0.0f);
+        rmin = make_float4(__uint_as_float(r[6]), __uint_as_float(r[7]), __uint_as_float(r[8]), __uint_as_float(r[15]));
+        rmax = make_float4(__uint_as_float(r[9]), __uint_as_float(r[10]), __uint_as_float(r[11]), 0.0f);
     }
     __device__ __forceinline__ static Cur enter(bool right, float4 lmin, float4, float4 rmin, float4) { return __float_as_uint(right ? rmin.w : lmin.w); }
     __device__ __forceinline__ uint32_t far_entry(Cur c, bool far_is_left) const { return far_is_left ? c : c + 1u; }
@@ -349,10 +369,28 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
 #endif
             /* inner node (:207-229): test both children against the current best t */
             float4 lmin, lmax, rmin, rmax;
-            view.children(cur, lmin, lmax, rmin, rmax);
             float tl, tr;
-            const bool hit_l = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t, tl);
-            const bool hit_r = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t, tr);
+            bool hit_l, hit_r;
+            if constexpr (View::kUniformScalar) {
+                /* all the lanes of this step on ONE node (a wave of camera rays: nearly always): its record comes through the scalar cache, and the
+                 * slab tests read the planes as scalar operands (tested INSIDE the branch: merged behind it, fourteen v_mov would carry them into VGPRs) */
+                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                if (rpt_ballot(cur == c0) == rpt_ballot(true)) {
+                    view.children_uniform(c0, lmin, lmax, rmin, rmax);
+                    hit_l = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t, tl);
+                    hit_r = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t, tr);
+                    asm volatile("" : "+v"(tl), "+v"(tr));      /* (or the optimiser sinks both branches' tests into ONE copy behind the branch) */
+                } else {
+                    asm volatile("" ::: "memory");      /* (keeps the four vector loads on THIS side of the branch: hoisted above it they are issued on every step) */
+                    view.children(cur, lmin, lmax, rmin, rmax);
+                    hit_l = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t, tl);
+                    hit_r = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t, tr);
+                }
+            } else {
+                view.children(cur, lmin, lmax, rmin, rmax);
+                hit_l = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t, tl);
+                hit_r = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t, tr);
+            }
             const bool swap = hit_r && (!hit_l || tl > tr);     /* strict: ties keep left first */
             if (hit_l || hit_r) {
                 if (hit_l && hit_r && sp < STACK) {
@@ -1027,6 +1065,9 @@ __host__ __device__ constexpr int gstream_rays_nearest(int stack, int width) {
 /* (measured and dropped, round 3: dealing a span's rays grouped by the octant of their direction — the slots of a wave belong to
  * one or two pixels, so after a bounce their rays leave almost one point — 2 M-node stand-in + 2.4 %, PBRTest - 1.3 %, VeachMIS - 0.8 %,
  * the fat-leaf stand-in +- 0) */
+#ifndef RPT_GSTREAM_REFILL_FIRST
+#define RPT_GSTREAM_REFILL_FIRST 64      /* nearest-hit walk, iteration 0 of a batch: see k_traverse_nearest_gstream */
+#endif
 #ifndef RPT_GSTREAM_REFILL
 #define RPT_GSTREAM_REFILL 24      /* (round 3, 64 pixels per wave: 8 / 16 / 24 idle lanes: PBRTest 7 390 / 7 390 / 7 445, VeachMIS 6 560 / 6 615 / 6 655 Mrays/s;
                                       trips 4 / 8 / 12 / 16: 7 355 / 7 390 / 7 320 / 7 250 and 6 620 / 6 615 / 6 530 / 6 480) */
@@ -1094,11 +1135,15 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
     w.cur = View::dead();
     uint32_t slot = 0u, next = 0u;                             /* next: wave-uniform position in the list */
     bool have = false;                                         /* this lane holds a ray whose result is not written yet */
+    /* The first iteration of a batch walks CAMERA rays: the 64 slots a wave deals together are one 8 x 8 pixel block at one sample index, their
+     * rays stand on the same node step after step (k_traverse.h children_uniform: the scalar-cache path) and end within a few steps of each other.
+     * A refill would put rays at the root beside rays deep in the tree and end that: there the wave takes its next 64 slots only when all are done. */
+    const uint32_t refill_at = (View::kUniformScalar && iteration == 0u) ? (uint32_t)RPT_GSTREAM_REFILL_FIRST : (uint32_t)RPT_GSTREAM_REFILL;
     for (;;) {
         const unsigned long long idle_m = rpt_ballot(walk_dead(w));
         const uint32_t n_idle = (uint32_t)__popcll(idle_m);
         const bool more = next < count;                        /* wave-uniform */
-        if ((more && n_idle >= (uint32_t)RPT_GSTREAM_REFILL) || idle_m == ~0ull) {
+        if ((more && n_idle >= refill_at) || idle_m == ~0ull) {
             if (walk_dead(w)) {
                 if (have) {
                     st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
