@@ -32,6 +32,7 @@
     fmt_pre "[48:49]" fmt_post "\n" fmt_pre "[50:51]" fmt_post "\n" fmt_pre "[52:53]" fmt_post "\n" fmt_pre "[54:55]" fmt_post "\n"
 #define P32(p, q) P8(p, q) P8(p, q) P8(p, q) P8(p, q)
 #define CL "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s40","s41","s42","s43"
+#define CLS "scc", CL      /* kernels with SALU instructions: they write SCC, which the loop's own compare may keep live across the asm block */
 
 DEFINE_KERNEL(k_fma_f32, R32("v_fma_f32 v", ", %0, %1, %2"), CL)
 DEFINE_KERNEL(k_mul_f32, R32("v_mul_f32 v", ", %0, %1"), CL)
@@ -67,7 +68,7 @@ DEFINE_KERNEL(k_lshl_add_u64, P32("v_lshl_add_u64 v", ", v[56:57], 3, v[58:59]")
 DEFINE_KERNEL(k_ds_bpermute, R32("ds_bpermute_b32 v", ", %0, %1"), CL)
 DEFINE_KERNEL(k_readlane, R32("v_readlane_b32 s42, %0, 3 ; v", ""), CL)
 DEFINE_KERNEL(k_mbcnt, R32("v_mbcnt_lo_u32_b32 v", ", -1, 0"), CL)
-DEFINE_KERNEL(k_s_and, R32("s_and_b64 s[40:41], s[42:43], exec ; v", ""), CL)
+DEFINE_KERNEL(k_s_and, R32("s_and_b64 s[40:41], s[42:43], exec ; v", ""), CLS)
 
 
 #define PAIR8(a, b) a "40" b "40, %0, %1, " "\n" a "41" b "41, %0, %1, " "\n"
@@ -188,6 +189,20 @@ DEFINE_KERNEL(k_inter_dep_lag, FFMP(40, 41, 48, 46, 47) FFMP(42, 43, 49, 40, 41)
                                FFMP(40, 41, 48, 46, 47) FFMP(42, 43, 49, 40, 41) FFMP(44, 45, 50, 42, 43) FFMP(46, 47, 51, 44, 45) FFMP(40, 41, 52, 46, 47) FFMP(42, 43, 53, 40, 41) FFMP(44, 45, 54, 42, 43) FFMP(46, 47, 55, 44, 45)
                                FFMP(40, 41, 48, 46, 47) FFMP(42, 43, 49, 40, 41) FFMP(44, 45, 50, 42, 43) FFMP(46, 47, 51, 44, 45) FFMP(40, 41, 52, 46, 47) FFMP(42, 43, 53, 40, 41) FFMP(44, 45, 54, 42, 43) FFMP(46, 47, 55, 44, 45), CL)
 
+
+// ---- round 4: does the scalar unit take issue slots from the VALU?  The LDS walk issues 0.45 SALU per VALU instruction (SQ_INSTS_SALU / SQ_INSTS_VALU:
+// mask logic, exec save / restore, loop control).  32 v_fma per trip alone, with 16 and with 32 independent s_and_b64 between them.
+
+#define FS1(a) F(a) "s_and_b64 s[40:41], s[42:43], exec\n"
+#define FFS(a, b) F(a) F(b) "s_and_b64 s[40:41], s[42:43], exec\n"
+DEFINE_KERNEL(k_fma32_salu16, FFS(40, 41) FFS(42, 43) FFS(44, 45) FFS(46, 47) FFS(40, 41) FFS(42, 43) FFS(44, 45) FFS(46, 47)
+                              FFS(40, 41) FFS(42, 43) FFS(44, 45) FFS(46, 47) FFS(40, 41) FFS(42, 43) FFS(44, 45) FFS(46, 47), CLS)
+DEFINE_KERNEL(k_fma32_salu32, FS1(40) FS1(41) FS1(42) FS1(43) FS1(44) FS1(45) FS1(46) FS1(47) FS1(40) FS1(41) FS1(42) FS1(43) FS1(44) FS1(45) FS1(46) FS1(47)
+                              FS1(40) FS1(41) FS1(42) FS1(43) FS1(44) FS1(45) FS1(46) FS1(47) FS1(40) FS1(41) FS1(42) FS1(43) FS1(44) FS1(45) FS1(46) FS1(47), CLS)
+// and with the mask chained through the scalar unit into the VALU (v_cmp -> s_and -> v_cndmask with that mask), as the walk's predicates are
+#define CSC(a) "v_cmp_lt_f32 s[40:41], %0, %1\n s_and_b64 s[42:43], s[40:41], exec\n v_cndmask_b32 v" #a ", %0, %1, s[42:43]\n"
+DEFINE_KERNEL(k_cmp_sand_cnd, CSC(40) CSC(41) CSC(42) CSC(43) CSC(44) CSC(45) CSC(46) CSC(47) CSC(40) CSC(41) CSC(42) CSC(43) CSC(44) CSC(45) CSC(46) CSC(47), CLS)
+
 struct Case { const char *name; void (*fn)(float *); int n_instr = 32; };
 
 int main(int argc, char **argv) {
@@ -211,6 +226,7 @@ int main(int argc, char **argv) {
         {"v_fma_f64 exec=lo32", k_f64_lo32}, {"v_fma_f64 exec=lo16", k_f64_lo16}, {"v_rcp_f32 exec=lo32", k_rcp_lo32}, {"v_rcp_f32 exec=lo16", k_rcp_lo16},
         {"72: 48 fma then 24 min (independent)", k_blocked_48_24, 72}, {"72: 24 x (2 fma, 1 min) (independent)", k_inter_2_1, 72},
         {"72: 48 fma then 24 min of their results", k_blocked_dep, 72}, {"72: 24 x (2 fma, min of the two)", k_inter_dep, 72}, {"72: 24 x (2 fma, min of the previous two)", k_inter_dep_lag, 72},
+        {"32 fma + 16 s_and (cycles per VALU)", k_fma32_salu16}, {"32 fma + 32 s_and (cycles per VALU)", k_fma32_salu32}, {"16 x (cmp -> s_and -> cnd) (per VALU)", k_cmp_sand_cnd},
         {"Horner step f64 (1 v_fma_f64)", k_horner_f64}, {"Horner step double-float (16 f32)", k_horner_df32},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
