@@ -358,6 +358,8 @@ def main():
         raise SystemExit("bench.py: RPT_RCCL_LIBRARY is set — that override loads a stand-in for RCCL (tests/fake_rccl); nothing measured with it is a measurement")
     if args.all_ranks_on_device0:
         local_rank = 0
+    elif world_size > 1 and torch.cuda.device_count() == 1:
+        local_rank = 0            # a launcher that exposes ONE GPU per process (HIP_VISIBLE_DEVICES per rank): this rank's GPU is its device 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world_size > 1:
