@@ -589,6 +589,9 @@ inline float get_weight(uint32_t nee_mode, float p1, float p2) {
     return nee_mode == RPT_NEE_MIS ? power_heuristic(p1, p2) : 1.0f;
 }
 
+extern thread_local float *g_shadow_dump;
+extern thread_local uint32_t g_cur_bounce, g_ray_dump_bounce;
+extern thread_local bool g_shadow_dump_hit;
 DirectLightSample sample_direct_lighting(uint32_t nee_mode, const Scene &sc, V3 throughput, const PBR &surface_bsdf,
                                          V3 surface_point, V3 surface_normal, V3 ray_direction, RngState &rng,
                                          Counters &cnt) {
@@ -624,6 +627,13 @@ DirectLightSample sample_direct_lighting(uint32_t nee_mode, const Scene &sc, V3 
 
     V3 direct = splat3(0.0f);
     cnt.shadow_rays++;
+    if (g_shadow_dump && g_cur_bounce == g_ray_dump_bounce) {
+        V3 so = surface_point + light_direction * EPS;
+        g_shadow_dump[0] = so.x; g_shadow_dump[1] = so.y; g_shadow_dump[2] = so.z;
+        g_shadow_dump[3] = light_direction.x; g_shadow_dump[4] = light_direction.y; g_shadow_dump[5] = light_direction.z;
+        g_shadow_dump[6] = light_distance - EPS * 2.0f; g_shadow_dump[7] = (float)idx;
+        g_shadow_dump_hit = true;
+    }
     TraceResult light_trace = intersect_front_to_back<false>(sc, surface_point + light_direction * EPS, light_direction,
                                                              light_distance - EPS * 2.0f, cnt);
     if (!light_trace.hit) {
@@ -728,6 +738,9 @@ struct PixelResult { V4 radiance; uint32_t next_n, next_offset; };
 thread_local float *g_ray_dump = nullptr;      /* 6 floats: origin, direction */
 thread_local uint32_t g_ray_dump_bounce = 0;
 thread_local bool g_ray_dump_hit = false;
+thread_local float *g_shadow_dump = nullptr;   /* analysis hook: 8 floats: origin, direction, max_t, light-table index */
+thread_local uint32_t g_cur_bounce = 0;
+thread_local bool g_shadow_dump_hit = false;
 
 PixelResult trace_pixel(uint32_t id_x, uint32_t id_y, const rpt_tracing_config &config, rpt_rng_state rng,
                         const Scene &sc, Counters &cnt) {
@@ -752,6 +765,7 @@ PixelResult trace_pixel(uint32_t id_x, uint32_t id_y, const rpt_tracing_config &
 
     for (uint32_t bounce = 0; bounce < config.max_bounces; ++bounce) {
         cnt.extension_rays++;
+        g_cur_bounce = bounce;
         if (g_ray_dump && bounce == g_ray_dump_bounce) {
             g_ray_dump[0] = ray_origin.x; g_ray_dump[1] = ray_origin.y; g_ray_dump[2] = ray_origin.z;
             g_ray_dump[3] = ray_direction.x; g_ray_dump[4] = ray_direction.y; g_ray_dump[5] = ray_direction.z;
@@ -991,18 +1005,38 @@ int oracle_trace_events(const oracle_scene *scene, size_t n, const float *origin
     return 0;
 }
 
-/* Analysis hook (tools/uniform_visit_share.py): per ray the sequence of popped node indices of the nearest-hit walk. */
-int oracle_trace_nodes(const oracle_scene *scene, size_t n, const float *origins, const float *dirs, uint32_t *nodes_out, uint32_t max_nodes,
-                       uint32_t *lengths) {
+/* Analysis hook (tools/uniform_visit_share.py): per ray the sequence of popped node indices of the nearest-hit walk (max_t null) or of the
+ * any-hit walk with the given max_t. */
+int oracle_trace_nodes(const oracle_scene *scene, size_t n, const float *origins, const float *dirs, const float *max_t, uint32_t *nodes_out,
+                       uint32_t max_nodes, uint32_t *lengths) {
     Scene sc = make_scene(scene);
     Counters cnt;
     for (size_t i = 0; i < n; ++i) {
         cnt.node_log = nodes_out + i * (size_t)max_nodes;
         cnt.node_cap = max_nodes;
         cnt.node_len = 0;
-        intersect_front_to_back<true>(sc, xyz(origins + 3 * i), xyz(dirs + 3 * i), 0.0f, cnt);
+        if (max_t) intersect_front_to_back<false>(sc, xyz(origins + 3 * i), xyz(dirs + 3 * i), max_t[i], cnt);
+        else intersect_front_to_back<true>(sc, xyz(origins + 3 * i), xyz(dirs + 3 * i), 0.0f, cnt);
         lengths[i] = cnt.node_len;
     }
+    return 0;
+}
+
+/* shadow[(y*W + x)*8..] = (origin, direction, max_t, light-table index) of the shadow ray that bounce `bounce` of sample rng[i] of every pixel traces */
+int oracle_dump_shadow_rays(const rpt_tracing_config *config, const oracle_scene *scene, const rpt_rng_state *rng, uint32_t bounce,
+                            float *shadow, uint8_t *valid) {
+    Scene sc = make_scene(scene);
+    Counters cnt;
+    g_ray_dump_bounce = bounce;
+    for (uint32_t y = 0; y < config->height; ++y)
+        for (uint32_t x = 0; x < config->width; ++x) {
+            size_t i = (size_t)y * config->width + x;
+            g_shadow_dump = shadow + 8 * i;
+            g_shadow_dump_hit = false;
+            trace_pixel(x, y, *config, rng[i], sc, cnt);
+            valid[i] = g_shadow_dump_hit ? 1 : 0;
+        }
+    g_shadow_dump = nullptr;
     return 0;
 }
 

@@ -50,7 +50,7 @@ def main():
                 o = np.ascontiguousarray(rays[idx, :3]); d = np.ascontiguousarray(rays[idx, 3:])
                 cap = 256
                 nl = np.zeros((64, cap), np.uint32); ln = np.zeros(64, np.uint32)
-                orc.lib.oracle_trace_nodes(C.byref(sc), C.c_size_t(64), o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                orc.lib.oracle_trace_nodes(C.byref(sc), C.c_size_t(64), o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), None,
                                            nl.ctypes.data_as(C.c_void_p), C.c_uint32(cap), ln.ctypes.data_as(C.c_void_p))
                 ln = np.where(v, np.minimum(ln, cap), 0)
                 pos = np.zeros(64, np.int64)
