@@ -71,3 +71,14 @@ def test_sky_exp_is_within_one_ulp_of_the_correctly_rounded_value(oracle):
     xs = np.sort(rng.uniform(-20, 0, 100_000).astype(np.float32))
     ys = oracle.math(10, xs)
     assert np.all(np.diff(ys) >= -np.spacing(ys[:-1]))        # never decreases by more than its own last bit
+
+
+def test_exp_sky_specials_without_branches(tmp_path):
+    """exp_sky clamps its argument and passes a NaN through with one select (rpt_math.h, round 4) instead of three special-case branches: the two forms
+    agree on every 64th float bit pattern and on EVERY pattern near 89, -104, the infinities and the NaNs (tools/exp_sky_check.cpp; with stride 1 — all 2^32
+    floats, ~30 s — it reports 0 mismatches as well)."""
+    import subprocess
+    exe = tmp_path / "exp_sky_check"
+    subprocess.run(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-mfma", "-pthread", "-I" + ROOT, "-o", str(exe), os.path.join(ROOT, "tools", "exp_sky_check.cpp")], check=True)
+    out = subprocess.run([str(exe), "64"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-500:]
