@@ -111,12 +111,32 @@ int rpt_world_load_cache(const char *path, rpt_world **out) {
          h.n_triangles < LIMIT && h.n_nodes < LIMIT && h.n_materials < LIMIT && h.n_light_pick < LIMIT && h.atlas_w <= 65536 &&
          h.atlas_h <= 65536;
     if (!ok) { fclose(f); set_error("not an .rptscene file"); return RPT_HOST_ELOAD; }
-    auto *w = new rpt_world();
+    {
+        /* the counts of an untrusted header size nothing before the FILE is known to hold that many records (a mutated count of 2^31 - 1 vertices
+           used to ask for 128 GB: std::bad_alloc across the C ABI; found by tools/fuzz_glb.py under AddressSanitizer, round 4) */
+        const uint64_t need = sizeof(h) + h.n_vertices * sizeof(rpt_per_vertex_data) + h.n_triangles * sizeof(rpt_triangle) + h.n_nodes * sizeof(rpt_bvh_node) +
+                              h.n_materials * sizeof(rpt_material_data) + h.n_light_pick * sizeof(rpt_light_pick_entry) + (uint64_t)h.atlas_w * h.atlas_h * 4u;
+        long here = ftell(f);
+        bool sized = here >= 0 && fseek(f, 0, SEEK_END) == 0;
+        const long end = sized ? ftell(f) : -1;
+        sized = sized && end >= 0 && fseek(f, here, SEEK_SET) == 0;
+        if (!sized || (uint64_t)end < need) { fclose(f); set_error("truncated or inconsistent .rptscene file"); return RPT_HOST_ELOAD; }
+    }
+    rpt_world *w = nullptr;
+    try {
+        w = new rpt_world();
+        World &d0 = w->w;
+        d0.per_vertex.resize(h.n_vertices); d0.indices.resize(h.n_triangles); d0.nodes.resize(h.n_nodes);
+        d0.materials.resize(h.n_materials); d0.light_pick.resize(h.n_light_pick);
+        d0.atlas.resize((size_t)h.atlas_w * h.atlas_h * 4);
+    } catch (const std::exception &) {
+        delete w;
+        fclose(f);
+        set_error("out of memory loading the .rptscene file");
+        return RPT_HOST_ELOAD;
+    }
     World &d = w->w;
-    d.per_vertex.resize(h.n_vertices); d.indices.resize(h.n_triangles); d.nodes.resize(h.n_nodes);
-    d.materials.resize(h.n_materials); d.light_pick.resize(h.n_light_pick);
     d.atlas_w = h.atlas_w; d.atlas_h = h.atlas_h;
-    d.atlas.resize((size_t)h.atlas_w * h.atlas_h * 4);
     auto get = [&](void *p, size_t bytes) { if (ok && bytes) ok = fread(p, 1, bytes, f) == bytes; };
     get(d.per_vertex.data(), d.per_vertex.size() * sizeof(rpt_per_vertex_data));
     get(d.indices.data(), d.indices.size() * sizeof(rpt_triangle));

@@ -158,6 +158,26 @@ def test_scene_cache_with_a_cyclic_bvh_is_rejected_at_once(rpt, tmp_path):
     assert len(rpt.World.from_cache(str(good)).nodes) == len(w.nodes)
 
 
+def test_scene_cache_with_absurd_counts_is_rejected_before_anything_is_allocated(rpt, tmp_path):
+    """The counts of an .rptscene header are untrusted: 2^31 - 1 vertices used to size a 128 GB vector before a single record was read
+    (std::bad_alloc across the C ABI; tools/fuzz_glb.py under AddressSanitizer, round 4).  A header that promises more records than the
+    file holds is an error at once."""
+    import time
+    w = rpt.World.from_path(rpt.fixture("DarkCornell.glb"))
+    good = tmp_path / "good.rptscene"
+    w.save(str(good))
+    for field in range(5):                                                      # n_vertices, n_triangles, n_nodes, n_materials, n_light_pick
+        data = bytearray(good.read_bytes())
+        data[8 + 8 * field: 16 + 8 * field] = (0x7fffffff).to_bytes(8, "little")
+        bad = tmp_path / f"bad{field}.rptscene"
+        bad.write_bytes(bytes(data))
+        t = time.time()
+        with pytest.raises(rpt.host.HostError):
+            rpt.World.from_cache(str(bad))
+        assert time.time() - t < 2.0
+    assert len(rpt.World.from_cache(str(good)).nodes) == len(w.nodes)
+
+
 def test_loader_mutation_fuzz_slice():
     """A fixed-seed slice of tools/fuzz_glb.py (bit flips, truncations, splices, digit and length mutations of .glb, .obj,
     .png, .hdr and .rptscene files): every file is loaded or rejected, none crashes or hangs the loader."""
