@@ -100,8 +100,7 @@ struct DevScene {
     uint32_t lds_scene;            /* the traversal image fits in RPT_LDS_SCENE_BYTES: traverse out of LDS */
     const float4 *lds_image;       /* LDS-resident traversal image (k_traverse.h SceneViewLds), lds_vecs float4 */
     uint32_t lds_pairs, lds_vecs, lds_root;
-    const float4 *gpairs;          /* streamed global-memory walks: 48 bytes of boxes per child pair (k_traverse.h SceneViewPairsT), or null */
-    const uint2 *gplinks;          /* (link L, link R) per pair */
+    const float4 *gpairs;          /* streamed global-memory walks: one 64-byte record per child pair (k_traverse.h SceneViewPairsT), or null */
     const uint32_t *glinks;        /* triangle_count << 24 | left child / first triangle, per node */
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */
     uint32_t fastdiv_ok;           /* every node bound is 0 or in [2^-60, 2^40): exact fast division allowed */

@@ -154,14 +154,17 @@ struct SceneViewGlobalT {
 typedef SceneViewGlobalT<true> SceneViewGlobal;
 
 /* The streamed global-memory walks read a PAIR array instead (round 4).  Counters first (profiles/r04_*_pmc_ta.txt): these walks keep the CU's
- * texture-address unit busy 83-92 % of the time (TA_TA_BUSY / TCP_GATE_EN1: VeachMIS shadow 92 %, PBRTest nearest 91 %; the LDS walk 12 %) at
- * ~20 TA cycles per 16-byte wave load — that unit, 64 bytes per clock and CU, is what bounds them, and a visit costs it 4 x 16 bytes per lane: the
- * two 32-byte nodes as uploaded, 48 bytes of boxes and 16 of (count, child / first) words.  Here a child pair is ONE 64-byte-aligned record
+ * texture-address unit busy 83-92 % of the time (TA_TA_BUSY / TCP_GATE_EN1: VeachMIS shadow 92 %, PBRTest nearest 91 %; the LDS walk 12 %) — that
+ * front end is what bounds them.  What a load costs it (tools/microbench/ta_rates.hip, profiles/r04_ta_rates.txt): ~0.5 cycles per LIVE lane and
+ * ~10 per instruction whatever the width when the lanes diverge, the data return (64 bytes per clock) on top where lanes share lines.  A visit was
+ * four 16-byte loads per lane — the two 32-byte nodes as uploaded, 48 bytes of boxes and 16 of (count, child / first) words.  Here a child pair is
+ * ONE 64-byte-aligned record
  *     q0 = (L.lo.xyz, L.hi.x)  q1 = (L.hi.yz, R.lo.xy)  q2 = (R.lo.z, R.hi.xyz)  [8 bytes unused]  (link L, link R)
- * with link = triangle_count << 24 | left child / first triangle: three 16-byte loads and one 8-byte load,
- * 56 instead of 64 bytes per lane and visit through the TA, and a popped node index costs one 4-byte load from `links[]` instead of two.  Pair p = the children (2p + 1, 2p + 2) of the
- * reference's node pool (its builder allocates children in pairs after the root); a scene whose pool is not pair-shaped, or with a leaf of 255+
- * triangles or 2^24+ triangles, keeps the one-shot generic walks.  The node is one register: an inner node is its left child's index (< 2^24). */
+ * with link = triangle_count << 24 | left child / first triangle: three 16-byte loads and one 8-byte load (still four instructions: boxes are 48
+ * bytes; the 8-byte one returns half the data on the shared lines near the top of the tree), and a popped node index costs one 4-byte load from
+ * `links[]` instead of two.  Pair p = the children (2p + 1, 2p + 2) of the reference's node pool (its builder allocates children in pairs after the
+ * root); a scene whose pool is not pair-shaped, or with a leaf of 255+ triangles or 2^24+ triangles, keeps the one-shot generic walks.  The node
+ * is one register: an inner node is its left child's index (< 2^24). */
 #ifndef RPT_GSTREAM_UNIFORM_SCALAR
 #define RPT_GSTREAM_UNIFORM_SCALAR 1
 #endif
@@ -169,9 +172,8 @@ template <bool COOP>
 struct SceneViewPairsT {
     static constexpr bool kCoopLeaves = COOP;
     const float4 *pairs;          /* 64 bytes per pair: 3 x float4 of boxes, 8 bytes unused, (link L, link R) in the LAST 8 bytes — at offset 48, 16-byte aligned,
-                                     the compiler widens the 8-byte load to a 16-byte one and the record costs the TA 64 bytes again */
-    const uint2 *plinks;          /* (unused) */
-    const uint32_t *links;
+                                     the compiler widens the 8-byte load to a 16-byte one; in an array of their own the links cost large scenes a second line */
+    const uint32_t *links;        /* per NODE: what a popped stack entry (a node index) resolves to */
     const float *tri_isect;
     typedef uint32_t Cur;
     __device__ __forceinline__ Cur root() const { return links[0]; }
@@ -238,7 +240,7 @@ struct SceneViewPairsT {
 #define RPT_GSTREAM_PAIRS 1
 #endif
 #if RPT_GSTREAM_PAIRS
-#define RPT_GSTREAM_VIEW(COOP, sc) SceneViewPairsT<COOP>{(sc).gpairs, (sc).gplinks, (sc).glinks, (sc).tri_isect}
+#define RPT_GSTREAM_VIEW(COOP, sc) SceneViewPairsT<COOP>{(sc).gpairs, (sc).glinks, (sc).tri_isect}
 template <bool COOP> struct GstreamView { typedef SceneViewPairsT<COOP> type; };
 #else
 #define RPT_GSTREAM_VIEW(COOP, sc) SceneViewGlobalT<COOP>{(sc).nodes, (sc).tri_isect}

@@ -71,7 +71,6 @@ struct rpt_ctx {
     DevBuf<float> tri_isect;
     DevBuf<float4> gpairs;                     /* pair records + links of the streamed global-memory walks (k_traverse.h SceneViewPairsT) */
     DevBuf<uint32_t> glinks;
-    DevBuf<uint2> gplinks;
     DevBuf<rpt_light_pick_entry> light_pick;
     DevBuf<uchar4> atlas;
     DevBuf<float4> skybox;

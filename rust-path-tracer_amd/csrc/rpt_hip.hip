@@ -474,7 +474,7 @@ void rpt_destroy(rpt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rpt_comm_release(c);
     release_state(c);
-    c->gpairs.release(); c->glinks.release(); c->gplinks.release();
+    c->gpairs.release(); c->glinks.release();
     c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_isect.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->light_rec.release(); c->atlas.release(); c->skybox.release();
@@ -632,7 +632,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     }
     if (const char *env = getenv("RPT_NO_LDS_SCENE"); env && env[0] == '1') s.lds_scene = 0u;
     /* pair records for the streamed global-memory walks (k_traverse.h SceneViewPairsT); a pool they cannot express keeps the one-shot walks */
-    s.gpairs = nullptr; s.glinks = nullptr; s.gplinks = nullptr;
+    s.gpairs = nullptr; s.glinks = nullptr;
     {
         bool ok = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
         std::vector<uint32_t> links(nn);
@@ -645,7 +645,6 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         if (ok) {
             const size_t P = (nn - 1) / 2;
             std::vector<float4> pairs(4 * P, make_float4(0, 0, 0, 0));
-            std::vector<uint2> plinks(1);
             for (size_t p = 0; p < P; ++p) {
                 const rpt_bvh_node &L = nodes[2 * p + 1], &R = nodes[2 * p + 2];
                 float fl, fr;
@@ -656,12 +655,10 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
                 pairs[4 * p + 3] = make_float4(0.0f, 0.0f, fl, fr);
             }
             HIP_TRY(c, c->gpairs.alloc(std::max<size_t>(1, pairs.size())));
-            HIP_TRY(c, c->gplinks.alloc(std::max<size_t>(1, plinks.size())));
             HIP_TRY(c, c->glinks.alloc(nn));
             HIP_TRY(c, hipMemcpy(c->gpairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
-            HIP_TRY(c, hipMemcpy(c->gplinks.p, plinks.data(), plinks.size() * sizeof(uint2), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(c->glinks.p, links.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice));
-            s.gpairs = c->gpairs.p; s.glinks = c->glinks.p; s.gplinks = c->gplinks.p;
+            s.gpairs = c->gpairs.p; s.glinks = c->glinks.p;
         }
     }
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
