@@ -73,3 +73,31 @@ def test_no_stage_kernel_of_the_shipped_scenes_spills(resources):
                    "k_shadow_resolve", "void k_traverse_nearest_gstream<32, 16, true>", "void k_traverse_shadow_gstream<32, 16, true>"):
         for vgpr, sgpr, scratch, lds in _find(resources, prefix):
             assert scratch == 0, prefix
+
+
+def test_scalar_cache_path_of_the_global_walks_survives_the_compiler(tmp_path):
+    """The wave-uniform node visit of the streamed nearest-hit walk (k_traverse.h children_uniform) lives on two things the optimiser undid when it
+    was first written: the scalar load with scalar-operand slab tests behind it (sunk into a common tail it needs fourteen v_mov), and the vector
+    loads staying on the other side of the branch (hoisted above it they are issued on every step).  Checked in the ISA of the built library: the
+    kernel holds s_load_dwordx16, v_sub_f32 with a scalar first operand right behind it, and no vector load between the uniformity test and it."""
+    if not (os.path.exists(LIB) and os.path.exists(OBJDUMP)):
+        pytest.skip("librpt_hip.so or the LLVM tools are not here")
+    import shutil
+    work = tmp_path / "isa"
+    work.mkdir()
+    shutil.copy(LIB, work / "lib.so")
+    subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=work, capture_output=True, check=True)
+    co = [f for f in os.listdir(work) if "gfx950" in f]
+    assert co
+    text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co[0]], cwd=work, capture_output=True, text=True, check=True).stdout
+    m = re.search(r"<_Z26k_traverse_nearest_gstreamILi24ELi16ELb0EEv[^>]*>:\n(.*?)s_endpgm", text, re.S)
+    assert m, "kernel not found in the disassembly"
+    lines = [l.strip() for l in m.group(1).splitlines() if l.startswith("\t")]
+    at = [i for i, l in enumerate(lines) if l.startswith("s_load_dwordx16")]
+    assert len(at) >= 1                                                     # (the exact-division and the IEEE-division instantiation of the walk)
+    for i in at:
+        behind = lines[i + 1:i + 12]
+        assert any(re.match(r"v_sub_f32_e32 v\d+, s\d+, v\d+", l) for l in behind), behind      # planes read as scalar operands, no v_mov detour
+        before = lines[max(0, i - 12):i]
+        assert not any(l.startswith("global_load_dwordx4") for l in before), before                # the vector loads were not hoisted above the branch
+    assert any(l.startswith("s_load_dwordx8") for l in lines)               # wave-uniform leaves: triangle records through the scalar cache
