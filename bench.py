@@ -110,9 +110,15 @@ def load_traffic(hip, workload):
         return None, f"profiles/traffic_{workload}.json unreadable: {e}"
 
 
-def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipeline_bytes):
-    """(roofline of the dominant kernel, whole-batch traffic / VALU figures) from the HIP events recorded in this run and the kept
-    PMC passes of the same kernel sources"""
+# kernels whose time the library's per-stage HIP events attribute to one stage (rpt_stats.kernel_ms): the any-hit walk and the
+# dense pass that adds the unoccluded NEE terms are timed together as "shadow"
+STAGE_KERNELS = {"shadow": ("shadow", "shadow_resolve")}
+
+
+def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipeline_bytes, share=1.0):
+    """(roofline of the dominant stage, whole-batch traffic / VALU figures) from the HIP events recorded in this run and the kept
+    PMC passes of the same kernel sources.  `share`: the part of the image this rank renders — the kept PMC passes are of
+    whole-image launches on one GPU, so at N > 1 every per-launch counter figure is scaled by it (and says so)."""
     kms = {k: s1["kernel_ms"][k] - s0["kernel_ms"][k] for k in s1["kernel_ms"]}
     klaunch = {k: s1["kernel_launches"][k] - s0["kernel_launches"][k] for k in s1["kernel_launches"]}
     dominant = max(kms, key=lambda k: kms[k])
@@ -120,59 +126,83 @@ def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipe
         return None, None
     avg_ms = kms[dominant] / max(klaunch[dominant], 1)
     unit_key, bytes_per_unit = STAGE_MODEL[dominant]
-    units = (s1["first_" + unit_key] - s0["first_" + unit_key]) / max(klaunch[dominant], 1)   # (of the pipeline whose launches were timed)
+    units = (s1[unit_key] - s0[unit_key]) / max(klaunch[dominant], 1)
     achieved = bytes_per_unit * units / (avg_ms * 1e-3) / 1e9
     tj, traffic_source = load_traffic(hip, workload)
-    traffic = valu = None
-    if tj and dominant in tj.get("stages", {}):
-        traffic = tj["stages"][dominant]["hbm_bytes_per_launch"]
-        valu = tj["stages"][dominant].get("valu")       # SQ pass of the same profiling run: what actually bounds the kernel
+    stages = tj.get("stages", {}) if tj else {}
+    # the stage's figures = the sum over every kernel its avg_launch_ms covers
+    covered = [k for k in STAGE_KERNELS.get(dominant, (dominant,)) if k in stages]
+    traffic = valu = ta = None
+    if dominant in covered:
+        traffic = int(sum(stages[k]["hbm_bytes_per_launch"] for k in covered) * share)
+        if all("valu" in stages[k] for k in covered):
+            insts = sum(stages[k]["valu"]["wave_instructions_per_launch"] for k in covered)
+            valu = {"wave_instructions_per_launch": int(insts * share),
+                    "lane_utilisation": round(sum(stages[k]["valu"]["lane_utilisation"] * stages[k]["valu"]["wave_instructions_per_launch"]
+                                                  for k in covered) / max(insts, 1), 4)}
+            for key in ("class_mix", "issue_cycles_per_wave_instruction"):
+                if key in stages[dominant]["valu"]:
+                    valu[key] = stages[dominant]["valu"][key]
+        ta = stages[dominant].get("ta")
+    algorithmic = bytes_per_unit * units
     roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "traffic_over_algorithmic": round(traffic / algorithmic, 4) if traffic and algorithmic > 0 else None,
+                "traffic_kernels": ["k_" + k for k in covered] or None, "traffic_source": traffic_source,
                 "avg_launch_ms": round(avg_ms, 5), "launches": int(klaunch[dominant]),
                 "units_per_launch": round(units, 1), "units_are": unit_key, "algorithmic_bytes_per_unit": bytes_per_unit,
                 "stage_ms": {k: round(v, 3) for k, v in kms.items()},
                 "stage_launches": {k: int(v) for k, v in klaunch.items()}}
-    if tj and dominant in tj.get("stages", {}) and tj["stages"][dominant].get("ta"):
+    if share != 1.0 and traffic is not None:
+        roofline["traffic_scaled_by"] = round(share, 6)      # whole-image PMC launches -> this rank's part of the image
+    if ta:
         # the streamed global-memory walks are bound by the CU's texture-address unit, not by HBM: its busy share from the kept TA pass
-        roofline["ta"] = tj["stages"][dominant]["ta"]
+        roofline["ta"] = ta
     simds = cus * 4
     if valu:
         # not an HBM kernel: the VALU issue figures of the kept SQ pass (same fingerprint rule as `traffic`), and from them
         # and THIS run's launch time the SIMD time per wave-instruction
-        roofline["valu"] = {"lane_utilisation": valu["lane_utilisation"],
-                            "wave_instructions_per_launch": valu["wave_instructions_per_launch"],
-                            "simd_ns_per_wave_instruction": round(avg_ms * 1e6 * simds / valu["wave_instructions_per_launch"], 4),
-                            "simd_cycles_per_wave_instruction": round(avg_ms * 1e3 * clock_mhz * simds / valu["wave_instructions_per_launch"], 3),
-                            "simds": simds, "clock_mhz": clock_mhz,
-                            "note": "the traversal mix issues in ~2.7 SIMD cycles per wave64 instruction (DESIGN.md 4)"}
+        n_inst = max(valu["wave_instructions_per_launch"], 1)
+        roofline["valu"] = dict(valu, simd_ns_per_wave_instruction=round(avg_ms * 1e6 * simds / n_inst, 4),
+                                simd_cycles_per_wave_instruction=round(avg_ms * 1e3 * clock_mhz * simds / n_inst, 3),
+                                simds=simds, clock_mhz=clock_mhz,
+                                note="the traversal mix issues in ~2.7 SIMD cycles per wave64 instruction (DESIGN.md 4)")
     # whole batch: measured HBM bytes of ALL kernels (FETCH x 2 + WRITE per launch x this run's launches) against SURVEY.md 8d's
     # algorithmic bytes, and the share of the SIMD issue cycles of the timed region the VALU instructions of all kernels need
     whole = None
     if tj:
         launches_of = dict(klaunch)
         launches_of["shadow_resolve"] = klaunch.get("shadow", 0)
-        tot_bytes, tot_insts, covered, missing = 0.0, 0.0, [], []
-        for st, rec in tj.get("stages", {}).items():
+        tot_bytes, tot_insts, tot_issue, covered_all, missing = 0.0, 0.0, 0.0, [], []
+        for st, rec in stages.items():
             n = launches_of.get(st, 0)
             if n <= 0:
                 continue
-            tot_bytes += rec["hbm_bytes_per_launch"] * n
+            tot_bytes += rec["hbm_bytes_per_launch"] * n * share
             if "valu" in rec:
-                tot_insts += rec["valu"]["wave_instructions_per_launch"] * n
-            covered.append(st)
+                ni = rec["valu"]["wave_instructions_per_launch"] * n * share
+                tot_insts += ni
+                # issue cycles per wave-instruction of THIS kernel's measured class mix (tools/valu_from_pmc.py) where the kept
+                # SQ passes carry one, the fastest class's figure otherwise
+                tot_issue += ni * rec["valu"].get("issue_cycles_per_wave_instruction", VALU_ISSUE_CYCLES_FLOOR)
+            covered_all.append(st)
         for st, n in klaunch.items():
-            if n > 0 and st not in tj.get("stages", {}):
+            if n > 0 and st not in stages:
                 missing.append(st)
         avail = simds * clock_mhz * 1e6 * elapsed_s
+        mixed = any("issue_cycles_per_wave_instruction" in rec.get("valu", {}) for rec in stages.values())
         whole = {"traffic": int(tot_bytes / max(steps, 1)), "traffic_over_algorithmic": round(tot_bytes / max(pipeline_bytes, 1), 4),
-                 "traffic_is": "HBM bytes per batch, all kernels: (2 x FETCH_SIZE + WRITE_SIZE) per launch of the kept PMC passes x the launches of this run",
-                 "stages_covered": covered, "stages_without_counters": missing,
+                 "traffic_is": "HBM bytes per batch, all kernels: (2 x FETCH_SIZE + WRITE_SIZE) per launch of the kept PMC passes x the launches of this run"
+                               + ("" if share == 1.0 else f" x this rank's share of the image ({share:.4f})"),
+                 "stages_covered": covered_all, "stages_without_counters": missing,
                  "valu": {"wave_instructions_per_batch": int(tot_insts / max(steps, 1)),
                           "simd_cycles_per_wave_instruction": round(avail / tot_insts, 3) if tot_insts else None,
-                          "issue_frac": round(tot_insts * VALU_ISSUE_CYCLES_FLOOR / avail, 4) if tot_insts else None,
-                          "issue_frac_is": f"all kernels' VALU wave-instructions x {VALU_ISSUE_CYCLES_FLOOR} cycles (the fastest class, v_fma_f32; "
-                                           "compares / min / max / integer take ~4) / (SIMDs x clock x timed seconds)"}}
+                          "issue_frac": round(tot_issue / avail, 4) if tot_insts else None,
+                          "issue_frac_is": ("sum over kernels of VALU wave-instructions x the issue cycles of that kernel's measured instruction-class mix "
+                                            "(SQ_INSTS_VALU_* passes; fma-class 2.1, other classes 3.45 SIMD cycles, a third of 'other' hides: profiles/r04_valu_pipes.txt)"
+                                            if mixed else
+                                            f"all kernels' VALU wave-instructions x {VALU_ISSUE_CYCLES_FLOOR} cycles (the fastest class, v_fma_f32; "
+                                            "compares / min / max / integer take ~4)") + " / (SIMDs x clock x timed seconds)"}}
     return roofline, whole
 
 
@@ -237,24 +267,18 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
         for _ in range(2):                                           # set-up: touch every page of the path state, clocks up
             r.render(spp_per_step)
         r.reset(seeds)
-
-        def stats():
-            st = r.stats()
-            for k in ("extension_rays", "shadow_rays", "samples", "sky_evals"):
-                st["first_" + k] = st[k]
-            return st
         for _ in range(warmup):
             r.render_async(spp_per_step)
         r.wait()
         torch.cuda.synchronize()
-        s0 = stats()
+        s0 = r.stats()
         t0 = time.perf_counter()
         for _ in range(steps):
             r.render_async(spp_per_step)
         r.wait()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        s1 = stats()
+        s1 = r.stats()
         n_ext, n_shadow = s1["extension_rays"] - s0["extension_rays"], s1["shadow_rays"] - s0["shadow_rays"]
         n_samples, n_sky = s1["samples"] - s0["samples"], s1["sky_evals"] - s0["sky_evals"]
         n_mis = n_shadow if cfg.nee == 1 else 0
@@ -288,6 +312,24 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
             "roofline": roofline, "pipeline_roofline": pipeline, "parity_check": par}
 
 
+def launch_ranks(n, argv):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv>` as a child process on a free
+    port of 127.0.0.1, pass its stdout (rank 0's JSON line) and stderr through, return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench: no launcher in the environment: starting " + " ".join(cmd[1:8]) + " as a child process", file=sys.stderr)
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,10 +345,6 @@ def main():
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"],
                     help="rccl: the per-batch gather runs inside librpt_hip.so (C ABI, RCCL); torch: tiles.Gatherer over torch.distributed")
     ap.add_argument("--with-gather", action="store_true", help="N = 1 only: still run the per-batch gather (a 1-rank communicator), to exercise that path")
-    ap.add_argument("--pipelines", type=int, default=1,
-                    help="contexts per rank, each with its own stream and share of the rank's pixels (rpt_comm_add_pipeline).  Measured on one "
-                         "GPU with the per-batch gather (tools/pipeline_probe.py, profiles/r03_pipeline_probe.txt): 2 pipelines + 1.1 %% at 1/8 of "
-                         "the image, - 0.3 %% at 1/4, 3 pipelines lose everywhere — so the default is 1")
     ap.add_argument("--rehearsal", action="store_true",
                     help="dress rehearsal of the N > 1 path on a box with ONE GPU: N processes on device 0, torch.distributed over gloo, the "
                          "library's gather over the test stand-in for RCCL (RPT_RCCL_LIBRARY).  Exercises every line the scaling run executes; "
@@ -320,6 +358,13 @@ def main():
     ap.add_argument("--extra-warmup", type=int, default=1)
     ap.add_argument("--no-readback", action="store_true", help="skip the extra render -> read_accum loop (reference loop shape, src/trace.rs:182-204)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no launcher (the driver's plain command; a caller of src/trace.rs:136-224 does not
+    # bring one either): this process becomes the launcher.  It has not imported torch nor touched HIP; the N ranks are CHILD
+    # processes (python -m torch.distributed.run, one rank per GPU over RCCL), never an exec; their one JSON line and the return
+    # code are relayed.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # Rank 0 prints ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner through C stdio when
     # a communicator is created, and it is flushed at exit — after the JSON line), so for the whole run file descriptor 1
@@ -345,8 +390,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -434,23 +477,7 @@ def main():
         else:
             gather_impl = "torch.distributed (explicit --gather torch / --dist-backend gloo: NOT the product's gather)"
     use_lib_gather = gather_impl == "rccl-c-abi"
-    # more than one pipeline per rank (only with the library's gather, which snapshots every pipeline's block on its own stream)
-    pipelines = max(1, args.pipelines)
-    if pipelines > 1 and not use_lib_gather:
-        raise SystemExit("--pipelines > 1 needs the library's gather (N > 1, or --with-gather)")
-    ctxs = [r]
-    if pipelines > 1:
-        for _ in range(pipelines - 1):
-            e = hip.Renderer(local_rank)
-            r.comm_add_pipeline(e)                                   # re-partitions r and e: sub-ranks of world_size * pipelines
-            ctxs.append(e)
-        for p in ctxs:                                               # set-up again for the new partition, as above
-            p.upload_scene(world)
-            p.set_config(cfg)
-            p.reset(seeds)
-            for _ in range(2):
-                p.render(args.spp_per_step)
-            p.reset(seeds)
+    comm_world_seen = list(r.comm_world()) if use_lib_gather else None
     gatherer = lib_stream = local_block = staged = None
     if gather_impl and not use_lib_gather:
         local_block = tiles.device_block_as_tensor(r, device)
@@ -470,8 +497,7 @@ def main():
             r.untile(recv.data_ptr(), image.data_ptr(), gatherer.stride)     # launch only, on the same stream
 
     def step():
-        for p in ctxs:
-            p.render_async(args.spp_per_step)
+        r.render_async(args.spp_per_step)
         if use_lib_gather:
             r.gather_async()                                         # stream-ordered; returns at once
         elif gatherer is not None:
@@ -485,32 +511,20 @@ def main():
         elif gatherer is not None:
             with torch.cuda.stream(lib_stream):
                 finish_gather()
-        for p in ctxs:
-            p.wait()
-
-    COUNTERS = ("extension_rays", "shadow_rays", "samples", "sky_evals")
-
-    def rank_stats():
-        """counters summed over this rank's pipelines; kernel times and launches of the first one (the roofline's kernel)"""
-        all_st = [p.stats() for p in ctxs]
-        st = dict(all_st[0])
-        for k in COUNTERS:
-            st[k] = sum(a[k] for a in all_st)
-            st["first_" + k] = all_st[0][k]
-        return st
+        r.wait()
 
     for _ in range(args.warmup):
         step()
     drain()
     barrier()
-    s0 = rank_stats()
+    s0 = r.stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()                                                          # the last batch's image is complete inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
-    s1 = rank_stats()
+    s1 = r.stats()
 
     def delta(key):
         return s1[key] - s0[key]
@@ -525,7 +539,7 @@ def main():
     # the host, repeat.  Timed separately — it is not `value` (inputs and outputs of `value` stay in HBM) — so that the
     # PCIe-inclusive rate is a measurement too.  One device-side un-tile + one DMA into pinned memory per read-back.
     readback = None
-    if world_size == 1 and not args.no_readback and pipelines == 1:
+    if world_size == 1 and not args.no_readback:
         host_image = np.empty((H, W, 4), np.float32)
         r.reset(seeds)
         r.render(args.spp_per_step)
@@ -590,7 +604,8 @@ def main():
     cus, clock_mhz = hip.device_info(local_rank)
     pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
     pipeline_gbs = pipeline_bytes / elapsed_max / 1e9
-    roofline, whole = stage_roofline(hip, args.workload, s0, s1, args.steps, elapsed_max, cus, clock_mhz, pipeline_bytes / world_size)
+    share = r.local_pixels() / float(W * H)                            # rank 0's part of the image (its kernels are the ones timed)
+    roofline, whole = stage_roofline(hip, args.workload, s0, s1, args.steps, elapsed_max, cus, clock_mhz, pipeline_bytes * share, share)
 
     # --- CPU baseline: the oracle (a port of trace_cpu) on this host's cores, bounded sample of the same workload
     cpu = None
@@ -622,7 +637,7 @@ def main():
     # --- the other single-GPU BASELINE workloads (C2 with MIS, C3, C4 as one GPU sees it, the C5 stand-in): after the headline, never
     # inside its timed region, each on a fresh context
     workloads = None
-    if world_size == 1 and args.workload == "darkcornell" and not args.no_extra_workloads and not args.with_gather and pipelines == 1:
+    if world_size == 1 and args.workload == "darkcornell" and not args.no_extra_workloads and not args.with_gather:
         r.close()
         workloads = {}
         for name in [w for w in args.extra_workloads.split(",") if w]:
@@ -644,7 +659,8 @@ def main():
                  if not scene.startswith("procedural:") else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
         "config": {"workload": workload_label(scene, W, H, args.steps, args.spp_per_step, total_spp, cfg),
                    "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU",
-                   "kernel_sources": hip.build_fingerprint(), "gather": gather_impl, "collective_library": hip.comm_library() or None, "pipelines_per_rank": pipelines},
+                   "kernel_sources": hip.build_fingerprint(), "gather": gather_impl, "collective_library": hip.comm_library() or None,
+                   "rpt_comm_world": comm_world_seen},
         "samples_per_s": round(n_samples / elapsed_max, 1),
         "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
                  "per_sample": round(rays / max(n_samples, 1), 4)},

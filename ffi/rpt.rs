@@ -93,7 +93,6 @@ extern "C" {
     pub fn rpt_comm_unique_id(id_out: *mut u8) -> c_int;                            // RPT_COMM_ID_BYTES, rank 0
     pub fn rpt_comm_init(ctx: *mut rpt_ctx, unique_id: *const u8, rank: u32, world_size: u32) -> c_int;
     pub fn rpt_comm_init_local(ctx: *mut rpt_ctx) -> c_int;                         // one GPU, no RCCL: overlapped read-back
-    pub fn rpt_comm_add_pipeline(owner: *mut rpt_ctx, extra: *mut rpt_ctx) -> c_int; // a second pipeline of this rank on the same device
     pub fn rpt_gather_async(ctx: *mut rpt_ctx) -> c_int;
     pub fn rpt_gather_wait(ctx: *mut rpt_ctx) -> c_int;
     pub fn rpt_read_gathered(ctx: *mut rpt_ctx, out: *mut Vec4, out_samples: *mut u32) -> c_int;   // rank 0

@@ -197,15 +197,6 @@ int rpt_comm_init(rpt_ctx *ctx, const uint8_t *unique_id, uint32_t rank, uint32_
  * loop (render a batch, read it back: src/trace.rs:182-204) reads batch k while batch k+1 renders:
  *   rpt_render_async ; rpt_gather_async ; rpt_render_async (next batch) ; rpt_read_gathered -> the image after the first. */
 int rpt_comm_init_local(rpt_ctx *ctx);
-/* More than one pipeline per rank: `extra` (a plain context on the owner's device) renders its own share of the rank's pixels on
- * its own stream.  The K local contexts become sub-ranks rank*K .. rank*K + K-1 of world*K of the tile partition (set by this call
- * on all of them: rpt_reset each afterwards); EVERY rank must add the same number.  The caller drives each context (scene,
- * configuration, reset, rpt_render_async); rpt_gather_async on the OWNER covers all K blocks, each snapshotted on its own
- * stream after that pipeline's batch, so the pipelines never wait for each other.  EXPERIMENTAL: measured with the per-batch
- * gather in the loop it pays + 1.1 % per GPU at 1/8 of a 1024^2 image, nothing or a loss elsewhere (profiles/r03_pipeline_probe.txt);
- * one pipeline per rank is the default everywhere.  All or nothing: on failure every context keeps the partition it had.  An
- * extra that is destroyed hands its pixels back to the remaining contexts (rpt_reset them before rendering on). */
-int rpt_comm_add_pipeline(rpt_ctx *owner, rpt_ctx *extra);
 int rpt_comm_world(rpt_ctx *ctx, uint32_t *rank_out, uint32_t *world_size_out);   /* as RCCL reports it (ncclCommCount) */
 /* Which collective library the process resolved (dlopen): "librccl.so.1" ..., "" before the first communicator, or the path
  * given in RPT_RCCL_LIBRARY — an override that exists for tests/fake_rccl (N processes on a one-GPU test box); a

@@ -196,13 +196,15 @@ struct SceneViewPairsT {
      * of four vector loads — no texture-address cycles at all.  A wave of the first iteration is an 8 x 8 pixel block at one sample index, and at
      * the BASELINE resolutions its 64 camera rays walk the same nodes: 98 % of the inner steps of primary-ray waves are wave-uniform on PBRTest
      * 2048^2 and VeachMIS 1080p (tools/uniform_visit_share.py, profiles/r04_uniform_visit_share.txt).  The wait is inside the asm statement: the
-     * compiler's s_waitcnt insertion does not see a load it did not emit. */
+     * compiler's s_waitcnt insertion does not see a load it did not emit.  Destinations are early-clobber ("=&s"): an SMEM destination that overlapped
+     * its own base pair would be re-read clobbered if the load were ever replayed (XNACK) — LLVM does the same for its own scalar loads on xnack-any
+     * targets; tests/test_scalar_path_isa.py checks the emitted registers. */
     static constexpr bool kUniformScalar = RPT_GSTREAM_UNIFORM_SCALAR != 0;
     __device__ __forceinline__ void children_uniform(uint32_t c, float4 &lmin, float4 &lmax, float4 &rmin, float4 &rmax) const {
         typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
         const float4 *p = pairs + 4u * (c >> 1);
         u32x16 r;
-        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
         lmin = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[14]));
         lmax = make_float4(__uint_as_float(r[3]), __uint_as_float(r[4]), __uint_as_float(r[5]), 0.0f);
         rmin = make_float4(__uint_as_float(r[6]), __uint_as_float(r[7]), __uint_as_float(r[8]), __uint_as_float(r[15]));
@@ -214,7 +216,7 @@ struct SceneViewPairsT {
     /* the same for a wave-uniform popped index / a wave-uniform triangle: scalar cache */
     __device__ __forceinline__ Cur from_entry_uniform(uint32_t e) const {
         uint32_t r;
-        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(links + e) : "memory");
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(links + e) : "memory");
         return r;
     }
     __device__ __forceinline__ void triangle_uniform(uint32_t ti, F3 &e1, F3 &e2, F3 &a) const {

@@ -125,11 +125,6 @@ struct rpt_comm {
     uint32_t conf_w = 0, conf_h = 0;
     uint32_t gathered_samples = 0;
     bool started = false;
-    /* extra pipelines of this rank (rpt_comm_add_pipeline): contexts on the same device, each with its own stream and its own
-       share of the rank's pixels; their blocks follow the owner's in `send`.  K = 1 + pipes.size() sub-ranks per rank. */
-    std::vector<rpt_ctx *> pipes;
-    std::vector<hipEvent_t> pipe_staged;
-    std::vector<uint64_t> sub_offset;   /* where each local context's block starts in `send` (owner first) */
 };
 
 void rpt_image_release(rpt_ctx *c) {
@@ -141,30 +136,10 @@ void rpt_image_release(rpt_ctx *c) {
     c->untile_key = 0;
 }
 
-namespace { int comm_repartition(rpt_ctx *c); }
-
 void rpt_comm_release(rpt_ctx *c) {
-    if (c->pipeline_of && c->pipeline_of->comm) {
-        /* an extra pipeline leaves its owner's communicator: the owner's gathers no longer cover this context's pixels */
-        rpt_comm *ocm = c->pipeline_of->comm;
-        if (ocm->stream) (void)hipStreamSynchronize(ocm->stream);
-        for (size_t j = 0; j < ocm->pipes.size(); ++j)
-            if (ocm->pipes[j] == c) {
-                (void)hipEventDestroy(ocm->pipe_staged[j]);
-                ocm->pipes.erase(ocm->pipes.begin() + (long)j);
-                ocm->pipe_staged.erase(ocm->pipe_staged.begin() + (long)j);
-                break;
-            }
-        ocm->conf_w = ocm->conf_h = 0;
-        ocm->started = false;
-        (void)comm_repartition(c->pipeline_of);      /* the remaining contexts cover the rank's pixels again (rpt_reset each before rendering on) */
-    }
-    c->pipeline_of = nullptr;
     rpt_comm *cm = c->comm;
     if (!cm) return;
     if (cm->stream) (void)hipStreamSynchronize(cm->stream);
-    for (rpt_ctx *p : cm->pipes) p->pipeline_of = nullptr;
-    for (hipEvent_t e : cm->pipe_staged) (void)hipEventDestroy(e);
     if (cm->comm && cm->owns_comm) (void)rccl().CommDestroy(cm->comm);
     cm->send.release(); cm->gathered.release(); cm->map.release(); cm->full_image.release();
     if (cm->host_full) (void)hipHostFree(cm->host_full);
@@ -204,7 +179,7 @@ int enqueue_readback(rpt_ctx *c) {
     return RPT_OK;
 }
 
-int comm_check_partitions(rpt_ctx *c);
+int comm_check_partition(rpt_ctx *c);
 
 /* (re)size the gather buffers for the current configuration: block sizes of every rank, the padded stride, and — root —
  * the destination map, the landing buffer and the full image.  Runs when the configuration changed, never per batch. */
@@ -213,23 +188,15 @@ int comm_configure(rpt_ctx *c) {
     const uint32_t W = c->cfg.c.width, H = c->cfg.c.height;
     if (cm->conf_w == W && cm->conf_h == H && cm->send.p) return RPT_OK;
     HIP_TRY(c, hipStreamSynchronize(cm->stream));
-    /* a rank's block = the blocks of its K sub-ranks r K .. r K + K - 1 of world K, one after the other (K = 1: the rank itself) */
-    const uint32_t K = 1u + (uint32_t)cm->pipes.size();
     std::vector<std::vector<uint32_t>> orders(cm->world);
     cm->sizes.assign(cm->world, 0);
     cm->stride = 0;
-    cm->sub_offset.assign(K, 0);
-    std::vector<uint32_t> sub;
     for (uint32_t r = 0; r < cm->world; ++r) {
-        for (uint32_t j = 0; j < K; ++j) {
-            if (r == cm->rank) cm->sub_offset[j] = orders[r].size();
-            rpt_build_pixel_order(W, H, r * K + j, cm->world * K, sub);
-            orders[r].insert(orders[r].end(), sub.begin(), sub.end());
-        }
+        rpt_build_pixel_order(W, H, r, cm->world, orders[r]);
         cm->sizes[r] = orders[r].size();
         cm->stride = std::max<uint64_t>(cm->stride, orders[r].size());
     }
-    int prc = comm_check_partitions(c);
+    int prc = comm_check_partition(c);
     if (prc) return prc;
     cm->started = false;             /* no gathered image exists for this configuration yet (rpt_read_gathered refuses until one does) */
     HIP_TRY(c, cm->send.alloc(std::max<uint64_t>(cm->stride, 1)));
@@ -254,33 +221,12 @@ int comm_configure(rpt_ctx *c) {
     return RPT_OK;
 }
 
-/* every local context of the communicator renders the sub-rank the gather's map assumes, at the size the map was built for */
-int comm_check_partitions(rpt_ctx *c) {
+/* the context renders the rank the gather's map assumes, at the size the map was built for */
+int comm_check_partition(rpt_ctx *c) {
     rpt_comm *cm = c->comm;
-    const uint32_t K = 1u + (uint32_t)cm->pipes.size();
-    for (uint32_t j = 0; j < K; ++j) {
-        rpt_ctx *p = j ? cm->pipes[j - 1] : c;
-        const uint64_t end = j + 1 < K ? cm->sub_offset[j + 1] : (cm->sizes.empty() ? 0 : cm->sizes[cm->rank]);
-        if (p->rank != cm->rank * K + j || p->world != cm->world * K || (!cm->sizes.empty() && end - cm->sub_offset[j] != p->n_pixels)) {
-            c->error = "gather: partition of the context and of the communicator differ";
-            return RPT_EINVAL;
-        }
-        if (j && (!p->has_config || !p->has_state || p->cfg.c.width != c->cfg.c.width || p->cfg.c.height != c->cfg.c.height)) {
-            c->error = "gather: a pipeline context has no configuration of the owner's size";
-            return RPT_EINVAL;
-        }
-    }
-    return RPT_OK;
-}
-
-/* the K local contexts of a communicator (owner first) are sub-ranks rank K .. rank K + K - 1 of world K of the tile partition */
-int comm_repartition(rpt_ctx *c) {
-    rpt_comm *cm = c->comm;
-    const uint32_t K = 1u + (uint32_t)cm->pipes.size();
-    for (uint32_t j = 0; j < K; ++j) {
-        rpt_ctx *p = j ? cm->pipes[j - 1] : c;
-        int rc = rpt_set_partition(p, cm->rank * K + j, cm->world * K);
-        if (rc) { if (p != c) c->error = p->error; return rc; }
+    if (c->rank != cm->rank || c->world != cm->world || (!cm->sizes.empty() && cm->sizes[cm->rank] != c->n_pixels)) {
+        c->error = "gather: partition of the context and of the communicator differ";
+        return RPT_EINVAL;
     }
     return RPT_OK;
 }
@@ -310,19 +256,13 @@ int gather_stage(rpt_ctx *c) {
     if (rc) return rc;
     /* a caller that re-partitioned a context behind the communicator's back must neither overrun the snapshot buffer nor —
        same block size, other rank — have its block un-tiled through another rank's map */
-    rc = comm_check_partitions(c);
+    rc = comm_check_partition(c);
     if (rc) return rc;
-    const uint32_t K = 1u + (uint32_t)cm->pipes.size();
-    for (uint32_t j = 0; j < K; ++j) {
-        rpt_ctx *p = j ? cm->pipes[j - 1] : c;
-        if (p->samples != c->samples) { c->error = "gather: the pipelines of this rank have rendered different sample counts"; return RPT_EINVAL; }
-        hipEvent_t staged = j ? cm->pipe_staged[j - 1] : cm->staged;
-        /* on THIS pipeline's stream: after everything it has enqueued (its batch) and after the previous gather released `send` */
-        if (cm->started) HIP_TRY(c, hipStreamWaitEvent(p->stream, cm->sent, 0));
-        if (p->n_pixels) HIP_TRY(c, hipMemcpyAsync(cm->send.p + cm->sub_offset[j], p->accum.p, (size_t)p->n_pixels * sizeof(float4), hipMemcpyDeviceToDevice, p->stream));
-        HIP_TRY(c, hipEventRecord(staged, p->stream));
-        HIP_TRY(c, hipStreamWaitEvent(cm->stream, staged, 0));
-    }
+    /* on the render stream: after everything it has enqueued (the batch) and after the previous gather released `send` */
+    if (cm->started) HIP_TRY(c, hipStreamWaitEvent(c->stream, cm->sent, 0));
+    if (c->n_pixels) HIP_TRY(c, hipMemcpyAsync(cm->send.p, c->accum.p, (size_t)c->n_pixels * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(cm->staged, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(cm->stream, cm->staged, 0));
     cm->gathered_samples = c->samples;
     return RPT_OK;
 }
@@ -460,46 +400,6 @@ int rpt_comm_init_local(rpt_ctx *c) {
     if (!c) return RPT_EINVAL;
     if (c->world != 1u) { c->error = "rpt_comm_init_local: the context is one rank of several (rpt_set_partition); use rpt_comm_init"; return RPT_EINVAL; }
     return comm_attach(c, nullptr, false, 0u, 1u);
-}
-
-/* Another context on the same device joins this rank: it renders its own share of the rank's pixels on its own stream.  The K
- * local contexts become sub-ranks rank K .. rank K + K - 1 of world K of the tile partition (set here; every rank must add the
- * same number of pipelines), the caller drives each (scene, configuration, reset, rpt_render_async), and rpt_gather_async on
- * the OWNER snapshots all K blocks — each on its own stream, after that pipeline's batch, none waiting for another — before
- * the one exchange.  Why: a rank that owns 1/8 of an image launches kernels over 4 M slots whose drain tails a 33 M-slot
- * launch amortises; two pipelines whose batches are not fenced against each other hide them.  MEASURED with the per-batch gather in
- * the loop (tools/pipeline_probe.py, profiles/r03_pipeline_probe.txt): + 1.1 % per GPU at 1/8 of DarkCornell 1024^2, - 0.3 % at 1/4, three
- * pipelines lose everywhere — experimental, opt-in, one pipeline per rank is the default everywhere.  Every rank must add the same
- * number: the root posts its receives from its OWN K (block sizes are not exchanged). */
-int rpt_comm_add_pipeline(rpt_ctx *c, rpt_ctx *extra) {
-    if (!c || !extra) return RPT_EINVAL;
-    rpt_comm *cm = c->comm;
-    if (!cm || (!cm->comm && cm->world != 1u)) { c->error = "rpt_comm_add_pipeline: the owner has no communicator (rpt_comm_init / rpt_comm_init_local)"; return RPT_EINVAL; }
-    if (extra == c || extra->comm || extra->pipeline_of || c->pipeline_of) { c->error = "rpt_comm_add_pipeline: the extra context must be a plain context, not a communicator's owner or member"; return RPT_EINVAL; }
-    if (extra->device != c->device) { c->error = "rpt_comm_add_pipeline: both contexts must be on the owner's device"; return RPT_EINVAL; }
-    if (cm->pipes.size() >= 7) { c->error = "rpt_comm_add_pipeline: at most 8 pipelines per rank"; return RPT_EINVAL; }
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(cm->stream));
-    hipEvent_t ev = nullptr;
-    HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    cm->pipes.push_back(extra);
-    cm->pipe_staged.push_back(ev);
-    extra->pipeline_of = c;
-    cm->conf_w = cm->conf_h = 0;         /* sizes, offsets and the root's map are rebuilt at the next gather */
-    cm->started = false;
-    int rc = comm_repartition(c);
-    if (rc) {
-        /* all or nothing: the extra context leaves again and everybody gets the partition back that held before the call */
-        const std::string why = c->error;
-        cm->pipes.pop_back();
-        cm->pipe_staged.pop_back();
-        (void)hipEventDestroy(ev);
-        extra->pipeline_of = nullptr;
-        (void)rpt_set_partition(extra, 0u, 1u);
-        (void)comm_repartition(c);
-        c->error = why;
-    }
-    return rc;
 }
 
 int rpt_comm_world(rpt_ctx *c, uint32_t *rank, uint32_t *world_size) {

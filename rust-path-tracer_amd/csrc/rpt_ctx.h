@@ -124,7 +124,6 @@ struct rpt_ctx {
 
     /* read-back and multi-GPU gather (rpt_comm.hip) */
     rpt_comm *comm = nullptr;
-    rpt_ctx *pipeline_of = nullptr;       /* this context is an extra pipeline of that context's communicator (rpt_comm_add_pipeline) */
     DevBuf<float4> image;                 /* row-major W x H accumulator image (device), built by k_untile */
     float *host_image = nullptr;          /* pinned twin of it: rpt_read_accum is one DMA */
     size_t host_image_floats = 0;

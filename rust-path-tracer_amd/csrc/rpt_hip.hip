@@ -659,6 +659,10 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
             HIP_TRY(c, hipMemcpy(c->gpairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(c->glinks.p, links.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice));
             s.gpairs = c->gpairs.p; s.glinks = c->glinks.p;
+        } else {
+            /* a previous, pair-shaped scene's records are of no use to this one (36 bytes per node of the OLD scene otherwise stay until rpt_destroy) */
+            c->gpairs.release();
+            c->glinks.release();
         }
     }
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
@@ -905,10 +909,15 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     /* safety net against a stuck pipeline (a bug), far above what deferral of sky work can cost */
     const uint64_t it_limit = (uint64_t)n_samples * (uint64_t)(c->cfg.c.max_bounces + 2u) * 16u + 4096u;
     while (!drained) {
-        if (ev && ev->size() < ev_at + EVENTS_PER_ITER + EVENTS_TAIL) {
-            size_t old = ev->size();
-            ev->resize(ev_at + EVENTS_PER_ITER * 64 + EVENTS_TAIL);
-            for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
+        /* only the synchronous call's vector grows as it goes (its iteration count is unknown); an asynchronous batch got exactly
+           timing_events_needed() events from the pool above — 2 per iteration at level 2 — and hands exactly those back in rpt_wait */
+        if (ev && !async) {
+            const size_t per_iter = c->timing_level == 2 ? 2u : (size_t)(EVENTS_PER_ITER + EVENTS_TAIL);
+            if (ev->size() < ev_at + per_iter) {
+                size_t old = ev->size();
+                ev->resize(ev_at + per_iter * 64);
+                for (size_t k = old; k < ev->size(); ++k) HIP_TRY(c, hipEventCreate(&(*ev)[k]));
+            }
         }
         const bool complete_each = known_iterations == 0 && c->group_shift != 0;
         const bool sky_now = it + 1 == known_iterations - short_batch;      /* (sky_at_end: the one sky launch of the batch) */

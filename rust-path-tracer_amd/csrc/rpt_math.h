@@ -262,8 +262,9 @@ RPT_HD float exp_sky(float x) {
     const float c[RPT_EXPF_C_N] = RPT_EXPF_C_INIT;
     /* Specials without their own branches (84 calls per sky miss: three compares, three selects and their constants were a third of this function): the
      * argument is clamped to [-104, 89] — at 89 the two scaling multiplies below overflow to +inf (1.32 * 2^128), at -104 they round 0.97 * 2^-150 to +0,
-     * exactly what x > 89 and x < -104 must return — and a NaN is passed through by ONE select at the end.  Checked against the branching form for every
-     * one of the 2^32 floats (tests/test_math.py::test_exp_sky_specials_exhaustive builds tools/exp_sky_check.cpp). */
+     * exactly what x > 89 and x < -104 must return — and a NaN is passed through by ONE select at the end.  Checked against the branching form by
+     * tools/exp_sky_check.cpp: every one of the 2^32 floats in a manual run (stride 1, host build), stride 64 plus the windows around every boundary on each
+     * test run (tests/test_math.py::test_exp_sky_specials_without_branches); the device at the special arguments in tests/test_gpu_math_exhaustive.py. */
     const float x_in = x;
     x = fmaxr(fminr(x, 89.0f), -104.0f);
     const float M = 12582912.0f;                        /* 1.5 * 2^23: round to nearest even integer, |t| < 2^22 */

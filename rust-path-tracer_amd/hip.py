@@ -23,7 +23,7 @@ EXPORTS = [
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
-    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_comm_add_pipeline", "rpt_build_fingerprint", "rpt_debug_comm_selftest", "rpt_device_info",
+    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_build_fingerprint", "rpt_debug_comm_selftest", "rpt_device_info",
 ]
 COMM_ID_BYTES = 128
 MULTI_ALLOW_SHARED_DEVICE = 1
@@ -81,7 +81,6 @@ def lib():
         L.rpt_comm_library.argtypes = []
         L.rpt_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.rpt_comm_init_local.argtypes = [C.c_void_p]
-        L.rpt_comm_add_pipeline.argtypes = [C.c_void_p, C.c_void_p]
         L.rpt_device_info.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rpt_debug_comm_selftest.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         L.rpt_comm_world.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -266,11 +265,6 @@ class Renderer:
     def comm_init_local(self):
         """rpt_comm_init_local: a one-rank communicator without RCCL (overlapped read-back on one GPU)."""
         self._check(lib().rpt_comm_init_local(self._h))
-
-    def comm_add_pipeline(self, extra):
-        """rpt_comm_add_pipeline: `extra` (a plain Renderer on this device) becomes another pipeline of this rank; all local
-        contexts are re-partitioned (sub-ranks of world * K): reset each afterwards."""
-        self._check(lib().rpt_comm_add_pipeline(self._h, extra._h))
 
     def comm_world(self):
         r, w = C.c_uint32(), C.c_uint32()

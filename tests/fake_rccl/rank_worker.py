@@ -31,7 +31,6 @@ def main():
     ap.add_argument("--nee", type=int, default=1)
     ap.add_argument("--batches", default="4,4,2")
     ap.add_argument("--read-every-batch", action="store_true", help="rank 0 reads the gathered image after every batch (overlapped loop)")
-    ap.add_argument("--pipelines", type=int, default=1, help="contexts per rank (rpt_comm_add_pipeline)")
     ap.add_argument("--second-image", action="store_true", help="afterwards: reset and render once more (flush path), saved as image2.npy")
     args = ap.parse_args()
 
@@ -46,25 +45,18 @@ def main():
     r.comm_init(bytes.fromhex(args.uid), args.rank, args.world)
     seen_rank, seen_world = r.comm_world()
     ring_bad = r.comm_selftest(70001) if args.world > 1 else 0     # rpt_debug_comm_selftest: a ring of grouped send / receive over all ranks
-    extras = [hip.Renderer(0) for _ in range(args.pipelines - 1)]
-    for e in extras:
-        r.comm_add_pipeline(e)                               # re-partitions r and every extra: sub-ranks of world * pipelines
-    for p in [r] + extras:
-        p.upload_scene(world); p.set_config(cfg); p.reset(seeds)
+    r.upload_scene(world); r.set_config(cfg); r.reset(seeds)
     per_batch = []
     for k, n in enumerate(batches):
-        for p in [r] + extras:
-            p.render_async(n)
+        r.render_async(n)
         if args.read_every_batch and args.rank == 0 and k > 0:
             img, s = r.read_gathered()                       # the image after batch k-1, while batch k renders
             per_batch.append((int(s), img.copy()))
         r.gather_async()
     r.gather_wait()
-    for p in [r] + extras:
-        p.wait()
-    sts = [p.stats() for p in [r] + extras]
-    st = {k: sum(s[k] for s in sts) for k in ("extension_rays", "shadow_rays", "samples")}
-    info = {"ring_mismatches": int(ring_bad), "rank": seen_rank, "world": seen_world, "library": hip.comm_library(), "pixels": int(sum(p.local_pixels() for p in [r] + extras)),
+    r.wait()
+    st = r.stats()
+    info = {"ring_mismatches": int(ring_bad), "rank": seen_rank, "world": seen_world, "library": hip.comm_library(), "pixels": int(r.local_pixels()),
             "extension_rays": int(st["extension_rays"]), "shadow_rays": int(st["shadow_rays"]), "samples": int(st["samples"])}
     if args.rank == 0:
         img, s = r.read_gathered()
@@ -74,21 +66,17 @@ def main():
             np.save(os.path.join(args.out, f"image_after_batch{i}.npy"), img_k)
         info["per_batch_samples"] = [s_k for s_k, _ in per_batch]
     if args.second_image:
-        for p in [r] + extras:
-            p.reset(seeds)
-            p.render_async(3)
+        r.reset(seeds)
+        r.render_async(3)
         r.gather_async()
         r.gather_wait()
-        for p in [r] + extras:
-            p.wait()
+        r.wait()
         if args.rank == 0:
             img, s = r.read_gathered()
             info["second_samples"] = int(s)
             np.save(os.path.join(args.out, "image2.npy"), img)
     with open(os.path.join(args.out, f"rank{args.rank}.json"), "w") as f:
         json.dump(info, f)
-    for e in extras:
-        e.close()
     r.close()
 
 

@@ -164,55 +164,6 @@ def test_multi_driver_with_more_ranks_than_tiles(hipmod, rpt, world, W, H, ranks
     m.close()
 
 
-@pytest.mark.parametrize("pipelines", [2, 3])
-def test_local_communicator_with_several_pipelines(hipmod, rpt, world, pipelines):
-    """rpt_comm_init_local + rpt_comm_add_pipeline on ONE GPU: K contexts render K shares of the image on K streams, one gather
-    per batch covers them all; the gathered image is the single-context image bit for bit.  Misuse is an error: a gather asked
-    of an extra, pipelines that rendered different sample counts, an extra that is already somebody's, a second owner."""
-    w = world("DarkCornell")
-    W, H = 264, 136
-    cfg = rpt.default_config(W, H, nee=1)
-    seeds = rpt.blue_noise_seeds(W, H)
-    ref, _, st_ref = _single_image(hipmod, rpt, w, cfg, seeds, (4, 4, 2))
-    owner = hipmod.Renderer(0)
-    owner.comm_init_local()
-    extras = [hipmod.Renderer(0) for _ in range(pipelines - 1)]
-    for e in extras:
-        owner.comm_add_pipeline(e)
-    ctxs = [owner] + extras
-    for p in ctxs:
-        p.upload_scene(w); p.set_config(cfg); p.reset(seeds)
-    assert sum(p.local_pixels() for p in ctxs) == W * H
-    for n in (4, 4, 2):
-        for p in ctxs:
-            p.render_async(n)
-        owner.gather_async()
-    img, s = owner.read_gathered()
-    assert s == 10 and np.array_equal(img.view(np.uint32), ref.view(np.uint32))
-    for p in ctxs:
-        p.wait()
-    assert sum(p.stats()["extension_rays"] for p in ctxs) == st_ref["extension_rays"]
-    with pytest.raises(hipmod.RptError):
-        extras[0].gather_async()                            # only the owner gathers
-    owner.render_async(1)                                   # the owner one batch ahead of its pipelines: refused, not a torn image
-    with pytest.raises(hipmod.RptError, match="sample counts"):
-        owner.gather_async()
-    for e in extras:
-        e.render_async(1)
-    owner.gather_async()
-    assert owner.read_gathered()[1] == 11
-    other = hipmod.Renderer(0)
-    other.comm_init_local()
-    with pytest.raises(hipmod.RptError):
-        other.comm_add_pipeline(extras[0])                  # already a pipeline of `owner`
-    with pytest.raises(hipmod.RptError):
-        owner.comm_add_pipeline(other)                      # an owner cannot become an extra
-    other.close()
-    for e in extras:
-        e.close()
-    owner.close()
-
-
 def test_gathered_image_is_refused_after_a_resize_until_the_next_gather(hipmod, rpt, world):
     """rpt_read_gathered copies the image of the configuration it was GATHERED under; a caller that resized the configuration
     sizes its buffer for the new one.  Until the next gather there is no image of that size: an error, not an overrun."""

@@ -28,3 +28,27 @@ def test_device_sqrt_equals_the_host_sqrt_on_samples(renderer):
                         np.array([0.0, -0.0, 1e-45, 1e-38, 1.17549435e-38, 3.4e38, np.inf, 1.0, 2.0, 4.0, 0.25], np.float32)])
     got = renderer.debug_math(7, x)
     assert np.array_equal(got.view(np.uint32), np.sqrt(x).view(np.uint32))
+
+
+def test_device_exp_sky_at_its_special_arguments(renderer, hipmod):
+    """exp_sky without special-case branches (rpt_math.h): on the DEVICE the clamp is __builtin_fminf / fmaxf, another expression than
+    the host's — known answers at NaN, the infinities, the clamp bounds and their neighbours, and device == host build bit for bit
+    on windows of every float around them."""
+    nan = np.float32(np.nan)
+    x = np.array([nan, -nan, np.inf, -np.inf, 89.0, np.nextafter(np.float32(89.0), np.float32(np.inf)), np.nextafter(np.float32(89.0), np.float32(0)),
+                  -104.0, np.nextafter(np.float32(-104.0), np.float32(-np.inf)), np.nextafter(np.float32(-104.0), np.float32(0)), 0.0, -0.0, 3.0e38, -3.0e38],
+                 np.float32)
+    got = renderer.debug_math(10, x)
+    assert np.isnan(got[0]) and np.isnan(got[1])
+    assert got[2] == np.inf and got[3] == 0.0 and not np.signbit(got[3])
+    assert got[4] == np.inf and got[5] == np.inf and np.isfinite(got[6]) and got[6] > 3.0e38
+    assert got[7] == 0.0 and got[8] == 0.0 and got[9] >= 0.0 and got[10] == 1.0 and got[11] == 1.0
+    assert got[12] == np.inf and got[13] == 0.0
+    for centre in (np.float32(89.0), np.float32(-104.0), np.float32(np.inf), np.float32(-np.inf), np.float32(88.72), np.float32(-87.3), np.float32(0.0)):
+        c = int(np.array([centre], np.float32).view(np.uint32)[0])
+        bits = (np.arange(-4096, 4096, dtype=np.int64) + c) & 0xffffffff
+        w = bits.astype(np.uint32).view(np.float32)
+        dev, host = renderer.debug_math(10, w), hipmod.debug_math_host(10, w)
+        both_nan = np.isnan(dev) & np.isnan(host)
+        assert np.array_equal(dev.view(np.uint32)[~both_nan], host.view(np.uint32)[~both_nan]), float(centre)
+        assert np.array_equal(np.isnan(dev), np.isnan(host))

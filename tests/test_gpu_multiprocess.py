@@ -97,27 +97,6 @@ def test_n_processes_gather_the_one_rank_image(hipmod, rpt, world, tmp_path, ran
     assert np.array_equal(np.load(tmp_path / "image2.npy").view(np.uint32), ref2[0].view(np.uint32))
 
 
-@pytest.mark.parametrize("ranks,pipelines", [(2, 2), (4, 2), (3, 3)])
-def test_several_pipelines_per_rank_gather_the_one_rank_image(hipmod, rpt, world, tmp_path, ranks, pipelines):
-    """rpt_comm_add_pipeline: every rank drives K contexts on its device (sub-ranks of world * K, each on its own stream, never
-    fenced against each other); the owner's gather snapshots all K blocks and the image rank 0 reads is still the 1-rank image
-    bit for bit — also across a reset, and with rank 0 reading batch k while batch k+1 renders."""
-    W, H, batches = 264, 200, (3, 3, 2)
-    ref, st_ref = _single(hipmod, rpt, world, W, H, 1, batches)
-    infos = _run_ranks(tmp_path, ranks, ["--width", str(W), "--height", str(H), "--nee", "1", "--batches", ",".join(map(str, batches)),
-                                         "--pipelines", str(pipelines), "--second-image", "--read-every-batch"])
-    for r, info in enumerate(infos):
-        assert (info["rank"], info["world"]) == (r, ranks)
-    assert sum(i["pixels"] for i in infos) == W * H
-    assert infos[0]["per_batch_samples"] == [3, 6]
-    for k in range(2):
-        assert np.array_equal(np.load(tmp_path / f"image_after_batch{k}.npy").view(np.uint32), ref[k].view(np.uint32)), k
-    assert np.array_equal(np.load(tmp_path / "image.npy").view(np.uint32), ref[-1].view(np.uint32))
-    assert sum(i["extension_rays"] for i in infos) == st_ref["extension_rays"] and sum(i["shadow_rays"] for i in infos) == st_ref["shadow_rays"]
-    ref2, _ = _single(hipmod, rpt, world, W, H, 1, (3,))
-    assert np.array_equal(np.load(tmp_path / "image2.npy").view(np.uint32), ref2[0].view(np.uint32))
-
-
 def test_overlapped_reads_see_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, world, tmp_path):
     """Rank 0 reads the gathered image after every batch while the next one renders on all ranks: each read is exactly the
     1-rank image after that many batches (the snapshot precedes the next batch; the send buffer is not reused early)."""
@@ -133,32 +112,49 @@ def test_overlapped_reads_see_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, 
     assert sum(i["samples"] for i in infos) == W * H * sum(batches)
 
 
-@pytest.mark.parametrize("ranks,pipelines", [(2, 1), (8, 1), (4, 2)])
-def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks, pipelines):
-    """`bench.py --gpus N` exactly as the driver's scaling run starts it (torch.distributed.run, one process per rank), except that
-    every rank sits on the one GPU of this box (--rehearsal: gloo for torch.distributed, the stand-in for RCCL inside the library).
-    Every line the 2 / 4 / 8-GPU run executes runs here: unique id broadcast, rpt_comm_init, render + gather per step, drain,
-    barriers, statistics reduction, rank 0's JSON line — whose image (gathered from all ranks) must pass the bitwise parity
-    check against the oracle, with the gather reported as the library's.  The number itself is not a measurement and says so."""
+@pytest.mark.parametrize("ranks,launcher", [(2, "torchrun"), (8, "torchrun"), (2, "plain"), (4, "plain")])
+def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks, launcher):
+    """`bench.py --gpus N` exactly as the driver's scaling run starts it — under torch.distributed.run (one process per rank) AND as
+    the plain `python bench.py --gpus N` with no launcher in the environment, where bench.py starts its ranks itself as child
+    processes — except that every rank sits on the one GPU of this box (--rehearsal: gloo for torch.distributed, the stand-in for
+    RCCL inside the library).  Every line the 2 / 4 / 8-GPU run executes runs here: unique id broadcast, rpt_comm_init, render +
+    gather per step, drain, barriers, statistics reduction, rank 0's JSON line — whose image (gathered from all ranks) must pass
+    the bitwise parity check against the oracle, with the gather reported as the library's.  The number itself is not a
+    measurement and says so."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--rehearsal", "--pipelines", str(pipelines)]
-    p = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    bench_args = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--rehearsal"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + bench_args
+    else:
+        cmd = [sys.executable] + bench_args
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert "rehearsal" in out and out["n_gpus"] == ranks and out["steps"] == 2 and out["warmup"] == 1
     assert out["config"]["gather"] == "rccl-c-abi" and out["config"]["collective_library"] == FAKE
-    assert out["config"]["pipelines_per_rank"] == pipelines
+    assert out["config"]["rpt_comm_world"] == [0, ranks]
     assert out["parity_check"]["bitwise"] is True and out["parity_check"]["windows"] >= 2 and out["parity_check"]["image_spp"] == 96
     assert out["rays"]["extension"] > 1024 * 1024 * 64 and out["roofline"]["kernel"] == "k_traverse"
+    # counter-derived per-launch figures are the kept whole-image passes scaled to rank 0's part of the image, or absent — never N x too high
+    rf = out["roofline"]
+    if rf["traffic"] is not None:
+        assert abs(rf["traffic_scaled_by"] - 1.0 / ranks) < 0.02 and 0.9 < rf["traffic_over_algorithmic"] < 1.6
+        assert 0.9 < out["pipeline_roofline"]["traffic_over_algorithmic"] < 1.6
+    if launcher == "plain":
+        assert "starting -m torch.distributed.run" in p.stderr
+        return
     # and WITHOUT the rehearsal flag the stand-in is refused: a scaling number can only come from RCCL
     cmd_real = [c for c in cmd if c != "--rehearsal"]
-    p2 = subprocess.run(cmd_real, env=_env(), capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    p2 = subprocess.run(cmd_real, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert p2.returncode != 0 and "RPT_RCCL_LIBRARY" in (p2.stderr + p2.stdout)
 
 
@@ -187,5 +183,11 @@ def test_bench_line_carries_the_other_single_gpu_workloads(tmp_path):
         assert r["bound"] == "hbm" and r["kernel"].startswith("k_") and 0 < r["frac"] < 1 and r["avg_launch_ms"] > 0
         assert abs(r["achieved"] - r["algorithmic_bytes_per_unit"] * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-2 * r["achieved"]
         assert 0 < w["pipeline_roofline"]["frac"] < 1
+        # a stage cannot move fewer HBM bytes than its algorithmic bytes: the counter figure covers every kernel the stage's time covers
+        if r["traffic"] is not None:
+            assert r["traffic"] >= 0.98 * r["algorithmic_bytes_per_unit"] * r["units_per_launch"], (name, r)
+            assert r["traffic_over_algorithmic"] >= 0.98
+            if r["kernel"] == "k_shadow":
+                assert r["traffic_kernels"] == ["k_shadow", "k_shadow_resolve"]
         pc = w["parity_check"]
         assert pc["bitwise"] is True and pc["windows"] >= 2 and pc["image_spp"] == pc["spp"] == 32
