@@ -46,6 +46,7 @@ extern "C" {
     pub fn rpt_build_fingerprint() -> *const c_char;                                // fingerprint of the kernel sources the library was built from
     pub fn rpt_last_error(ctx: *mut rpt_ctx) -> *const c_char;
     pub fn rpt_device_info(device_id: c_int, compute_units_out: *mut u32, clock_khz_out: *mut u32) -> c_int;   // compute units / peak clock of a HIP device
+    pub fn rpt_shadow_order(ctx: *mut rpt_ctx, fixed_out: *mut u32, visits_near_out: *mut f64, visits_fixed_out: *mut f64, probe_rays_out: *mut u32) -> c_int;   // which (bit-exact) order the shadow walks use
 
     // --- one GPU: what trace_gpu needs (each line: the reference call it replaces) -------------------------------
     pub fn rpt_create(device_id: c_int, out: *mut *mut rpt_ctx) -> c_int;          // FW / adaptor creation, trace.rs:3-6,25-38

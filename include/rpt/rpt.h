@@ -245,6 +245,11 @@ int rpt_abi_version(void);
 const char *rpt_build_fingerprint(void);
 /* compute units and peak engine clock of a HIP device, as the runtime reports them (bench.py: SIMD issue cycles available) */
 int rpt_device_info(int device_id, uint32_t *compute_units_out, uint32_t *clock_khz_out);
+/* Which visiting order the shadow (any-hit) walks of the uploaded scene use, and the probe that decided it.  The reference's shadow query
+ * reads `.hit` only (kernels/src/light_pick.rs:148) and `.hit` does not depend on the order siblings are visited in (intersection.rs:191-213),
+ * so the library may choose: fixed_out = 0 the reference's near-first order, 1 a fixed opaque-first order over a flipped copy of the tree —
+ * chosen at rpt_upload_scene by the node visits of synthetic shadow rays under both (csrc/shadow_order.h).  The image is the same either way. */
+int rpt_shadow_order(rpt_ctx *ctx, uint32_t *fixed_out, double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out);
 
 /* --- scene preparation on the device ---------------------- */
 /* BVHBuilder::new(vertices, indices).sah_samples(n).build()  (reference src/bvh.rs:59-324, the call at
@@ -265,6 +270,12 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
 int rpt_debug_math(rpt_ctx *ctx, int op, const float *x, const float *y, float *out, size_t n);
 /* Same on the HOST build (no device needed, ctx may be NULL). */
 int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size_t n);
+/* The decision rpt_upload_scene takes about the shadow walks' visiting order (rpt_shadow_order), without a device: the probe is host code.
+ * flip_out (nullable): per child pair p = nodes (2p + 1, 2p + 2), 1 where the fixed order enters the right child first. */
+int rpt_debug_shadow_order_host(const rpt_per_vertex_data *vertices, size_t n_vertices, const rpt_triangle *indices, size_t n_triangles,
+                                const rpt_bvh_node *nodes, size_t n_nodes, const rpt_material_data *materials, size_t n_materials,
+                                const rpt_light_pick_entry *light_pick, size_t n_light_pick, uint32_t *fixed_out, double *visits_near_out,
+                                double *visits_fixed_out, uint32_t *probe_rays_out, uint8_t *flip_out);
 /* Exhaustive device-side check of a cheap exact operation of rpt_math.h against its IEEE form over the float bit patterns
  * [lo_bits, lo_bits + count): op 0 sqrtr vs the correctly rounded sqrtf, op 1 div_const_nontiny(x, y, RN(1/y)) vs x / y.  Returns the
  * number of arguments whose results differ in any bit (NaN == NaN) and the smallest such bit pattern (0xffffffff if none). */

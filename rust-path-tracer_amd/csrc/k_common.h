@@ -102,6 +102,10 @@ struct DevScene {
     uint32_t lds_pairs, lds_vecs, lds_root;
     const float4 *gpairs;          /* streamed global-memory walks: one 64-byte record per child pair (k_traverse.h SceneViewPairsT), or null */
     const uint32_t *glinks;        /* triangle_count << 24 | left child / first triangle, per node */
+    uint32_t shadow_fixed;         /* the any-hit walks use a fixed left-first order over the flipped copies below (shadow_order.h) */
+    const float4 *lds_image_shadow;
+    const float4 *gpairs_shadow;
+    const uint32_t *glinks_shadow;
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */
     uint32_t fastdiv_ok;           /* every node bound is 0 or in [2^-60, 2^40): exact fast division allowed */
     uint32_t textured;             /* some material has a texture flag set */

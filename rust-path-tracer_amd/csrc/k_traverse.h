@@ -17,9 +17,15 @@
  *   - leaf triangles come from a pre-gathered (a, b-a, c-a) array instead of
  *     index buffer -> 3 x 64-byte vertex records (same f32 subtractions, done
  *     once at upload).
- * Traversal order is part of the result (ties in t keep the first triangle
- * visited), so no reordering / no "max_t" box pruning in any-hit mode (:212-213
- * prune against result.t only).
+ * Traversal order is part of the NEAREST-hit result (ties in t keep the first
+ * triangle visited): no reordering there.  The ANY-hit walk (light_pick.rs:141-148
+ * + intersection.rs:173-234 with NEAREST_HIT = false) must match the reference in
+ * `.hit` ONLY — light_pick.rs:148 reads nothing else: result.t stays 1e6 until the
+ * first accept, which returns (:191-203), boxes are pruned against that constant
+ * (:212-213: no "max_t" box pruning), so the set of boxes a ray may enter and with
+ * it `.hit` are independent of the order siblings are visited in.  FIXED = true
+ * walks a copy of the tree whose pairs were flipped at upload (shadow_order.h: the
+ * preferred child in the left slot) left-first: no `tl > tr`, no swap.
  */
 #ifndef RPT_K_TRAVERSE_H
 #define RPT_K_TRAVERSE_H
@@ -243,9 +249,11 @@ struct SceneViewPairsT {
 #endif
 #if RPT_GSTREAM_PAIRS
 #define RPT_GSTREAM_VIEW(COOP, sc) SceneViewPairsT<COOP>{(sc).gpairs, (sc).glinks, (sc).tri_isect}
+#define RPT_GSTREAM_VIEW_SHADOW(COOP, sc) SceneViewPairsT<COOP>{(sc).gpairs_shadow, (sc).glinks_shadow, (sc).tri_isect}
 template <bool COOP> struct GstreamView { typedef SceneViewPairsT<COOP> type; };
 #else
 #define RPT_GSTREAM_VIEW(COOP, sc) SceneViewGlobalT<COOP>{(sc).nodes, (sc).tri_isect}
+#define RPT_GSTREAM_VIEW_SHADOW(COOP, sc) SceneViewGlobalT<COOP>{(sc).nodes, (sc).tri_isect}
 template <bool COOP> struct GstreamView { typedef SceneViewGlobalT<COOP> type; };
 #endif
 
@@ -384,8 +392,9 @@ __device__ __forceinline__ typename View::Cur walk_pop(const View &view, uint32_
     }
 }
 
-template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackRef>
+template <int STACK, bool ANY_HIT, bool FAST, bool FIXED = false, typename View, typename StackRef>
 __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro, F3 rd, F3 ird, float max_t, StackRef &stack, int budget) {
+    static_assert(!FIXED || ANY_HIT, "only the any-hit walk may choose its order");
     typedef typename View::Cur Cur;
     HitRecord res = w.res;
     int sp = w.sp;
@@ -424,7 +433,7 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
                 hit_l = slab_test<FAST>(lmin, lmax, ro, rd, ird, res.t, tl);
                 hit_r = slab_test<FAST>(rmin, rmax, ro, rd, ird, res.t, tr);
             }
-            const bool swap = hit_r && (!hit_l || tl > tr);     /* strict: ties keep left first */
+            const bool swap = FIXED ? (hit_r && !hit_l) : (hit_r && (!hit_l || tl > tr));     /* strict: ties keep left first */
             if (hit_l || hit_r) {
                 if (hit_l && hit_r && sp < STACK) {
                     stack_put(stack, sp, view.far_entry(cur, swap));
@@ -570,11 +579,11 @@ __device__ __forceinline__ void walk_run(const View &view, Walk<View> &w, F3 ro,
     w.res = res;
 }
 
-template <int STACK, bool ANY_HIT, bool FAST, typename View, typename StackRef>
+template <int STACK, bool ANY_HIT, bool FAST, bool FIXED = false, typename View, typename StackRef>
 __device__ __forceinline__ HitRecord traverse_loop(const View &view, F3 ro, F3 rd, F3 ird, float max_t, StackRef &stack) {
     Walk<View> w;
     walk_begin(view, w);
-    walk_run<STACK, ANY_HIT, FAST>(view, w, ro, rd, ird, max_t, stack, 0x7fffffff);
+    walk_run<STACK, ANY_HIT, FAST, FIXED>(view, w, ro, rd, ird, max_t, stack, 0x7fffffff);
     return w.res;
 }
 
@@ -641,9 +650,10 @@ __device__ __forceinline__ void lds_walk_begin(const SceneViewLds &view, LdsWalk
 
 /* At most `budget` trips of the deferred-leaf loop (see traverse_loop) for the lanes of this wave; returns early when
  * no lane has anything left.  Per ray the visiting order and every comparison are the reference's. */
-template <int STACK, bool ANY_HIT, bool SIGNED>
+template <int STACK, bool ANY_HIT, bool SIGNED, bool FIXED = false>
 __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &w, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack,
                                              int budget) {
+    static_assert(!FIXED || ANY_HIT, "only the any-hit walk may choose its order");
     const uint32_t P = view.pairs;
     /* per-ray plane-record bases (float4 units): x | y | z, A or B variant by the sign of the direction */
     const float4 *px = view.img + ((SIGNED && rd.x < 0.0f) ? P : 0u);
@@ -674,7 +684,7 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
             float tl, tr;
             const bool hit_l = slab_pair_lds<SIGNED>(X.x, Y.x, Z.x, X.z, Y.z, Z.z, ro, rd, ird, res.t, tl);
             const bool hit_r = slab_pair_lds<SIGNED>(X.y, Y.y, Z.y, X.w, Y.w, Z.w, ro, rd, ird, res.t, tr);
-            const bool swap = hit_r && (!hit_l || tl > tr);     /* strict: ties keep left first */
+            const bool swap = FIXED ? (hit_r && !hit_l) : (hit_r && (!hit_l || tl > tr));     /* strict: ties keep left first */
             if (hit_l || hit_r) {
                 const uint32_t nf = __builtin_amdgcn_alignbit(d, d, swap ? 16u : 0u);    /* near | far << 16 */
                 if (hit_l && hit_r && sp < STACK) {
@@ -723,11 +733,11 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
     w.res = res;
 }
 
-template <int STACK, bool ANY_HIT, bool SIGNED>
+template <int STACK, bool ANY_HIT, bool SIGNED, bool FIXED = false>
 __device__ __forceinline__ HitRecord traverse_loop_lds(const SceneViewLds &view, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack) {
     LdsWalk w;
     lds_walk_begin(view, w);
-    lds_walk_run<STACK, ANY_HIT, SIGNED>(view, w, ro, rd, ird, max_t, stack, 0x7fffffff);
+    lds_walk_run<STACK, ANY_HIT, SIGNED, FIXED>(view, w, ro, rd, ird, max_t, stack, 0x7fffffff);
     return w.res;
 }
 
@@ -756,8 +766,9 @@ template <bool LDS_SCENE> struct SceneViewOf { typedef SceneViewGlobal type; };
 template <> struct SceneViewOf<true> { typedef SceneViewLds type; };
 
 template <int THREADS>
-__device__ __forceinline__ SceneViewLds stage_scene_lds(const DevScene &sc, float4 *lds_scene) {
-    for (uint32_t k = threadIdx.x; k < sc.lds_vecs; k += THREADS) lds_scene[k] = sc.lds_image[k];
+__device__ __forceinline__ SceneViewLds stage_scene_lds(const DevScene &sc, float4 *lds_scene, bool shadow_copy = false) {
+    const float4 *image = shadow_copy ? sc.lds_image_shadow : sc.lds_image;       /* (the flipped copy: same sizes, same root) */
+    for (uint32_t k = threadIdx.x; k < sc.lds_vecs; k += THREADS) lds_scene[k] = image[k];
     __syncthreads();
     return SceneViewLds{lds_scene, sc.lds_pairs, sc.n_triangles, sc.lds_root};
 }
@@ -1022,7 +1033,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow(DevScene sc, DevSta
  * visits: lane utilisation of the one-ray-per-lane kernel was 40 % (profiles/r02base_darkcornell_mis_pmc_sq.txt).
  * Lanes only record "occluded" in the unused .w of the entry's contribution record; k_shadow_resolve then adds the NEE
  * terms in one dense pass (all lanes busy, none of the walk's registers live). */
-template <int STACK, int THREADS>
+template <int STACK, int THREADS, bool FIXED /* fixed left-first order over the flipped image (shadow_order.h) */>
 __attribute__((amdgpu_num_sgpr(RPT_LDS_WALK_SGPRS)))
 __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc, DevState st, DevQueues q, DevStats *stats, uint32_t SPAN) {
     constexpr uint32_t NW = THREADS / RPT_WAVE;
@@ -1042,7 +1053,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
     }
     __syncthreads();
     if ((uint32_t)(pool.word >> 32) == 0u) return;             /* block-uniform: nothing (left) to trace */
-    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);
+    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene, FIXED);
     uint16_t *stack = &lds_stack[wave][0][lane];
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     float max_t = 0.0f;
@@ -1078,7 +1089,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
                         ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         lds_walk_begin(view, w);
                     } else {
-                        w.res = traverse_loop_lds<STACK, true, false>(view, ro, rd, rd, max_t, stack);   /* alone; recorded at the next refill */
+                        w.res = traverse_loop_lds<STACK, true, false, FIXED>(view, ro, rd, rd, max_t, stack);   /* alone; recorded at the next refill */
                     }
                 }
             }
@@ -1089,7 +1100,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_shadow_stream(DevScene sc,
             if (!pool_open) break;                             /* nothing in flight and nothing left to hand out */
             continue;
         }
-        lds_walk_run<STACK, true, true>(view, w, ro, rd, ird, max_t, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
+        lds_walk_run<STACK, true, true, FIXED>(view, w, ro, rd, ird, max_t, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
     }
     if (have) q.sh_c[entry].w = w.res.tri == HIT_MISS ? 0.0f : 1.0f;
 }
@@ -1269,7 +1280,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shadow_resolve(DevState st, DevQu
  * any-hit walk has ended (found an occluder after two visits, or crossed the whole scene without one).  Lanes only note
  * "occluded" per entry in LDS while walking; the NEE terms are added afterwards in one dense pass over the span (all
  * lanes busy, and the registers of the walk are dead by then: 61 instead of 91 VGPRs). */
-template <int STACK, int WIDTH, bool COOP>
+template <int STACK, int WIDTH, bool COOP, bool FIXED /* fixed left-first order over the flipped pair array (shadow_order.h) */>
 __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
  __global__ __launch_bounds__(RPT_WAVE) void k_traverse_shadow_gstream(DevScene sc, DevState st, DevQueues q, DevConfig cfg, DevStats *stats,
                                                                       uint32_t SPAN) {
@@ -1285,7 +1296,7 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
     const uint32_t end = begin + SPAN < n ? begin + SPAN : n;
     {
         typedef typename GstreamView<COOP>::type View;
-        const View view = RPT_GSTREAM_VIEW(COOP, sc);
+        const View view = FIXED ? RPT_GSTREAM_VIEW_SHADOW(COOP, sc) : RPT_GSTREAM_VIEW(COOP, sc);
         auto stack = lds_stack.column(lane);
         F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
         float max_t = 0.0f;
@@ -1315,7 +1326,7 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
                             ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                             walk_begin(view, w);
                         } else {
-                            w.res = traverse_loop<STACK, true, false>(view, ro, rd, rd, max_t, stack);   /* alone; noted at the next refill */
+                            w.res = traverse_loop<STACK, true, false, FIXED>(view, ro, rd, rd, max_t, stack);   /* alone; noted at the next refill */
                         }
                     }
                 }
@@ -1323,7 +1334,7 @@ __attribute__((amdgpu_waves_per_eu(gstream_waves(STACK, WIDTH, COOP), 8)))
                 next += n_idle;
                 continue;
             }
-            walk_run<STACK, true, true>(view, w, ro, rd, ird, max_t, stack, more ? RPT_GSTREAM_TRIPS : 0x7fffffff);
+            walk_run<STACK, true, true, FIXED>(view, w, ro, rd, ird, max_t, stack, more ? RPT_GSTREAM_TRIPS : 0x7fffffff);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -12,6 +12,7 @@
 
 #include "../../include/rpt/rpt.h"
 #include "k_common.h"
+#include "shadow_order.h"
 
 #define HIP_TRY(ctx, expr)                                                                         \
     do {                                                                                           \
@@ -71,6 +72,9 @@ struct rpt_ctx {
     DevBuf<float> tri_isect;
     DevBuf<float4> gpairs;                     /* pair records + links of the streamed global-memory walks (k_traverse.h SceneViewPairsT) */
     DevBuf<uint32_t> glinks;
+    DevBuf<float4> lds_image_shadow, gpairs_shadow;   /* the same tree with its pairs flipped for the fixed-order any-hit walks (shadow_order.h) */
+    DevBuf<uint32_t> glinks_shadow;
+    ShadowOrder shadow_order;
     DevBuf<rpt_light_pick_entry> light_pick;
     DevBuf<uchar4> atlas;
     DevBuf<float4> skybox;

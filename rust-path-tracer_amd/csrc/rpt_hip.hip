@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "rpt_ctx.h"
+#include "shadow_order.h"
 #include "k_traverse.h"
 #include "k_bvh_build.h"
 #include "k_shade.h"
@@ -317,12 +318,17 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
             span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
             span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
             const uint32_t n_spans = (c->n_slots + span - 1) / span;
-            k_traverse_shadow_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
+            if (c->scene.lds_image_shadow) k_traverse_shadow_stream<16, LDS_THREADS, true><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
+            else k_traverse_shadow_stream<16, LDS_THREADS, false><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
             k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
         } else if (STACK == 16 && c->scene.lds_scene)
             k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
         else if (c->gstream && (!RPT_GSTREAM_PAIRS || c->scene.gpairs)) {
-#define RPT_LAUNCH_SHADOW(W, COOP) k_traverse_shadow_gstream<STACK, W, COOP><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan)
+#define RPT_LAUNCH_SHADOW(W, COOP)                                                                                                                         \
+    do {                                                                                                                                                   \
+        if (RPT_GSTREAM_PAIRS && c->scene.gpairs_shadow) k_traverse_shadow_gstream<STACK, W, COOP, true><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan); \
+        else k_traverse_shadow_gstream<STACK, W, COOP, false><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);   \
+    } while (0)
             if (c->fat_leaves) {
                 if (stack_width == 16) RPT_LAUNCH_SHADOW(16, true); else if (stack_width == 21) RPT_LAUNCH_SHADOW(21, true);
                 else if (stack_width == 24) RPT_LAUNCH_SHADOW(24, true); else RPT_LAUNCH_SHADOW(32, true);
@@ -413,6 +419,38 @@ int rpt_device_info(int device_id, uint32_t *compute_units_out, uint32_t *clock_
     return RPT_OK;
 }
 
+int rpt_shadow_order(rpt_ctx *c, uint32_t *fixed_out, double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out) {
+    if (!c) return RPT_EINVAL;
+    if (!c->has_scene) { c->error = "rpt_shadow_order: no scene"; return RPT_EINVAL; }
+    if (fixed_out) *fixed_out = c->scene.shadow_fixed;
+    if (visits_near_out) *visits_near_out = c->shadow_order.visits_near;
+    if (visits_fixed_out) *visits_fixed_out = c->shadow_order.visits_fixed;
+    if (probe_rays_out) *probe_rays_out = c->shadow_order.probe_rays;
+    return RPT_OK;
+}
+
+/* the same decision without a device (tests: the probe is host code) */
+int rpt_debug_shadow_order_host(const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
+                                const rpt_material_data *mats, size_t nm, const rpt_light_pick_entry *lp, size_t nlp, uint32_t *fixed_out,
+                                double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out, uint8_t *flip_out /* (nn - 1) / 2, nullable */) {
+    if (!pv || !idx || !nodes || !mats || !lp || nn == 0) return RPT_EINVAL;
+    bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
+    for (size_t i = 0; i < nn; ++i) {
+        const rpt_bvh_node &n = nodes[i];
+        if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
+        if (n.triangle_count != 0u && (size_t)n.left_or_first + n.triangle_count > nt) return RPT_ESCENE;
+    }
+    for (size_t t = 0; t < nt; ++t)
+        if (idx[t].v0 >= nv || idx[t].v1 >= nv || idx[t].v2 >= nv || idx[t].material >= nm) return RPT_ESCENE;
+    const ShadowOrder so = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped);
+    if (fixed_out) *fixed_out = so.fixed ? 1u : 0u;
+    if (visits_near_out) *visits_near_out = so.visits_near;
+    if (visits_fixed_out) *visits_fixed_out = so.visits_fixed;
+    if (probe_rays_out) *probe_rays_out = so.probe_rays;
+    if (flip_out && !so.flip.empty()) memcpy(flip_out, so.flip.data(), so.flip.size());
+    return RPT_OK;
+}
+
 const char *rpt_last_error(rpt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 int rpt_create(int device_id, rpt_ctx **out) {
@@ -474,7 +512,7 @@ void rpt_destroy(rpt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rpt_comm_release(c);
     release_state(c);
-    c->gpairs.release(); c->glinks.release();
+    c->gpairs.release(); c->glinks.release(); c->lds_image_shadow.release(); c->gpairs_shadow.release(); c->glinks_shadow.release();
     c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_isect.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->light_rec.release(); c->atlas.release(); c->skybox.release();
@@ -633,38 +671,74 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     if (const char *env = getenv("RPT_NO_LDS_SCENE"); env && env[0] == '1') s.lds_scene = 0u;
     /* pair records for the streamed global-memory walks (k_traverse.h SceneViewPairsT); a pool they cannot express keeps the one-shot walks */
     s.gpairs = nullptr; s.glinks = nullptr;
-    {
-        bool ok = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
-        std::vector<uint32_t> links(nn);
-        for (size_t i = 0; i < nn && ok; ++i) {
-            const rpt_bvh_node &n = nodes[i];
-            if (n.triangle_count >= 255u || n.left_or_first >= (1u << 24)) ok = false;
-            else if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) ok = false;
-            links[i] = (n.triangle_count << 24) | n.left_or_first;
-        }
-        if (ok) {
-            const size_t P = (nn - 1) / 2;
-            std::vector<float4> pairs(4 * P, make_float4(0, 0, 0, 0));
-            for (size_t p = 0; p < P; ++p) {
-                const rpt_bvh_node &L = nodes[2 * p + 1], &R = nodes[2 * p + 2];
-                float fl, fr;
-                memcpy(&fl, &links[2 * p + 1], 4); memcpy(&fr, &links[2 * p + 2], 4);
-                pairs[4 * p + 0] = make_float4(L.aabb_min[0], L.aabb_min[1], L.aabb_min[2], L.aabb_max[0]);
-                pairs[4 * p + 1] = make_float4(L.aabb_max[1], L.aabb_max[2], R.aabb_min[0], R.aabb_min[1]);
-                pairs[4 * p + 2] = make_float4(R.aabb_min[2], R.aabb_max[0], R.aabb_max[1], R.aabb_max[2]);
-                pairs[4 * p + 3] = make_float4(0.0f, 0.0f, fl, fr);
-            }
-            HIP_TRY(c, c->gpairs.alloc(std::max<size_t>(1, pairs.size())));
-            HIP_TRY(c, c->glinks.alloc(nn));
-            HIP_TRY(c, hipMemcpy(c->gpairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
-            HIP_TRY(c, hipMemcpy(c->glinks.p, links.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice));
-            s.gpairs = c->gpairs.p; s.glinks = c->glinks.p;
-        } else {
-            /* a previous, pair-shaped scene's records are of no use to this one (36 bytes per node of the OLD scene otherwise stay until rpt_destroy) */
-            c->gpairs.release();
-            c->glinks.release();
-        }
+    bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
+    for (size_t i = 0; i < nn && pair_shaped; ++i) {
+        const rpt_bvh_node &n = nodes[i];
+        if (n.triangle_count >= 255u || n.left_or_first >= (1u << 24)) pair_shaped = false;
+        else if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
     }
+    auto build_pairs = [nn](const rpt_bvh_node *pool, std::vector<float4> &pairs, std::vector<uint32_t> &links) {
+        links.resize(nn);
+        for (size_t i = 0; i < nn; ++i) links[i] = (pool[i].triangle_count << 24) | pool[i].left_or_first;
+        const size_t P = (nn - 1) / 2;
+        pairs.assign(4 * P, make_float4(0, 0, 0, 0));
+        for (size_t p = 0; p < P; ++p) {
+            const rpt_bvh_node &L = pool[2 * p + 1], &R = pool[2 * p + 2];
+            float fl, fr;
+            memcpy(&fl, &links[2 * p + 1], 4); memcpy(&fr, &links[2 * p + 2], 4);
+            pairs[4 * p + 0] = make_float4(L.aabb_min[0], L.aabb_min[1], L.aabb_min[2], L.aabb_max[0]);
+            pairs[4 * p + 1] = make_float4(L.aabb_max[1], L.aabb_max[2], R.aabb_min[0], R.aabb_min[1]);
+            pairs[4 * p + 2] = make_float4(R.aabb_min[2], R.aabb_max[0], R.aabb_max[1], R.aabb_max[2]);
+            pairs[4 * p + 3] = make_float4(0.0f, 0.0f, fl, fr);
+        }
+    };
+    if (pair_shaped) {
+        std::vector<float4> pairs;
+        std::vector<uint32_t> links;
+        build_pairs(nodes, pairs, links);
+        HIP_TRY(c, c->gpairs.alloc(std::max<size_t>(1, pairs.size())));
+        HIP_TRY(c, c->glinks.alloc(nn));
+        HIP_TRY(c, hipMemcpy(c->gpairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->glinks.p, links.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice));
+        s.gpairs = c->gpairs.p; s.glinks = c->glinks.p;
+    } else {
+        /* a previous, pair-shaped scene's records are of no use to this one (36 bytes per node of the OLD scene otherwise stay until rpt_destroy) */
+        c->gpairs.release();
+        c->glinks.release();
+    }
+    /* The any-hit (shadow) walks may visit siblings in any order (shadow_order.h: only `.hit` is read, light_pick.rs:148).  Probe rays decide per
+     * scene between the reference's near-first order and a fixed opaque-first order; the latter walks a copy of the tree whose pairs are flipped so
+     * that the preferred child is the LEFT one: a second LDS image / pair array, read by the shadow kernels only. */
+    s.shadow_fixed = 0u; s.lds_image_shadow = nullptr; s.gpairs_shadow = nullptr; s.glinks_shadow = nullptr;
+    c->shadow_order = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped);
+    if (c->shadow_order.fixed) {
+        const std::vector<rpt_bvh_node> pool = flipped_nodes(nodes, nn, c->shadow_order.flip);
+        bool built = false;
+        if (s.lds_scene) {
+            std::vector<float4> image;
+            uint32_t pairs = 0, root = 0;
+            if (build_lds_image(pool.data(), nn, geom, nt, image, pairs, root) && image.size() == (size_t)s.lds_vecs && pairs == s.lds_pairs && root == s.lds_root) {
+                HIP_TRY(c, c->lds_image_shadow.alloc(std::max<size_t>(1, image.size())));
+                HIP_TRY(c, hipMemcpy(c->lds_image_shadow.p, image.data(), image.size() * sizeof(float4), hipMemcpyHostToDevice));
+                s.lds_image_shadow = c->lds_image_shadow.p;
+                built = true;
+            }
+        }
+        if (s.gpairs) {
+            std::vector<float4> pairs;
+            std::vector<uint32_t> links;
+            build_pairs(pool.data(), pairs, links);
+            HIP_TRY(c, c->gpairs_shadow.alloc(std::max<size_t>(1, pairs.size())));
+            HIP_TRY(c, c->glinks_shadow.alloc(nn));
+            HIP_TRY(c, hipMemcpy(c->gpairs_shadow.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(c->glinks_shadow.p, links.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice));
+            s.gpairs_shadow = c->gpairs_shadow.p; s.glinks_shadow = c->glinks_shadow.p;
+            built = true;
+        }
+        s.shadow_fixed = built ? 1u : 0u;
+    }
+    if (!s.lds_image_shadow) c->lds_image_shadow.release();
+    if (!s.gpairs_shadow) { c->gpairs_shadow.release(); c->glinks_shadow.release(); }
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
     s.fastdiv_ok = 1u;
     for (size_t i = 0; i < nn && s.fastdiv_ok; ++i)

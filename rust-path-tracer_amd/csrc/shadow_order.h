@@ -1,0 +1,218 @@
+/*
+ * shadow_order.h — the visiting order of the any-hit (shadow) walks, decided once per scene at upload (host code of librpt_hip.so).
+ *
+ * What the reference fixes and what it leaves free.  A shadow query (kernels/src/light_pick.rs:141-148) is intersect_any
+ * (intersection.rs:173-175): intersect_front_to_back<false>, of whose result ONLY `.hit` is read (light_pick.rs:148).  Inside that walk
+ * `result.t` stays 1 000 000.0 until the first triangle is accepted, every box is tested against that constant (:212-213), and the first
+ * accepted triangle returns (:201-203).  So whether a node is entered depends on the boxes of its ancestors alone — not on the order
+ * siblings are visited in — and `.hit` is the OR of the accept test (:191-194 with t <= max_t) over the triangles of the reachable leaves.
+ * ANY visiting order gives the reference's `.hit` bit for bit (tests/test_anyhit_order.py: left-first, right-first, far-first, random
+ * per (ray, node) and breadth-first against intersect_front_to_back<false> on 10^6 rays).  Nearest-hit walks have no such freedom: their
+ * order decides ties in t (k_traverse.h header).
+ *
+ * What the freedom is worth (tools/anyhit_order_sim.py, profiles/r05_anyhit_order_sim.txt): an UNOCCLUDED ray visits the same nodes under
+ * every order; an occluded ray stops at the first occluder it meets, and how soon that is depends on the scene.  Replayed on the real
+ * shadow rays of the streamed kernels: DarkCornell — near-first finds the occluder after 28.9 node visits of the 30.6 an unoccluded ray
+ * makes (a ray leaves a wall: the boxes around its origin are nearest and hold its own surface), a FIXED order that enters the more
+ * OPAQUE child first (triangle surface / box surface of the subtree) after 14.1: - 28 % wave-instructions per shadow ray; VeachMIS (most
+ * occluders are the far side of the very light sphere a ray aims at) near-first 16.2, opaque-first 20.9: + 7 %.  Packet descent
+ * (one stack of (node, lane mask) per wave) needs + 98 % / + 1 245 %, a stackless threaded layout + 9 % / + 12 %, a wave vote - 2 % / + 7 %.
+ * Neither order wins everywhere, so the library measures: at upload it throws SHADOW_PROBE_RAYS synthetic shadow rays (surface points
+ * chosen by area on the non-emissive triangles, light points through the scene's own light-pick table as light_pick.rs:8-23 draws them)
+ * through both orders on the host and counts node visits.  If opaque-first needs fewer than SHADOW_FIXED_GAIN of near-first's, the shadow
+ * kernels walk a copy of the tree whose child pairs are flipped so that the preferred child sits in the left slot, in fixed left-first
+ * order (no `tl > tr`, no swap); otherwise they keep the reference's near-first order.  Deterministic (fixed seed), a few milliseconds, and
+ * whatever it decides the image is the same.  RPT_SHADOW_ORDER=near|fixed overrides (tests run every NEE case both ways).
+ */
+#ifndef RPT_SHADOW_ORDER_H
+#define RPT_SHADOW_ORDER_H
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rpt/shared_structs.h"
+
+#define SHADOW_PROBE_RAYS 4096
+#define SHADOW_FIXED_GAIN 0.95
+
+struct ShadowOrder {
+    bool fixed = false;                 /* walk the flipped tree left-first */
+    std::vector<uint8_t> flip;          /* per child pair p = nodes (2p + 1, 2p + 2): the right child is the preferred one */
+    double visits_near = 0.0, visits_fixed = 0.0;   /* node visits per probe ray under either order */
+    uint32_t probe_rays = 0, probe_occluded = 0;
+    const char *why = "no lights";
+};
+
+namespace shadow_order_detail {
+
+struct V { float x, y, z; };
+inline V sub(V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V cross(V a, V b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V vtx(const rpt_per_vertex_data &p) { return V{p.vertex[0], p.vertex[1], p.vertex[2]}; }
+
+/* the box test of the walk with prev_min_t = 1e6 (plain float code: this is a cost estimate, not a result) */
+inline bool box(const rpt_bvh_node &n, V o, V d, float &tmin) {
+    float tx1 = (n.aabb_min[0] - o.x) / d.x, tx2 = (n.aabb_max[0] - o.x) / d.x;
+    float lo = std::fmin(tx1, tx2), hi = std::fmax(tx1, tx2);
+    float ty1 = (n.aabb_min[1] - o.y) / d.y, ty2 = (n.aabb_max[1] - o.y) / d.y;
+    lo = std::fmax(lo, std::fmin(ty1, ty2)); hi = std::fmin(hi, std::fmax(ty1, ty2));
+    float tz1 = (n.aabb_min[2] - o.z) / d.z, tz2 = (n.aabb_max[2] - o.z) / d.z;
+    lo = std::fmax(lo, std::fmin(tz1, tz2)); hi = std::fmin(hi, std::fmax(tz1, tz2));
+    tmin = lo;
+    return hi >= lo && hi > 0.0f && lo < 1000000.0f;
+}
+
+inline bool tri(const rpt_per_vertex_data *pv, const rpt_triangle &t, V o, V d, float max_t) {
+    V a = vtx(pv[t.v0]), e1 = sub(vtx(pv[t.v1]), a), e2 = sub(vtx(pv[t.v2]), a);
+    V p = cross(d, e2);
+    float det = dot(e1, p);
+    if (std::fabs(det) < 1e-6f) return false;
+    float inv = 1.0f / det;
+    V tv = sub(o, a);
+    float u = dot(tv, p) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    V q = cross(tv, e1);
+    float v = dot(d, q) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float tt = dot(e2, q) * inv;
+    return tt > 0.001f && tt <= max_t;
+}
+
+struct ProbeRng {
+    uint64_t s;
+    float next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((s >> 40) & 0xffffffu) * (1.0f / 16777216.0f); }
+};
+
+/* node visits of one any-hit walk; FIXED: the preferred child of every pair first, else near first */
+template <bool FIXED>
+inline uint32_t walk(const rpt_bvh_node *nodes, const rpt_per_vertex_data *pv, const rpt_triangle *idx, const std::vector<uint8_t> &flip, V o, V d,
+                     float max_t, bool &occluded) {
+    uint32_t stack[64];
+    int sp = 0;
+    uint32_t visits = 0, node = 0;
+    occluded = false;
+    for (;;) {
+        visits += 1;
+        const rpt_bvh_node &n = nodes[node];
+        bool descend = false;
+        if (n.triangle_count != 0u) {
+            for (uint32_t k = 0; k < n.triangle_count; ++k)
+                if (tri(pv, idx[n.left_or_first + k], o, d, max_t)) { occluded = true; return visits; }
+        } else {
+            const uint32_t L = n.left_or_first, R = L + 1u;
+            float tl, tr;
+            const bool hl = box(nodes[L], o, d, tl), hr = box(nodes[R], o, d, tr);
+            const bool right = FIXED ? (hr && (!hl || flip[L >> 1] != 0)) : (hr && (!hl || tl > tr));
+            if (hl || hr) {
+                if (hl && hr && sp < 64) stack[sp++] = right ? L : R;
+                node = right ? R : L;
+                descend = true;
+            }
+        }
+        if (!descend) {
+            if (sp == 0) return visits;
+            node = stack[--sp];
+        }
+    }
+}
+
+}  // namespace shadow_order_detail
+
+/* Expects a validated scene (rpt_hip.hip validate_scene: links in range, no cycles, leaf ranges inside the index buffer).  `pair_shaped`: children of
+ * every inner node are the nodes (2p + 1, 2p + 2) of one pair — what the flipped copies can express; otherwise near-first stays. */
+inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
+                                       const rpt_material_data *mats, const rpt_light_pick_entry *lp, size_t nlp, bool pair_shaped) {
+    using namespace shadow_order_detail;
+    ShadowOrder so;
+    if (nlp == 0 || lp[0].ratio < 0.0f || nt == 0) return so;
+    if (!pair_shaped || nn < 3) { so.why = "node pool is not pair-shaped"; return so; }
+    /* triangle surface below every node, children before parents (explicit post-order: the pool's index order is the builder's business) */
+    std::vector<double> area(nn, 0.0), tri_area(nt, 0.0);
+    for (size_t t = 0; t < nt; ++t) {
+        V a = vtx(pv[idx[t].v0]), x = cross(sub(vtx(pv[idx[t].v1]), a), sub(vtx(pv[idx[t].v2]), a));
+        tri_area[t] = 0.5 * std::sqrt((double)dot(x, x));
+    }
+    {
+        std::vector<uint32_t> order;
+        order.reserve(nn);
+        std::vector<uint32_t> st(1, 0u);
+        while (!st.empty()) {
+            uint32_t n = st.back(); st.pop_back();
+            order.push_back(n);
+            if (nodes[n].triangle_count == 0u) { st.push_back(nodes[n].left_or_first); st.push_back(nodes[n].left_or_first + 1u); }
+        }
+        for (size_t i = order.size(); i-- > 0;) {
+            const rpt_bvh_node &n = nodes[order[i]];
+            if (n.triangle_count == 0u) area[order[i]] = area[n.left_or_first] + area[n.left_or_first + 1u];
+            else for (uint32_t k = 0; k < n.triangle_count; ++k) area[order[i]] += tri_area[n.left_or_first + k];
+        }
+    }
+    auto opacity = [&](uint32_t n) {
+        const rpt_bvh_node &b = nodes[n];
+        const double ex = (double)b.aabb_max[0] - b.aabb_min[0], ey = (double)b.aabb_max[1] - b.aabb_min[1], ez = (double)b.aabb_max[2] - b.aabb_min[2];
+        const double half = std::max(ex * ey + ey * ez + ez * ex, 1e-30);
+        return std::min(1.0, area[n] / half);
+    };
+    so.flip.assign((nn - 1) / 2, 0);
+    for (size_t p = 0; p < so.flip.size(); ++p) so.flip[p] = opacity((uint32_t)(2 * p + 2)) > opacity((uint32_t)(2 * p + 1)) ? 1 : 0;
+
+    /* probe rays: surface point by area on the non-emissive triangles (all triangles if everything emits), light point as pick_light +
+     * pick_triangle_point draw it (light_pick.rs:8-23, 100-134) */
+    std::vector<double> cdf(nt);
+    double total = 0.0;
+    auto emissive = [&](size_t t) { const float *e = mats[idx[t].material].emissive; return e[0] != 0.0f || e[1] != 0.0f || e[2] != 0.0f; };
+    for (size_t t = 0; t < nt; ++t) { total += emissive(t) ? 0.0 : tri_area[t]; cdf[t] = total; }
+    if (!(total > 0.0)) { total = 0.0; for (size_t t = 0; t < nt; ++t) { total += tri_area[t]; cdf[t] = total; } }
+    if (!(total > 0.0)) { so.why = "degenerate geometry"; return so; }
+    ProbeRng rng{0x9e3779b97f4a7c15ull};
+    auto point_on = [&](size_t t, float r1, float r2) {
+        V a = vtx(pv[idx[t].v0]), b = vtx(pv[idx[t].v1]), c = vtx(pv[idx[t].v2]);
+        const float s = std::sqrt(r1), wa = 1.0f - s, wb = s * (1.0f - r2), wc = s * r2;
+        return V{wa * a.x + wb * b.x + wc * c.x, wa * a.y + wb * b.y + wc * c.y, wa * a.z + wb * b.z + wc * c.z};
+    };
+    uint64_t vn = 0, vf = 0;
+    for (int i = 0; i < SHADOW_PROBE_RAYS; ++i) {
+        const double pick = (double)rng.next() * total;
+        const size_t t0 = (size_t)(std::lower_bound(cdf.begin(), cdf.end(), pick) - cdf.begin());
+        const V p = point_on(std::min(t0, nt - 1), rng.next(), rng.next());
+        const rpt_light_pick_entry &e = lp[std::min((size_t)(rng.next() * (float)nlp), nlp - 1)];
+        const uint32_t lt = rng.next() < e.ratio ? e.triangle_index_a : e.triangle_index_b;
+        if (lt >= nt) continue;
+        const V q = point_on(lt, rng.next(), rng.next());
+        V d = sub(q, p);
+        const float dist = std::sqrt(dot(d, d));
+        if (!(dist > 1e-4f)) continue;
+        d = V{d.x / dist, d.y / dist, d.z / dist};
+        const V o = V{p.x + d.x * 0.001f, p.y + d.y * 0.001f, p.z + d.z * 0.001f};          /* light_pick.rs:141-147, EPS = 0.001 */
+        bool occ_n = false, occ_f = false;
+        vn += walk<false>(nodes, pv, idx, so.flip, o, d, dist - 0.002f, occ_n);
+        vf += walk<true>(nodes, pv, idx, so.flip, o, d, dist - 0.002f, occ_f);
+        so.probe_rays += 1;
+        so.probe_occluded += occ_n ? 1u : 0u;
+    }
+    if (so.probe_rays == 0) { so.why = "no probe ray could be formed"; return so; }
+    so.visits_near = (double)vn / so.probe_rays;
+    so.visits_fixed = (double)vf / so.probe_rays;
+    so.fixed = so.visits_fixed < SHADOW_FIXED_GAIN * so.visits_near;
+    so.why = so.fixed ? "opaque-first needs fewer node visits on the probe rays" : "near-first needs no more node visits on the probe rays";
+    if (const char *env = getenv("RPT_SHADOW_ORDER")) {
+        if (!strcmp(env, "fixed")) { so.fixed = true; so.why = "RPT_SHADOW_ORDER=fixed"; }
+        else if (!strcmp(env, "near")) { so.fixed = false; so.why = "RPT_SHADOW_ORDER=near"; }
+    }
+    return so;
+}
+
+/* the node pool with the children of every flipped pair exchanged (contents move, pair positions stay: links into pairs remain valid) */
+inline std::vector<rpt_bvh_node> flipped_nodes(const rpt_bvh_node *nodes, size_t nn, const std::vector<uint8_t> &flip) {
+    std::vector<rpt_bvh_node> out(nodes, nodes + nn);
+    for (size_t p = 0; p < flip.size(); ++p)
+        if (flip[p]) std::swap(out[2 * p + 1], out[2 * p + 2]);
+    return out;
+}
+
+#endif /* RPT_SHADOW_ORDER_H */

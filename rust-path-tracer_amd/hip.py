@@ -23,7 +23,7 @@ EXPORTS = [
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
-    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_build_fingerprint", "rpt_debug_comm_selftest", "rpt_device_info",
+    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_build_fingerprint", "rpt_debug_comm_selftest", "rpt_device_info", "rpt_shadow_order", "rpt_debug_shadow_order_host",
 ]
 COMM_ID_BYTES = 128
 MULTI_ALLOW_SHARED_DEVICE = 1
@@ -82,6 +82,7 @@ def lib():
         L.rpt_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.rpt_comm_init_local.argtypes = [C.c_void_p]
         L.rpt_device_info.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.rpt_shadow_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.rpt_debug_comm_selftest.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         L.rpt_comm_world.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rpt_gather_async.argtypes = [C.c_void_p]
@@ -265,6 +266,13 @@ class Renderer:
     def comm_init_local(self):
         """rpt_comm_init_local: a one-rank communicator without RCCL (overlapped read-back on one GPU)."""
         self._check(lib().rpt_comm_init_local(self._h))
+
+    def shadow_order(self):
+        """rpt_shadow_order: {"fixed": bool, "visits_near", "visits_fixed", "probe_rays"} — which (bit-exact) order the shadow walks of the scene use."""
+        f, n = C.c_uint32(), C.c_uint32()
+        vn, vf = C.c_double(), C.c_double()
+        self._check(lib().rpt_shadow_order(self._h, C.byref(f), C.byref(vn), C.byref(vf), C.byref(n)))
+        return {"fixed": bool(f.value), "visits_near": vn.value, "visits_fixed": vf.value, "probe_rays": n.value}
 
     def comm_world(self):
         r, w = C.c_uint32(), C.c_uint32()
@@ -454,6 +462,22 @@ def tile_order(width, height, rank, world_size):
     if rc != 0:
         raise RptError(rc, "rpt_tile_order")
     return out
+
+
+def shadow_order_host(world):
+    """rpt_debug_shadow_order_host: the upload-time decision about the shadow walks' order for a World, without a GPU."""
+    f, n = C.c_uint32(), C.c_uint32()
+    vn, vf = C.c_double(), C.c_double()
+    flip = np.zeros(max(1, (len(world.nodes) - 1) // 2), np.uint8)
+    L = lib()
+    L.rpt_debug_shadow_order_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                              C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_void_p]
+    rc = L.rpt_debug_shadow_order_host(ptr(world.per_vertex), len(world.per_vertex), ptr(world.indices), len(world.indices), ptr(world.nodes), len(world.nodes),
+                                       ptr(world.materials), len(world.materials), ptr(world.light_pick), len(world.light_pick),
+                                       C.byref(f), C.byref(vn), C.byref(vf), C.byref(n), ptr(flip))
+    if rc != 0:
+        raise RptError(rc, "rpt_debug_shadow_order_host")
+    return {"fixed": bool(f.value), "visits_near": vn.value, "visits_fixed": vf.value, "probe_rays": n.value, "flip": flip}
 
 
 def debug_math_host(op, x, y=None):

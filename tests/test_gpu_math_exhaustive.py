@@ -36,14 +36,15 @@ def test_device_exp_sky_at_its_special_arguments(renderer, hipmod):
     on windows of every float around them."""
     nan = np.float32(np.nan)
     x = np.array([nan, -nan, np.inf, -np.inf, 89.0, np.nextafter(np.float32(89.0), np.float32(np.inf)), np.nextafter(np.float32(89.0), np.float32(0)),
-                  -104.0, np.nextafter(np.float32(-104.0), np.float32(-np.inf)), np.nextafter(np.float32(-104.0), np.float32(0)), 0.0, -0.0, 3.0e38, -3.0e38],
-                 np.float32)
+                  -104.0, np.nextafter(np.float32(-104.0), np.float32(-np.inf)), np.nextafter(np.float32(-104.0), np.float32(0)), 0.0, -0.0, 3.0e38, -3.0e38,
+                  88.5, -103.0], np.float32)
     got = renderer.debug_math(10, x)
     assert np.isnan(got[0]) and np.isnan(got[1])
     assert got[2] == np.inf and got[3] == 0.0 and not np.signbit(got[3])
-    assert got[4] == np.inf and got[5] == np.inf and np.isfinite(got[6]) and got[6] > 3.0e38
-    assert got[7] == 0.0 and got[8] == 0.0 and got[9] >= 0.0 and got[10] == 1.0 and got[11] == 1.0
+    assert got[4] == np.inf and got[5] == np.inf and got[6] == np.inf          # e^88.72... is the largest float already
+    assert got[7] == 0.0 and got[8] == 0.0 and got[9] == 0.0 and got[10] == 1.0 and got[11] == 1.0
     assert got[12] == np.inf and got[13] == 0.0
+    assert abs(float(got[14]) / 2.723088e38 - 1.0) < 1e-6 and got[15].view(np.uint32) == 1      # a large finite value; the smallest denormal
     for centre in (np.float32(89.0), np.float32(-104.0), np.float32(np.inf), np.float32(-np.inf), np.float32(88.72), np.float32(-87.3), np.float32(0.0)):
         c = int(np.array([centre], np.float32).view(np.uint32)[0])
         bits = (np.arange(-4096, 4096, dtype=np.int64) + c) & 0xffffffff

@@ -188,6 +188,60 @@ def test_image_parity_with_oracle(renderer, oracle, rpt, world, scene, W, H, spp
     assert n_diff == 0, "accumulators are expected to be bit-identical to the oracle"
 
 
+@pytest.mark.parametrize("order", ["near", "fixed"])
+@pytest.mark.parametrize("scene,W,H,spp,nee,over", [c for c in CASES if c[4] != 0 and c[1] <= 200] + [("deep_bvh", 96, 64, 2, 1, {"cam_position": (0.0, 2.5, -0.5, 0.0)}),
+                                                                                                  ("scatter", 96, 64, 2, 1, {"cam_position": (0.0, 1.8, -0.9, 0.0)})])
+def test_either_shadow_order_gives_the_oracles_image(monkeypatch, hipmod, oracle, rpt, world, scene, W, H, spp, nee, over, order):
+    """The shadow (any-hit) walks may visit siblings in any order (light_pick.rs:148 reads `.hit` only; tests/test_anyhit_order.py).  The library picks
+    per scene at upload (rpt_shadow_order); forced either way — the reference's near-first order, or the fixed opaque-first order over the flipped
+    copy of the tree (LDS image for DarkCornell, pair arrays for the others, thin and fat leaves, 16- and 21-bit stack entries) — every NEE image is
+    the oracle's bit for bit, and so are the ray counts."""
+    monkeypatch.setenv("RPT_SHADOW_ORDER", order)
+    if scene == "deep_bvh":
+        from scenes import deep_bvh_scene
+        w = deep_bvh_scene(60_000)
+    elif scene == "scatter":
+        from scenes import scatter_scene
+        w = scatter_scene(80_000)
+    else:
+        w = world(scene)
+    cfg = rpt.default_config(W, H, nee=nee, **over)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    try:
+        r.upload_scene(w)
+        so = r.shadow_order()
+        assert so["fixed"] == (order == "fixed") and so["probe_rays"] > 0
+        r.set_config(cfg); r.reset(seeds)
+        r.render(spp)
+        acc_g, _ = r.read_accum()
+        st_g = r.stats()
+    finally:
+        r.close()
+    acc_c, _, st_c = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
+    assert st_g["shadow_rays"] == st_c.shadow_rays > 0 and st_g["extension_rays"] == st_c.extension_rays
+    assert np.array_equal(acc_g.view(np.uint32), acc_c.view(np.uint32))
+
+
+def test_the_library_chooses_the_shadow_order_per_scene(monkeypatch, hipmod, rpt, world):
+    """rpt_shadow_order after rpt_upload_scene: DarkCornell walks its shadow rays opaque-first (the probe rays find their occluders in half the node
+    visits), VeachMIS near-first, PBRTest (no lights) is not probed; re-uploading another scene into the same context re-decides."""
+    monkeypatch.delenv("RPT_SHADOW_ORDER", raising=False)
+    r = hipmod.Renderer(0)
+    try:
+        r.upload_scene(world("DarkCornell"))
+        so = r.shadow_order()
+        assert so["fixed"] and so["visits_fixed"] < 0.7 * so["visits_near"] and so == {k: v for k, v in hipmod.shadow_order_host(world("DarkCornell")).items() if k != "flip"}
+        r.upload_scene(world("VeachMIS"))
+        assert not r.shadow_order()["fixed"]
+        r.upload_scene(world("PBRTest"))
+        assert not r.shadow_order()["fixed"] and r.shadow_order()["probe_rays"] == 0
+        r.upload_scene(world("DarkCornell"))
+        assert r.shadow_order()["fixed"]
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("nee,has_skybox", [(0, 1), (1, 1), (2, 0), (1, 0)])
 def test_textured_scene_and_image_skybox_parity(renderer, oracle, rpt, nee, has_skybox):
     """Atlas sampling (CPU-polyfill semantics, image_polyfill.rs:32-55), normal mapping (lib.rs:132-141), uv wrap

@@ -35,7 +35,7 @@ def _find(table, prefix):
     return hits
 
 
-@pytest.mark.parametrize("kernel", ["void k_traverse_nearest_stream<16, 1024>", "void k_traverse_shadow_stream<16, 1024>"])
+@pytest.mark.parametrize("kernel", ["void k_traverse_nearest_stream<16, 1024>", "void k_traverse_shadow_stream<16, 1024, false>", "void k_traverse_shadow_stream<16, 1024, true>"])
 def test_streamed_lds_walks_fit_two_workgroups_per_cu(resources, kernel):
     for vgpr, sgpr, scratch, lds in _find(resources, kernel):
         assert vgpr <= 64 and scratch == 0
@@ -44,8 +44,8 @@ def test_streamed_lds_walks_fit_two_workgroups_per_cu(resources, kernel):
 
 
 @pytest.mark.parametrize("kernel", ["void k_shade<0, false, false>", "void k_traverse_nearest_gstream<24, 16, false>",
-                                    "void k_traverse_shadow_gstream<24, 16, false>", "void k_traverse_nearest_gstream<16, 16, false>",
-                                    "void k_traverse_nearest_gstream<32, 21, false>", "void k_traverse_shadow_gstream<32, 21, false>"])
+                                    "void k_traverse_shadow_gstream<24, 16, false, false>", "void k_traverse_shadow_gstream<24, 16, false, true>", "void k_traverse_nearest_gstream<16, 16, false>",
+                                    "void k_traverse_nearest_gstream<32, 21, false>", "void k_traverse_shadow_gstream<32, 21, false, false>", "void k_traverse_shadow_gstream<32, 21, false, true>"])
 def test_eight_waves_per_simd_where_asked(resources, kernel):
     for vgpr, sgpr, scratch, lds in _find(resources, kernel):
         assert vgpr <= 64 and sgpr <= 80 and scratch == 0
@@ -70,7 +70,7 @@ def test_registers_of_the_nee_and_packed_shade_variants_do_not_creep(resources, 
 def test_no_stage_kernel_of_the_shipped_scenes_spills(resources):
     """every kernel a shipped scene (or the two stand-ins) launches: no scratch"""
     for prefix in ("void k_shade<0, false, ", "void k_shade<1, false, ", "void k_shade<2, false, ", "void k_sky<", "k_generate_first", "k_complete",
-                   "k_shadow_resolve", "void k_traverse_nearest_gstream<32, 16, true>", "void k_traverse_shadow_gstream<32, 16, true>"):
+                   "k_shadow_resolve", "void k_traverse_nearest_gstream<32, 16, true>", "void k_traverse_shadow_gstream<32, 16, true, "):
         for vgpr, sgpr, scratch, lds in _find(resources, prefix):
             assert scratch == 0, prefix
 
