@@ -741,6 +741,10 @@ thread_local bool g_ray_dump_hit = false;
 thread_local float *g_shadow_dump = nullptr;   /* analysis hook: 8 floats: origin, direction, max_t, light-table index */
 thread_local uint32_t g_cur_bounce = 0;
 thread_local bool g_shadow_dump_hit = false;
+/* analysis hook (tools/shade_bin_sim.py): what the shade stage does with the path at each bounce — 1 miss, 2 ends on an emitter (lib.rs:86-109),
+ * 3 diffuse lobe sampled, 4 specular lobe sampled; 0 = the path did not reach that bounce */
+thread_local uint8_t *g_kind_log = nullptr;
+inline void log_kind(uint32_t bounce, uint8_t kind) { if (g_kind_log && bounce < 8) g_kind_log[bounce] = kind; }
 
 PixelResult trace_pixel(uint32_t id_x, uint32_t id_y, const rpt_tracing_config &config, rpt_rng_state rng,
                         const Scene &sc, Counters &cnt) {
@@ -775,6 +779,7 @@ PixelResult trace_pixel(uint32_t id_x, uint32_t id_y, const rpt_tracing_config &
         V3 hit = ray_origin + ray_direction * trace_result.t;
 
         if (!trace_result.hit) {
+            log_kind(bounce, 1);
             cnt.sky_evals++;
             if (config.has_skybox == 0) {
                 radiance = radiance + throughput * sky_scatter(config.sun_direction, ray_origin, ray_direction);
@@ -792,6 +797,7 @@ PixelResult trace_pixel(uint32_t id_x, uint32_t id_y, const rpt_tracing_config &
 
         const rpt_material_data &material = sc.materials[trace_result.triangle.material];
         if (ne_zero3(xyz(material.emissive))) {
+            log_kind(bounce, 2);
             if (trace_result.backface) break;
             if (!nee || bounce == 0 || last_bsdf_sample.sampled_lobe != DiffuseReflection) {
                 radiance = radiance + mask_nan(throughput * xyz(material.emissive));
@@ -827,6 +833,7 @@ PixelResult trace_pixel(uint32_t id_x, uint32_t id_y, const rpt_tracing_config &
         PBR bsdf = get_pbr_bsdf(config, material, tuv, sc.atlas);
         BSDFSample bsdf_sample = bsdf.sample(-ray_direction, normal, rng_state);
         last_bsdf_sample = bsdf_sample;
+        log_kind(bounce, bsdf_sample.sampled_lobe == DiffuseReflection ? 3 : 4);
 
         if (nee && bsdf_sample.sampled_lobe == DiffuseReflection) {
             last_light_sample = sample_direct_lighting(nee_mode, sc, throughput, bsdf, hit, normal, ray_direction,
@@ -1037,6 +1044,23 @@ int oracle_dump_shadow_rays(const rpt_tracing_config *config, const oracle_scene
             valid[i] = g_shadow_dump_hit ? 1 : 0;
         }
     g_shadow_dump = nullptr;
+    return 0;
+}
+
+/* Analysis hook (tools/shade_bin_sim.py): kinds[i * 8 + b] = what bounce b of sample rng[i].n + sample of pixel pixels[i] (x | y << 16) is to the shade stage */
+int oracle_path_kinds(const rpt_tracing_config *config, const oracle_scene *scene, const rpt_rng_state *rng_full, uint32_t sample,
+                      const uint32_t *pixels, size_t n_pixels, uint8_t *kinds) {
+    Scene sc = make_scene(scene);
+    Counters cnt;
+    memset(kinds, 0, n_pixels * 8);
+    for (size_t i = 0; i < n_pixels; ++i) {
+        const uint32_t x = pixels[i] & 0xffffu, y = pixels[i] >> 16;
+        rpt_rng_state r = rng_full[(size_t)y * config->width + x];
+        r.n += sample;
+        g_kind_log = kinds + 8 * i;
+        trace_pixel(x, y, *config, r, sc, cnt);
+    }
+    g_kind_log = nullptr;
     return 0;
 }
 

@@ -500,6 +500,24 @@ __device__ __forceinline__ uint32_t block_rank(bool pred, uint32_t *scratch, uin
     return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+/* the same for two disjoint predicates in one pass (one pair of barriers): ranks and totals of both */
+__device__ __forceinline__ void block_rank2(bool a, bool b, uint32_t *scratch, uint32_t &rank_a, uint32_t &rank_b, uint32_t &total_a, uint32_t &total_b) {
+    const uint32_t lane = __lane_id(), wave = threadIdx.x / RPT_WAVE;
+    constexpr uint32_t NW = RPT_BLOCK / RPT_WAVE;
+    const unsigned long long ma = rpt_ballot(a), mb = rpt_ballot(b);
+    if (lane == 0u) scratch[wave] = (uint32_t)__popcll(ma) | ((uint32_t)__popcll(mb) << 16);
+    __syncthreads();
+    uint32_t base = 0u, sum = 0u;
+    for (uint32_t w = 0; w < NW; ++w) {
+        if (w == wave) base = sum;
+        sum += scratch[w];                   /* (each half stays below 2^16: at most RPT_BLOCK entries) */
+    }
+    total_a = sum & 0xffffu; total_b = sum >> 16;
+    __syncthreads();     /* scratch may be reused */
+    rank_a = (base & 0xffffu) + __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+    rank_b = (base >> 16) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+}
+
 /* side-queue emission of one pass over up to 256 slots: wave64 ballot + mbcnt prefix, one atomic per workgroup
  * (block-uniform early outs keep the barriers inside block_push legal) */
 template <int NEE>
@@ -548,22 +566,33 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             const uint32_t s0 = base + (uint32_t)r * RPT_BLOCK + threadIdx.x;
             hws[r] = s0 < st.n_slots ? st.hit[s0] : make_float2(0.0f, __uint_as_float(HIT_PARKED));
         }
-        uint32_t total = 0u;                                   /* block-uniform */
+        /* Binned by what the stage will do with the slot (lib.rs:64-79 vs :80-181): HITS fill the list from the front, MISSES from the back, and the
+         * hits are padded to whole waves — so no wave holds both.  A miss only parks its slot and queues it for the sky stage (~25 instructions); in
+         * slot order it sat beside lanes running the ~1 400-instruction surface body: from the second bounce on 40-80 % of the traversed slots of an
+         * open scene are misses, the stage ran at 45 % lanes (profiles/r04_{veachmis,pbrtest}_pmc_sq.txt; tools/shade_bin_sim.py replays it:
+         * 26-31 % fewer wave-instructions).  The order inside the list is no part of any result: every entry touches only its own slot. */
+        constexpr uint32_t CAP = RPT_BLOCK * RPT_SHADE_ROUNDS;
+        uint32_t total_h = 0u, total_m = 0u;                   /* block-uniform */
 #pragma unroll
         for (int r = 0; r < RPT_SHADE_ROUNDS; ++r) {
             const uint32_t s0 = base + (uint32_t)r * RPT_BLOCK + threadIdx.x;
             const uint32_t word = __float_as_uint(hws[r].y);
-            const bool traversed = word < HIT_IDLE || word == HIT_MISS;
-            uint32_t n_r = 0u;
-            const uint32_t idx = block_rank(traversed, push_scratch, n_r);
-            if (traversed) c_slot[total + idx] = s0;
-            total += n_r;
+            const bool is_hit = word < HIT_IDLE, is_miss = word == HIT_MISS;
+            uint32_t ih, im, nh, nm;
+            block_rank2(is_hit, is_miss, push_scratch, ih, im, nh, nm);
+            if (is_hit) c_slot[total_h + ih] = s0;
+            if (is_miss) c_slot[CAP - 1u - (total_m + im)] = s0;
+            total_h += nh; total_m += nm;
         }
         __syncthreads();
+        const uint32_t hits_padded = (total_h + RPT_WAVE - 1u) & ~(uint32_t)(RPT_WAVE - 1u);
+        const uint32_t total = hits_padded + total_m;
         for (uint32_t first = 0u; first < total; first += RPT_BLOCK) {      /* block-uniform trip count */
-            const bool active = first + threadIdx.x < total;
-            const uint32_t slot = active ? c_slot[first + threadIdx.x] : 0u;
-            const float2 hw = active ? st.hit[slot] : make_float2(0.0f, __uint_as_float(HIT_PARKED));
+            const uint32_t v = first + threadIdx.x;
+            const bool a_hit = v < total_h, a_miss = v >= hits_padded && v < total;
+            const bool active = a_hit || a_miss;
+            const uint32_t slot = a_hit ? c_slot[v] : (a_miss ? c_slot[CAP - 1u - (v - hits_padded)] : 0u);
+            const float2 hw = a_hit ? st.hit[slot] : make_float2(0.0f, __uint_as_float(a_miss ? HIT_MISS : HIT_PARKED));
             bool to_sky = false, emit_shadow = false;
             float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
             shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples);

@@ -189,7 +189,7 @@ def test_image_parity_with_oracle(renderer, oracle, rpt, world, scene, W, H, spp
 
 
 @pytest.mark.parametrize("order", ["near", "fixed"])
-@pytest.mark.parametrize("scene,W,H,spp,nee,over", [c for c in CASES if c[4] != 0 and c[1] <= 200] + [("deep_bvh", 96, 64, 2, 1, {"cam_position": (0.0, 2.5, -0.5, 0.0)}),
+@pytest.mark.parametrize("scene,W,H,spp,nee,over", [c for c in CASES if c[4] != 0 and c[1] <= 200 and c[0] != "PBRTest"] + [("deep_bvh", 96, 64, 2, 1, {"cam_position": (0.0, 2.5, -0.5, 0.0)}),
                                                                                                   ("scatter", 96, 64, 2, 1, {"cam_position": (0.0, 1.8, -0.9, 0.0)})])
 def test_either_shadow_order_gives_the_oracles_image(monkeypatch, hipmod, oracle, rpt, world, scene, W, H, spp, nee, over, order):
     """The shadow (any-hit) walks may visit siblings in any order (light_pick.rs:148 reads `.hit` only; tests/test_anyhit_order.py).  The library picks
