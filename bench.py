@@ -73,7 +73,7 @@ def usable_cores():
 STAGE_MODEL = {
     "traverse": ("extension_rays", TRAVERSE_BYTES_PER_RAY),          # hit word 8 + ray 24 read, hit record 8 written
     "shade": ("extension_rays", 96),                                  # hit 8 + ray 24 + thr 16 read, ray 24 + hit 8 + thr 16 written
-    "shadow": ("shadow_rays", 80),                                    # entry 32 + contribution 16 read, radiance 16 + 16 RMW
+    "shadow": ("shadow_rays_traced", 80),                                    # entry 32 + contribution 16 read, radiance 16 + 16 RMW
     "sky": ("sky_evals", 76),                                         # slot id 4 + ray 24 + thr 16 + rad 16 read, rad 16 written
     "generate": ("samples", 80),
     "complete": ("samples", 72),                                      # per slot hit 8 + rad 16 read, hit 8 written; per pixel accum 32 + rng 16 (amortised)
@@ -279,9 +279,12 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         s1 = r.stats()
-        n_ext, n_shadow = s1["extension_rays"] - s0["extension_rays"], s1["shadow_rays"] - s0["shadow_rays"]
+        # shadow rays WALKED on the device (what Mrays/s counts); rpt_stats.shadow_rays keeps the reference's count — one per NEE evaluation —
+        # of which shadow_rays_elided were not walked: their term is zero whatever the walk finds (k_shade.h)
+        n_ext, n_shadow = s1["extension_rays"] - s0["extension_rays"], s1["shadow_rays_traced"] - s0["shadow_rays_traced"]
+        n_elided = s1["shadow_rays_elided"] - s0["shadow_rays_elided"]
         n_samples, n_sky = s1["samples"] - s0["samples"], s1["sky_evals"] - s0["sky_evals"]
-        n_mis = n_shadow if cfg.nee == 1 else 0
+        n_mis = (n_shadow + n_elided) if cfg.nee == 1 else 0                    # the MIS carry is written per NEE evaluation
         pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
         roofline, whole = stage_roofline(hip, name, s0, s1, steps, elapsed, cus, clock_mhz, pipeline_bytes)
         pgbs = pipeline_bytes / elapsed / 1e9
@@ -307,8 +310,9 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
             "data": ("fixtures/" + scene + ".glb (reference scene file)" if not scene.startswith("procedural:")
                      else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
             "config": {"workload": workload_label(scene, W, H, steps, spp_per_step, total_spp, cfg), "spp_per_step": spp_per_step},
-            "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
-                     "per_sample": round((n_ext + n_shadow) / max(n_samples, 1), 4)},
+            "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "shadow_elided": int(n_elided), "sky_evals": int(n_sky),
+                     "per_sample": round((n_ext + n_shadow) / max(n_samples, 1), 4),
+                     "per_sample_as_the_reference_counts": round((n_ext + n_shadow + n_elided) / max(n_samples, 1), 4)},
             "roofline": roofline, "pipeline_roofline": pipeline, "parity_check": par}
 
 
@@ -551,7 +555,7 @@ def main():
             r.read_accum(host_image)
         tb = time.perf_counter() - ta
         sb = r.stats()
-        rb_rays = (sb["extension_rays"] - sa["extension_rays"]) + (sb["shadow_rays"] - sa["shadow_rays"])
+        rb_rays = (sb["extension_rays"] - sa["extension_rays"]) + (sb["shadow_rays_traced"] - sa["shadow_rays_traced"])
         readback = {"loop": "rpt_render(spp_per_step) -> rpt_read_accum (host buffer), as src/trace.rs:182-204",
                     "ms_per_step": round(tb / args.steps * 1e3, 4), "value": round(rb_rays / tb / 1e6, 3), "unit": "Mrays/s",
                     "all_samples_arrived": bool((host_image[..., 3] == float(args.spp_per_step * (args.steps + 1))).all())}
@@ -572,24 +576,24 @@ def main():
             _, seen = r.read_gathered(host_image)            # the last batch: nothing left to hide it behind
             tb = time.perf_counter() - ta
             sb = r.stats()
-            rb_rays = (sb["extension_rays"] - sa["extension_rays"]) + (sb["shadow_rays"] - sa["shadow_rays"])
+            rb_rays = (sb["extension_rays"] - sa["extension_rays"]) + (sb["shadow_rays_traced"] - sa["shadow_rays_traced"])
             readback["overlapped"] = {
                 "loop": "rpt_render_async(k+1) ; rpt_read_gathered(k) ; rpt_gather_async: batch k reaches the host while k+1 renders",
                 "ms_per_step": round(tb / args.steps * 1e3, 4), "value": round(rb_rays / tb / 1e6, 3), "unit": "Mrays/s",
                 "all_samples_arrived": bool(seen == args.spp_per_step * (args.steps + 1) and (host_image[..., 3] == float(seen)).all())}
 
-    local = torch.tensor([elapsed, float(delta("extension_rays")), float(delta("shadow_rays")), float(delta("samples")),
-                          float(delta("sky_evals"))], dtype=torch.float64, device=comm_device if world_size > 1 else device)
+    local = torch.tensor([elapsed, float(delta("extension_rays")), float(delta("shadow_rays_traced")), float(delta("samples")),
+                          float(delta("sky_evals")), float(delta("shadow_rays_elided"))], dtype=torch.float64, device=comm_device if world_size > 1 else device)
     if world_size > 1:
         tmax = local[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         sums = local[1:].clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         elapsed_max = float(tmax[0])
-        n_ext, n_shadow, n_samples, n_sky = (float(x) for x in sums)
+        n_ext, n_shadow, n_samples, n_sky, n_elided = (float(x) for x in sums)
     else:
         elapsed_max = elapsed
-        n_ext, n_shadow, n_samples, n_sky = (float(x) for x in local[1:])
+        n_ext, n_shadow, n_samples, n_sky, n_elided = (float(x) for x in local[1:])
 
     if rank != 0:
         if world_size > 1:
@@ -598,7 +602,7 @@ def main():
 
     rays = n_ext + n_shadow
     mrays = rays / elapsed_max / 1e6
-    n_mis = n_shadow if cfg.nee == 1 else 0.0
+    n_mis = (n_shadow + n_elided) if cfg.nee == 1 else 0.0                   # the MIS carry is written per NEE evaluation, walked or not
 
     # --- roofline of the dominant kernel, from the HIP events recorded in this run (rank 0's stream)
     cus, clock_mhz = hip.device_info(local_rank)
@@ -662,8 +666,9 @@ def main():
                    "kernel_sources": hip.build_fingerprint(), "gather": gather_impl, "collective_library": hip.comm_library() or None,
                    "rpt_comm_world": comm_world_seen},
         "samples_per_s": round(n_samples / elapsed_max, 1),
-        "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "sky_evals": int(n_sky),
-                 "per_sample": round(rays / max(n_samples, 1), 4)},
+        "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "shadow_elided": int(n_elided), "sky_evals": int(n_sky),
+                 "per_sample": round(rays / max(n_samples, 1), 4),
+                 "counted": "rays walked on the device; shadow_elided = NEE evaluations whose shadow ray decides nothing (zero term whatever the walk finds) and is not walked"},
         "roofline": roofline,
         "pipeline_roofline": {"bound": "hbm", "achieved": round(pipeline_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(pipeline_gbs / HBM_PEAK_GBS, 6),

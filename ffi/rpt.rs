@@ -39,10 +39,11 @@ pub struct rpt_stats {
     pub render_ms: f64,
     pub kernel_ms: [f64; 8],
     pub kernel_launches: [u64; 8],
+    pub shadow_rays_elided: u64,   // of shadow_rays: not walked, their NEE term is zero whatever the walk finds
 }
 
 extern "C" {
-    pub fn rpt_abi_version() -> c_int;                                              // == 2
+    pub fn rpt_abi_version() -> c_int;                                              // == 3
     pub fn rpt_build_fingerprint() -> *const c_char;                                // fingerprint of the kernel sources the library was built from
     pub fn rpt_last_error(ctx: *mut rpt_ctx) -> *const c_char;
     pub fn rpt_device_info(device_id: c_int, compute_units_out: *mut u32, clock_khz_out: *mut u32) -> c_int;   // compute units / peak clock of a HIP device

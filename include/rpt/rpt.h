@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RPT_ABI_VERSION 2
+#define RPT_ABI_VERSION 3
 
 enum {
     RPT_OK = 0,
@@ -54,6 +54,9 @@ typedef struct rpt_stats {
     double   render_ms;        /* wall time of rpt_render calls, host clock               */
     double   kernel_ms[8];     /* HIP-event time per stage: see RPT_STAGE_*               */
     uint64_t kernel_launches[8];
+    uint64_t shadow_rays_elided; /* of shadow_rays: NEE evaluations whose shadow ray was not walked because the term it gates is zero
+                                    whatever the walk finds (light_pdf = 0 or bsdf_pdf = 0, light_pick.rs:150-158); rays traced on the
+                                    device = extension_rays + shadow_rays - shadow_rays_elided */
 } rpt_stats;
 
 enum {

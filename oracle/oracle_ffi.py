@@ -95,6 +95,14 @@ class Oracle:
             raise RuntimeError(f"oracle_trace_cpu failed: {rc}")
         return accum, rng, st
 
+    def dead_shadow_rays(self, config, scene, rng, n_samples, stride=1):
+        """Analysis hook oracle_dead_shadow_rays: (shadow rays, those whose NEE term is zero whatever the walk finds, those of them that are occluded,
+        all occluded ones) over n_samples samples of every stride-th pixel."""
+        out = np.zeros(4, np.uint64)
+        rng = np.ascontiguousarray(rng)
+        self.lib.oracle_dead_shadow_rays(C.byref(config), C.byref(scene), _p(rng), C.c_uint32(n_samples), C.c_uint32(stride), _p(out))
+        return tuple(int(v) for v in out)
+
     def bvh_build(self, vertices_xyzw, triangles, sah_samples=128):
         """BVHBuilder::new(vertices, indices).sah_samples(n).build() (reference: src/bvh.rs:59-324), restated in oracle/bvh_oracle.cpp.
         Returns (nodes, reordered triangles) as arrays of the input dtypes' layouts (nodes: 32-byte records as 8 x u32)."""

@@ -592,6 +592,7 @@ inline float get_weight(uint32_t nee_mode, float p1, float p2) {
 extern thread_local float *g_shadow_dump;
 extern thread_local uint32_t g_cur_bounce, g_ray_dump_bounce;
 extern thread_local bool g_shadow_dump_hit;
+extern thread_local uint64_t *g_dead_shadow_rays;
 DirectLightSample sample_direct_lighting(uint32_t nee_mode, const Scene &sc, V3 throughput, const PBR &surface_bsdf,
                                          V3 surface_point, V3 surface_normal, V3 ray_direction, RngState &rng,
                                          Counters &cnt) {
@@ -646,6 +647,21 @@ DirectLightSample sample_direct_lighting(uint32_t nee_mode, const Scene &sc, V3 
                 direct = (bsdf_attenuation * light_emission * weight / light_pdf) / light_pick_pdf;
             }
         }
+    }
+    if (g_dead_shadow_rays) {
+        /* analysis hook (tools/dead_shadow_rays.py): would this shadow ray's term be zero whatever the walk finds?  (the term an UNOCCLUDED ray adds:
+         * light_pdf <= 0 — the light faces away — or bsdf_pdf <= 0 — the light is below the surface's horizon — or a masked non-finite product) */
+        V3 would = splat3(0.0f);
+        float light_pdf = calculate_light_pdf(light_area, light_distance, light_normal, light_direction);
+        if (light_pdf > 0.0f) {
+            V3 att = surface_bsdf.evaluate(-ray_direction, surface_normal, light_direction, DiffuseReflection);
+            float bsdf_pdf = surface_bsdf.pdf(-ray_direction, surface_normal, light_direction, DiffuseReflection);
+            if (bsdf_pdf > 0.0f) would = (att * light_emission * get_weight(nee_mode, light_pdf, bsdf_pdf) / light_pdf) / light_pick_pdf;
+        }
+        V3 term = mask_nan(throughput * would);
+        g_dead_shadow_rays[0] += 1;
+        if (term.x == 0.0f && term.y == 0.0f && term.z == 0.0f) { g_dead_shadow_rays[1] += 1; if (light_trace.hit) g_dead_shadow_rays[2] += 1; }
+        if (light_trace.hit) g_dead_shadow_rays[3] += 1;
     }
     info.light_area = light_area;
     info.light_normal = light_normal;
@@ -741,6 +757,7 @@ thread_local bool g_ray_dump_hit = false;
 thread_local float *g_shadow_dump = nullptr;   /* analysis hook: 8 floats: origin, direction, max_t, light-table index */
 thread_local uint32_t g_cur_bounce = 0;
 thread_local bool g_shadow_dump_hit = false;
+thread_local uint64_t *g_dead_shadow_rays = nullptr;   /* analysis hook: [shadow rays, of them with a zero term, of those occluded, all occluded] */
 /* analysis hook (tools/shade_bin_sim.py): what the shade stage does with the path at each bounce — 1 miss, 2 ends on an emitter (lib.rs:86-109),
  * 3 diffuse lobe sampled, 4 specular lobe sampled; 0 = the path did not reach that bounce */
 thread_local uint8_t *g_kind_log = nullptr;
@@ -1044,6 +1061,22 @@ int oracle_dump_shadow_rays(const rpt_tracing_config *config, const oracle_scene
             valid[i] = g_shadow_dump_hit ? 1 : 0;
         }
     g_shadow_dump = nullptr;
+    return 0;
+}
+
+/* Analysis hook (tools/dead_shadow_rays.py): out[4] = shadow rays of n_samples samples of the pixels of rect, those whose NEE term is zero whatever the walk
+ * finds, those of them that are occluded, all occluded ones */
+int oracle_dead_shadow_rays(const rpt_tracing_config *config, const oracle_scene *scene, const rpt_rng_state *rng, uint32_t n_samples, uint32_t stride, uint64_t *out) {
+    Scene sc = make_scene(scene);
+    Counters cnt;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    g_dead_shadow_rays = out;
+    for (uint32_t y = 0; y < config->height; y += stride)
+        for (uint32_t x = 0; x < config->width; x += stride) {
+            rpt_rng_state r = rng[(size_t)y * config->width + x];
+            for (uint32_t s = 0; s < n_samples; ++s) { trace_pixel(x, y, *config, r, sc, cnt); r.n += 1; }
+        }
+    g_dead_shadow_rays = nullptr;
     return 0;
 }
 

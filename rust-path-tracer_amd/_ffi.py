@@ -71,6 +71,7 @@ class Stats(C.Structure):
         ("samples", C.c_uint64), ("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
         ("sky_evals", C.c_uint64), ("light_index_clamped", C.c_uint64), ("iterations", C.c_uint64),
         ("render_ms", C.c_double), ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8),
+        ("shadow_rays_elided", C.c_uint64),
     ]
 
 

@@ -158,7 +158,7 @@ template <int NEE, bool TEXTURED, bool COMPACT>
 __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &st, const DevQueues &q, const DevConfig &cfg, DevStats *stats,
                                            uint32_t slot, float2 hw, bool active, bool &to_sky, bool &emit_shadow, float4 &sh_o, float4 &sh_d,
                                            float4 &sh_c, bool first /* iteration 0 of the call: every path is a first path (k_path.h) */,
-                                           uint32_t n_samples) {
+                                           uint32_t n_samples, bool &elided /* an NEE evaluation whose shadow ray decides nothing: not queued */) {
     const uint32_t hit_tri = __float_as_uint(hw.y);
     if (active) {
         const float4 ra = st.ray_a[slot];
@@ -418,8 +418,17 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                             }
                         }
                         const F3 contribution = throughput * direct;
+                        /* The reference traces the shadow ray first and looks at light_pdf / bsdf_pdf afterwards (light_pick.rs:141-158).  Where the term
+                         * an UNOCCLUDED ray adds is zero — the light point faces away (light_pdf = 0), lies below this surface's horizon (bsdf_pdf = 0), or
+                         * the product is masked as non-finite — `radiance += mask_nan(term)` (lib.rs:164) leaves every bit of radiance as it was whatever the
+                         * walk finds (radiance starts at +0.0 and x + y is -0.0 only for two negative zeros: it is never -0.0, so x + (+-0.0) == x), and
+                         * nothing else reads `.hit`: the ray is not queued.  48 % of DarkCornell's shadow rays, 57 % of VeachMIS's (tools/dead_shadow_rays.py);
+                         * counted in rpt_stats.shadow_rays_elided, and rpt_stats.shadow_rays keeps counting what the reference executes. */
+                        const F3 term = mask_nan3(contribution);
+                        const bool decides = term.x != 0.0f || term.y != 0.0f || term.z != 0.0f;
+                        elided = !decides;
                         const F3 so = hit + light_direction * RPT_EPS;
-                        emit_shadow = true;
+                        emit_shadow = decides;
                         sh_o = make_float4(so.x, so.y, so.z, light_distance - RPT_EPS * 2.0f);
                         sh_d = make_float4(light_direction.x, light_direction.y, light_direction.z, 0.0f);
                         sh_c = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
@@ -539,6 +548,12 @@ __device__ __forceinline__ void shade_emit(const DevQueues &q, uint32_t *push_sc
     }
 }
 
+/* wave-aggregated count into the workgroup's LDS word */
+__device__ __forceinline__ void count_elided(uint32_t *lds_counter, bool elided) {
+    const unsigned long long m = rpt_ballot(elided);
+    if (m != 0ull && __lane_id() == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(lds_counter, (uint32_t)__popcll(m));
+}
+
 template <int NEE, bool TEXTURED, bool COMPACT>
 /* Occupancy asked of the compiler where it costs no spill (left alone it stops at 68 and 104 VGPRs): the plain nee = 0
  * variant runs at 8 waves per SIMD in 64 VGPRs (DarkCornell shade 31.7 -> 31.0 ms per 8 batches), its packed form at 5 in 96
@@ -555,7 +570,9 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     const bool first_paths = iteration == 0u;                  /* every traversed slot holds the first path of its call (k_path.h) */
     __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
     __shared__ uint32_t c_slot[COMPACT ? RPT_BLOCK * RPT_SHADE_ROUNDS : 1];
+    __shared__ uint32_t n_elided;                              /* NEE evaluations of this workgroup whose shadow ray was not queued (shade_slot) */
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
+    if (NEE != RPT_NEE_NONE && threadIdx.x == 0u) n_elided = 0u;   /* (ordered before its first use by the barriers of block_rank2 / shade_emit) */
     if (NEE != RPT_NEE_NONE && blockIdx.x == 0u && threadIdx.x == 0u) q.count[Q_SPOOL] = 0u;   /* the shadow stage that follows starts its pool at entry 0 */
     if (COMPACT) {
         const uint32_t base = blockIdx.x * (RPT_BLOCK * RPT_SHADE_ROUNDS);
@@ -593,9 +610,10 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             const bool active = a_hit || a_miss;
             const uint32_t slot = a_hit ? c_slot[v] : (a_miss ? c_slot[CAP - 1u - (v - hits_padded)] : 0u);
             const float2 hw = a_hit ? st.hit[slot] : make_float2(0.0f, __uint_as_float(a_miss ? HIT_MISS : HIT_PARKED));
-            bool to_sky = false, emit_shadow = false;
+            bool to_sky = false, emit_shadow = false, elided = false;
             float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples);
+            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided);
+            if (NEE != RPT_NEE_NONE) count_elided(&n_elided, elided);
             shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
         }
     } else {
@@ -604,10 +622,16 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
         if (slot < st.n_slots) hw = st.hit[slot];
         const uint32_t hit_tri = __float_as_uint(hw.y);
         const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;        /* traversed in this iteration */
-        bool to_sky = false, emit_shadow = false;
+        bool to_sky = false, emit_shadow = false, elided = false;
         float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples);
+        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided);
+        if (NEE != RPT_NEE_NONE) count_elided(&n_elided, elided);
         shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
+    }
+    if (NEE != RPT_NEE_NONE) {
+        /* one sharded, non-returning atomic per workgroup (element 1 of the shard's line: element 0 counts extension rays) */
+        __syncthreads();
+        if (threadIdx.x == 0u && n_elided != 0u) atomicAdd(&q.ray_shards[(blockIdx.x % RPT_STAT_SHARDS) * RPT_STAT_STRIDE + 1u], (unsigned long long)n_elided);
     }
 }
 

@@ -705,7 +705,7 @@ int rpt_multi_get_stats(rpt_multi *m, rpt_stats *out) {
         rpt_stats s;
         int rc = rpt_get_stats(c, &s);
         if (rc) return multi_fail(m, c, rc);
-        sum.samples += s.samples; sum.extension_rays += s.extension_rays; sum.shadow_rays += s.shadow_rays; sum.sky_evals += s.sky_evals;
+        sum.samples += s.samples; sum.extension_rays += s.extension_rays; sum.shadow_rays += s.shadow_rays; sum.shadow_rays_elided += s.shadow_rays_elided; sum.sky_evals += s.sky_evals;
         sum.light_index_clamped += s.light_index_clamped;
         sum.iterations = std::max(sum.iterations, s.iterations);
         sum.render_ms = std::max(sum.render_ms, s.render_ms);

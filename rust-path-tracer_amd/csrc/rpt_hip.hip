@@ -1159,9 +1159,11 @@ int rpt_get_stats(rpt_ctx *c, rpt_stats *out) {
     std::vector<unsigned long long> shards(RPT_STAT_SHARDS * RPT_STAT_STRIDE, 0ull);
     if (c->ray_shards.p) HIP_TRY(c, hipMemcpy(shards.data(), c->ray_shards.p, shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     ds.extension_rays = 0;
-    for (int k = 0; k < RPT_STAT_SHARDS; ++k) ds.extension_rays += shards[(size_t)k * RPT_STAT_STRIDE];
+    unsigned long long elided = 0ull;
+    for (int k = 0; k < RPT_STAT_SHARDS; ++k) { ds.extension_rays += shards[(size_t)k * RPT_STAT_STRIDE]; elided += shards[(size_t)k * RPT_STAT_STRIDE + 1]; }
     c->stats.extension_rays = ds.extension_rays;
-    c->stats.shadow_rays = ds.shadow_rays;
+    c->stats.shadow_rays = ds.shadow_rays + elided;     /* as the reference counts: one per executed intersect_any (light_pick.rs:141) */
+    c->stats.shadow_rays_elided = elided;               /* of those, not walked: their NEE term is zero whatever the walk finds (k_shade.h) */
     c->stats.sky_evals = ds.sky_evals;
     c->stats.light_index_clamped = ds.light_index_clamped;
     *out = c->stats;

@@ -230,8 +230,9 @@ class Renderer:
     def stats(self):
         s = Stats()
         self._check(lib().rpt_get_stats(self._h, C.byref(s)))
-        d = {k: getattr(s, k) for k in ("samples", "extension_rays", "shadow_rays", "sky_evals", "light_index_clamped",
+        d = {k: getattr(s, k) for k in ("samples", "extension_rays", "shadow_rays", "shadow_rays_elided", "sky_evals", "light_index_clamped",
                                          "iterations", "render_ms")}
+        d["shadow_rays_traced"] = d["shadow_rays"] - d["shadow_rays_elided"]       # walked on the device; shadow_rays counts as the reference does
         d["kernel_ms"] = {n: s.kernel_ms[i] for i, n in enumerate(_ffi.STAGE_NAMES)}
         d["kernel_launches"] = {n: s.kernel_launches[i] for i, n in enumerate(_ffi.STAGE_NAMES)}
         return d
@@ -448,7 +449,7 @@ class MultiRenderer:
     def stats(self):
         s = Stats()
         self._check(lib().rpt_multi_get_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k in ("samples", "extension_rays", "shadow_rays", "sky_evals", "light_index_clamped", "iterations")}
+        return {k: getattr(s, k) for k in ("samples", "extension_rays", "shadow_rays", "shadow_rays_elided", "sky_evals", "light_index_clamped", "iterations")}
 
 
 def tile_order(width, height, rank, world_size):

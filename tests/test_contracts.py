@@ -48,7 +48,7 @@ def test_hip_library_exports_every_declared_symbol(hipmod):
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(hipmod.EXPORTS) == declared
-    assert L.rpt_abi_version() == 2
+    assert L.rpt_abi_version() == 3
 
 
 def test_host_library_exports_every_declared_symbol(rpt):

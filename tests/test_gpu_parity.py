@@ -177,6 +177,16 @@ def test_image_parity_with_oracle(renderer, oracle, rpt, world, scene, W, H, spp
     assert st_g["extension_rays"] == st_c.extension_rays
     assert st_g["shadow_rays"] == st_c.shadow_rays
     assert st_g["sky_evals"] == st_c.sky_evals
+    if nee == 0:
+        assert st_g["shadow_rays_elided"] == 0
+    elif W <= 200:
+        # NEE evaluations whose shadow ray decides nothing (light_pdf = 0 or bsdf_pdf = 0: the term is zero whatever the walk finds, light_pick.rs:150-158)
+        # are not walked on the device: exactly the ones the oracle's analysis hook identifies, and their share is what tools/dead_shadow_rays.py reports
+        n_all, n_dead, _, _ = oracle.dead_shadow_rays(cfg, oracle.scene(w), seeds, spp)
+        assert n_all == st_c.shadow_rays and st_g["shadow_rays_elided"] == n_dead
+        assert st_g["shadow_rays_traced"] == n_all - n_dead
+        if st_c.shadow_rays > 10000:
+            assert 0.2 * n_all < n_dead < 0.8 * n_all
     # rng[i].x += 1 per sample (kernels/src/lib.rs:226)
     rng_g = renderer.read_rng()
     assert np.array_equal(rng_g["n"], rng_c["n"]) and np.array_equal(rng_g["offset"], rng_c["offset"])
