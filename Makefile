@@ -12,7 +12,7 @@ CXX      ?= g++
 
 HOST_SRCS := $(CSRC)/host/host_api.cpp $(CSRC)/host/glb_scene.cpp $(CSRC)/host/bvh_build.cpp \
              $(CSRC)/host/light_table.cpp $(CSRC)/host/bluenoise.cpp $(CSRC)/host/image_io.cpp $(CSRC)/host/textures.cpp $(CSRC)/host/obj_scene.cpp $(CSRC)/host/jpeg_decode.cpp
-HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_comm.hip
+HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_comm.hip $(CSRC)/rpt_lights.hip
 HIP_DEPS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hip) $(wildcard include/rpt/*.h)
 
 CXXFLAGS_COMMON := -std=c++20 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unknown-pragmas

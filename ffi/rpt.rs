@@ -47,6 +47,9 @@ extern "C" {
     pub fn rpt_build_fingerprint() -> *const c_char;                                // fingerprint of the kernel sources the library was built from
     pub fn rpt_last_error(ctx: *mut rpt_ctx) -> *const c_char;
     pub fn rpt_device_info(device_id: c_int, compute_units_out: *mut u32, clock_khz_out: *mut u32) -> c_int;   // compute units / peak clock of a HIP device
+    pub fn rpt_light_table_build_gpu(device_id: c_int, vertices_xyzw: *const f32, n_vertices: usize, triangles: *const [u32; 4], n_triangles: usize,
+                                     materials: *const MaterialData, n_materials: usize, entries_out: *mut LightPickEntry, entries_capacity: usize,
+                                     n_entries_out: *mut usize, n_emissive_out: *mut u32, ms_out: *mut f64) -> c_int;   // build_light_pick_table, src/light_pick.rs:24-122
     pub fn rpt_shadow_order(ctx: *mut rpt_ctx, fixed_out: *mut u32, visits_near_out: *mut f64, visits_fixed_out: *mut f64, probe_rays_out: *mut u32) -> c_int;   // which (bit-exact) order the shadow walks use
 
     // --- one GPU: what trace_gpu needs (each line: the reference call it replaces) -------------------------------

@@ -227,4 +227,74 @@ int oracle_bvh_build(const float *vertices_xyzw, size_t n_vertices, rpt_triangle
     return 0;
 }
 
+/* build_light_pick_table (reference src/light_pick.rs:24-122) with mask = compute_emissive_mask (:13-21), restated on its own (the product's
+ * host mirror is csrc/host/light_table.cpp, its GPU form csrc/rpt_lights.hip; this is what both are checked against).  Writes at most `capacity`
+ * entries; returns the number the table has (1 for the sentinel), or -1 on bad arguments.  Where the reference would panic — every emissive triangle
+ * degenerate (bins[usize::MAX]), or the most probable cursor stepping below bin 0 — the loop stops instead. */
+long oracle_light_table(const float *vertices_xyzw, size_t n_vertices, const rpt_triangle *tri, size_t n_triangles, const rpt_material_data *materials,
+                        size_t n_materials, rpt_light_pick_entry *out, size_t capacity) {
+    if (!vertices_xyzw || !tri || !materials || !out || capacity == 0) return -1;
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (tri[i].v0 >= n_vertices || tri[i].v1 >= n_vertices || tri[i].v2 >= n_vertices || tri[i].material >= n_materials) return -1;
+    auto P = [&](uint32_t v) { return Vec3{vertices_xyzw[4 * (size_t)v], vertices_xyzw[4 * (size_t)v + 1], vertices_xyzw[4 * (size_t)v + 2]}; };
+    auto sub = [](Vec3 a, Vec3 b) { return Vec3{a.x - b.x, a.y - b.y, a.z - b.z}; };
+    auto length = [](Vec3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); };                            /* glam: dot(self).sqrt(), dot = x x + y y + z z left to right */
+    std::vector<float> areas(n_triangles, 0.0f), powers(n_triangles, 0.0f), probabilities(n_triangles, 0.0f);
+    float total_power = 0.0f;
+    uint32_t total_tris = 0;
+    for (size_t i = 0; i < n_triangles; ++i) {
+        const float *em = materials[tri[i].material].emissive;
+        if (!(em[0] != 0.0f || em[1] != 0.0f || em[2] != 0.0f)) continue;                                           /* :13-21, :36-38 */
+        total_tris += 1;
+        const Vec3 a = P(tri[i].v0), b = P(tri[i].v1), c = P(tri[i].v2);
+        const Vec3 side_a = sub(b, a), side_b = sub(c, b), side_c = sub(a, c);                                      /* triangle_area, :5-11 */
+        const float s = (length(side_a) + length(side_b) + length(side_c)) / 2.0f;
+        const float area = std::sqrt(s * (s - length(side_a)) * (s - length(side_b)) * (s - length(side_c)));
+        areas[i] = area;
+        const float power = (em[0] * 1.0f + em[1] * 1.0f + em[2] * 1.0f) * area;                                    /* emissive.xyz().dot(Vec3::ONE) * area */
+        powers[i] = power;
+        total_power += power;
+    }
+    rpt_light_pick_entry sentinel{};
+    sentinel.ratio = -1.0f;
+    if (total_tris == 0) { out[0] = sentinel; return 1; }                                                           /* :52-58 */
+    for (size_t i = 0; i < n_triangles; ++i) probabilities[i] = powers[i] / total_power;
+    float sum = 0.0f;                                                                                               /* iter().sum::<f32>(): a fold from 0.0 */
+    for (size_t i = 0; i < n_triangles; ++i) sum += probabilities[i];
+    const float average_probability = sum / (float)total_tris;
+    struct Bin { size_t index_a; float probability_a; size_t index_b; float probability_b; };
+    std::vector<Bin> bins;
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (probabilities[i] != 0.0f) bins.push_back(Bin{i, probabilities[i], 0, 0.0f});
+    /* slice::sort_by is a stable merge sort; partial_cmp(..).unwrap_or(Equal) */
+    std::stable_sort(bins.begin(), bins.end(), [](const Bin &x, const Bin &y) { return x.probability_a < y.probability_a; });
+    const size_t num_bins = bins.size();
+    if (num_bins == 0) { out[0] = sentinel; return 1; }
+    size_t most_probable = num_bins - 1;
+    for (size_t i = 0; i < num_bins; ++i) {                                                                         /* :89-104 */
+        const float needed = average_probability - bins[i].probability_a;
+        if (needed <= 0.0f) break;
+        bins[i].index_b = bins[most_probable].index_a;
+        bins[i].probability_b = needed;
+        bins[most_probable].probability_a -= needed;
+        if (bins[most_probable].probability_a <= average_probability) {
+            if (most_probable == 0) break;
+            most_probable -= 1;
+        }
+    }
+    for (size_t i = 0; i < num_bins && i < capacity; ++i) {                                                         /* :106-119 */
+        const Bin &x = bins[i];
+        rpt_light_pick_entry e;
+        e.triangle_index_a = (uint32_t)x.index_a;
+        e.triangle_index_b = (uint32_t)x.index_b;
+        e.triangle_pick_pdf_a = probabilities[x.index_a];
+        e.triangle_area_a = areas[x.index_a];
+        e.triangle_area_b = areas[x.index_b];
+        e.triangle_pick_pdf_b = probabilities[x.index_b];
+        e.ratio = x.probability_a / (x.probability_a + x.probability_b);
+        out[i] = e;
+    }
+    return (long)num_bins;
+}
+
 }  // extern "C"

@@ -117,6 +117,19 @@ class Oracle:
             raise RuntimeError(f"oracle_bvh_build failed: {rc}")
         return nodes[:n.value].copy(), t
 
+    def light_table(self, vertices_xyzw, triangles, materials):
+        """build_light_pick_table (reference: src/light_pick.rs:13-122), restated in oracle/bvh_oracle.cpp -> (n, 28-byte records as 7 x u32)."""
+        v = np.ascontiguousarray(vertices_xyzw, np.float32).reshape(-1, 4)
+        t = np.ascontiguousarray(triangles)
+        m = np.ascontiguousarray(materials)
+        assert t.dtype.itemsize == 16 and m.dtype.itemsize == 96
+        out = np.zeros((max(1, len(t)), 7), np.uint32)
+        self.lib.oracle_light_table.restype = C.c_long
+        n = self.lib.oracle_light_table(_p(v), C.c_size_t(len(v)), _p(t), C.c_size_t(len(t)), _p(m), C.c_size_t(len(m)), _p(out), C.c_size_t(len(out)))
+        if n < 0:
+            raise RuntimeError("oracle_light_table failed")
+        return out[:n].copy()
+
     def trace_rays(self, scene, mode, origins, dirs, max_t=None):
         origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
         dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)

@@ -1,0 +1,301 @@
+/*
+ * rpt_lights.hip — build_light_pick_table (reference src/light_pick.rs:24-122) on the GPU: the second half of "Startup time"
+ * (benches/benchmark.rs:11-16) that SURVEY.md 8f N1 names next to the BVH build.  Bit-identical to the sequential builder
+ * (csrc/host/light_table.cpp, oracle/bvh_oracle.cpp oracle_light_table): same entries, same order, same f32 values.
+ *
+ * What is parallel and what is not.  The reference computes, in this order,
+ *   1  per emissive triangle: Heron area (5 sqrt) and power = emissive . (1,1,1) * area              independent per triangle
+ *   2  total_power = the f32 sum of the powers IN INDEX ORDER                                        a rounding chain: order is the result
+ *   3  probability_i = power_i / total_power                                                         independent
+ *   4  average = (f32 sum of the probabilities in index order) / #emissive                           chain
+ *   5  bins = the triangles with probability != 0, STABLY sorted ascending by probability           parallel: LSD radix sort is stable
+ *   6  "robin hood": walk the bins upwards, top each up to `average` from the current most probable bin, which steps down when it is used up
+ *                                                                                                    a two-cursor f32 recurrence
+ *   7  the table: areas / pdfs gathered through index_a / index_b, ratio = p_a / (p_a + p_b)         independent
+ * 1, 3, 5, 7 are kernels (5 = rocPRIM's radix sort on order-preserving keys).  2 and 4 are one-wave kernels that keep the reference's
+ * association: 64 lanes load 64 consecutive values, v_readlane hands them to one running sum in index order (adding the 0.0 of a
+ * non-emissive triangle changes nothing: the sum is never -0.0) — ~7 cycles per element, latency of the dependent add.
+ * 6 runs on the HOST between two device passes: each step depends on the previous one through two rounded subtractions and a
+ * compare that moves a cursor; a latency-optimised core takes ~3 ns per step where one GPU lane takes ~50 (measured: DESIGN.md 7), and the
+ * data it needs — the sorted probabilities and indices, 8 bytes per bin — crosses PCIe in less time than either.  No part of the RESULT is
+ * computed differently: the same f32 operations in the same order, wherever they run.
+ *
+ * A NaN probability (a NaN vertex, or total_power = 0 / inf / NaN) has no place in the order-preserving keys — Rust's sort_by treats it as
+ * equal to everything, which is not an order — and is refused (RPT_ESCENE), like a NaN coordinate by the BVH builder.
+ */
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "rpt_ctx.h"
+
+namespace {
+
+constexpr int LT_BLOCK = 256;
+
+/* device buffers of one call: released on every way out */
+template <typename T> struct Scoped : DevBuf<T> {
+    Scoped() = default;
+    Scoped(const Scoped &) = delete;
+    Scoped &operator=(const Scoped &) = delete;
+    ~Scoped() { this->release(); }
+};
+
+struct LtScalars {
+    float total_power, average, prob_sum;
+    uint32_t total_tris, n_bins, has_nan;
+};
+
+__device__ __forceinline__ float lt_len(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }      /* glam Vec3::length: dot(self).sqrt() */
+
+/* step 1 (light_pick.rs:5-11, 34-51) */
+__global__ __launch_bounds__(LT_BLOCK) void k_lt_power(const float4 *vertices, const uint4 *triangles, const float4 *emissive /* per material */, uint32_t nt,
+                                                       float *area, float *power, LtScalars *sc) {
+    const uint32_t i = blockIdx.x * LT_BLOCK + threadIdx.x;
+    bool mask = false;
+    if (i < nt) {
+        const uint4 t = triangles[i];
+        const float4 e = emissive[t.w];
+        mask = e.x != 0.0f || e.y != 0.0f || e.z != 0.0f;                     /* compute_emissive_mask, :13-21 */
+        float a_out = 0.0f, p_out = 0.0f;
+        if (mask) {
+            const float4 a = vertices[t.x], b = vertices[t.y], c = vertices[t.z];
+            const float la = lt_len(b.x - a.x, b.y - a.y, b.z - a.z), lb = lt_len(c.x - b.x, c.y - b.y, c.z - b.z), lc = lt_len(a.x - c.x, a.y - c.y, a.z - c.z);
+            const float s = ((la + lb) + lc) / 2.0f;
+            a_out = sqrtf(((s * (s - la)) * (s - lb)) * (s - lc));
+            p_out = ((e.x * 1.0f + e.y * 1.0f) + e.z * 1.0f) * a_out;          /* emissive.xyz().dot(Vec3::ONE) * area */
+        }
+        area[i] = a_out;
+        power[i] = p_out;
+    }
+    const unsigned long long m = __ballot(mask);
+    if (m != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&sc->total_tris, (uint32_t)__popcll(m));
+}
+
+/* steps 2 and 4: the f32 sum of x[0 .. n) in index order, by ONE wave.  mode 0: total_power; mode 1: average = sum / total_tris */
+__global__ __launch_bounds__(64) void k_lt_seqsum(const float *x, uint32_t n, LtScalars *sc, int mode) {
+    const uint32_t lane = threadIdx.x;
+    float acc = 0.0f;
+    float cur = lane < n ? x[lane] : 0.0f;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t nb = base + 64u + lane;
+        const float nxt = nb < n ? x[nb] : 0.0f;                               /* the next 64 are in flight while these are added */
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const float v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cur), k));
+            acc = acc + v;                                                     /* (the padding 0.0 past n changes nothing either) */
+        }
+        cur = nxt;
+    }
+    if (lane == 0u) {
+        if (mode == 0) sc->total_power = acc;
+        else { sc->prob_sum = acc; sc->average = acc / (float)sc->total_tris; }
+    }
+}
+
+/* step 3 (:59-62) + the bin predicate of :74-83 */
+__global__ __launch_bounds__(LT_BLOCK) void k_lt_prob(const float *power, uint32_t nt, float *prob, LtScalars *sc, uint32_t *block_counts) {
+    const uint32_t i = blockIdx.x * LT_BLOCK + threadIdx.x;
+    bool bin = false, nan = false;
+    if (i < nt) {
+        const float p = power[i] / sc->total_power;
+        prob[i] = p;
+        nan = p != p;
+        bin = p != 0.0f;                                                       /* (true for a NaN, as in the reference) */
+    }
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0u) cnt = 0u;
+    __syncthreads();
+    const unsigned long long m = __ballot(bin);
+    if (m != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&cnt, (uint32_t)__popcll(m));
+    if (__ballot(nan) != 0ull && (threadIdx.x & 63u) == 0u) sc->has_nan = 1u;
+    __syncthreads();
+    if (threadIdx.x == 0u) block_counts[blockIdx.x] = cnt;
+}
+
+/* exclusive scan of the per-block bin counts (one workgroup; a few thousand values) */
+__global__ __launch_bounds__(1024) void k_lt_scan(uint32_t *block_counts, uint32_t nb, LtScalars *sc) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nb + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    uint32_t s = 0u;
+    for (uint32_t k = lo; k < hi; ++k) s += block_counts[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t run = 0u;
+        for (int k = 0; k < 1024; ++k) { const uint32_t v = part[k]; part[k] = run; run += v; }
+        sc->n_bins = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t k = lo; k < hi; ++k) { const uint32_t v = block_counts[k]; block_counts[k] = run; run += v; }
+}
+
+/* the bins in index order: (order-preserving key of the probability, triangle index) */
+__device__ __forceinline__ uint32_t lt_key(float p) { const uint32_t u = __float_as_uint(p); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float lt_unkey(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__global__ __launch_bounds__(LT_BLOCK) void k_lt_bins(const float *prob, uint32_t nt, const uint32_t *block_offsets, uint32_t *keys, uint32_t *vals) {
+    const uint32_t i = blockIdx.x * LT_BLOCK + threadIdx.x;
+    const bool bin = i < nt && prob[i] != 0.0f;
+    __shared__ uint32_t wave_cnt[LT_BLOCK / 64];
+    const unsigned long long m = __ballot(bin);
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0u) wave_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t base = block_offsets[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) base += wave_cnt[w];
+    if (bin) {
+        const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        keys[at] = lt_key(prob[i]);
+        vals[at] = i;
+    }
+}
+
+__global__ __launch_bounds__(LT_BLOCK) void k_lt_unkey(const uint32_t *keys, uint32_t n, float *pa) {
+    const uint32_t i = blockIdx.x * LT_BLOCK + threadIdx.x;
+    if (i < n) pa[i] = lt_unkey(keys[i]);
+}
+
+/* step 7 (:106-119) */
+__global__ __launch_bounds__(LT_BLOCK) void k_lt_table(const float *pa, const float *pb, const uint32_t *ia, const uint32_t *ib, const float *area, const float *prob,
+                                                       uint32_t n, rpt_light_pick_entry *out) {
+    const uint32_t i = blockIdx.x * LT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = ia[i], b = ib[i];
+    rpt_light_pick_entry e;
+    e.triangle_index_a = a;
+    e.triangle_area_a = area[a];
+    e.triangle_pick_pdf_a = prob[a];
+    e.triangle_index_b = b;
+    e.triangle_area_b = area[b];
+    e.triangle_pick_pdf_b = prob[b];
+    e.ratio = pa[i] / (pa[i] + pb[i]);
+    out[i] = e;
+}
+
+}  // namespace
+
+extern "C" int rpt_light_table_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertices, const rpt_triangle *triangles, size_t n_triangles,
+                                         const rpt_material_data *materials, size_t n_materials, rpt_light_pick_entry *entries_out, size_t entries_capacity,
+                                         size_t *n_entries_out, uint32_t *n_emissive_out, double *ms_out /* nullable, 4 doubles: total, device passes, host fill, transfers */) {
+    std::string &err = rpt_create_error();
+    if (!vertices_xyzw || !triangles || !materials || !entries_out || !n_entries_out || n_vertices == 0 || n_materials == 0 || entries_capacity == 0) {
+        err = "rpt_light_table_build_gpu: null or empty argument";
+        return RPT_EINVAL;
+    }
+    if (n_triangles >= (1ull << 31)) { err = "rpt_light_table_build_gpu: too many triangles"; return RPT_EINVAL; }
+    for (size_t i = 0; i < n_triangles; ++i)
+        if (triangles[i].v0 >= n_vertices || triangles[i].v1 >= n_vertices || triangles[i].v2 >= n_vertices || triangles[i].material >= n_materials) {
+            err = "rpt_light_table_build_gpu: vertex or material index out of range";
+            return RPT_ESCENE;
+        }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { err = "no HIP device"; return RPT_ENODEV; }
+    if (device_id < 0 || device_id >= n_dev) { err = "device id out of range"; return RPT_EINVAL; }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    double ms_transfer = 0.0, ms_fill = 0.0;
+    auto sentinel = [&](uint32_t emissive) {
+        rpt_light_pick_entry s{};
+        s.ratio = -1.0f;                                                       /* :52-58 */
+        entries_out[0] = s;
+        *n_entries_out = 1;
+        if (n_emissive_out) *n_emissive_out = emissive;
+        if (ms_out) { ms_out[0] = since(t_begin); ms_out[1] = ms_out[0] - ms_transfer; ms_out[2] = 0.0; ms_out[3] = ms_transfer; }
+        return RPT_OK;
+    };
+    if (n_triangles == 0) return sentinel(0u);
+
+#define LT_TRY(x)                                                                                       \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess) { err = std::string("rpt_light_table_build_gpu: ") + hipGetErrorString(e_); return RPT_EHIP; } \
+    } while (0)
+    const uint32_t nt = (uint32_t)n_triangles, nb = (nt + LT_BLOCK - 1) / LT_BLOCK;
+    Scoped<float4> d_verts, d_emissive;
+    Scoped<uint4> d_tris;
+    Scoped<float> d_area, d_power, d_prob, d_pa, d_pb;
+    Scoped<uint32_t> d_counts, d_keys, d_keys2, d_vals, d_vals2, d_ib;
+    Scoped<LtScalars> d_sc;
+    Scoped<rpt_light_pick_entry> d_out;
+    Scoped<char> d_tmp;
+    LT_TRY(hipSetDevice(device_id));
+    std::vector<float4> emissive(n_materials);
+    for (size_t m = 0; m < n_materials; ++m) emissive[m] = make_float4(materials[m].emissive[0], materials[m].emissive[1], materials[m].emissive[2], 0.0f);
+    LT_TRY(d_verts.alloc(n_vertices)); LT_TRY(d_tris.alloc(nt)); LT_TRY(d_emissive.alloc(n_materials));
+    LT_TRY(d_area.alloc(nt)); LT_TRY(d_power.alloc(nt)); LT_TRY(d_prob.alloc(nt)); LT_TRY(d_counts.alloc(nb)); LT_TRY(d_sc.alloc(1));
+    auto t0 = std::chrono::steady_clock::now();
+    LT_TRY(hipMemcpy(d_verts.p, vertices_xyzw, n_vertices * sizeof(float4), hipMemcpyHostToDevice));
+    LT_TRY(hipMemcpy(d_tris.p, triangles, (size_t)nt * sizeof(uint4), hipMemcpyHostToDevice));
+    LT_TRY(hipMemcpy(d_emissive.p, emissive.data(), n_materials * sizeof(float4), hipMemcpyHostToDevice));
+    LT_TRY(hipMemset(d_sc.p, 0, sizeof(LtScalars)));
+    ms_transfer += since(t0);
+
+    k_lt_power<<<nb, LT_BLOCK>>>(d_verts.p, d_tris.p, d_emissive.p, nt, d_area.p, d_power.p, d_sc.p);
+    k_lt_seqsum<<<1, 64>>>(d_power.p, nt, d_sc.p, 0);
+    LtScalars sc;
+    LT_TRY(hipMemcpy(&sc, d_sc.p, sizeof(sc), hipMemcpyDeviceToHost));
+    if (sc.total_tris == 0u) return sentinel(0u);
+    k_lt_prob<<<nb, LT_BLOCK>>>(d_power.p, nt, d_prob.p, d_sc.p, d_counts.p);
+    k_lt_seqsum<<<1, 64>>>(d_prob.p, nt, d_sc.p, 1);
+    k_lt_scan<<<1, 1024>>>(d_counts.p, nb, d_sc.p);
+    LT_TRY(hipMemcpy(&sc, d_sc.p, sizeof(sc), hipMemcpyDeviceToHost));
+    if (sc.has_nan) { err = "rpt_light_table_build_gpu: a pick probability is NaN (NaN vertex, or a total power of 0 / inf): such a scene must be built by the host builder"; return RPT_ESCENE; }
+    const uint32_t n = sc.n_bins;
+    if (n == 0u) return sentinel(sc.total_tris);       /* every emissive triangle is degenerate: the reference would index bins[usize::MAX] and panic */
+    if ((size_t)n > entries_capacity) { err = "rpt_light_table_build_gpu: the table needs " + std::to_string(n) + " entries"; return RPT_EINVAL; }
+    LT_TRY(d_keys.alloc(n)); LT_TRY(d_keys2.alloc(n)); LT_TRY(d_vals.alloc(n)); LT_TRY(d_vals2.alloc(n));
+    LT_TRY(d_pa.alloc(n)); LT_TRY(d_pb.alloc(n)); LT_TRY(d_ib.alloc(n)); LT_TRY(d_out.alloc(n));
+    k_lt_bins<<<nb, LT_BLOCK>>>(d_prob.p, nt, d_counts.p, d_keys.p, d_vals.p);
+    size_t tmp_bytes = 0;
+    LT_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, (size_t)n, 0u, 32u, (hipStream_t)0));
+    LT_TRY(d_tmp.alloc(tmp_bytes ? tmp_bytes : 1));
+    LT_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, (size_t)n, 0u, 32u, (hipStream_t)0));   /* LSD radix sort: stable */
+    const uint32_t nbn = (n + LT_BLOCK - 1) / LT_BLOCK;
+    k_lt_unkey<<<nbn, LT_BLOCK>>>(d_keys2.p, n, d_pa.p);
+
+    /* step 6, :89-104, on the host: (pa, index_a) of the sorted bins down, (pa', index_b, pb) up */
+    std::vector<float> pa(n), pb(n, 0.0f);
+    std::vector<uint32_t> ia(n), ib(n, 0u);
+    t0 = std::chrono::steady_clock::now();
+    LT_TRY(hipMemcpy(pa.data(), d_pa.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    LT_TRY(hipMemcpy(ia.data(), d_vals2.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    ms_transfer += since(t0);
+    t0 = std::chrono::steady_clock::now();
+    {
+        const float average = sc.average;
+        size_t most_probable = (size_t)n - 1;
+        for (size_t i = 0; i < n; ++i) {
+            const float needed = average - pa[i];
+            if (needed <= 0.0f) break;
+            ib[i] = ia[most_probable];
+            pb[i] = needed;
+            pa[most_probable] -= needed;
+            if (pa[most_probable] <= average) {
+                if (most_probable == 0) break;                                 /* (the reference: usize underflow) */
+                most_probable -= 1;
+            }
+        }
+    }
+    ms_fill = since(t0);
+    t0 = std::chrono::steady_clock::now();
+    LT_TRY(hipMemcpy(d_pa.p, pa.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    LT_TRY(hipMemcpy(d_pb.p, pb.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    LT_TRY(hipMemcpy(d_ib.p, ib.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ms_transfer += since(t0);
+    k_lt_table<<<nbn, LT_BLOCK>>>(d_pa.p, d_pb.p, d_vals2.p, d_ib.p, d_area.p, d_prob.p, n, d_out.p);
+    LT_TRY(hipGetLastError());
+    t0 = std::chrono::steady_clock::now();
+    LT_TRY(hipMemcpy(entries_out, d_out.p, (size_t)n * sizeof(rpt_light_pick_entry), hipMemcpyDeviceToHost));
+    ms_transfer += since(t0);           /* (includes the wait for k_lt_table) */
+    *n_entries_out = n;
+    if (n_emissive_out) *n_emissive_out = sc.total_tris;
+    if (ms_out) { ms_out[0] = since(t_begin); ms_out[2] = ms_fill; ms_out[3] = ms_transfer; ms_out[1] = ms_out[0] - ms_fill - ms_transfer; }
+#undef LT_TRY
+    return RPT_OK;
+}

@@ -19,7 +19,7 @@ EXPORTS = [
     "rpt_abi_version", "rpt_create", "rpt_set_partition", "rpt_set_samples_in_flight", "rpt_upload_scene", "rpt_set_config", "rpt_reset",
     "rpt_render", "rpt_render_async", "rpt_wait", "rpt_stream", "rpt_read_accum", "rpt_resolve", "rpt_read_rng", "rpt_local_pixels", "rpt_local_block_device_ptr",
     "rpt_rank_pixels", "rpt_tile_order", "rpt_untile", "rpt_get_stats", "rpt_destroy", "rpt_last_error",
-    "rpt_comm_init_local", "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_math_sweep", "rpt_debug_trace_rays", "rpt_debug_bsdf", "rpt_bvh_build_gpu",
+    "rpt_comm_init_local", "rpt_debug_math", "rpt_debug_math_host", "rpt_debug_math_sweep", "rpt_debug_trace_rays", "rpt_debug_bsdf", "rpt_bvh_build_gpu", "rpt_light_table_build_gpu",
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
@@ -490,6 +490,26 @@ def debug_math_host(op, x, y=None):
     if rc != 0:
         raise RptError(rc, "rpt_debug_math_host")
     return out
+
+
+def light_table_build_gpu(vertices_xyzw, triangles, materials, device=0):
+    """build_light_pick_table on the GPU (rpt_light_table_build_gpu; reference src/light_pick.rs:13-122).
+    Returns (table as LIGHT_PICK_DTYPE array, number of emissive triangles, {"total", "device", "host_fill", "transfers"} in milliseconds)."""
+    from ._ffi import LIGHT_PICK_DTYPE, MATERIAL_DTYPE, TRIANGLE_DTYPE
+    v = np.ascontiguousarray(vertices_xyzw, np.float32).reshape(-1, 4)
+    t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
+    m = np.ascontiguousarray(materials, MATERIAL_DTYPE)
+    table = np.zeros(max(1, len(t)), LIGHT_PICK_DTYPE)
+    n, n_em = C.c_size_t(0), C.c_uint32(0)
+    ms = (C.c_double * 4)()
+    L = lib()
+    L.rpt_light_table_build_gpu.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    rc = L.rpt_light_table_build_gpu(device, v.ctypes.data, len(v), t.ctypes.data, len(t), m.ctypes.data, len(m), table.ctypes.data, len(table),
+                                     C.byref(n), C.byref(n_em), ms)
+    if rc != 0:
+        raise RptError(rc, L.rpt_last_error(None).decode())
+    return table[: n.value].copy(), n_em.value, {"total": ms[0], "device": ms[1], "host_fill": ms[2], "transfers": ms[3]}
 
 
 def bvh_build_gpu(vertices_xyzw, triangles, sah_samples=128, device=0):

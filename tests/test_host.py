@@ -242,3 +242,13 @@ def test_host_bvh_builder_equals_the_oracle_builder_on_tie_soups(rpt, oracle, bi
     hn, ht = rpt.host.bvh_build(v, t, bins)
     on, ot = oracle.bvh_build(v, t, bins)
     assert hn.tobytes() == on.tobytes() and ht.tobytes() == ot.tobytes()
+
+
+@pytest.mark.parametrize("scene", ["DarkCornell", "VeachMIS", "FurnaceTest", "PBRTest"])
+def test_light_table_of_the_host_mirror_equals_the_oracles_restatement(oracle, world, scene):
+    """src/light_pick.rs:13-122 restated twice — csrc/host/light_table.cpp (what World::from_path uses) and oracle/bvh_oracle.cpp
+    oracle_light_table (the checker of the GPU build, tests/test_gpu_light_table.py): the same table bit for bit."""
+    w = world(scene)
+    v = np.ascontiguousarray(w.per_vertex["vertex"], np.float32).reshape(-1, 4)
+    ref = oracle.light_table(v, w.indices, w.materials)
+    assert np.array_equal(np.ascontiguousarray(w.light_pick).view(np.uint32).reshape(-1, 7), ref)
