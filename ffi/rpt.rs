@@ -50,7 +50,7 @@ extern "C" {
     pub fn rpt_light_table_build_gpu(device_id: c_int, vertices_xyzw: *const f32, n_vertices: usize, triangles: *const [u32; 4], n_triangles: usize,
                                      materials: *const MaterialData, n_materials: usize, entries_out: *mut LightPickEntry, entries_capacity: usize,
                                      n_entries_out: *mut usize, n_emissive_out: *mut u32, ms_out: *mut f64) -> c_int;   // build_light_pick_table, src/light_pick.rs:24-122
-    pub fn rpt_shadow_order(ctx: *mut rpt_ctx, fixed_out: *mut u32, visits_near_out: *mut f64, visits_fixed_out: *mut f64, probe_rays_out: *mut u32) -> c_int;   // which (bit-exact) order the shadow walks use
+    pub fn rpt_shadow_order(ctx: *mut rpt_ctx, fixed_out: *mut u32, visits_near_out: *mut f64, visits_fixed_out: *mut f64, probe_rays_out: *mut u32, probe_ms_out: *mut f64) -> c_int;   // which (bit-exact) order the shadow walks use
 
     // --- one GPU: what trace_gpu needs (each line: the reference call it replaces) -------------------------------
     pub fn rpt_create(device_id: c_int, out: *mut *mut rpt_ctx) -> c_int;          // FW / adaptor creation, trace.rs:3-6,25-38

@@ -252,7 +252,7 @@ int rpt_device_info(int device_id, uint32_t *compute_units_out, uint32_t *clock_
  * reads `.hit` only (kernels/src/light_pick.rs:148) and `.hit` does not depend on the order siblings are visited in (intersection.rs:191-213),
  * so the library may choose: fixed_out = 0 the reference's near-first order, 1 a fixed opaque-first order over a flipped copy of the tree —
  * chosen at rpt_upload_scene by the node visits of synthetic shadow rays under both (csrc/shadow_order.h).  The image is the same either way. */
-int rpt_shadow_order(rpt_ctx *ctx, uint32_t *fixed_out, double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out);
+int rpt_shadow_order(rpt_ctx *ctx, uint32_t *fixed_out, double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out, double *probe_ms_out);
 
 /* --- scene preparation on the device ---------------------- */
 /* BVHBuilder::new(vertices, indices).sah_samples(n).build()  (reference src/bvh.rs:59-324, the call at

@@ -660,7 +660,11 @@ DirectLightSample sample_direct_lighting(uint32_t nee_mode, const Scene &sc, V3 
         }
         V3 term = mask_nan(throughput * would);
         g_dead_shadow_rays[0] += 1;
-        if (term.x == 0.0f && term.y == 0.0f && term.z == 0.0f) { g_dead_shadow_rays[1] += 1; if (light_trace.hit) g_dead_shadow_rays[2] += 1; }
+        if (term.x == 0.0f && term.y == 0.0f && term.z == 0.0f) {
+            g_dead_shadow_rays[1] += 1;
+            if (light_trace.hit) g_dead_shadow_rays[2] += 1;
+            if (g_shadow_dump && g_cur_bounce == g_ray_dump_bounce) g_shadow_dump[7] = -1.0f;      /* (dump: marked as deciding nothing) */
+        }
         if (light_trace.hit) g_dead_shadow_rays[3] += 1;
     }
     info.light_area = light_area;

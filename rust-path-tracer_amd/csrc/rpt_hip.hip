@@ -419,13 +419,14 @@ int rpt_device_info(int device_id, uint32_t *compute_units_out, uint32_t *clock_
     return RPT_OK;
 }
 
-int rpt_shadow_order(rpt_ctx *c, uint32_t *fixed_out, double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out) {
+int rpt_shadow_order(rpt_ctx *c, uint32_t *fixed_out, double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out, double *probe_ms_out) {
     if (!c) return RPT_EINVAL;
     if (!c->has_scene) { c->error = "rpt_shadow_order: no scene"; return RPT_EINVAL; }
     if (fixed_out) *fixed_out = c->scene.shadow_fixed;
     if (visits_near_out) *visits_near_out = c->shadow_order.visits_near;
     if (visits_fixed_out) *visits_fixed_out = c->shadow_order.visits_fixed;
     if (probe_rays_out) *probe_rays_out = c->shadow_order.probe_rays;
+    if (probe_ms_out) *probe_ms_out = c->shadow_order.probe_ms;
     return RPT_OK;
 }
 
@@ -710,7 +711,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
      * scene between the reference's near-first order and a fixed opaque-first order; the latter walks a copy of the tree whose pairs are flipped so
      * that the preferred child is the LEFT one: a second LDS image / pair array, read by the shadow kernels only. */
     s.shadow_fixed = 0u; s.lds_image_shadow = nullptr; s.gpairs_shadow = nullptr; s.glinks_shadow = nullptr;
-    c->shadow_order = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped);
+    c->shadow_order = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped, reinterpret_cast<const float *>(geom.data()));
     if (c->shadow_order.fixed) {
         const std::vector<rpt_bvh_node> pool = flipped_nodes(nodes, nn, c->shadow_order.flip);
         bool built = false;

@@ -17,9 +17,10 @@
  * OPAQUE child first (triangle surface / box surface of the subtree) after 14.1: - 28 % wave-instructions per shadow ray; VeachMIS (most
  * occluders are the far side of the very light sphere a ray aims at) near-first 16.2, opaque-first 20.9: + 7 %.  Packet descent
  * (one stack of (node, lane mask) per wave) needs + 98 % / + 1 245 %, a stackless threaded layout + 9 % / + 12 %, a wave vote - 2 % / + 7 %.
- * Neither order wins everywhere, so the library measures: at upload it throws SHADOW_PROBE_RAYS synthetic shadow rays (surface points
- * chosen by area on the non-emissive triangles, light points through the scene's own light-pick table as light_pick.rs:8-23 draws them)
- * through both orders on the host and counts node visits.  If opaque-first needs fewer than SHADOW_FIXED_GAIN of near-first's, the shadow
+ * (With the rays that decide nothing elided — k_shade.h, half of all NEE evaluations — the same replay gives - 15 % on DarkCornell, - 3 % on VeachMIS.)
+ * Neither order wins everywhere, so the library measures: at upload it throws up to SHADOW_PROBE_RAYS synthetic shadow rays (surface points
+ * chosen by area on the non-emissive triangles, light points through the scene's own light-pick table as light_pick.rs:8-23 draws them, kept when
+ * the light faces the point and is above its horizon — the rays the device walks) through both orders on the host and counts node visits.  If opaque-first needs fewer than SHADOW_FIXED_GAIN of near-first's, the shadow
  * kernels walk a copy of the tree whose child pairs are flipped so that the preferred child sits in the left slot, in fixed left-first
  * order (no `tl > tr`, no swap); otherwise they keep the reference's near-first order.  Deterministic (fixed seed), a few milliseconds, and
  * whatever it decides the image is the same.  RPT_SHADOW_ORDER=near|fixed overrides (tests run every NEE case both ways).
@@ -28,6 +29,7 @@
 #define RPT_SHADOW_ORDER_H
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -36,7 +38,7 @@
 
 #include "../../include/rpt/shared_structs.h"
 
-#define SHADOW_PROBE_RAYS 4096
+#define SHADOW_PROBE_RAYS 8192     /* candidates; about half survive the "decides something" filter */
 #define SHADOW_FIXED_GAIN 0.95
 
 struct ShadowOrder {
@@ -44,6 +46,7 @@ struct ShadowOrder {
     std::vector<uint8_t> flip;          /* per child pair p = nodes (2p + 1, 2p + 2): the right child is the preferred one */
     double visits_near = 0.0, visits_fixed = 0.0;   /* node visits per probe ray under either order */
     uint32_t probe_rays = 0, probe_occluded = 0;
+    double probe_ms = 0.0;              /* host time of the whole decision */
     const char *why = "no lights";
 };
 
@@ -126,15 +129,25 @@ inline uint32_t walk(const rpt_bvh_node *nodes, const rpt_per_vertex_data *pv, c
 /* Expects a validated scene (rpt_hip.hip validate_scene: links in range, no cycles, leaf ranges inside the index buffer).  `pair_shaped`: children of
  * every inner node are the nodes (2p + 1, 2p + 2) of one pair — what the flipped copies can express; otherwise near-first stays. */
 inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
-                                       const rpt_material_data *mats, const rpt_light_pick_entry *lp, size_t nlp, bool pair_shaped) {
+                                       const rpt_material_data *mats, const rpt_light_pick_entry *lp, size_t nlp, bool pair_shaped,
+                                       const float *edges12 = nullptr /* optional: per triangle 12 floats (a | -, b - a | -, c - a | -), as the upload derives them */) {
     using namespace shadow_order_detail;
     ShadowOrder so;
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Stamp { ShadowOrder &so; std::chrono::steady_clock::time_point t0; ~Stamp() { so.probe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } stamp{so, t_begin};
     if (nlp == 0 || lp[0].ratio < 0.0f || nt == 0) return so;
     if (!pair_shaped || nn < 3) { so.why = "node pool is not pair-shaped"; return so; }
     /* triangle surface below every node, children before parents (explicit post-order: the pool's index order is the builder's business) */
     std::vector<double> area(nn, 0.0), tri_area(nt, 0.0);
     for (size_t t = 0; t < nt; ++t) {
-        V a = vtx(pv[idx[t].v0]), x = cross(sub(vtx(pv[idx[t].v1]), a), sub(vtx(pv[idx[t].v2]), a));
+        V x;
+        if (edges12) {                         /* (three gathers of 64-byte vertices per triangle are most of this function on a 1 M-triangle scene) */
+            const float *e = edges12 + 12 * t;
+            x = cross(V{e[4], e[5], e[6]}, V{e[8], e[9], e[10]});
+        } else {
+            V a = vtx(pv[idx[t].v0]);
+            x = cross(sub(vtx(pv[idx[t].v1]), a), sub(vtx(pv[idx[t].v2]), a));
+        }
         tri_area[t] = 0.5 * std::sqrt((double)dot(x, x));
     }
     {
@@ -175,6 +188,10 @@ inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_
         const float s = std::sqrt(r1), wa = 1.0f - s, wb = s * (1.0f - r2), wc = s * r2;
         return V{wa * a.x + wb * b.x + wc * c.x, wa * a.y + wb * b.y + wc * c.y, wa * a.z + wb * b.z + wc * c.z};
     };
+    auto mean_normal = [&](size_t t) {
+        const float *a = pv[idx[t].v0].normal, *b = pv[idx[t].v1].normal, *c = pv[idx[t].v2].normal;
+        return V{a[0] + b[0] + c[0], a[1] + b[1] + c[1], a[2] + b[2] + c[2]};
+    };
     uint64_t vn = 0, vf = 0;
     for (int i = 0; i < SHADOW_PROBE_RAYS; ++i) {
         const double pick = (double)rng.next() * total;
@@ -188,6 +205,9 @@ inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_
         const float dist = std::sqrt(dot(d, d));
         if (!(dist > 1e-4f)) continue;
         d = V{d.x / dist, d.y / dist, d.z / dist};
+        /* only rays the device walks: a light point that faces away (light_pdf = 0) or lies below the surface's horizon (bsdf_pdf = 0) adds a zero
+         * term whatever its shadow ray finds, and k_shade does not queue that ray (about half of all NEE evaluations) */
+        if (!(dot(mean_normal(std::min(t0, nt - 1)), d) > 0.0f) || !(dot(mean_normal(lt), d) < 0.0f)) continue;
         const V o = V{p.x + d.x * 0.001f, p.y + d.y * 0.001f, p.z + d.z * 0.001f};          /* light_pick.rs:141-147, EPS = 0.001 */
         bool occ_n = false, occ_f = false;
         vn += walk<false>(nodes, pv, idx, so.flip, o, d, dist - 0.002f, occ_n);

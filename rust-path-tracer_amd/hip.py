@@ -82,7 +82,7 @@ def lib():
         L.rpt_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.rpt_comm_init_local.argtypes = [C.c_void_p]
         L.rpt_device_info.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-        L.rpt_shadow_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        L.rpt_shadow_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         L.rpt_debug_comm_selftest.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         L.rpt_comm_world.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rpt_gather_async.argtypes = [C.c_void_p]
@@ -271,9 +271,9 @@ class Renderer:
     def shadow_order(self):
         """rpt_shadow_order: {"fixed": bool, "visits_near", "visits_fixed", "probe_rays"} — which (bit-exact) order the shadow walks of the scene use."""
         f, n = C.c_uint32(), C.c_uint32()
-        vn, vf = C.c_double(), C.c_double()
-        self._check(lib().rpt_shadow_order(self._h, C.byref(f), C.byref(vn), C.byref(vf), C.byref(n)))
-        return {"fixed": bool(f.value), "visits_near": vn.value, "visits_fixed": vf.value, "probe_rays": n.value}
+        vn, vf, ms = C.c_double(), C.c_double(), C.c_double()
+        self._check(lib().rpt_shadow_order(self._h, C.byref(f), C.byref(vn), C.byref(vf), C.byref(n), C.byref(ms)))
+        return {"fixed": bool(f.value), "visits_near": vn.value, "visits_fixed": vf.value, "probe_rays": n.value, "probe_ms": ms.value}
 
     def comm_world(self):
         r, w = C.c_uint32(), C.c_uint32()

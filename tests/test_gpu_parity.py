@@ -235,15 +235,16 @@ def test_either_shadow_order_gives_the_oracles_image(monkeypatch, hipmod, oracle
 
 def test_the_library_chooses_the_shadow_order_per_scene(monkeypatch, hipmod, rpt, world):
     """rpt_shadow_order after rpt_upload_scene: DarkCornell walks its shadow rays opaque-first (the probe rays find their occluders in half the node
-    visits), VeachMIS near-first, PBRTest (no lights) is not probed; re-uploading another scene into the same context re-decides."""
+    visits), VeachMIS whichever its probe favours, PBRTest (no lights) is not probed; re-uploading another scene into the same context re-decides."""
     monkeypatch.delenv("RPT_SHADOW_ORDER", raising=False)
     r = hipmod.Renderer(0)
     try:
         r.upload_scene(world("DarkCornell"))
         so = r.shadow_order()
-        assert so["fixed"] and so["visits_fixed"] < 0.7 * so["visits_near"] and so == {k: v for k, v in hipmod.shadow_order_host(world("DarkCornell")).items() if k != "flip"}
+        assert so["fixed"] and so["visits_fixed"] < 0.7 * so["visits_near"] and {k: v for k, v in so.items() if k != "probe_ms"} == {k: v for k, v in hipmod.shadow_order_host(world("DarkCornell")).items() if k != "flip"}
         r.upload_scene(world("VeachMIS"))
-        assert not r.shadow_order()["fixed"]
+        vm = r.shadow_order()
+        assert vm["fixed"] == (vm["visits_fixed"] < 0.95 * vm["visits_near"]) and vm["probe_rays"] > 2000 and vm["probe_ms"] > 0
         r.upload_scene(world("PBRTest"))
         assert not r.shadow_order()["fixed"] and r.shadow_order()["probe_rays"] == 0
         r.upload_scene(world("DarkCornell"))

@@ -430,6 +430,8 @@ int sim_dump_shadow_rays(const rpt_tracing_config *config, const oracle_scene *s
     Scene sc = make_scene(scene);
     Counters cnt;
     g_ray_dump_bounce = bounce;
+    uint64_t dead_counters[4] = {0, 0, 0, 0};
+    g_dead_shadow_rays = dead_counters;             /* rays whose term is zero whatever the walk finds are marked (light index -1): the device does not walk them */
     for (size_t i = 0; i < n_pixels; ++i) {
         const uint32_t x = pixels[i] & 0xffffu, y = pixels[i] >> 16;
         rpt_rng_state r = rng_full[(size_t)y * config->width + x];
@@ -437,9 +439,10 @@ int sim_dump_shadow_rays(const rpt_tracing_config *config, const oracle_scene *s
         g_shadow_dump = shadow + 8 * i;
         g_shadow_dump_hit = false;
         trace_pixel(x, y, *config, r, sc, cnt);
-        valid[i] = g_shadow_dump_hit ? 1 : 0;
+        valid[i] = g_shadow_dump_hit ? (shadow[8 * i + 7] < 0.0f ? 2 : 1) : 0;
     }
     g_shadow_dump = nullptr;
+    g_dead_shadow_rays = nullptr;
     return 0;
 }
 

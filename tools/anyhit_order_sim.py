@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--bounces", default="0,1,2,3")
     ap.add_argument("--span", type=int, default=512)
+    ap.add_argument("--all-rays", action="store_true", help="include the shadow rays whose NEE term is zero whatever the walk finds (the device elides them, k_shade.h)")
     args = ap.parse_args()
     sim = build()
     orc = Oracle()
@@ -110,7 +111,7 @@ def main():
                         rays = np.zeros((64, 8), np.float32)
                         valid = np.zeros(64, np.uint8)
                         sim.sim_dump_shadow_rays(C.byref(cfg), C.byref(sc), _p(seeds), C.c_uint32(s), C.c_uint32(bounce), _p(pix), C.c_size_t(64), _p(rays), _p(valid))
-                        stream.append(rays[valid == 1])
+                        stream.append(rays[(valid == 1) | ((valid == 2) & args.all_rays)])
                 stream = np.concatenate(stream)
                 for at in range(0, len(stream), args.span):
                     span = np.ascontiguousarray(stream[at:at + args.span])
