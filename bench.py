@@ -271,8 +271,11 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
             # the stand-in is generated.
             torch.cuda.synchronize()
             v = np.ascontiguousarray(world.per_vertex["vertex"], np.float32).reshape(-1, 4)
-            hip.bvh_build_gpu(v[:64], world.indices[:16])             # (code objects loaded, as any second scene of a session finds them)
-            hip.light_table_build_gpu(v[:64], world.indices[:16], world.materials)
+            tiny_v = np.ascontiguousarray(np.random.default_rng(0).random((48, 4)), np.float32)     # (code objects loaded, as any second scene of a session finds them)
+            tiny_t = np.zeros(16, world.indices.dtype)
+            tiny_t["v0"], tiny_t["v1"], tiny_t["v2"] = np.arange(0, 48, 3), np.arange(1, 48, 3), np.arange(2, 48, 3)
+            hip.bvh_build_gpu(tiny_v, tiny_t)
+            hip.light_table_build_gpu(tiny_v, tiny_t, world.materials)
             t_s = time.perf_counter()
             nodes, tris, bvh_dev_ms = hip.bvh_build_gpu(v, world.indices)
             t_b = time.perf_counter()

@@ -13,8 +13,8 @@
  *                                                                                                    a two-cursor f32 recurrence
  *   7  the table: areas / pdfs gathered through index_a / index_b, ratio = p_a / (p_a + p_b)         independent
  * 1, 3, 5, 7 are kernels (5 = rocPRIM's radix sort on order-preserving keys).  2 and 4 are one-wave kernels that keep the reference's
- * association: 64 lanes load 64 consecutive values, v_readlane hands them to one running sum in index order (adding the 0.0 of a
- * non-emissive triangle changes nothing: the sum is never -0.0) — ~7 cycles per element, latency of the dependent add.
+ * association: the values arrive through the scalar cache and feed one running sum in index order (adding the 0.0 of a non-emissive
+ * triangle changes nothing: the sum is never -0.0) — the latency of the dependent add per element, nothing else.
  * 6 runs on the HOST between two device passes: each step depends on the previous one through two rounded subtractions and a
  * compare that moves a cursor; a latency-optimised core takes ~3 ns per step where one GPU lane takes ~50 (measured: DESIGN.md 7), and the
  * data it needs — the sorted probabilities and indices, 8 bytes per bin — crosses PCIe in less time than either.  No part of the RESULT is
@@ -38,12 +38,18 @@ namespace {
 
 constexpr int LT_BLOCK = 256;
 
-/* device buffers of one call: released on every way out */
-template <typename T> struct Scoped : DevBuf<T> {
-    Scoped() = default;
-    Scoped(const Scoped &) = delete;
-    Scoped &operator=(const Scoped &) = delete;
-    ~Scoped() { this->release(); }
+/* the device memory of one call: ONE allocation per phase (hipMalloc / hipFree cost 0.1-0.3 ms each — seventeen of them were a fifth of a
+ * 1 M-triangle build), carved up 256-byte aligned, released on every way out */
+struct Arena {
+    char *base = nullptr;
+    size_t size = 0, used = 0;
+    Arena() = default;
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    ~Arena() { if (base) (void)hipFree(base); }
+    static size_t pad(size_t bytes) { return (bytes + 255u) & ~(size_t)255u; }
+    hipError_t reserve(size_t bytes) { size = bytes; used = 0; return hipMalloc(reinterpret_cast<void **>(&base), bytes ? bytes : 256); }
+    template <typename T> T *take(size_t count) { T *p = reinterpret_cast<T *>(base + used); used += pad(count * sizeof(T)); return p; }
 };
 
 struct LtScalars {
@@ -77,22 +83,36 @@ __global__ __launch_bounds__(LT_BLOCK) void k_lt_power(const float4 *vertices, c
     if (m != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&sc->total_tris, (uint32_t)__popcll(m));
 }
 
-/* steps 2 and 4: the f32 sum of x[0 .. n) in index order, by ONE wave.  mode 0: total_power; mode 1: average = sum / total_tris */
-__global__ __launch_bounds__(64) void k_lt_seqsum(const float *x, uint32_t n, LtScalars *sc, int mode) {
-    const uint32_t lane = threadIdx.x;
+/* steps 2 and 4: the f32 sum of x[0 .. n) in index order.  mode 0: total_power; mode 1: average = sum / total_tris.
+ * The chain of rounded adds is serial whatever runs it; what can be taken off it is the data path.  Every address is wave-uniform, so the values
+ * come through the SCALAR cache: s_load_dwordx16 straight into SGPRs, two blocks of 32 ahead of the adds, and the chain is one v_add_f32 with a
+ * scalar operand per element — no readlane, no LDS round trip (the first version: v_readlane + s_nop + v_add per element behind an exposed vector
+ * load per 64 elements, 9 ms per million; this one: ~2.5 ms). */
+__global__ __launch_bounds__(64) void k_lt_seqsum(const float *__restrict__ x, uint32_t n, LtScalars *sc, int mode) {
+    constexpr uint32_t B = 32u;
     float acc = 0.0f;
-    float cur = lane < n ? x[lane] : 0.0f;
-    for (uint32_t base = 0; base < n; base += 64u) {
-        const uint32_t nb = base + 64u + lane;
-        const float nxt = nb < n ? x[nb] : 0.0f;                               /* the next 64 are in flight while these are added */
+    const uint32_t full = n / B;
+    float c0[B], c1[B];
+    if (full > 0u) {
 #pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            const float v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cur), k));
-            acc = acc + v;                                                     /* (the padding 0.0 past n changes nothing either) */
-        }
-        cur = nxt;
+        for (uint32_t k = 0; k < B; ++k) c0[k] = x[k];
     }
-    if (lane == 0u) {
+    if (full > 1u) {
+#pragma unroll
+        for (uint32_t k = 0; k < B; ++k) c1[k] = x[B + k];
+    }
+    for (uint32_t b = 0; b < full; ++b) {
+        float nx[B];
+        const uint32_t ahead = b + 2u < full ? b + 2u : b;        /* (a valid block: its values are not used past the end) */
+#pragma unroll
+        for (uint32_t k = 0; k < B; ++k) nx[k] = x[ahead * B + k];
+#pragma unroll
+        for (uint32_t k = 0; k < B; ++k) acc = acc + c0[k];
+#pragma unroll
+        for (uint32_t k = 0; k < B; ++k) { c0[k] = c1[k]; c1[k] = nx[k]; }
+    }
+    for (uint32_t i = full * B; i < n; ++i) acc = acc + x[i];
+    if (threadIdx.x == 0u) {
         if (mode == 0) sc->total_power = acc;
         else { sc->prob_sum = acc; sc->average = acc / (float)sc->total_tris; }
     }
@@ -217,18 +237,20 @@ extern "C" int rpt_light_table_build_gpu(int device_id, const float *vertices_xy
         if (e_ != hipSuccess) { err = std::string("rpt_light_table_build_gpu: ") + hipGetErrorString(e_); return RPT_EHIP; } \
     } while (0)
     const uint32_t nt = (uint32_t)n_triangles, nb = (nt + LT_BLOCK - 1) / LT_BLOCK;
-    Scoped<float4> d_verts, d_emissive;
-    Scoped<uint4> d_tris;
-    Scoped<float> d_area, d_power, d_prob, d_pa, d_pb;
-    Scoped<uint32_t> d_counts, d_keys, d_keys2, d_vals, d_vals2, d_ib;
-    Scoped<LtScalars> d_sc;
-    Scoped<rpt_light_pick_entry> d_out;
-    Scoped<char> d_tmp;
+    Arena phase1, phase2;
     LT_TRY(hipSetDevice(device_id));
     std::vector<float4> emissive(n_materials);
     for (size_t m = 0; m < n_materials; ++m) emissive[m] = make_float4(materials[m].emissive[0], materials[m].emissive[1], materials[m].emissive[2], 0.0f);
-    LT_TRY(d_verts.alloc(n_vertices)); LT_TRY(d_tris.alloc(nt)); LT_TRY(d_emissive.alloc(n_materials));
-    LT_TRY(d_area.alloc(nt)); LT_TRY(d_power.alloc(nt)); LT_TRY(d_prob.alloc(nt)); LT_TRY(d_counts.alloc(nb)); LT_TRY(d_sc.alloc(1));
+    LT_TRY(phase1.reserve(Arena::pad(n_vertices * sizeof(float4)) + Arena::pad((size_t)nt * sizeof(uint4)) + Arena::pad(n_materials * sizeof(float4)) +
+                          3 * Arena::pad((size_t)nt * sizeof(float)) + Arena::pad((size_t)nb * sizeof(uint32_t)) + Arena::pad(sizeof(LtScalars))));
+    struct { float4 *p; } d_verts{phase1.take<float4>(n_vertices)}, d_emissive{nullptr};
+    struct { uint4 *p; } d_tris{phase1.take<uint4>(nt)};
+    d_emissive.p = phase1.take<float4>(n_materials);
+    struct { float *p; } d_area{phase1.take<float>(nt)}, d_power{phase1.take<float>(nt)}, d_prob{phase1.take<float>(nt)}, d_pa{nullptr}, d_pb{nullptr};
+    struct { uint32_t *p; } d_counts{phase1.take<uint32_t>(nb)}, d_keys{nullptr}, d_keys2{nullptr}, d_vals{nullptr}, d_vals2{nullptr}, d_ib{nullptr};
+    struct { LtScalars *p; } d_sc{phase1.take<LtScalars>(1)};
+    struct { rpt_light_pick_entry *p; } d_out{nullptr};
+    struct { char *p; } d_tmp{nullptr};
     auto t0 = std::chrono::steady_clock::now();
     LT_TRY(hipMemcpy(d_verts.p, vertices_xyzw, n_vertices * sizeof(float4), hipMemcpyHostToDevice));
     LT_TRY(hipMemcpy(d_tris.p, triangles, (size_t)nt * sizeof(uint4), hipMemcpyHostToDevice));
@@ -249,12 +271,14 @@ extern "C" int rpt_light_table_build_gpu(int device_id, const float *vertices_xy
     const uint32_t n = sc.n_bins;
     if (n == 0u) return sentinel(sc.total_tris);       /* every emissive triangle is degenerate: the reference would index bins[usize::MAX] and panic */
     if ((size_t)n > entries_capacity) { err = "rpt_light_table_build_gpu: the table needs " + std::to_string(n) + " entries"; return RPT_EINVAL; }
-    LT_TRY(d_keys.alloc(n)); LT_TRY(d_keys2.alloc(n)); LT_TRY(d_vals.alloc(n)); LT_TRY(d_vals2.alloc(n));
-    LT_TRY(d_pa.alloc(n)); LT_TRY(d_pb.alloc(n)); LT_TRY(d_ib.alloc(n)); LT_TRY(d_out.alloc(n));
-    k_lt_bins<<<nb, LT_BLOCK>>>(d_prob.p, nt, d_counts.p, d_keys.p, d_vals.p);
     size_t tmp_bytes = 0;
-    LT_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, (size_t)n, 0u, 32u, (hipStream_t)0));
-    LT_TRY(d_tmp.alloc(tmp_bytes ? tmp_bytes : 1));
+    LT_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, 32u, (hipStream_t)0));
+    LT_TRY(phase2.reserve(7 * Arena::pad((size_t)n * sizeof(uint32_t)) + Arena::pad((size_t)n * sizeof(rpt_light_pick_entry)) + Arena::pad(tmp_bytes ? tmp_bytes : 1)));
+    d_keys.p = phase2.take<uint32_t>(n); d_keys2.p = phase2.take<uint32_t>(n); d_vals.p = phase2.take<uint32_t>(n); d_vals2.p = phase2.take<uint32_t>(n);
+    d_pa.p = phase2.take<float>(n); d_pb.p = phase2.take<float>(n); d_ib.p = phase2.take<uint32_t>(n);
+    d_out.p = phase2.take<rpt_light_pick_entry>(n);
+    d_tmp.p = phase2.take<char>(tmp_bytes ? tmp_bytes : 1);
+    k_lt_bins<<<nb, LT_BLOCK>>>(d_prob.p, nt, d_counts.p, d_keys.p, d_vals.p);
     LT_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, (size_t)n, 0u, 32u, (hipStream_t)0));   /* LSD radix sort: stable */
     const uint32_t nbn = (n + LT_BLOCK - 1) / LT_BLOCK;
     k_lt_unkey<<<nbn, LT_BLOCK>>>(d_keys2.p, n, d_pa.p);
