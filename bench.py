@@ -295,7 +295,8 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
                        "triangles": int(len(world.indices)), "nodes": int(len(nodes)), "light_table_entries": int(len(table)),
                        "bvh_build_gpu_ms": round((t_b - t_s) * 1e3, 2), "bvh_build_device_ms": round(bvh_dev_ms, 2),
                        "light_table_gpu_ms": round((t_l - t_b) * 1e3, 2), "light_table_breakdown_ms": {k: round(x, 2) for k, x in lt_ms.items()},
-                       "upload_scene_ms": round((t_u - t_l) * 1e3, 2), "set_config_reset_ms": round((t_c - t_u) * 1e3, 2),
+                       "upload_scene_ms": round((t_u - t_l) * 1e3, 2), "upload_scene_shadow_order_probe_ms": round(r.shadow_order()["probe_ms"], 2),
+                       "set_config_reset_ms": round((t_c - t_u) * 1e3, 2),
                        "startup_ms": round((t_c - t_s) * 1e3, 2), "first_batch_ms": round((t_f - t_c) * 1e3, 2),
                        "checked_by": "tests/test_gpu_bvh_build.py, tests/test_gpu_light_table.py: both builds equal the sequential builders bit for bit"}
         # (the measured loop and its parity check run on the scene as the host built it: the triangles above were already in BVH order,

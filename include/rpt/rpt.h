@@ -266,10 +266,10 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
 
 /* build_light_pick_table(vertices, indices, compute_emissive_mask(..), materials)  (reference src/light_pick.rs:13-122, the call at
  * src/asset.rs:197-198) with its parallel parts on the GPU — Heron areas and powers, probabilities, the stable sort, the table — and the
- * f32 sums in the reference's own order; the robin-hood fill (:89-104), a two-cursor recurrence, runs on the host between two device passes
- * (csrc/rpt_lights.hip).  Same entries, same order, same bits as the sequential builder (tests/test_gpu_light_table.py).  Host pointers, no
+ * three order-dependent f32 chains (the two sums of :39-64 in index order, the robin-hood fill of :89-104) on the host between the device passes
+ * (csrc/rpt_lights.hip: a question of latency per dependent operation, measured).  Same entries, same order, same bits as the sequential builder (tests/test_gpu_light_table.py).  Host pointers, no
  * context; entries_capacity >= the number of emissive triangles (>= 1: a scene without lights yields the one-entry sentinel, ratio = -1).
- * ms_out (nullable): 4 doubles — total, device passes, host fill, transfers.  A NaN probability is refused (RPT_ESCENE). */
+ * ms_out (nullable): 4 doubles — total, device passes, host chains, transfers.  A NaN probability is refused (RPT_ESCENE). */
 int rpt_light_table_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertices, const rpt_triangle *triangles, size_t n_triangles,
                               const rpt_material_data *materials, size_t n_materials, rpt_light_pick_entry *entries_out, size_t entries_capacity,
                               size_t *n_entries_out, uint32_t *n_emissive_out, double *ms_out);

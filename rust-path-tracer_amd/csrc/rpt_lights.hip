@@ -12,13 +12,14 @@
  *   6  "robin hood": walk the bins upwards, top each up to `average` from the current most probable bin, which steps down when it is used up
  *                                                                                                    a two-cursor f32 recurrence
  *   7  the table: areas / pdfs gathered through index_a / index_b, ratio = p_a / (p_a + p_b)         independent
- * 1, 3, 5, 7 are kernels (5 = rocPRIM's radix sort on order-preserving keys).  2 and 4 are one-wave kernels that keep the reference's
- * association: the values arrive through the scalar cache and feed one running sum in index order (adding the 0.0 of a non-emissive
- * triangle changes nothing: the sum is never -0.0) — the latency of the dependent add per element, nothing else.
- * 6 runs on the HOST between two device passes: each step depends on the previous one through two rounded subtractions and a
- * compare that moves a cursor; a latency-optimised core takes ~3 ns per step where one GPU lane takes ~50 (measured: DESIGN.md 7), and the
- * data it needs — the sorted probabilities and indices, 8 bytes per bin — crosses PCIe in less time than either.  No part of the RESULT is
- * computed differently: the same f32 operations in the same order, wherever they run.
+ * 1, 3, 5, 7 are kernels (5 = rocPRIM's radix sort on order-preserving keys).  The three chains — 2, 4, 6 — run on the HOST between the
+ * device passes: each of their steps waits for the rounded result of the one before, so what runs them is a question of latency per
+ * dependent operation, not of width.  Measured on MI355X (profiles/r05_light_table.txt): one wave adding a million floats in index order —
+ * values through the scalar cache, one v_add_f32 per element — takes 10.5 ms, 22 cycles per element on a GPU that idles around that one wave
+ * (the first version, v_readlane per element behind vector loads: 9 ms); the host core does it in 1.2 ms, and the robin-hood walk over a
+ * million bins in 0.6 ms.  What the chains need crosses PCIe in less time than that: the powers down (4 bytes per triangle), two scalars up,
+ * the sorted bins down and their fill up (8 + 12 bytes per bin).  No part of the RESULT is computed differently: the same f32 operations in the
+ * same order, wherever they run (the probabilities the host sums are the quotients the device computes: IEEE division on both sides).
  *
  * A NaN probability (a NaN vertex, or total_power = 0 / inf / NaN) has no place in the order-preserving keys — Rust's sort_by treats it as
  * equal to everything, which is not an order — and is refused (RPT_ESCENE), like a NaN coordinate by the BVH builder.
@@ -81,41 +82,6 @@ __global__ __launch_bounds__(LT_BLOCK) void k_lt_power(const float4 *vertices, c
     }
     const unsigned long long m = __ballot(mask);
     if (m != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&sc->total_tris, (uint32_t)__popcll(m));
-}
-
-/* steps 2 and 4: the f32 sum of x[0 .. n) in index order.  mode 0: total_power; mode 1: average = sum / total_tris.
- * The chain of rounded adds is serial whatever runs it; what can be taken off it is the data path.  Every address is wave-uniform, so the values
- * come through the SCALAR cache: s_load_dwordx16 straight into SGPRs, two blocks of 32 ahead of the adds, and the chain is one v_add_f32 with a
- * scalar operand per element — no readlane, no LDS round trip (the first version: v_readlane + s_nop + v_add per element behind an exposed vector
- * load per 64 elements, 9 ms per million; this one: ~2.5 ms). */
-__global__ __launch_bounds__(64) void k_lt_seqsum(const float *__restrict__ x, uint32_t n, LtScalars *sc, int mode) {
-    constexpr uint32_t B = 32u;
-    float acc = 0.0f;
-    const uint32_t full = n / B;
-    float c0[B], c1[B];
-    if (full > 0u) {
-#pragma unroll
-        for (uint32_t k = 0; k < B; ++k) c0[k] = x[k];
-    }
-    if (full > 1u) {
-#pragma unroll
-        for (uint32_t k = 0; k < B; ++k) c1[k] = x[B + k];
-    }
-    for (uint32_t b = 0; b < full; ++b) {
-        float nx[B];
-        const uint32_t ahead = b + 2u < full ? b + 2u : b;        /* (a valid block: its values are not used past the end) */
-#pragma unroll
-        for (uint32_t k = 0; k < B; ++k) nx[k] = x[ahead * B + k];
-#pragma unroll
-        for (uint32_t k = 0; k < B; ++k) acc = acc + c0[k];
-#pragma unroll
-        for (uint32_t k = 0; k < B; ++k) { c0[k] = c1[k]; c1[k] = nx[k]; }
-    }
-    for (uint32_t i = full * B; i < n; ++i) acc = acc + x[i];
-    if (threadIdx.x == 0u) {
-        if (mode == 0) sc->total_power = acc;
-        else { sc->prob_sum = acc; sc->average = acc / (float)sc->total_tris; }
-    }
 }
 
 /* step 3 (:59-62) + the bin predicate of :74-83 */
@@ -202,7 +168,7 @@ __global__ __launch_bounds__(LT_BLOCK) void k_lt_table(const float *pa, const fl
 
 extern "C" int rpt_light_table_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertices, const rpt_triangle *triangles, size_t n_triangles,
                                          const rpt_material_data *materials, size_t n_materials, rpt_light_pick_entry *entries_out, size_t entries_capacity,
-                                         size_t *n_entries_out, uint32_t *n_emissive_out, double *ms_out /* nullable, 4 doubles: total, device passes, host fill, transfers */) {
+                                         size_t *n_entries_out, uint32_t *n_emissive_out, double *ms_out /* nullable, 4 doubles: total, device passes, host chains, transfers */) {
     std::string &err = rpt_create_error();
     if (!vertices_xyzw || !triangles || !materials || !entries_out || !n_entries_out || n_vertices == 0 || n_materials == 0 || entries_capacity == 0) {
         err = "rpt_light_table_build_gpu: null or empty argument";
@@ -259,12 +225,27 @@ extern "C" int rpt_light_table_build_gpu(int device_id, const float *vertices_xy
     ms_transfer += since(t0);
 
     k_lt_power<<<nb, LT_BLOCK>>>(d_verts.p, d_tris.p, d_emissive.p, nt, d_area.p, d_power.p, d_sc.p);
-    k_lt_seqsum<<<1, 64>>>(d_power.p, nt, d_sc.p, 0);
     LtScalars sc;
+    std::vector<float> power(nt);
+    t0 = std::chrono::steady_clock::now();
     LT_TRY(hipMemcpy(&sc, d_sc.p, sizeof(sc), hipMemcpyDeviceToHost));
     if (sc.total_tris == 0u) return sentinel(0u);
+    LT_TRY(hipMemcpy(power.data(), d_power.p, (size_t)nt * sizeof(float), hipMemcpyDeviceToHost));
+    ms_transfer += since(t0);
+    /* steps 2 and 4 (:39-51, :59-64): both sums in index order (the 0.0 of a non-emissive triangle changes nothing: the sums are never -0.0) */
+    t0 = std::chrono::steady_clock::now();
+    {
+        float total_power = 0.0f;
+        for (uint32_t i = 0; i < nt; ++i) total_power += power[i];
+        float prob_sum = 0.0f;
+        for (uint32_t i = 0; i < nt; ++i) prob_sum += power[i] / total_power;
+        sc.total_power = total_power;
+        sc.prob_sum = prob_sum;
+        sc.average = prob_sum / (float)sc.total_tris;
+    }
+    ms_fill += since(t0);
+    LT_TRY(hipMemcpy(d_sc.p, &sc, sizeof(sc), hipMemcpyHostToDevice));
     k_lt_prob<<<nb, LT_BLOCK>>>(d_power.p, nt, d_prob.p, d_sc.p, d_counts.p);
-    k_lt_seqsum<<<1, 64>>>(d_prob.p, nt, d_sc.p, 1);
     k_lt_scan<<<1, 1024>>>(d_counts.p, nb, d_sc.p);
     LT_TRY(hipMemcpy(&sc, d_sc.p, sizeof(sc), hipMemcpyDeviceToHost));
     if (sc.has_nan) { err = "rpt_light_table_build_gpu: a pick probability is NaN (NaN vertex, or a total power of 0 / inf): such a scene must be built by the host builder"; return RPT_ESCENE; }
@@ -306,7 +287,7 @@ extern "C" int rpt_light_table_build_gpu(int device_id, const float *vertices_xy
             }
         }
     }
-    ms_fill = since(t0);
+    ms_fill += since(t0);
     t0 = std::chrono::steady_clock::now();
     LT_TRY(hipMemcpy(d_pa.p, pa.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     LT_TRY(hipMemcpy(d_pb.p, pb.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));

@@ -494,7 +494,7 @@ def debug_math_host(op, x, y=None):
 
 def light_table_build_gpu(vertices_xyzw, triangles, materials, device=0):
     """build_light_pick_table on the GPU (rpt_light_table_build_gpu; reference src/light_pick.rs:13-122).
-    Returns (table as LIGHT_PICK_DTYPE array, number of emissive triangles, {"total", "device", "host_fill", "transfers"} in milliseconds)."""
+    Returns (table as LIGHT_PICK_DTYPE array, number of emissive triangles, {"total", "device", "host_chains", "transfers"} in milliseconds)."""
     from ._ffi import LIGHT_PICK_DTYPE, MATERIAL_DTYPE, TRIANGLE_DTYPE
     v = np.ascontiguousarray(vertices_xyzw, np.float32).reshape(-1, 4)
     t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
@@ -509,7 +509,7 @@ def light_table_build_gpu(vertices_xyzw, triangles, materials, device=0):
                                      C.byref(n), C.byref(n_em), ms)
     if rc != 0:
         raise RptError(rc, L.rpt_last_error(None).decode())
-    return table[: n.value].copy(), n_em.value, {"total": ms[0], "device": ms[1], "host_fill": ms[2], "transfers": ms[3]}
+    return table[: n.value].copy(), n_em.value, {"total": ms[0], "device": ms[1], "host_chains": ms[2], "transfers": ms[3]}
 
 
 def bvh_build_gpu(vertices_xyzw, triangles, sah_samples=128, device=0):
