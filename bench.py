@@ -346,6 +346,7 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
     if "valu" in pipeline:
         pipeline["valu"].pop("issue_frac_is", None)
     return {"value": round((n_ext + n_shadow) / elapsed / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "value_as_the_reference_counts": round((n_ext + n_shadow + n_elided) / elapsed / 1e6, 3),   # + the shadow rays the reference traces and this build proves irrelevant
             "steps": steps, "warmup": warmup, "samples_per_s": round(n_samples / elapsed, 1),
             "data": ("fixtures/" + scene + ".glb (reference scene file)" if not scene.startswith("procedural:")
                      else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
@@ -707,6 +708,7 @@ def main():
                    "kernel_sources": hip.build_fingerprint(), "gather": gather_impl, "collective_library": hip.comm_library() or None,
                    "rpt_comm_world": comm_world_seen},
         "samples_per_s": round(n_samples / elapsed_max, 1),
+        "value_as_the_reference_counts": round((rays + n_elided) / elapsed_max / 1e6, 3),
         "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "shadow_elided": int(n_elided), "sky_evals": int(n_sky),
                  "per_sample": round(rays / max(n_samples, 1), 4),
                  "counted": "rays walked on the device; shadow_elided = NEE evaluations whose shadow ray decides nothing (zero term whatever the walk finds) and is not walked"},

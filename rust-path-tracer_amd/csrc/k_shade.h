@@ -572,7 +572,10 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     __shared__ uint32_t c_slot[COMPACT ? RPT_BLOCK * RPT_SHADE_ROUNDS : 1];
     __shared__ uint32_t n_elided;                              /* NEE evaluations of this workgroup whose shadow ray was not queued (shade_slot) */
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
-    if (NEE != RPT_NEE_NONE && threadIdx.x == 0u) n_elided = 0u;   /* (ordered before its first use by the barriers of block_rank2 / shade_emit) */
+    if (NEE != RPT_NEE_NONE) {
+        if (threadIdx.x == 0u) n_elided = 0u;
+        __syncthreads();                                       /* before any wave's count_elided (one barrier per workgroup; block-uniform: the returns above are) */
+    }
     if (NEE != RPT_NEE_NONE && blockIdx.x == 0u && threadIdx.x == 0u) q.count[Q_SPOOL] = 0u;   /* the shadow stage that follows starts its pool at entry 0 */
     if (COMPACT) {
         const uint32_t base = blockIdx.x * (RPT_BLOCK * RPT_SHADE_ROUNDS);

@@ -38,7 +38,7 @@
 
 #include "../../include/rpt/shared_structs.h"
 
-#define SHADOW_PROBE_RAYS 8192     /* candidates; about half survive the "decides something" filter */
+#define SHADOW_PROBE_RAYS 4096     /* candidates; about half survive the "decides something" filter */
 #define SHADOW_FIXED_GAIN 0.95
 
 struct ShadowOrder {
@@ -58,13 +58,13 @@ inline V cross(V a, V b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z
 inline float dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V vtx(const rpt_per_vertex_data &p) { return V{p.vertex[0], p.vertex[1], p.vertex[2]}; }
 
-/* the box test of the walk with prev_min_t = 1e6 (plain float code: this is a cost estimate, not a result) */
-inline bool box(const rpt_bvh_node &n, V o, V d, float &tmin) {
-    float tx1 = (n.aabb_min[0] - o.x) / d.x, tx2 = (n.aabb_max[0] - o.x) / d.x;
+/* the box test of the walk with prev_min_t = 1e6 (plain float code with a reciprocal direction: this is a cost estimate, not a result) */
+inline bool box(const rpt_bvh_node &n, V o, V id, float &tmin) {
+    float tx1 = (n.aabb_min[0] - o.x) * id.x, tx2 = (n.aabb_max[0] - o.x) * id.x;
     float lo = std::fmin(tx1, tx2), hi = std::fmax(tx1, tx2);
-    float ty1 = (n.aabb_min[1] - o.y) / d.y, ty2 = (n.aabb_max[1] - o.y) / d.y;
+    float ty1 = (n.aabb_min[1] - o.y) * id.y, ty2 = (n.aabb_max[1] - o.y) * id.y;
     lo = std::fmax(lo, std::fmin(ty1, ty2)); hi = std::fmin(hi, std::fmax(ty1, ty2));
-    float tz1 = (n.aabb_min[2] - o.z) / d.z, tz2 = (n.aabb_max[2] - o.z) / d.z;
+    float tz1 = (n.aabb_min[2] - o.z) * id.z, tz2 = (n.aabb_max[2] - o.z) * id.z;
     lo = std::fmax(lo, std::fmin(tz1, tz2)); hi = std::fmin(hi, std::fmax(tz1, tz2));
     tmin = lo;
     return hi >= lo && hi > 0.0f && lo < 1000000.0f;
@@ -99,6 +99,7 @@ inline uint32_t walk(const rpt_bvh_node *nodes, const rpt_per_vertex_data *pv, c
     int sp = 0;
     uint32_t visits = 0, node = 0;
     occluded = false;
+    const V id{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     for (;;) {
         visits += 1;
         const rpt_bvh_node &n = nodes[node];
@@ -109,7 +110,7 @@ inline uint32_t walk(const rpt_bvh_node *nodes, const rpt_per_vertex_data *pv, c
         } else {
             const uint32_t L = n.left_or_first, R = L + 1u;
             float tl, tr;
-            const bool hl = box(nodes[L], o, d, tl), hr = box(nodes[R], o, d, tr);
+            const bool hl = box(nodes[L], o, id, tl), hr = box(nodes[R], o, id, tr);
             const bool right = FIXED ? (hr && (!hl || flip[L >> 1] != 0)) : (hr && (!hl || tl > tr));
             if (hl || hr) {
                 if (hl && hr && sp < 64) stack[sp++] = right ? L : R;
