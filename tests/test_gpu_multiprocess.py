@@ -173,12 +173,16 @@ def test_bench_line_carries_the_other_single_gpu_workloads(tmp_path):
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["metric"] == "Mrays/s" and out["n_gpus"] == 1 and out["parity_check"]["bitwise"] is True
+    assert out["rays"]["shadow"] == 0 and out["rays"]["shadow_elided"] == 0 and out["value_as_the_reference_counts"] == out["value"]      # nee = 0
     sm = out["roofline"]["stage_ms"]
     assert sm["generate"] > 0 and sm["complete"] > 0 and sm["traverse"] > sm["shade"] > 0
     assert set(out["workloads"]) == {"darkcornell_mis", "veachmis"}
     for name, w in out["workloads"].items():
         assert w["value"] > 100 and w["unit"] == "Mrays/s" and w["steps"] == 1 and w["ms_per_step"] > 0
         assert w["rays"]["shadow"] > 0 and w["config"]["workload"].startswith(("DarkCornell.glb 1024x1024", "VeachMIS.glb 1920x1080"))
+        # Mrays/s counts the rays WALKED on the device; the NEE evaluations whose shadow ray decides nothing (about half) are reported beside them
+        assert 0.2 * w["rays"]["shadow"] < w["rays"]["shadow_elided"] < 5 * w["rays"]["shadow"]
+        assert w["value_as_the_reference_counts"] > w["value"] and w["rays"]["per_sample_as_the_reference_counts"] > w["rays"]["per_sample"]
         r = w["roofline"]
         assert r["bound"] == "hbm" and r["kernel"].startswith("k_") and 0 < r["frac"] < 1 and r["avg_launch_ms"] > 0
         assert abs(r["achieved"] - r["algorithmic_bytes_per_unit"] * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-2 * r["achieved"]

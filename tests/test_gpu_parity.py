@@ -244,7 +244,7 @@ def test_the_library_chooses_the_shadow_order_per_scene(monkeypatch, hipmod, rpt
         assert so["fixed"] and so["visits_fixed"] < 0.7 * so["visits_near"] and {k: v for k, v in so.items() if k != "probe_ms"} == {k: v for k, v in hipmod.shadow_order_host(world("DarkCornell")).items() if k != "flip"}
         r.upload_scene(world("VeachMIS"))
         vm = r.shadow_order()
-        assert vm["fixed"] == (vm["visits_fixed"] < 0.95 * vm["visits_near"]) and vm["probe_rays"] > 2000 and vm["probe_ms"] > 0
+        assert vm["fixed"] == (vm["visits_fixed"] < 0.95 * vm["visits_near"]) and vm["probe_rays"] > 1000 and vm["probe_ms"] > 0
         r.upload_scene(world("PBRTest"))
         assert not r.shadow_order()["fixed"] and r.shadow_order()["probe_rays"] == 0
         r.upload_scene(world("DarkCornell"))
