@@ -654,7 +654,7 @@ def main():
 
     # --- CPU baseline: the oracle (a port of trace_cpu) on this host's cores, bounded sample of the same workload
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world_size == 1:                 # (rank 0 at N = 1 only: the scaling runs do not repeat the ~12 s CPU leg)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from oracle_ffi import Oracle
         orc = Oracle("rpt_math")
