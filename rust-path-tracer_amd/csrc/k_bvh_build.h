@@ -763,4 +763,38 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
     }
 }
 
+/* ---- renumbering to the reference's node order, on the device -----------------------------------------------------------
+ * The build above numbers nodes level by level; the reference (src/bvh.rs:296-320) gives the two children of a node the next two free indices at the
+ * moment the node is popped from its stack, left subtree first: children(b) = 1 + 2 r(b), 2 + 2 r(b) with r(b) = the number of INNER nodes popped
+ * before b = b's rank among the inner nodes in left-first pre-order.  With I(b) = the inner nodes of b's subtree (bottom-up, one launch per level):
+ * r(left) = r(b) + 1, r(right) = r(b) + 1 + I(left) (top-down, one launch per level), and every node is written straight to its place in the
+ * reference's 32-byte layout.  (Round 4 read the build-order pool back and renumbered 2 M nodes on the host: 128 ms + 23 ms of read-back, more
+ * than the build itself took; profiles/r05_startup_sections.txt.) */
+__global__ __launch_bounds__(BVB_THREADS) void k_bvb_inner_count(const BvbNode *nodes, uint32_t *inner, uint32_t begin, uint32_t end) {
+    const uint32_t b = begin + blockIdx.x * BVB_THREADS + threadIdx.x;
+    if (b >= end) return;
+    const uint32_t l = nodes[b].left;
+    inner[b] = l == BVB_NONE ? 0u : 1u + inner[l] + inner[l + 1u];
+}
+__global__ __launch_bounds__(BVB_THREADS) void k_bvb_place(const BvbNode *nodes, const uint32_t *inner, uint32_t *rank, uint32_t *oidx, rpt_bvh_node *out,
+                                                           uint32_t begin, uint32_t end) {
+    const uint32_t b = begin + blockIdx.x * BVB_THREADS + threadIdx.x;
+    if (b >= end) return;
+    const BvbNode n = nodes[b];
+    rpt_bvh_node o;
+    o.aabb_min[0] = n.mn[0]; o.aabb_min[1] = n.mn[1]; o.aabb_min[2] = n.mn[2];
+    o.aabb_max[0] = n.mx[0]; o.aabb_max[1] = n.mx[1]; o.aabb_max[2] = n.mx[2];
+    if (n.left == BVB_NONE) {
+        o.triangle_count = n.count;
+        o.left_or_first = n.first;
+    } else {
+        const uint32_t r = rank[b], c = 1u + 2u * r;
+        o.triangle_count = 0u;
+        o.left_or_first = c;
+        oidx[n.left] = c;          oidx[n.left + 1u] = c + 1u;
+        rank[n.left] = r + 1u;     rank[n.left + 1u] = r + 1u + inner[n.left];
+    }
+    out[oidx[b]] = o;
+}
+
 #endif /* RPT_K_BVH_BUILD_H */

@@ -21,6 +21,28 @@
 
 #include "rpt_ctx.h"
 #include "shadow_order.h"
+
+/* RPT_UPLOAD_TIMING=1: host-side section times of rpt_upload_scene / rpt_bvh_build_gpu on stderr (where the start-up time of a large scene goes) */
+struct SectionTimer {
+    bool on;
+    const char *title;
+    std::chrono::steady_clock::time_point last;
+    std::string line;
+    explicit SectionTimer(const char *t) : on(false), title(t) {
+        const char *e = getenv("RPT_UPLOAD_TIMING");
+        on = e && e[0] == '1';
+        last = std::chrono::steady_clock::now();
+    }
+    void mark(const char *name) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof buf, " %s %.1f", name, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~SectionTimer() { if (on) fprintf(stderr, "%s (ms):%s\n", title, line.c_str()); }
+};
 #include "k_traverse.h"
 #include "k_bvh_build.h"
 #include "k_shade.h"
@@ -398,6 +420,52 @@ static void timing_accumulate(rpt_ctx *c, const std::vector<hipEvent_t> &ev, uin
 
 }  // namespace
 
+/* The 64-byte pair records + per-node links of the streamed global-memory walks (k_traverse.h SceneViewPairsT) from the uploaded node pool; with `flip`
+ * (shadow_order.h) the two nodes of a flipped pair exchange slots: the copy the fixed-order shadow walks read.  (On the host this loop took 27 ms for 2 M nodes.) */
+__global__ __launch_bounds__(RPT_BLOCK) void k_build_pairs(const float4 *nodes, const uint8_t *flip, uint32_t n_pairs, float4 *pairs, uint32_t *links) {
+    const uint32_t p = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    auto link_of = [](float4 lo, float4 hi) { return (__float_as_uint(lo.w) << 24) | __float_as_uint(hi.w); };      /* triangle_count << 24 | left child / first triangle */
+    if (p == 0u) links[0] = link_of(nodes[0], nodes[1]);
+    if (p >= n_pairs) return;
+    const bool f = flip != nullptr && flip[p] != 0;
+    const uint32_t l = f ? 2u * p + 2u : 2u * p + 1u, r = f ? 2u * p + 1u : 2u * p + 2u;
+    const float4 llo = nodes[2u * (size_t)l], lhi = nodes[2u * (size_t)l + 1u], rlo = nodes[2u * (size_t)r], rhi = nodes[2u * (size_t)r + 1u];
+    const uint32_t kl = link_of(llo, lhi), kr = link_of(rlo, rhi);
+    pairs[4u * (size_t)p + 0u] = make_float4(llo.x, llo.y, llo.z, lhi.x);
+    pairs[4u * (size_t)p + 1u] = make_float4(lhi.y, lhi.z, rlo.x, rlo.y);
+    pairs[4u * (size_t)p + 2u] = make_float4(rlo.z, rhi.x, rhi.y, rhi.z);
+    pairs[4u * (size_t)p + 3u] = make_float4(0.0f, 0.0f, __uint_as_float(kl), __uint_as_float(kr));
+    links[2u * p + 1u] = kl;
+    links[2u * p + 2u] = kr;
+}
+
+/* tri_geom / tri_isect / tri_shade of every triangle (DevScene, k_common.h) and |e1 x e2|^2 for the shadow-order probe, from the uploaded reference buffers:
+ *   tri_geom : a, e1 = b - a, e2 = c - a (muller_trumbore, intersection.rs:13-14; barycentric v0, v1, util.rs:239-240)
+ *              with d00 = e1.e1, d01 = e1.e2, d11 = e2.e2 (util.rs:242-244) in the .w lanes — dot = (x x' + y y') + z z', as glam's
+ *   tri_isect: e1, e2, a packed in 36 bytes        tri_shade: the three vertex normals, the three uv0 pairs and the material index in 64 bytes */
+__global__ __launch_bounds__(RPT_BLOCK) void k_derive_triangles(const float4 *per_vertex, const uint4 *indices, uint32_t nt, float4 *tri_geom, float *tri_isect,
+                                                                float4 *tri_shade, float *cross_sq) {
+    const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (i >= nt) return;
+    const uint4 t = indices[i];
+    const float4 *A = per_vertex + 4u * (size_t)t.x, *B = per_vertex + 4u * (size_t)t.y, *C = per_vertex + 4u * (size_t)t.z;
+    const float4 a = A[0], b = B[0], cc = C[0];
+    const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+    const float e2x = cc.x - a.x, e2y = cc.y - a.y, e2z = cc.z - a.z;
+    tri_geom[3u * (size_t)i + 0u] = make_float4(a.x, a.y, a.z, (e1x * e1x + e1y * e1y) + e1z * e1z);
+    tri_geom[3u * (size_t)i + 1u] = make_float4(e1x, e1y, e1z, (e1x * e2x + e1y * e2y) + e1z * e2z);
+    tri_geom[3u * (size_t)i + 2u] = make_float4(e2x, e2y, e2z, (e2x * e2x + e2y * e2y) + e2z * e2z);
+    float *p = tri_isect + 9u * (size_t)i;
+    p[0] = e1x; p[1] = e1y; p[2] = e1z; p[3] = e2x; p[4] = e2y; p[5] = e2z; p[6] = a.x; p[7] = a.y; p[8] = a.z;
+    const float4 na = A[1], nb = B[1], nc = C[1], ua = A[3], ub = B[3], uc = C[3];
+    tri_shade[4u * (size_t)i + 0u] = make_float4(na.x, na.y, na.z, ua.x);
+    tri_shade[4u * (size_t)i + 1u] = make_float4(nb.x, nb.y, nb.z, ua.y);
+    tri_shade[4u * (size_t)i + 2u] = make_float4(nc.x, nc.y, nc.z, __uint_as_float(t.w));
+    tri_shade[4u * (size_t)i + 3u] = make_float4(ub.x, ub.y, uc.x, uc.y);
+    const float cx = e1y * e2z - e1z * e2y, cy = e1z * e2x - e1x * e2z, cz = e1x * e2y - e1y * e2x;       /* (the probe's estimate of areas: no part of a result) */
+    cross_sq[i] = (cx * cx + cy * cy) + cz * cz;
+}
+
 extern "C" {
 
 int rpt_abi_version(void) { return RPT_ABI_VERSION; }
@@ -556,6 +624,8 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
             c->error = "a material references the texture atlas but no atlas was supplied";
             return RPT_ESCENE;
         }
+    SectionTimer sections("rpt_upload_scene");
+    sections.mark("validate");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;
     c->fat_leaves = false;
@@ -568,23 +638,23 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
      *              with d00 = e1.e1, d01 = e1.e2, d11 = e2.e2 (util.rs:242-244) in the .w lanes
      *   tri_shade: the three vertex normals, the three uv0 pairs and the material index in 64 contiguous bytes
      *   mat_lite : emissive / albedo colours + roughness.x / metallic.x in 32 bytes (untextured scenes) */
-    auto dot = [](const float *u, const float *v) { return (u[0] * v[0]) + (u[1] * v[1]) + (u[2] * v[2]); };
-    std::vector<float4> geom(3 * nt), shade(4 * nt), lite(2 * nm);
-    for (size_t i = 0; i < nt; ++i) {
-        const rpt_per_vertex_data &A = pv[idx[i].v0], &B = pv[idx[i].v1], &C = pv[idx[i].v2];
-        const float *a = A.vertex, *b = B.vertex, *cc = C.vertex;
-        float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-        float e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};
-        geom[3 * i + 0] = make_float4(a[0], a[1], a[2], dot(e1, e1));
-        geom[3 * i + 1] = make_float4(e1[0], e1[1], e1[2], dot(e1, e2));
-        geom[3 * i + 2] = make_float4(e2[0], e2[1], e2[2], dot(e2, e2));
-        uint32_t m = idx[i].material;
-        float mf;
-        memcpy(&mf, &m, 4);
-        shade[4 * i + 0] = make_float4(A.normal[0], A.normal[1], A.normal[2], A.uv0[0]);
-        shade[4 * i + 1] = make_float4(B.normal[0], B.normal[1], B.normal[2], A.uv0[1]);
-        shade[4 * i + 2] = make_float4(C.normal[0], C.normal[1], C.normal[2], mf);
-        shade[4 * i + 3] = make_float4(B.uv0[0], B.uv0[1], C.uv0[0], C.uv0[1]);
+    /* Computed ON THE DEVICE from the uploaded vertices and indices (k_derive_triangles: the same IEEE single operations, no contraction — the
+     * host loops over a million triangles, three scattered 64-byte vertices each, and the transfer of their 148 bytes per triangle were 90 ms of a
+     * 1 M-triangle upload, profiles/r05_startup_sections.txt).  The host derives `geom` itself only for a scene small enough for the LDS image,
+     * whose builder reads it. */
+    std::vector<float4> geom, lite(2 * nm);
+    const bool lds_candidate = nn * 50 + nt * 48 <= RPT_LDS_SCENE_BYTES && depth <= 15;
+    if (lds_candidate) {
+        auto dot = [](const float *u, const float *v) { return (u[0] * v[0]) + (u[1] * v[1]) + (u[2] * v[2]); };
+        geom.resize(3 * nt);
+        for (size_t i = 0; i < nt; ++i) {
+            const float *a = pv[idx[i].v0].vertex, *b = pv[idx[i].v1].vertex, *cc = pv[idx[i].v2].vertex;
+            float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+            float e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};
+            geom[3 * i + 0] = make_float4(a[0], a[1], a[2], dot(e1, e1));
+            geom[3 * i + 1] = make_float4(e1[0], e1[1], e1[2], dot(e1, e2));
+            geom[3 * i + 2] = make_float4(e2[0], e2[1], e2[2], dot(e2, e2));
+        }
     }
     uint32_t textured = 0;
     for (size_t i = 0; i < nm; ++i) {
@@ -592,32 +662,34 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         lite[2 * i + 1] = make_float4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].metallic[0]);
         if (mats[i].has_albedo_texture | mats[i].has_metallic_texture | mats[i].has_roughness_texture | mats[i].has_normal_texture) textured = 1;
     }
+    sections.mark("derive_host");
     HIP_TRY(c, c->nodes.alloc(2 * nn));
     HIP_TRY(c, c->tri_geom.alloc(3 * nt));
     HIP_TRY(c, c->tri_shade.alloc(4 * nt));
+    HIP_TRY(c, c->tri_isect.alloc(9 * nt));
     HIP_TRY(c, c->mat_lite.alloc(2 * nm));
-    HIP_TRY(c, hipMemcpy(c->tri_shade.p, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->mat_lite.p, lite.data(), lite.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(c, c->per_vertex.alloc(4 * nv));
     HIP_TRY(c, c->materials.alloc(6 * nm));
     HIP_TRY(c, c->indices.alloc(nt));
     HIP_TRY(c, c->light_pick.alloc(nlp));
-    HIP_TRY(c, hipMemcpy(c->nodes.p, nodes, nn * sizeof(rpt_bvh_node), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->tri_geom.p, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
-    {
-        std::vector<float> isect(9 * nt);
-        for (size_t i = 0; i < nt; ++i) {
-            const float4 &a = geom[3 * i], &e1 = geom[3 * i + 1], &e2 = geom[3 * i + 2];
-            float *p = &isect[9 * i];
-            p[0] = e1.x; p[1] = e1.y; p[2] = e1.z; p[3] = e2.x; p[4] = e2.y; p[5] = e2.z; p[6] = a.x; p[7] = a.y; p[8] = a.z;
-        }
-        HIP_TRY(c, c->tri_isect.alloc(isect.size()));
-        HIP_TRY(c, hipMemcpy(c->tri_isect.p, isect.data(), isect.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
+    DevBuf<float> d_cross_sq;
+    std::vector<float> cross_sq(nt);
+    HIP_TRY(c, d_cross_sq.alloc(nt));
     HIP_TRY(c, hipMemcpy(c->per_vertex.p, pv, nv * sizeof(rpt_per_vertex_data), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->materials.p, mats, nm * sizeof(rpt_material_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->indices.p, idx, nt * sizeof(rpt_triangle), hipMemcpyHostToDevice));
+    if (nt) k_derive_triangles<<<(unsigned)((nt + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK>>>(c->per_vertex.p, c->indices.p, (uint32_t)nt, c->tri_geom.p, c->tri_isect.p,
+                                                                                         c->tri_shade.p, d_cross_sq.p);
+    HIP_TRY(c, hipMemcpy(c->mat_lite.p, lite.data(), lite.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->nodes.p, nodes, nn * sizeof(rpt_bvh_node), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->materials.p, mats, nm * sizeof(rpt_material_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->light_pick.p, lp, nlp * sizeof(rpt_light_pick_entry), hipMemcpyHostToDevice));
+    {
+        const hipError_t e_cs = nt ? hipMemcpy(cross_sq.data(), d_cross_sq.p, nt * sizeof(float), hipMemcpyDeviceToHost) : hipSuccess;   /* (also waits for the kernel) */
+        d_cross_sq.release();
+        HIP_TRY(c, e_cs);
+        HIP_TRY(c, hipGetLastError());
+    }
+    sections.mark("h2d_derive_device");
     {
         /* per light-pick entry, for its two triangles: corners, the mean of the three vertex normals exactly as
          * sample_direct_lighting forms it ((na + nb + nc) / 3.0, light_pick.rs:129), and the material's emission */
@@ -640,6 +712,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         HIP_TRY(c, hipMemcpy(c->light_rec.p, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
     }
 
+    sections.mark("h2d_2_light_rec");
     static const uint8_t magenta_u8[16] = {255, 0, 255, 255, 255, 0, 255, 255, 255, 0, 255, 255, 255, 0, 255, 255};
     static const float magenta_f[16] = {1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1, 0, 1, 1};   /* src/asset.rs:283-290 */
     if (!atlas || !aw || !ah) { atlas = magenta_u8; aw = ah = 2; }
@@ -658,7 +731,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     s.n_nodes = (uint32_t)nn;
     s.n_triangles = (uint32_t)nt;
     s.lds_scene = 0u; s.lds_image = nullptr; s.lds_pairs = s.lds_vecs = s.lds_root = 0u;
-    if (nn * 50 + nt * 48 <= RPT_LDS_SCENE_BYTES && depth <= 15) {
+    if (lds_candidate) {
         std::vector<float4> image;
         uint32_t pairs = 0, root = 0;
         if (build_lds_image(nodes, nn, geom, nt, image, pairs, root) && image.size() * sizeof(float4) <= RPT_LDS_SCENE_BYTES) {
@@ -669,6 +742,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
             s.lds_pairs = pairs; s.lds_vecs = (uint32_t)image.size(); s.lds_root = root;
         }
     }
+    sections.mark("atlas_lds_image");
     if (const char *env = getenv("RPT_NO_LDS_SCENE"); env && env[0] == '1') s.lds_scene = 0u;
     /* pair records for the streamed global-memory walks (k_traverse.h SceneViewPairsT); a pool they cannot express keeps the one-shot walks */
     s.gpairs = nullptr; s.glinks = nullptr;
@@ -678,29 +752,12 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         if (n.triangle_count >= 255u || n.left_or_first >= (1u << 24)) pair_shaped = false;
         else if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
     }
-    auto build_pairs = [nn](const rpt_bvh_node *pool, std::vector<float4> &pairs, std::vector<uint32_t> &links) {
-        links.resize(nn);
-        for (size_t i = 0; i < nn; ++i) links[i] = (pool[i].triangle_count << 24) | pool[i].left_or_first;
-        const size_t P = (nn - 1) / 2;
-        pairs.assign(4 * P, make_float4(0, 0, 0, 0));
-        for (size_t p = 0; p < P; ++p) {
-            const rpt_bvh_node &L = pool[2 * p + 1], &R = pool[2 * p + 2];
-            float fl, fr;
-            memcpy(&fl, &links[2 * p + 1], 4); memcpy(&fr, &links[2 * p + 2], 4);
-            pairs[4 * p + 0] = make_float4(L.aabb_min[0], L.aabb_min[1], L.aabb_min[2], L.aabb_max[0]);
-            pairs[4 * p + 1] = make_float4(L.aabb_max[1], L.aabb_max[2], R.aabb_min[0], R.aabb_min[1]);
-            pairs[4 * p + 2] = make_float4(R.aabb_min[2], R.aabb_max[0], R.aabb_max[1], R.aabb_max[2]);
-            pairs[4 * p + 3] = make_float4(0.0f, 0.0f, fl, fr);
-        }
-    };
+    const uint32_t n_pairs = pair_shaped ? (uint32_t)((nn - 1) / 2) : 0u;
     if (pair_shaped) {
-        std::vector<float4> pairs;
-        std::vector<uint32_t> links;
-        build_pairs(nodes, pairs, links);
-        HIP_TRY(c, c->gpairs.alloc(std::max<size_t>(1, pairs.size())));
+        HIP_TRY(c, c->gpairs.alloc(std::max<size_t>(1, 4 * (size_t)n_pairs)));
         HIP_TRY(c, c->glinks.alloc(nn));
-        HIP_TRY(c, hipMemcpy(c->gpairs.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->glinks.p, links.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice));
+        k_build_pairs<<<(n_pairs + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK>>>(c->nodes.p, nullptr, n_pairs, c->gpairs.p, c->glinks.p);
+        HIP_TRY(c, hipGetLastError());
         s.gpairs = c->gpairs.p; s.glinks = c->glinks.p;
     } else {
         /* a previous, pair-shaped scene's records are of no use to this one (36 bytes per node of the OLD scene otherwise stay until rpt_destroy) */
@@ -710,12 +767,13 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     /* The any-hit (shadow) walks may visit siblings in any order (shadow_order.h: only `.hit` is read, light_pick.rs:148).  Probe rays decide per
      * scene between the reference's near-first order and a fixed opaque-first order; the latter walks a copy of the tree whose pairs are flipped so
      * that the preferred child is the LEFT one: a second LDS image / pair array, read by the shadow kernels only. */
+    sections.mark("pairs");
     s.shadow_fixed = 0u; s.lds_image_shadow = nullptr; s.gpairs_shadow = nullptr; s.glinks_shadow = nullptr;
-    c->shadow_order = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped, reinterpret_cast<const float *>(geom.data()));
+    c->shadow_order = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped, cross_sq.data());
     if (c->shadow_order.fixed) {
-        const std::vector<rpt_bvh_node> pool = flipped_nodes(nodes, nn, c->shadow_order.flip);
         bool built = false;
         if (s.lds_scene) {
+            const std::vector<rpt_bvh_node> pool = flipped_nodes(nodes, nn, c->shadow_order.flip);
             std::vector<float4> image;
             uint32_t pairs = 0, root = 0;
             if (build_lds_image(pool.data(), nn, geom, nt, image, pairs, root) && image.size() == (size_t)s.lds_vecs && pairs == s.lds_pairs && root == s.lds_root) {
@@ -726,18 +784,23 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
             }
         }
         if (s.gpairs) {
-            std::vector<float4> pairs;
-            std::vector<uint32_t> links;
-            build_pairs(pool.data(), pairs, links);
-            HIP_TRY(c, c->gpairs_shadow.alloc(std::max<size_t>(1, pairs.size())));
-            HIP_TRY(c, c->glinks_shadow.alloc(nn));
-            HIP_TRY(c, hipMemcpy(c->gpairs_shadow.p, pairs.data(), pairs.size() * sizeof(float4), hipMemcpyHostToDevice));
-            HIP_TRY(c, hipMemcpy(c->glinks_shadow.p, links.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice));
+            DevBuf<uint8_t> d_flip;
+            HIP_TRY(c, d_flip.alloc(std::max<size_t>(1, c->shadow_order.flip.size())));
+            hipError_t e_f = hipMemcpy(d_flip.p, c->shadow_order.flip.data(), c->shadow_order.flip.size(), hipMemcpyHostToDevice);
+            if (e_f == hipSuccess) e_f = c->gpairs_shadow.alloc(std::max<size_t>(1, 4 * (size_t)n_pairs));
+            if (e_f == hipSuccess) e_f = c->glinks_shadow.alloc(nn);
+            if (e_f == hipSuccess) {
+                k_build_pairs<<<(n_pairs + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK>>>(c->nodes.p, d_flip.p, n_pairs, c->gpairs_shadow.p, c->glinks_shadow.p);
+                e_f = hipDeviceSynchronize();                  /* (d_flip goes out of scope) */
+            }
+            d_flip.release();
+            HIP_TRY(c, e_f);
             s.gpairs_shadow = c->gpairs_shadow.p; s.glinks_shadow = c->glinks_shadow.p;
             built = true;
         }
         s.shadow_fixed = built ? 1u : 0u;
     }
+    sections.mark("shadow_order");
     if (!s.lds_image_shadow) c->lds_image_shadow.release();
     if (!s.gpairs_shadow) { c->gpairs_shadow.release(); c->glinks_shadow.release(); }
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
@@ -748,6 +811,9 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     if (const char *env = getenv("RPT_NO_FASTDIV"); env && env[0] == '1') s.fastdiv_ok = 0u;
     s.atlas = DevImage{c->atlas.p, aw, ah};
     s.skybox = DevImage{c->skybox.p, sw, sh};
+    sections.mark("fastdiv_check");
+    HIP_TRY(c, hipStreamSynchronize(nullptr));                 /* the derive / pair kernels ran on the null stream; the context renders on its own */
+    HIP_TRY(c, hipGetLastError());
     c->bvh_depth = depth;
     c->stack_cap = depth <= 15 ? 16 : (depth <= 23 ? 24 : 32);
     c->has_scene = true;
@@ -1394,6 +1460,7 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         g_create_error = "rpt_bvh_build_gpu: null or empty argument";
         return RPT_EINVAL;
     }
+    SectionTimer sections("rpt_bvh_build_gpu");
     if (sah_samples < 2) sah_samples = 2;
     if (sah_samples > BVB_MAX_BINS) { g_create_error = "rpt_bvh_build_gpu: at most 128 SAH bins"; return RPT_EINVAL; }
     if (n_triangles >= (1u << 28)) { g_create_error = "rpt_bvh_build_gpu: too many triangles"; return RPT_EINVAL; }
@@ -1428,7 +1495,9 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     DevBuf<uint32_t> d_order, d_order_tmp, d_tmp_a, d_tmp_b, d_count;
     DevBuf<BvbNode> d_nodes;
     DevBuf<BvbTeamScratch> d_scratch;
-    DevBuf<uint32_t> d_team_nodes;
+    DevBuf<uint32_t> d_team_nodes, d_inner, d_rank, d_oidx;
+    DevBuf<rpt_bvh_node> d_out;
+    std::vector<std::pair<uint32_t, uint32_t>> levels;          /* build-order id ranges, root level first */
     const char *no_teams = getenv("RPT_BVH_NO_TEAMS");
     const bool use_teams = !(no_teams && no_teams[0] == '1');
     uint32_t team_min = BVB_TEAM_MIN_COUNT;           /* RPT_BVH_TEAM_MIN: test aid, lets small nodes take the team path */
@@ -1436,6 +1505,7 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     std::vector<BvbNode> bn;
     std::vector<uint32_t> order;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    sections.mark("validate");
     const uint32_t nt = (uint32_t)n_triangles;
     {
         BVB_TRY(hipSetDevice(device_id));
@@ -1459,6 +1529,7 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BVB_TRY(hipMemcpy(d_count.p, &one, 4, hipMemcpyHostToDevice));
         BVB_TRY(hipEventCreate(&ev0));
         BVB_TRY(hipEventCreate(&ev1));
+        sections.mark("alloc_h2d");
         BvbArgs a{d_verts.p, d_tris.p, d_centroid.p, d_order.p, d_order_tmp.p, d_tmp_a.p, d_tmp_b.p, d_nodes.p, d_count.p, nt, sah_samples};
         BVB_TRY(hipEventRecord(ev0, nullptr));
         k_bvb_init<<<(nt + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(a);
@@ -1499,6 +1570,7 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
             else k_bvb_level<BVB_THREADS><<<end - begin, BVB_THREADS>>>(a, begin);
             uint32_t total = 0;
             BVB_TRY(hipMemcpy(&total, d_count.p, 4, hipMemcpyDeviceToHost));
+            levels.push_back({begin, end});
             begin = end;
             end = total;
         }
@@ -1507,47 +1579,43 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         float ms = 0.0f;
         BVB_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         if (device_ms_out) *device_ms_out = ms;
-        bn.resize(end);
-        order.resize(nt);
-        BVB_TRY(hipMemcpy(bn.data(), d_nodes.p, (size_t)end * sizeof(BvbNode), hipMemcpyDeviceToHost));
-        BVB_TRY(hipMemcpy(order.data(), d_order.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
-    }
-    {
-        /* renumber to the order in which the reference splits nodes: children get the next two indices when their
-         * parent is popped from its stack, left subtree first (bvh.rs:296-320) */
-        size_t node_count = 1;
-        std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 0u}};       /* (build-order id, output index) */
-        while (!stack.empty()) {
-            auto [b, o] = stack.back();
-            stack.pop_back();
-            const BvbNode &n = bn[b];
-            rpt_bvh_node &out = nodes_out[o];
-            for (int k = 0; k < 3; ++k) { out.aabb_min[k] = n.mn[k]; out.aabb_max[k] = n.mx[k]; }
-            if (n.left == BVB_NONE) {
-                out.triangle_count = n.count;
-                out.left_or_first = n.first;
-            } else {
-                out.triangle_count = 0;
-                out.left_or_first = (uint32_t)node_count;
-                stack.push_back({n.left + 1u, (uint32_t)node_count + 1u});
-                stack.push_back({n.left, (uint32_t)node_count});
-                node_count += 2;
-            }
+        sections.mark("device_build");
+        /* renumber to the order in which the reference splits nodes (bvh.rs:296-320), on the device: k_bvh_build.h, k_bvb_inner_count / k_bvb_place */
+        BVB_TRY(d_inner.alloc(end)); BVB_TRY(d_rank.alloc(end)); BVB_TRY(d_oidx.alloc(end)); BVB_TRY(d_out.alloc(end));
+        BVB_TRY(hipMemset(d_rank.p, 0, 4));
+        BVB_TRY(hipMemset(d_oidx.p, 0, 4));
+        for (size_t l = levels.size(); l-- > 0;) {
+            const uint32_t lb = levels[l].first, le = levels[l].second;
+            k_bvb_inner_count<<<(le - lb + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(d_nodes.p, d_inner.p, lb, le);
         }
-        *n_nodes_out = node_count;
+        for (size_t l = 0; l < levels.size(); ++l) {
+            const uint32_t lb = levels[l].first, le = levels[l].second;
+            k_bvb_place<<<(le - lb + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(d_nodes.p, d_inner.p, d_rank.p, d_oidx.p, d_out.p, lb, le);
+        }
+        sections.mark("renumber_device");
+        order.resize(nt);
+        BVB_TRY(hipMemcpy(nodes_out, d_out.p, (size_t)end * sizeof(rpt_bvh_node), hipMemcpyDeviceToHost));
+        BVB_TRY(hipMemcpy(order.data(), d_order.p, (size_t)nt * 4, hipMemcpyDeviceToHost));
+        *n_nodes_out = end;
+    }
+    sections.mark("d2h");
+    {
         std::vector<rpt_triangle> src(triangles, triangles + nt);
         for (uint32_t i = 0; i < nt; ++i) triangles[i] = src[order[i]];
+        sections.mark("reorder_triangles");
     }
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
     d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_nodes.release();
+    d_inner.release(); d_rank.release(); d_oidx.release(); d_out.release();
     return RPT_OK;
 fail:
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
     d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_nodes.release();
+    d_inner.release(); d_rank.release(); d_oidx.release(); d_out.release();
     return RPT_EHIP;
 #undef BVB_TRY
 }

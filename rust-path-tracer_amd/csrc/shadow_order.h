@@ -131,7 +131,7 @@ inline uint32_t walk(const rpt_bvh_node *nodes, const rpt_per_vertex_data *pv, c
  * every inner node are the nodes (2p + 1, 2p + 2) of one pair — what the flipped copies can express; otherwise near-first stays. */
 inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
                                        const rpt_material_data *mats, const rpt_light_pick_entry *lp, size_t nlp, bool pair_shaped,
-                                       const float *edges12 = nullptr /* optional: per triangle 12 floats (a | -, b - a | -, c - a | -), as the upload derives them */) {
+                                       const float *cross_sq = nullptr /* optional: |(b - a) x (c - a)|^2 per triangle, as the upload's derive kernel hands it out */) {
     using namespace shadow_order_detail;
     ShadowOrder so;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -141,15 +141,13 @@ inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_
     /* triangle surface below every node, children before parents (explicit post-order: the pool's index order is the builder's business) */
     std::vector<double> area(nn, 0.0), tri_area(nt, 0.0);
     for (size_t t = 0; t < nt; ++t) {
-        V x;
-        if (edges12) {                         /* (three gathers of 64-byte vertices per triangle are most of this function on a 1 M-triangle scene) */
-            const float *e = edges12 + 12 * t;
-            x = cross(V{e[4], e[5], e[6]}, V{e[8], e[9], e[10]});
+        if (cross_sq) {                        /* (three gathers of 64-byte vertices per triangle are most of this function on a 1 M-triangle scene) */
+            tri_area[t] = 0.5 * std::sqrt((double)cross_sq[t]);
         } else {
             V a = vtx(pv[idx[t].v0]);
-            x = cross(sub(vtx(pv[idx[t].v1]), a), sub(vtx(pv[idx[t].v2]), a));
+            V x = cross(sub(vtx(pv[idx[t].v1]), a), sub(vtx(pv[idx[t].v2]), a));
+            tri_area[t] = 0.5 * std::sqrt((double)dot(x, x));
         }
-        tri_area[t] = 0.5 * std::sqrt((double)dot(x, x));
     }
     {
         std::vector<uint32_t> order;
