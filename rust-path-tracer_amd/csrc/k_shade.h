@@ -150,385 +150,336 @@ __device__ __forceinline__ Mat load_material(const DevScene &sc, uint32_t index)
 
 /* NEE = NextEventEstimation mode (0 none, 1 MIS, 2 direct only), TEXTURED = the
  * scene has at least one texture flag.  Specialising removes the dead halves of
- * the stage (and their registers) for the common untextured / no-NEE case.
- *
- * The stage is two halves with a narrow waist.  shade_pre does everything of lib.rs:64-146 that does not depend on the sampled LOBE: the miss, the
- * emitter rules, interpolation, normal map, get_pbr_bsdf, the three random numbers of PBR::sample and the lobe choice (bsdf.rs:273-282).  What the other
- * half needs is a SurfaceWork of 23 words.  shade_post is the lobe's own work: the sampled direction, pdf and spectrum (bsdf.rs:283-334), the NEE set-up
- * (diffuse lobe only, lib.rs:149-165), throughput, respawn, roulette and the slot's new state (lib.rs:168-181).  One slot per thread calls them back to
- * back (shade_slot); the packed variant regroups the works of a chunk by lobe in between, so that its waves run ONE lobe's code. */
-struct SurfaceWork {
-    uint32_t slot, flags, rng_key;      /* flags: bounce | last lobe | LDS dimension BEFORE this bounce's draws; rng_key = n + offset of the sample */
-    F3 hit, rd, normal, albedo, throughput;
-    float roughness, metallic, w_spec, r1, r2;
-};
-#define SHADE_WORK_WORDS 23
-enum { SHADE_NONE = 0, SHADE_DIFFUSE = 1, SHADE_SPECULAR = 2 };
-
-/* Returns SHADE_NONE when the slot needs nothing more (inactive, a miss — queued for k_sky through to_sky —, or a path that ended on an emitter), else the
- * sampled lobe with `w` filled in. */
-template <int NEE, bool TEXTURED>
-__device__ __forceinline__ int shade_pre(const DevScene &sc, const DevState &st, const DevQueues &q, const DevConfig &cfg, DevStats *stats,
-                                         uint32_t slot, float2 hw, bool active, bool &to_sky,
-                                         bool first /* iteration 0 of the call: every path is a first path (k_path.h) */, uint32_t n_samples, SurfaceWork &w) {
-    const uint32_t hit_tri = __float_as_uint(hw.y);
-    if (!active) return SHADE_NONE;
-    if (hit_tri == HIT_MISS) {
-        to_sky = true;                           /* lib.rs:66-79: shaded by k_sky, which also ends the path */
-        st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
-        if (first) {                             /* k_sky reads the path state */
-            st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RPT_FRESH_FLAGS));
-            st.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(first_path_todo(st, slot, n_samples)));
-        }
-        return SHADE_NONE;
-    }
-    const float4 ra = st.ray_a[slot];
-    const float2 rb = st.ray_b[slot];
-    const F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
-    const float hit_t = hw.x;
-    const float4 tf = first ? make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RPT_FRESH_FLAGS)) : st.thr[slot];
-    const F3 throughput = f3(tf.x, tf.y, tf.z);
-    const uint32_t flags = __float_as_uint(tf.w);
-    const uint32_t bounce = FLAG_BOUNCE(flags);
-    const bool last_spec = FLAG_LOBE_SPEC(flags) != 0u;
-    constexpr bool nee = NEE != RPT_NEE_NONE;
-    const bool backface = (hit_tri >> 31) != 0u;
-    const uint32_t tri_index = hit_tri & 0x7fffffffu;
-    /* per-triangle shading record: normals, uvs, material in 64 contiguous bytes */
-    const float4 *ts = sc.tri_shade + 4u * tri_index;
-    const float4 s0 = ts[0], s1 = ts[1], s2 = ts[2];
-    const Mat mat = load_material<TEXTURED>(sc, __float_as_uint(s2.w));
-    const F3 hit = ro + rd * hit_t;
-
-    const F3 emissive = xyz4(mat.emissive);
-    if (emissive.x != 0.0f || emissive.y != 0.0f || emissive.z != 0.0f) {       /* lib.rs:86 */
-        /* radiance + samples still owed: read only by a lane whose path adds emission or ends here (never written back by
-         * this stage mid-path: the NEE terms are added by the shadow stage, everything else ends the path) */
-        bool ended = false;
-        F3 contribution = f3s(0.0f);
-        if (backface) {
-            ended = true;                                                        /* :88-90 */
-        } else if (!nee || bounce == 0u || last_spec) {                          /* :97-100 */
-            contribution = throughput * emissive;
-            ended = true;
-        } else if (NEE == RPT_NEE_MIS) {                                         /* :104-108, last lobe is diffuse here */
-            /* last_light_sample / last_bsdf_sample (lib.rs:59-60): the light sample is carried as the table entry it
-             * came from (its area, pick pdf, normal and emission are functions of the entry) + the throughput before
-             * that bounce; the BSDF sample as pdf + spectrum — 32 bytes per slot instead of 64 */
-            const float4 ma = st.mis_a[slot], mb = st.mis_b[slot];
-            const uint32_t code = __float_as_uint(ma.x);
-            if (code != 0xffffffffu) {                                           /* (0xffffffff: no light table, DirectLightSample::default()) */
-                const rpt_light_pick_entry e = sc.light_pick[code >> 1];
-                const bool side_b = (code & 1u) != 0u;
-                const uint32_t light_tri = side_b ? e.triangle_index_b : e.triangle_index_a;
-                if (tri_index == light_tri) {                                    /* light_pick.rs:185 */
-                    const float4 *lr = sc.light_rec + 8u * (code >> 1) + (side_b ? 4u : 0u);
-                    const float light_area = side_b ? e.triangle_area_b : e.triangle_area_a;
-                    const float light_pick_pdf = side_b ? e.triangle_pick_pdf_b : e.triangle_pick_pdf_a;
-                    F3 light_normal = f3(lr[0].w, lr[1].w, lr[2].w);
-                    float cos_theta = dot3(light_normal, -rd);                  /* last sampled_direction == rd */
-                    float light_pdf = cos_theta <= 0.0f ? 0.0f : rptm::powi2(hit_t) / (light_area * cos_theta);
-                    if (light_pdf > 0.0f) {
-                        float bsdf_pdf = mb.x;
-                        float p1 = bsdf_pdf * bsdf_pdf;
-                        float weight = p1 / (p1 + light_pdf * light_pdf);
-                        F3 spectrum = f3(mb.y, mb.z, mb.w), emission = xyz4(lr[3]);
-                        F3 direct = (spectrum * emission * weight / bsdf_pdf) / light_pick_pdf;
-                        contribution = f3(ma.y, ma.z, ma.w) * direct;
-                    }
-                }
-            }
-            ended = true;
-        }
-        /* nee == direct-only, diffuse bounce > 0: fall through, shade the light as a surface */
-        if (ended) {
-            /* the path ends here with nothing pending: one slot per pixel — accumulated and restarted on the spot; several —
-             * parked as HIT_DONE for k_complete */
-            F3 radiance = f3s(0.0f);
-            uint32_t todo;
-            if (first) {
-                todo = first_path_todo(st, slot, n_samples);                     /* radiance 0 */
-            } else {
-                const float4 r4 = st.rad[slot];
-                radiance = f3(r4.x, r4.y, r4.z);
-                todo = __float_as_uint(r4.w);
-            }
-            if (!backface) radiance = radiance + mask_nan3(contribution);
-            finish_in_side_stage(st, cfg, slot, radiance, todo);
-            return SHADE_NONE;
-        }
-    }
-
-    /* ---- interpolate vertex data (lib.rs:112-129); d00/d01/d11 are triangle constants ---- */
-    const float4 *tg = sc.tri_geom + 3u * tri_index;
-    const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
-    F3 bary;
-    {
-        F3 v0 = xyz4(g1), v1 = xyz4(g2), v2 = hit - xyz4(g0);
-        float d00 = g0.w, d01 = g1.w, d11 = g2.w;
-        float d20 = dot3(v2, v0), d21 = dot3(v2, v1);
-        float denom = d00 * d11 - d01 * d01;
-        float v = (d11 * d20 - d01 * d21) / denom;
-        float ww = (d00 * d21 - d01 * d20) / denom;
-        bary = f3(1.0f - v - ww, v, ww);
-    }
-    F3 normal = bary.x * xyz4(s0) + bary.y * xyz4(s1) + bary.z * xyz4(s2);
-    float uv_x = 0.0f, uv_y = 0.0f;
-    if (TEXTURED) {
-        const float4 s3 = ts[3];     /* (uvb.x, uvb.y, uvc.x, uvc.y); uva in s0.w, s1.w */
-        uv_x = (bary.x * s0.w + bary.y * s3.x) + bary.z * s3.z;
-        uv_y = (bary.x * s1.w + bary.y * s3.y) + bary.z * s3.w;
-        float cx = rptm::fminr(rptm::fmaxr(uv_x, 0.0f), 1.0f), cy = rptm::fminr(rptm::fmaxr(uv_y, 0.0f), 1.0f);
-        if (cx != uv_x || cy != uv_y) {
-            uv_x = uv_x - rptm::floorr(uv_x);
-            uv_y = uv_y - rptm::floorr(uv_y);
-        }
-        if (mat.has.w != 0u) {                                               /* lib.rs:132-141 */
-            float su = mat.normals.x + uv_x * mat.normals.z, sv = mat.normals.y + uv_y * mat.normals.w;
-            float4 s = sample_by_lod<true>(sc.atlas, su, sv);
-            F3 nm = f3(s.x * 2.0f - 1.0f, s.y * 2.0f - 1.0f, s.z * 2.0f - 1.0f);
-            const uint4 tri = sc.indices[tri_index];
-            F3 tangent = bary.x * xyz4(sc.per_vertex[4u * tri.x + 2u]) + bary.y * xyz4(sc.per_vertex[4u * tri.y + 2u]) +
-                         bary.z * xyz4(sc.per_vertex[4u * tri.z + 2u]);
-            F3 bitangent = cross3(tangent, normal);
-            F3 r = tangent * nm.x;
-            r = r + (bitangent * nm.y);
-            r = r + (normal * nm.z);
-            normal = norm3(r);
-        }
-    }
-
-    /* ---- get_pbr_bsdf (bsdf.rs:354-387) ---- */
-    Pbr bsdf;
-    bsdf.albedo = xyz4(mat.albedo);
-    float roughness = mat.roughness.x, metallic = mat.metallic.x;
-    if (TEXTURED) {
-        if (mat.has.x != 0u) {
-            float4 s = sample_by_lod<true>(sc.atlas, mat.albedo.x + uv_x * mat.albedo.z, mat.albedo.y + uv_y * mat.albedo.w);
-            bsdf.albedo = f3(s.x, s.y, s.z);
-        }
-        if (mat.has.z != 0u)
-            roughness = sample_by_lod<true>(sc.atlas, mat.roughness.x + uv_x * mat.roughness.z, mat.roughness.y + uv_y * mat.roughness.w).x;
-        if (mat.has.y != 0u)
-            metallic = sample_by_lod<true>(sc.atlas, mat.metallic.x + uv_x * mat.metallic.z, mat.metallic.y + uv_y * mat.metallic.w).x;
-    }
-    bsdf.roughness = rptm::fmaxr(roughness, RPT_EPS);
-    bsdf.metallic = rptm::fminr(metallic, 1.0f - RPT_EPS);
-    bsdf.clamp_lo = cfg.c.specular_weight_clamp[0];
-    bsdf.clamp_hi = cfg.c.specular_weight_clamp[1];
-
-    /* ---- the draws and the lobe choice of PBR::sample (bsdf.rs:273-282) ---- */
-    const uint2 rs = st.rng[slot_pix(st, slot)];
-    Rng rng{rs.x + slot_k(st, slot) + rs.y, FLAG_DIM(flags)};
-    const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
-    const float w_spec = bsdf.specular_weight(-rd, normal);
-    w.slot = slot; w.flags = flags; w.rng_key = rng.key;
-    w.hit = hit; w.rd = rd; w.normal = normal; w.albedo = bsdf.albedo; w.throughput = throughput;
-    w.roughness = bsdf.roughness; w.metallic = bsdf.metallic; w.w_spec = w_spec; w.r1 = r1; w.r2 = r2;
-    return !(r3 >= w_spec) ? SHADE_SPECULAR : SHADE_DIFFUSE;
-}
-
-/* The sampled lobe's half (see SurfaceWork).  `kind` is SHADE_DIFFUSE or SHADE_SPECULAR; in a wave of one kind the other lobe's code and — specular — the
- * NEE set-up are skipped by wave-uniform branches. */
-template <int NEE, bool TEXTURED>
-__device__ __forceinline__ void shade_post(const DevScene &sc, const DevState &st, const DevQueues &q, const DevConfig &cfg, DevStats *stats,
-                                           const SurfaceWork &w, int kind, bool &emit_shadow, float4 &sh_o, float4 &sh_d, float4 &sh_c, bool first,
-                                           uint32_t n_samples, bool &elided /* an NEE evaluation whose shadow ray decides nothing: not queued */) {
-    if (kind == SHADE_NONE) return;
-    constexpr bool nee = NEE != RPT_NEE_NONE;
-    const uint32_t slot = w.slot, flags = w.flags;
-    const uint32_t bounce = FLAG_BOUNCE(flags);
-    const F3 hit = w.hit, rd = w.rd, normal = w.normal;
-    F3 throughput = w.throughput;
-    Pbr bsdf;
-    bsdf.albedo = w.albedo; bsdf.roughness = w.roughness; bsdf.metallic = w.metallic;
-    bsdf.clamp_lo = cfg.c.specular_weight_clamp[0];
-    bsdf.clamp_hi = cfg.c.specular_weight_clamp[1];
-    Rng rng{w.rng_key, FLAG_DIM(flags) + 3u};
-    const float r1 = w.r1, r2 = w.r2, w_spec = w.w_spec;
-    const bool spec = kind == SHADE_SPECULAR;
-    const F3 view = -rd;
-
-    /* ---- PBR::sample after the lobe choice (bsdf.rs:283-334) ---- */
-    F3 sdir;
-    /* Both lobes turn one random number into an azimuth and take its sine and cosine (util.rs:27-28, 70), and
-     * both normalise their final direction (util.rs:31, 84): in a wave that holds both kinds of lanes the divergent
-     * branches would each issue those ~130 instructions.  They are issued once, on the lane's own operand. */
-    float sin_p, cos_p;
-    rptm::sincosr(2.0f * RPT_PI_F * (spec ? r1 : r2), sin_p, cos_p);
-    if (!spec) {
-        /* create_cartesian(normal) (util.rs:34-40) */
-        F3 temp_vec = norm3(cross3(normal, f3(0.1f, 0.5f, 0.9f)));
-        F3 nt = norm3(cross3(temp_vec, normal));       /* right   */
-        F3 nb = norm3(cross3(normal, nt));             /* forward */
-        /* cosine_sample_hemisphere (util.rs:24-32) */
-        float theta = rptm::acosr(rptm::sqrtr(r1));
-        float sin_t, cos_t;
-        rptm::sincosr(theta, sin_t, cos_t);
-        F3 s = f3(sin_t * cos_p, cos_t, sin_t * sin_p);
-        sdir = f3(s.x * nb.x + s.y * normal.x + s.z * nt.x,
-                  s.x * nb.y + s.y * normal.y + s.z * nt.y,
-                  s.x * nb.z + s.y * normal.z + s.z * nt.z);
-    } else {
-        /* reflect(-view, n) then sample_ggx (util.rs:42-44, 67-85) */
-        F3 inc = -view;
-        F3 refl = inc - normal * 2.0f * dot3(inc, normal);
-        float a = bsdf.roughness * bsdf.roughness;
-        float cos_theta = rptm::sqrtr((1.0f - r2) / (r2 * (a * a - 1.0f) + 1.0f));
-        float sin_theta = rptm::sqrtr(1.0f - cos_theta * cos_theta);
-        F3 h = f3(cos_p * sin_theta, sin_p * sin_theta, cos_theta);
-        F3 up = rptm::absr(refl.z) < 0.999f ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
-        F3 tangent = norm3(cross3(up, refl));
-        F3 bitangent = cross3(refl, tangent);
-        sdir = tangent * h.x + bitangent * h.y + refl * h.z;
-    }
-    sdir = norm3(sdir);
-    const float cos_theta = rptm::fmaxr(dot3(normal, sdir), RPT_EPS);
-    const F3 halfway = norm3(view + sdir);
-    const F3 ks = bsdf.ks_of(view, halfway);
-    float pdf;
-    F3 spectrum;
-    if (!spec) {
-        pdf = cos_theta / RPT_PI_F;
-        spectrum = bsdf.diffuse_term(cos_theta, w_spec, ks);
-    } else {
-        float d_term = ggx_d(normal, halfway, bsdf.roughness);
-        pdf = (d_term * dot3(normal, halfway)) / (4.0f * dot3(view, halfway));
-        spectrum = bsdf.specular_term(view, normal, sdir, cos_theta, d_term, w_spec, ks);
-    }
-
-    /* ---- next-event estimation set-up (light_pick.rs:100-173) ---- */
-    if (nee && !spec) {
-        if (sc.no_lights) {
-            /* sentinel: DirectLightSample::default() — zero contribution, zeroed carry */
-            if (NEE == RPT_NEE_MIS) st.mis_a[slot] = make_float4(__uint_as_float(0xffffffffu), 0, 0, 0);
-        } else {
-            const float l1 = rng.next(), l2 = rng.next();
-            uint32_t idx = rptm::f2u32_sat(l1 * (float)sc.n_light_pick);
-            if (idx >= sc.n_light_pick) {                       /* gen_r1() == 1.0: the reference panics (Appendix C) */
-                idx = sc.n_light_pick - 1u;
-                atomicAdd(&stats->light_index_clamped, 1ull);
-            }
-            const rpt_light_pick_entry e = sc.light_pick[idx];
-            const bool pick_a = l2 < e.ratio;
-            const float light_area = pick_a ? e.triangle_area_a : e.triangle_area_b;
-            const float light_pick_pdf = pick_a ? e.triangle_pick_pdf_a : e.triangle_pick_pdf_b;
-            /* the light triangle's corners, mean normal and emission: one 64-byte record built at upload
-             * (was: index buffer -> three 64-byte vertices + the material, four dependent scattered loads) */
-            const float4 *lr = sc.light_rec + 8u * idx + (pick_a ? 0u : 4u);
-            const float4 lra = lr[0], lrb = lr[1], lrc = lr[2], lre = lr[3];
-            const F3 light_normal = f3(lra.w, lrb.w, lrc.w);
-            const F3 light_emission = xyz4(lre);
-            const float p1 = rng.next(), p2 = rng.next();
-            const float r1_sqrt = rptm::sqrtr(p1);
-            const F3 light_point = (1.0f - r1_sqrt) * xyz4(lra) + (r1_sqrt * (1.0f - p2)) * xyz4(lrb) +
-                                   (r1_sqrt * p2) * xyz4(lrc);
-            const F3 unorm = light_point - hit;
-            const float light_distance = len3(unorm);
-            const F3 light_direction = unorm / light_distance;
-
-            /* everything after the visibility test, assuming it passes */
-            F3 direct = f3s(0.0f);
-            {
-                float cos_l = dot3(light_normal, -light_direction);
-                float light_pdf = cos_l <= 0.0f ? 0.0f : rptm::powi2(light_distance) / (light_area * cos_l);
-                if (light_pdf > 0.0f) {
-                    /* PBR::evaluate(view, n, L, Diffuse) and PBR::pdf(.., Diffuse) */
-                    float w_e = bsdf.specular_weight(view, normal);
-                    float cos_e = rptm::fmaxr(dot3(normal, light_direction), 0.0f);
-                    F3 h_e = norm3(view + light_direction);
-                    F3 ks_e = bsdf.ks_of(view, h_e);
-                    F3 attenuation = bsdf.diffuse_term(cos_e, w_e, ks_e);
-                    float bsdf_pdf = cos_e / RPT_PI_F;
-                    if (bsdf_pdf > 0.0f) {
-                        float weight = 1.0f;
-                        if (NEE == RPT_NEE_MIS) {
-                            float q1 = light_pdf * light_pdf;
-                            weight = q1 / (q1 + bsdf_pdf * bsdf_pdf);
-                        }
-                        direct = (attenuation * light_emission * weight / light_pdf) / light_pick_pdf;
-                    }
-                }
-            }
-            const F3 contribution = throughput * direct;
-            /* The reference traces the shadow ray first and looks at light_pdf / bsdf_pdf afterwards (light_pick.rs:141-158).  Where the term
-             * an UNOCCLUDED ray adds is zero — the light point faces away (light_pdf = 0), lies below this surface's horizon (bsdf_pdf = 0), or
-             * the product is masked as non-finite — `radiance += mask_nan(term)` (lib.rs:164) leaves every bit of radiance as it was whatever the
-             * walk finds (radiance starts at +0.0 and x + y is -0.0 only for two negative zeros: it is never -0.0, so x + (+-0.0) == x), and
-             * nothing else reads `.hit`: the ray is not queued.  48 % of DarkCornell's shadow rays, 57 % of VeachMIS's (tools/dead_shadow_rays.py);
-             * counted in rpt_stats.shadow_rays_elided, and rpt_stats.shadow_rays keeps counting what the reference executes. */
-            const F3 term = mask_nan3(contribution);
-            const bool decides = term.x != 0.0f || term.y != 0.0f || term.z != 0.0f;
-            elided = !decides;
-            const F3 so = hit + light_direction * RPT_EPS;
-            emit_shadow = decides;
-            sh_o = make_float4(so.x, so.y, so.z, light_distance - RPT_EPS * 2.0f);
-            sh_d = make_float4(light_direction.x, light_direction.y, light_direction.z, 0.0f);
-            sh_c = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
-            if (NEE == RPT_NEE_MIS)
-                st.mis_a[slot] = make_float4(__uint_as_float(2u * idx + (pick_a ? 0u : 1u)), throughput.x, throughput.y, throughput.z);
-        }
-    }
-    if (NEE == RPT_NEE_MIS) st.mis_b[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
-
-    /* ---- attenuate, respawn, roulette (lib.rs:168-181) ---- */
-    bool done = false;
-    throughput = throughput * (spectrum / pdf);
-    const F3 new_d = sdir;
-    const F3 new_o = hit + sdir * RPT_EPS;
-    if (bounce > cfg.c.min_bounces) {
-        float prob = rptm::fmaxr(throughput.x, rptm::fmaxr(throughput.y, throughput.z));
-        if (rng.next() > prob) {
-            done = true;
-        } else {
-            throughput = throughput * (1.0f / prob);
-        }
-    }
-    const uint32_t next_bounce = bounce + 1u;
-    if (next_bounce >= cfg.c.max_bounces) done = true;
-    const uint32_t new_flags = MAKE_FLAGS(next_bounce, spec ? 1u : 0u, rng.dim);
-
-    /* radiance + samples still owed: read only where the path ends here or begins its radiance record */
-    if (done && !emit_shadow) {
-        /* the path ends here with nothing pending: one slot per pixel — accumulated and restarted on the spot; several —
-         * parked as HIT_DONE for k_complete */
-        F3 radiance = f3s(0.0f);
-        uint32_t todo;
-        if (first) {
-            todo = first_path_todo(st, slot, n_samples);
-        } else {
-            const float4 r4 = st.rad[slot];
-            radiance = f3(r4.x, r4.y, r4.z);
-            todo = __float_as_uint(r4.w);
-        }
-        finish_in_side_stage(st, cfg, slot, radiance, todo);
-    } else {
-        if (first)                               /* the path goes on (or waits for its shadow ray): its radiance record begins here */
-            st.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(first_path_todo(st, slot, n_samples)));
-        if (!done) {
-            st.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(new_flags));
-            st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
-            st.ray_b[slot] = make_float2(new_d.y, new_d.z);
-            st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PENDING));
-            sh_d.w = __uint_as_float(slot);
-        } else {
-            /* the shadow stage adds the NEE term and then finishes the path */
-            st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
-            sh_d.w = __uint_as_float(slot | 0x80000000u);
-        }
-    }
-}
-
+ * the stage (and their registers) for the common untextured / no-NEE case. */
 /* What the stage does for ONE traversed slot (hit word `hw`): everything of lib.rs:64-181 after the intersection.  Outputs:
  * to_sky (a miss: queued for k_sky), emit_shadow + the shadow-queue entry; a path that ends here with nothing pending is
  * finished through finish_in_side_stage (k_path.h). */
-template <int NEE, bool TEXTURED>
+template <int NEE, bool TEXTURED, bool COMPACT>
 __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &st, const DevQueues &q, const DevConfig &cfg, DevStats *stats,
                                            uint32_t slot, float2 hw, bool active, bool &to_sky, bool &emit_shadow, float4 &sh_o, float4 &sh_d,
-                                           float4 &sh_c, bool first, uint32_t n_samples, bool &elided) {
-    SurfaceWork w;
-    const int kind = shade_pre<NEE, TEXTURED>(sc, st, q, cfg, stats, slot, hw, active, to_sky, first, n_samples, w);
-    shade_post<NEE, TEXTURED>(sc, st, q, cfg, stats, w, kind, emit_shadow, sh_o, sh_d, sh_c, first, n_samples, elided);
+                                           float4 &sh_c, bool first /* iteration 0 of the call: every path is a first path (k_path.h) */,
+                                           uint32_t n_samples, bool &elided /* an NEE evaluation whose shadow ray decides nothing: not queued */) {
+    const uint32_t hit_tri = __float_as_uint(hw.y);
+    if (active) {
+        const float4 ra = st.ray_a[slot];
+        const float2 rb = st.ray_b[slot];
+        const F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
+        const float hit_t = hw.x;
+        if (hit_tri == HIT_MISS) {
+            to_sky = true;                           /* lib.rs:66-79: shaded by k_sky, which also ends the path */
+            st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+            if (first) {                             /* k_sky reads the path state */
+                st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RPT_FRESH_FLAGS));
+                st.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(first_path_todo(st, slot, n_samples)));
+            }
+        } else {
+            const float4 tf = first ? make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(RPT_FRESH_FLAGS)) : st.thr[slot];
+            F3 throughput = f3(tf.x, tf.y, tf.z);
+            /* radiance + samples still owed: read only by a lane whose path adds emission or ends here (never written back by
+             * this stage mid-path: the NEE terms are added by the shadow stage, everything else ends the path) */
+            F3 radiance = f3s(0.0f);
+            uint32_t todo = 0u;
+            bool rad_loaded = false;
+            auto load_rad = [&]() {
+                if (!rad_loaded) {
+                    if (first) {
+                        todo = first_path_todo(st, slot, n_samples);     /* radiance 0 */
+                    } else {
+                        const float4 r4 = st.rad[slot];
+                        radiance = f3(r4.x, r4.y, r4.z);
+                        todo = __float_as_uint(r4.w);
+                    }
+                    rad_loaded = true;
+                }
+            };
+            const uint32_t flags = __float_as_uint(tf.w);
+            const uint32_t bounce = FLAG_BOUNCE(flags);
+            const bool last_spec = FLAG_LOBE_SPEC(flags) != 0u;
+            constexpr bool nee = NEE != RPT_NEE_NONE;
+            const bool backface = (hit_tri >> 31) != 0u;
+            const uint32_t tri_index = hit_tri & 0x7fffffffu;
+            /* per-triangle shading record: normals, uvs, material in 64 contiguous bytes */
+            const float4 *ts = sc.tri_shade + 4u * tri_index;
+            const float4 s0 = ts[0], s1 = ts[1], s2 = ts[2];
+            const Mat mat = load_material<TEXTURED>(sc, __float_as_uint(s2.w));
+            const F3 hit = ro + rd * hit_t;
+
+            bool done = false;
+            const F3 emissive = xyz4(mat.emissive);
+            if (emissive.x != 0.0f || emissive.y != 0.0f || emissive.z != 0.0f) {       /* lib.rs:86 */
+                if (backface) {
+                    done = true;                                                         /* :88-90 */
+                } else if (!nee || bounce == 0u || last_spec) {                          /* :97-100 */
+                    load_rad();
+                    radiance = radiance + mask_nan3(throughput * emissive);
+                    done = true;
+                } else if (NEE == RPT_NEE_MIS) {                                         /* :104-108, last lobe is diffuse here */
+                    /* last_light_sample / last_bsdf_sample (lib.rs:59-60): the light sample is carried as the table entry it
+                     * came from (its area, pick pdf, normal and emission are functions of the entry) + the throughput before
+                     * that bounce; the BSDF sample as pdf + spectrum — 32 bytes per slot instead of 64 */
+                    const float4 ma = st.mis_a[slot], mb = st.mis_b[slot];
+                    const uint32_t code = __float_as_uint(ma.x);
+                    F3 contribution = f3s(0.0f);
+                    if (code != 0xffffffffu) {                                           /* (0xffffffff: no light table, DirectLightSample::default()) */
+                        const rpt_light_pick_entry e = sc.light_pick[code >> 1];
+                        const bool side_b = (code & 1u) != 0u;
+                        const uint32_t light_tri = side_b ? e.triangle_index_b : e.triangle_index_a;
+                        if (tri_index == light_tri) {                                    /* light_pick.rs:185 */
+                            const float4 *lr = sc.light_rec + 8u * (code >> 1) + (side_b ? 4u : 0u);
+                            const float light_area = side_b ? e.triangle_area_b : e.triangle_area_a;
+                            const float light_pick_pdf = side_b ? e.triangle_pick_pdf_b : e.triangle_pick_pdf_a;
+                            F3 light_normal = f3(lr[0].w, lr[1].w, lr[2].w);
+                            float cos_theta = dot3(light_normal, -rd);                  /* last sampled_direction == rd */
+                            float light_pdf = cos_theta <= 0.0f ? 0.0f : rptm::powi2(hit_t) / (light_area * cos_theta);
+                            if (light_pdf > 0.0f) {
+                                float bsdf_pdf = mb.x;
+                                float p1 = bsdf_pdf * bsdf_pdf;
+                                float weight = p1 / (p1 + light_pdf * light_pdf);
+                                F3 spectrum = f3(mb.y, mb.z, mb.w), emission = xyz4(lr[3]);
+                                F3 direct = (spectrum * emission * weight / bsdf_pdf) / light_pick_pdf;
+                                contribution = f3(ma.y, ma.z, ma.w) * direct;
+                            }
+                        }
+                    }
+                    load_rad();
+                    radiance = radiance + mask_nan3(contribution);
+                    done = true;
+                }
+                /* nee == direct-only, diffuse bounce > 0: fall through, shade the light as a surface */
+            }
+
+            uint32_t new_flags = flags;
+            F3 new_o = ro, new_d = rd;
+            if (!done) {
+                /* ---- interpolate vertex data (lib.rs:112-129); d00/d01/d11 are triangle constants ---- */
+                const float4 *tg = sc.tri_geom + 3u * tri_index;
+                const float4 g0 = tg[0], g1 = tg[1], g2 = tg[2];
+                F3 bary;
+                {
+                    F3 v0 = xyz4(g1), v1 = xyz4(g2), v2 = hit - xyz4(g0);
+                    float d00 = g0.w, d01 = g1.w, d11 = g2.w;
+                    float d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+                    float denom = d00 * d11 - d01 * d01;
+                    float v = (d11 * d20 - d01 * d21) / denom;
+                    float w = (d00 * d21 - d01 * d20) / denom;
+                    bary = f3(1.0f - v - w, v, w);
+                }
+                F3 normal = bary.x * xyz4(s0) + bary.y * xyz4(s1) + bary.z * xyz4(s2);
+                float uv_x = 0.0f, uv_y = 0.0f;
+                if (TEXTURED) {
+                    const float4 s3 = ts[3];     /* (uvb.x, uvb.y, uvc.x, uvc.y); uva in s0.w, s1.w */
+                    uv_x = (bary.x * s0.w + bary.y * s3.x) + bary.z * s3.z;
+                    uv_y = (bary.x * s1.w + bary.y * s3.y) + bary.z * s3.w;
+                    float cx = rptm::fminr(rptm::fmaxr(uv_x, 0.0f), 1.0f), cy = rptm::fminr(rptm::fmaxr(uv_y, 0.0f), 1.0f);
+                    if (cx != uv_x || cy != uv_y) {
+                        uv_x = uv_x - rptm::floorr(uv_x);
+                        uv_y = uv_y - rptm::floorr(uv_y);
+                    }
+                    if (mat.has.w != 0u) {                                               /* lib.rs:132-141 */
+                        float su = mat.normals.x + uv_x * mat.normals.z, sv = mat.normals.y + uv_y * mat.normals.w;
+                        float4 s = sample_by_lod<true>(sc.atlas, su, sv);
+                        F3 nm = f3(s.x * 2.0f - 1.0f, s.y * 2.0f - 1.0f, s.z * 2.0f - 1.0f);
+                        const uint4 tri = sc.indices[tri_index];
+                        F3 tangent = bary.x * xyz4(sc.per_vertex[4u * tri.x + 2u]) + bary.y * xyz4(sc.per_vertex[4u * tri.y + 2u]) +
+                                     bary.z * xyz4(sc.per_vertex[4u * tri.z + 2u]);
+                        F3 bitangent = cross3(tangent, normal);
+                        F3 r = tangent * nm.x;
+                        r = r + (bitangent * nm.y);
+                        r = r + (normal * nm.z);
+                        normal = norm3(r);
+                    }
+                }
+
+                /* ---- get_pbr_bsdf (bsdf.rs:354-387) ---- */
+                Pbr bsdf;
+                bsdf.albedo = xyz4(mat.albedo);
+                float roughness = mat.roughness.x, metallic = mat.metallic.x;
+                if (TEXTURED) {
+                    if (mat.has.x != 0u) {
+                        float4 s = sample_by_lod<true>(sc.atlas, mat.albedo.x + uv_x * mat.albedo.z, mat.albedo.y + uv_y * mat.albedo.w);
+                        bsdf.albedo = f3(s.x, s.y, s.z);
+                    }
+                    if (mat.has.z != 0u)
+                        roughness = sample_by_lod<true>(sc.atlas, mat.roughness.x + uv_x * mat.roughness.z, mat.roughness.y + uv_y * mat.roughness.w).x;
+                    if (mat.has.y != 0u)
+                        metallic = sample_by_lod<true>(sc.atlas, mat.metallic.x + uv_x * mat.metallic.z, mat.metallic.y + uv_y * mat.metallic.w).x;
+                }
+                bsdf.roughness = rptm::fmaxr(roughness, RPT_EPS);
+                bsdf.metallic = rptm::fminr(metallic, 1.0f - RPT_EPS);
+                bsdf.clamp_lo = cfg.c.specular_weight_clamp[0];
+                bsdf.clamp_hi = cfg.c.specular_weight_clamp[1];
+
+                /* ---- PBR::sample (bsdf.rs:272-334) ---- */
+                const uint2 rs = st.rng[slot_pix(st, slot)];
+                Rng rng{rs.x + slot_k(st, slot) + rs.y, FLAG_DIM(flags)};
+                const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
+                const F3 view = -rd;
+                const float w_spec = bsdf.specular_weight(view, normal);
+                F3 sdir;
+                const bool spec = !(r3 >= w_spec);
+                /* Both lobes turn one random number into an azimuth and take its sine and cosine (util.rs:27-28, 70), and
+                 * both normalise their final direction (util.rs:31, 84): in a wave that holds both kinds of lanes — nearly
+                 * every wave — the divergent branches would each issue those ~130 instructions.  They are issued once,
+                 * on the lane's own operand. */
+                float sin_p, cos_p;
+                rptm::sincosr(2.0f * RPT_PI_F * (spec ? r1 : r2), sin_p, cos_p);
+                if (!spec) {
+                    /* create_cartesian(normal) (util.rs:34-40) */
+                    F3 temp_vec = norm3(cross3(normal, f3(0.1f, 0.5f, 0.9f)));
+                    F3 nt = norm3(cross3(temp_vec, normal));       /* right   */
+                    F3 nb = norm3(cross3(normal, nt));             /* forward */
+                    /* cosine_sample_hemisphere (util.rs:24-32) */
+                    float theta = rptm::acosr(rptm::sqrtr(r1));
+                    float sin_t, cos_t;
+                    rptm::sincosr(theta, sin_t, cos_t);
+                    F3 s = f3(sin_t * cos_p, cos_t, sin_t * sin_p);
+                    sdir = f3(s.x * nb.x + s.y * normal.x + s.z * nt.x,
+                              s.x * nb.y + s.y * normal.y + s.z * nt.y,
+                              s.x * nb.z + s.y * normal.z + s.z * nt.z);
+                } else {
+                    /* reflect(-view, n) then sample_ggx (util.rs:42-44, 67-85) */
+                    F3 inc = -view;
+                    F3 refl = inc - normal * 2.0f * dot3(inc, normal);
+                    float a = bsdf.roughness * bsdf.roughness;
+                    float cos_theta = rptm::sqrtr((1.0f - r2) / (r2 * (a * a - 1.0f) + 1.0f));
+                    float sin_theta = rptm::sqrtr(1.0f - cos_theta * cos_theta);
+                    F3 h = f3(cos_p * sin_theta, sin_p * sin_theta, cos_theta);
+                    F3 up = rptm::absr(refl.z) < 0.999f ? f3(0.0f, 0.0f, 1.0f) : f3(1.0f, 0.0f, 0.0f);
+                    F3 tangent = norm3(cross3(up, refl));
+                    F3 bitangent = cross3(refl, tangent);
+                    sdir = tangent * h.x + bitangent * h.y + refl * h.z;
+                }
+                sdir = norm3(sdir);
+                const float cos_theta = rptm::fmaxr(dot3(normal, sdir), RPT_EPS);
+                const F3 halfway = norm3(view + sdir);
+                const F3 ks = bsdf.ks_of(view, halfway);
+                float pdf;
+                F3 spectrum;
+                if (!spec) {
+                    pdf = cos_theta / RPT_PI_F;
+                    spectrum = bsdf.diffuse_term(cos_theta, w_spec, ks);
+                } else {
+                    float d_term = ggx_d(normal, halfway, bsdf.roughness);
+                    pdf = (d_term * dot3(normal, halfway)) / (4.0f * dot3(view, halfway));
+                    spectrum = bsdf.specular_term(view, normal, sdir, cos_theta, d_term, w_spec, ks);
+                }
+
+                /* ---- next-event estimation set-up (light_pick.rs:100-173) ---- */
+                if (nee && !spec) {
+                    if (sc.no_lights) {
+                        /* sentinel: DirectLightSample::default() — zero contribution, zeroed carry */
+                        if (NEE == RPT_NEE_MIS) st.mis_a[slot] = make_float4(__uint_as_float(0xffffffffu), 0, 0, 0);
+                    } else {
+                        const float l1 = rng.next(), l2 = rng.next();
+                        uint32_t idx = rptm::f2u32_sat(l1 * (float)sc.n_light_pick);
+                        if (idx >= sc.n_light_pick) {                       /* gen_r1() == 1.0: the reference panics (Appendix C) */
+                            idx = sc.n_light_pick - 1u;
+                            atomicAdd(&stats->light_index_clamped, 1ull);
+                        }
+                        const rpt_light_pick_entry e = sc.light_pick[idx];
+                        const bool pick_a = l2 < e.ratio;
+                        const float light_area = pick_a ? e.triangle_area_a : e.triangle_area_b;
+                        const float light_pick_pdf = pick_a ? e.triangle_pick_pdf_a : e.triangle_pick_pdf_b;
+                        /* the light triangle's corners, mean normal and emission: one 64-byte record built at upload
+                         * (was: index buffer -> three 64-byte vertices + the material, four dependent scattered loads) */
+                        const float4 *lr = sc.light_rec + 8u * idx + (pick_a ? 0u : 4u);
+                        const float4 lra = lr[0], lrb = lr[1], lrc = lr[2], lre = lr[3];
+                        const F3 light_normal = f3(lra.w, lrb.w, lrc.w);
+                        const F3 light_emission = xyz4(lre);
+                        const float p1 = rng.next(), p2 = rng.next();
+                        const float r1_sqrt = rptm::sqrtr(p1);
+                        const F3 light_point = (1.0f - r1_sqrt) * xyz4(lra) + (r1_sqrt * (1.0f - p2)) * xyz4(lrb) +
+                                               (r1_sqrt * p2) * xyz4(lrc);
+                        const F3 unorm = light_point - hit;
+                        const float light_distance = len3(unorm);
+                        const F3 light_direction = unorm / light_distance;
+
+                        /* everything after the visibility test, assuming it passes */
+                        F3 direct = f3s(0.0f);
+                        {
+                            float cos_l = dot3(light_normal, -light_direction);
+                            float light_pdf = cos_l <= 0.0f ? 0.0f : rptm::powi2(light_distance) / (light_area * cos_l);
+                            if (light_pdf > 0.0f) {
+                                /* PBR::evaluate(view, n, L, Diffuse) and PBR::pdf(.., Diffuse) */
+                                float w_e = bsdf.specular_weight(view, normal);
+                                float cos_e = rptm::fmaxr(dot3(normal, light_direction), 0.0f);
+                                F3 h_e = norm3(view + light_direction);
+                                F3 ks_e = bsdf.ks_of(view, h_e);
+                                F3 attenuation = bsdf.diffuse_term(cos_e, w_e, ks_e);
+                                float bsdf_pdf = cos_e / RPT_PI_F;
+                                if (bsdf_pdf > 0.0f) {
+                                    float weight = 1.0f;
+                                    if (NEE == RPT_NEE_MIS) {
+                                        float q1 = light_pdf * light_pdf;
+                                        weight = q1 / (q1 + bsdf_pdf * bsdf_pdf);
+                                    }
+                                    direct = (attenuation * light_emission * weight / light_pdf) / light_pick_pdf;
+                                }
+                            }
+                        }
+                        const F3 contribution = throughput * direct;
+                        /* The reference traces the shadow ray first and looks at light_pdf / bsdf_pdf afterwards (light_pick.rs:141-158).  Where the term
+                         * an UNOCCLUDED ray adds is zero — the light point faces away (light_pdf = 0), lies below this surface's horizon (bsdf_pdf = 0), or
+                         * the product is masked as non-finite — `radiance += mask_nan(term)` (lib.rs:164) leaves every bit of radiance as it was whatever the
+                         * walk finds (radiance starts at +0.0 and x + y is -0.0 only for two negative zeros: it is never -0.0, so x + (+-0.0) == x), and
+                         * nothing else reads `.hit`: the ray is not queued.  48 % of DarkCornell's shadow rays, 57 % of VeachMIS's (tools/dead_shadow_rays.py);
+                         * counted in rpt_stats.shadow_rays_elided, and rpt_stats.shadow_rays keeps counting what the reference executes. */
+                        const F3 term = mask_nan3(contribution);
+                        const bool decides = term.x != 0.0f || term.y != 0.0f || term.z != 0.0f;
+                        elided = !decides;
+                        const F3 so = hit + light_direction * RPT_EPS;
+                        emit_shadow = decides;
+                        sh_o = make_float4(so.x, so.y, so.z, light_distance - RPT_EPS * 2.0f);
+                        sh_d = make_float4(light_direction.x, light_direction.y, light_direction.z, 0.0f);
+                        sh_c = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
+                        if (NEE == RPT_NEE_MIS)
+                            st.mis_a[slot] = make_float4(__uint_as_float(2u * idx + (pick_a ? 0u : 1u)), throughput.x, throughput.y, throughput.z);
+                    }
+                }
+                if (NEE == RPT_NEE_MIS) st.mis_b[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
+
+                /* ---- attenuate, respawn, roulette (lib.rs:168-181) ---- */
+                throughput = throughput * (spectrum / pdf);
+                new_d = sdir;
+                new_o = hit + sdir * RPT_EPS;
+                if (bounce > cfg.c.min_bounces) {
+                    float prob = rptm::fmaxr(throughput.x, rptm::fmaxr(throughput.y, throughput.z));
+                    if (rng.next() > prob) {
+                        done = true;
+                    } else {
+                        throughput = throughput * (1.0f / prob);
+                    }
+                }
+                const uint32_t next_bounce = bounce + 1u;
+                if (next_bounce >= cfg.c.max_bounces) done = true;
+                new_flags = MAKE_FLAGS(next_bounce, spec ? 1u : 0u, rng.dim);
+            }
+
+            if (done && !emit_shadow) {
+                /* the path ends here with nothing pending: one slot per pixel — accumulated and restarted on the spot; several —
+                 * parked as HIT_DONE for k_complete */
+                load_rad();
+                finish_in_side_stage(st, cfg, slot, radiance, todo);
+            } else {
+                if (first) {                         /* the path goes on (or waits for its shadow ray): its radiance record begins here */
+                    load_rad();
+                    st.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, __uint_as_float(todo));
+                }
+                if (!done) {
+                    st.thr[slot] = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(new_flags));
+                    st.ray_a[slot] = make_float4(new_o.x, new_o.y, new_o.z, new_d.x);
+                    st.ray_b[slot] = make_float2(new_d.y, new_d.z);
+                    st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PENDING));
+                    sh_d.w = __uint_as_float(slot);
+                } else {
+                    /* the shadow stage adds the NEE term and then finishes the path */
+                    st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_PARKED));
+                    sh_d.w = __uint_as_float(slot | 0x80000000u);
+                }
+            }
+        }
+    }
+
 }
 
 /* COMPACT: a workgroup owns RPT_SHADE_ROUNDS x 256 consecutive slots; it first walks them in identity layout to pack the slots
@@ -597,23 +548,6 @@ __device__ __forceinline__ void shade_emit(const DevQueues &q, uint32_t *push_sc
     }
 }
 
-/* a SurfaceWork through LDS, word-major ([word][position]: conflict free) */
-__device__ __forceinline__ void work_store(uint32_t *lds, uint32_t pos, const SurfaceWork &w) {
-    const float f[20] = {w.hit.x, w.hit.y, w.hit.z, w.rd.x, w.rd.y, w.rd.z, w.normal.x, w.normal.y, w.normal.z, w.albedo.x, w.albedo.y, w.albedo.z,
-                         w.throughput.x, w.throughput.y, w.throughput.z, w.roughness, w.metallic, w.w_spec, w.r1, w.r2};
-    lds[0 * RPT_BLOCK + pos] = w.slot; lds[1 * RPT_BLOCK + pos] = w.flags; lds[2 * RPT_BLOCK + pos] = w.rng_key;
-#pragma unroll
-    for (int k = 0; k < 20; ++k) lds[(3 + k) * RPT_BLOCK + pos] = __float_as_uint(f[k]);
-}
-__device__ __forceinline__ void work_load(const uint32_t *lds, uint32_t pos, SurfaceWork &w) {
-    float f[20];
-#pragma unroll
-    for (int k = 0; k < 20; ++k) f[k] = __uint_as_float(lds[(3 + k) * RPT_BLOCK + pos]);
-    w.slot = lds[0 * RPT_BLOCK + pos]; w.flags = lds[1 * RPT_BLOCK + pos]; w.rng_key = lds[2 * RPT_BLOCK + pos];
-    w.hit = f3(f[0], f[1], f[2]); w.rd = f3(f[3], f[4], f[5]); w.normal = f3(f[6], f[7], f[8]); w.albedo = f3(f[9], f[10], f[11]);
-    w.throughput = f3(f[12], f[13], f[14]); w.roughness = f[15]; w.metallic = f[16]; w.w_spec = f[17]; w.r1 = f[18]; w.r2 = f[19];
-}
-
 /* wave-aggregated count into the workgroup's LDS word */
 __device__ __forceinline__ void count_elided(uint32_t *lds_counter, bool elided) {
     const unsigned long long m = rpt_ballot(elided);
@@ -636,7 +570,6 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
     const bool first_paths = iteration == 0u;                  /* every traversed slot holds the first path of its call (k_path.h) */
     __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
     __shared__ uint32_t c_slot[COMPACT ? RPT_BLOCK * RPT_SHADE_ROUNDS : 1];
-    __shared__ uint32_t work_lds[COMPACT ? SHADE_WORK_WORDS * RPT_BLOCK : 1];   /* the works of one chunk, regrouped by lobe (23.5 KB) */
     __shared__ uint32_t n_elided;                              /* NEE evaluations of this workgroup whose shadow ray was not queued (shade_slot) */
     if (q.count[Q_DRAINED] != 0u) return;                      /* surplus launch (grid-uniform) */
     if (NEE != RPT_NEE_NONE) {
@@ -682,21 +615,9 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             const float2 hw = a_hit ? st.hit[slot] : make_float2(0.0f, __uint_as_float(a_miss ? HIT_MISS : HIT_PARKED));
             bool to_sky = false, emit_shadow = false, elided = false;
             float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-            /* The lobe-independent half for the chunk's 256 entries, then the works change lanes: diffuse ones to the front of the chunk, specular ones
-             * to its back, so that three of its four waves run ONE lobe's code (a diffuse lane needs the cosine-hemisphere frame and — with NEE — the
-             * 430-instruction light sample, a specular one the GGX half vector: in slot order nearly every wave paid for both at 40-60 % of its lanes;
-             * tools/shade_bin_sim.py "4 bins": a further - 15 % wave-instructions).  Which lane finishes a slot is no part of any result. */
-            SurfaceWork w;
-            const int kind = shade_pre<NEE, TEXTURED>(sc, st, q, cfg, stats, slot, hw, active, to_sky, first_paths, n_samples, w);
-            uint32_t rank_d, rank_s, n_d, n_s;
-            block_rank2(kind == SHADE_DIFFUSE, kind == SHADE_SPECULAR, push_scratch, rank_d, rank_s, n_d, n_s);
-            if (kind != SHADE_NONE) work_store(work_lds, kind == SHADE_DIFFUSE ? rank_d : (uint32_t)RPT_BLOCK - 1u - rank_s, w);
-            __syncthreads();
-            const int mine = threadIdx.x < n_d ? SHADE_DIFFUSE : (threadIdx.x >= (uint32_t)RPT_BLOCK - n_s ? SHADE_SPECULAR : SHADE_NONE);
-            if (mine != SHADE_NONE) work_load(work_lds, threadIdx.x, w);
-            shade_post<NEE, TEXTURED>(sc, st, q, cfg, stats, w, mine, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided);
+            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided);
             if (NEE != RPT_NEE_NONE) count_elided(&n_elided, elided);
-            shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);      /* (the next chunk's stores follow its block_rank2 barriers) */
+            shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
         }
     } else {
         const uint32_t slot = blockIdx.x * RPT_BLOCK + threadIdx.x;
@@ -706,7 +627,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
         const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;        /* traversed in this iteration */
         bool to_sky = false, emit_shadow = false, elided = false;
         float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-        shade_slot<NEE, TEXTURED>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided);
+        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided);
         if (NEE != RPT_NEE_NONE) count_elided(&n_elided, elided);
         shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
     }
