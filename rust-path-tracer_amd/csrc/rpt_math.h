@@ -275,9 +275,10 @@ RPT_HD float exp_sky(float x) {
 RPT_UNROLL
     for (int i = RPT_EXPF_C_N - 2; i >= 0; --i) p = __builtin_fmaf(p, r, c[i]);
     p = __builtin_fmaf(r * r, p, r) + 1.0f;             /* 1 + r + r^2 P(r) */
-    int k = (int)kf;
-    int k1 = k / 2, k2 = k - k1;                        /* 2^k in two normal factors: gradual underflow handled by the multiplies */
-    const float e = (p * exp2i_f(k1)) * exp2i_f(k2);
+    /* p * 2^k with ONE rounding, into the denormals and over the top alike: ldexp — a single v_ldexp_f32 on the device.  Round 5: it replaces 2^k in two
+     * normal factors built with integer shifts and two multiplies ((p * 2^(k/2)) * 2^(k - k/2): the first product exact, the second rounding once — the
+     * same value for every float, tools/exp_sky_check.cpp compares the two forms), ten instructions of this function's twenty-four, 84 calls per sky miss. */
+    const float e = __builtin_ldexpf(p, (int)kf);
     return x_in != x_in ? x_in : e;
 #endif
 }

@@ -1,4 +1,5 @@
-// exp_sky of rpt_math.h (argument clamped to [-104, 89], one NaN select) == the form with explicit special-case branches it replaced (round 4), for
+// exp_sky of rpt_math.h (argument clamped to [-104, 89], one NaN select, 2^k applied with ldexp: round 5) == the form with explicit special-case branches and
+// 2^k in two normal factors it replaced (rounds 4 / 5), for
 // every float bit pattern (stride 1: 2^32 arguments, ~30 s on 8 threads) or every stride-th one plus all arguments within 2^20 patterns of the three
 // boundaries.  usage: exp_sky_check [stride]   build: g++ -O2 -std=c++20 -ffp-contract=off -mfma -pthread -I<repo> -o exp_sky_check tools/exp_sky_check.cpp
 #include <cstdint>
