@@ -365,7 +365,7 @@ def launch_ranks(n, argv):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -408,7 +408,7 @@ def main():
     # bring one either): this process becomes the launcher.  It has not imported torch nor touched HIP; the N ranks are CHILD
     # processes (python -m torch.distributed.run, one rank per GPU over RCCL), never an exec; their one JSON line and the return
     # code are relayed.
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1") or "1") <= 1:      # (an inherited WORLD_SIZE=1 is no launcher either)
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # Rank 0 prints ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner through C stdio when

@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_plain_multi_gpu_command_starts_its_own_ranks_and_relays_their_exit_code(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WORLD_SIZE"] = "1"                              # an inherited single-process "distributed" environment is no launcher either
+    env["RANK"] = "0"
     env["HIP_VISIBLE_DEVICES"] = ""                      # (were a GPU present: this test is about the launcher only)
     env["CUDA_VISIBLE_DEVICES"] = ""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
