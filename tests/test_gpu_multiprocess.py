@@ -191,7 +191,7 @@ def test_bench_line_carries_the_other_single_gpu_workloads(tmp_path):
         if r["traffic"] is not None:
             assert r["traffic"] >= 0.98 * r["algorithmic_bytes_per_unit"] * r["units_per_launch"], (name, r)
             assert r["traffic_over_algorithmic"] >= 0.98
-            if r["kernel"] == "k_shadow":
-                assert r["traffic_kernels"] == ["k_shadow", "k_shadow_resolve"]
+            if r["kernel"] == "k_shadow":            # (the streamed LDS walk has the dense k_shadow_resolve pass behind it, the global-memory walk resolves in its own kernel)
+                assert r["traffic_kernels"] in (["k_shadow", "k_shadow_resolve"], ["k_shadow"])
         pc = w["parity_check"]
         assert pc["bitwise"] is True and pc["windows"] >= 2 and pc["image_spp"] == pc["spp"] == 32
