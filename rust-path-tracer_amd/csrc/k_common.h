@@ -199,6 +199,7 @@ struct DevQueues {
     uint32_t *count;   /* Q_COUNT words, see the enum above */
     uint32_t *sky_cnt, *shadow_cnt;   /* RPT_Q_SHARDS counters each, RPT_Q_SHARD_STRIDE words apart: entries reserved per shard */
     uint32_t sky_threshold;   /* the sky stage runs once this many misses are queued (or nothing else is left) */
+    uint32_t known_length;    /* the call enqueues exactly max_bounces iterations (no slot takes a second sample): every traversed path of iteration i is at bounce i */
     uint32_t sky_at_end;      /* a batch of known length: misses only END paths, so they wait in the queue for ONE sky launch after the last iteration */
     uint32_t sky_wide_limit;  /* up to this many queued misses the sky march runs 16 lanes per miss */
     unsigned long long *ray_shards;  /* RPT_STAT_SHARDS x RPT_STAT_STRIDE: extension rays traced */

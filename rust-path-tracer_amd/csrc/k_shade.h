@@ -158,8 +158,31 @@ template <int NEE, bool TEXTURED, bool COMPACT>
 __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &st, const DevQueues &q, const DevConfig &cfg, DevStats *stats,
                                            uint32_t slot, float2 hw, bool active, bool &to_sky, bool &emit_shadow, float4 &sh_o, float4 &sh_d,
                                            float4 &sh_c, bool first /* iteration 0 of the call: every path is a first path (k_path.h) */,
-                                           uint32_t n_samples, bool &elided /* an NEE evaluation whose shadow ray decides nothing: not queued */) {
+                                           uint32_t n_samples, bool &elided /* an NEE evaluation whose shadow ray decides nothing: not queued */,
+                                           bool last_iteration /* wave-uniform: every path of this launch is at its last bounce and has a radiance record */) {
     const uint32_t hit_tri = __float_as_uint(hw.y);
+    if (NEE == RPT_NEE_NONE && last_iteration && active && hit_tri != HIT_MISS) {
+        /* The last bounce of every path of this launch, without NEE (see `last` below): all the stage can still do for a hit is add the emission of a
+         * front-facing emitter (lib.rs:86-100) and end the path — so it reads the hit word it was handed, the triangle's material index and emission, and
+         * nothing else: no ray, no throughput unless the surface emits, and where nothing is added the slot's radiance record (radiance, samples owed) already
+         * holds what finish_in_side_stage would write into it. */
+        const uint32_t tri_index = hit_tri & 0x7fffffffu;
+        const uint32_t m = __float_as_uint(sc.tri_shade[4u * tri_index + 2u].w);
+        const float4 e4 = TEXTURED ? sc.materials[6u * m] : sc.mat_lite[2u * m];
+        const bool emits = (e4.x != 0.0f || e4.y != 0.0f || e4.z != 0.0f) && (hit_tri >> 31) == 0u;
+        if (emits || st.group_shift == 0u) {
+            const float4 r4 = st.rad[slot];
+            F3 radiance = f3(r4.x, r4.y, r4.z);
+            if (emits) {
+                const float4 tf = st.thr[slot];
+                radiance = radiance + mask_nan3(f3(tf.x, tf.y, tf.z) * f3(e4.x, e4.y, e4.z));
+            }
+            finish_in_side_stage(st, cfg, slot, radiance, __float_as_uint(r4.w));
+        } else {
+            st.hit[slot] = make_float2(0.0f, __uint_as_float(HIT_DONE));
+        }
+        return;
+    }
     if (active) {
         const float4 ra = st.ray_a[slot];
         const float2 rb = st.ray_b[slot];
@@ -250,6 +273,15 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
 
             uint32_t new_flags = flags;
             F3 new_o = ro, new_d = rd;
+            /* The LAST bounce of a path (bounce + 1 == max_bounces: the loop of lib.rs:62 ends after it whatever the roulette says).  The reference still
+             * samples the BSDF there (lib.rs:144-146) and updates throughput and ray (:168-172), and then drops all of it: nothing reads the sampled direction,
+             * pdf or spectrum, last_bsdf_sample or last_light_sample again.  What the sample's radiance can still receive is the emission handled above and the
+             * NEE term of this hit — which needs the hit point, the normal, the BSDF's parameters, the three draws of PBR::sample (for the lobe choice and to
+             * keep the later draws on their dimensions) and nothing of the sampled lobe.  Without NEE the whole surface body is dead: the path just ends.
+             * In a batch of known length the last bounce is the last ITERATION — wave-uniform: the fourth shade launch of a DarkCornell batch sheds its
+             * ~1 300-instruction surface body (0.70 -> 0.3 ms). */
+            const bool last = bounce + 1u >= cfg.c.max_bounces;
+            if (!nee && last) done = true;
             if (!done) {
                 /* ---- interpolate vertex data (lib.rs:112-129); d00/d01/d11 are triangle constants ---- */
                 const float4 *tg = sc.tri_geom + 3u * tri_index;
@@ -315,8 +347,11 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                 const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
                 const F3 view = -rd;
                 const float w_spec = bsdf.specular_weight(view, normal);
-                F3 sdir;
+                F3 sdir = f3s(0.0f);
                 const bool spec = !(r3 >= w_spec);
+                float pdf = 1.0f;
+                F3 spectrum = f3s(0.0f);
+                if (!last) {
                 /* Both lobes turn one random number into an azimuth and take its sine and cosine (util.rs:27-28, 70), and
                  * both normalise their final direction (util.rs:31, 84): in a wave that holds both kinds of lanes — nearly
                  * every wave — the divergent branches would each issue those ~130 instructions.  They are issued once,
@@ -353,8 +388,6 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                 const float cos_theta = rptm::fmaxr(dot3(normal, sdir), RPT_EPS);
                 const F3 halfway = norm3(view + sdir);
                 const F3 ks = bsdf.ks_of(view, halfway);
-                float pdf;
-                F3 spectrum;
                 if (!spec) {
                     pdf = cos_theta / RPT_PI_F;
                     spectrum = bsdf.diffuse_term(cos_theta, w_spec, ks);
@@ -363,12 +396,13 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                     pdf = (d_term * dot3(normal, halfway)) / (4.0f * dot3(view, halfway));
                     spectrum = bsdf.specular_term(view, normal, sdir, cos_theta, d_term, w_spec, ks);
                 }
+                }       /* !last */
 
                 /* ---- next-event estimation set-up (light_pick.rs:100-173) ---- */
                 if (nee && !spec) {
                     if (sc.no_lights) {
                         /* sentinel: DirectLightSample::default() — zero contribution, zeroed carry */
-                        if (NEE == RPT_NEE_MIS) st.mis_a[slot] = make_float4(__uint_as_float(0xffffffffu), 0, 0, 0);
+                        if (NEE == RPT_NEE_MIS && !last) st.mis_a[slot] = make_float4(__uint_as_float(0xffffffffu), 0, 0, 0);
                     } else {
                         const float l1 = rng.next(), l2 = rng.next();
                         uint32_t idx = rptm::f2u32_sat(l1 * (float)sc.n_light_pick);
@@ -432,27 +466,29 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                         sh_o = make_float4(so.x, so.y, so.z, light_distance - RPT_EPS * 2.0f);
                         sh_d = make_float4(light_direction.x, light_direction.y, light_direction.z, 0.0f);
                         sh_c = make_float4(contribution.x, contribution.y, contribution.z, 0.0f);
-                        if (NEE == RPT_NEE_MIS)
+                        if (NEE == RPT_NEE_MIS && !last)      /* (the carry of a last bounce has no reader) */
                             st.mis_a[slot] = make_float4(__uint_as_float(2u * idx + (pick_a ? 0u : 1u)), throughput.x, throughput.y, throughput.z);
                     }
                 }
-                if (NEE == RPT_NEE_MIS) st.mis_b[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
+                if (last) {
+                    done = true;
+                } else {
+                    if (NEE == RPT_NEE_MIS) st.mis_b[slot] = make_float4(pdf, spectrum.x, spectrum.y, spectrum.z);
 
-                /* ---- attenuate, respawn, roulette (lib.rs:168-181) ---- */
-                throughput = throughput * (spectrum / pdf);
-                new_d = sdir;
-                new_o = hit + sdir * RPT_EPS;
-                if (bounce > cfg.c.min_bounces) {
-                    float prob = rptm::fmaxr(throughput.x, rptm::fmaxr(throughput.y, throughput.z));
-                    if (rng.next() > prob) {
-                        done = true;
-                    } else {
-                        throughput = throughput * (1.0f / prob);
+                    /* ---- attenuate, respawn, roulette (lib.rs:168-181) ---- */
+                    throughput = throughput * (spectrum / pdf);
+                    new_d = sdir;
+                    new_o = hit + sdir * RPT_EPS;
+                    if (bounce > cfg.c.min_bounces) {
+                        float prob = rptm::fmaxr(throughput.x, rptm::fmaxr(throughput.y, throughput.z));
+                        if (rng.next() > prob) {
+                            done = true;
+                        } else {
+                            throughput = throughput * (1.0f / prob);
+                        }
                     }
+                    new_flags = MAKE_FLAGS(bounce + 1u, spec ? 1u : 0u, rng.dim);
                 }
-                const uint32_t next_bounce = bounce + 1u;
-                if (next_bounce >= cfg.c.max_bounces) done = true;
-                new_flags = MAKE_FLAGS(next_bounce, spec ? 1u : 0u, rng.dim);
             }
 
             if (done && !emit_shadow) {
@@ -568,6 +604,9 @@ __attribute__((amdgpu_waves_per_eu((NEE == RPT_NEE_NONE && !TEXTURED) ? (COMPACT
 __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, DevQueues q, DevConfig cfg, uint32_t iteration,
                                                      DevStats *stats, uint32_t n_samples /* of this render call */) {
     const bool first_paths = iteration == 0u;                  /* every traversed slot holds the first path of its call (k_path.h) */
+    /* a batch of known length: iteration i shades bounce i of every path, so its last iteration is every path's last bounce (not the first one: a first
+       path has no radiance record yet) */
+    const bool last_iteration = q.known_length != 0u && iteration != 0u && iteration + 1u >= cfg.c.max_bounces;
     __shared__ uint32_t push_scratch[RPT_BLOCK / RPT_WAVE + 1];
     __shared__ uint32_t c_slot[COMPACT ? RPT_BLOCK * RPT_SHADE_ROUNDS : 1];
     __shared__ uint32_t n_elided;                              /* NEE evaluations of this workgroup whose shadow ray was not queued (shade_slot) */
@@ -615,7 +654,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
             const float2 hw = a_hit ? st.hit[slot] : make_float2(0.0f, __uint_as_float(a_miss ? HIT_MISS : HIT_PARKED));
             bool to_sky = false, emit_shadow = false, elided = false;
             float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided);
+            shade_slot<NEE, TEXTURED, true>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided, last_iteration);
             if (NEE != RPT_NEE_NONE) count_elided(&n_elided, elided);
             shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
         }
@@ -627,7 +666,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_shade(DevScene sc, DevState st, D
         const bool active = hit_tri < HIT_IDLE || hit_tri == HIT_MISS;        /* traversed in this iteration */
         bool to_sky = false, emit_shadow = false, elided = false;
         float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_c = sh_o;
-        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided);
+        shade_slot<NEE, TEXTURED, false>(sc, st, q, cfg, stats, slot, hw, active, to_sky, emit_shadow, sh_o, sh_d, sh_c, first_paths, n_samples, elided, last_iteration);
         if (NEE != RPT_NEE_NONE) count_elided(&n_elided, elided);
         shade_emit<NEE>(q, push_scratch, slot, to_sky, emit_shadow, sh_o, sh_d, sh_c);
     }

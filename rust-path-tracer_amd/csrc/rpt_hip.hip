@@ -201,7 +201,7 @@ int alloc_state(rpt_ctx *c) {
     c->sky_wide_cfg = 32768u;
     if (const char *env = getenv("RPT_SKY_WIDE_LIMIT")) c->sky_wide_cfg = (uint32_t)std::max(0, atoi(env));
     q.sky_wide_limit = (uint32_t)std::min<size_t>(n / 16, c->sky_wide_cfg);     /* re-clamped per call to that call's slot count */
-    q.sky_threshold = 1u; q.sky_at_end = 0u;
+    q.sky_threshold = 1u; q.sky_at_end = 0u; q.known_length = 0u;
     if (const char *env = getenv("RPT_SKY_THRESHOLD")) q.sky_threshold = (uint32_t)std::max(1, atoi(env));
     c->has_state = true;
     return RPT_OK;
@@ -1013,6 +1013,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     /* A miss ends its path (lib.rs:79) and in a batch of known length nothing is started in its place: the misses of all iterations
      * wait in the queue for ONE sky launch after the last iteration (three launches less per batch; RPT_SKY_AT_END=0: every iteration) */
     c->queues.sky_at_end = (known_iterations != 0 && c->sky_at_end_ok) ? 1u : 0u;
+    c->queues.known_length = known_iterations != 0 ? 1u : 0u;
     std::vector<hipEvent_t> async_events;
     std::vector<hipEvent_t> *ev = c->stage_timing ? (async ? &async_events : &c->timing_events) : nullptr;
     size_t ev_at = 0;
