@@ -51,6 +51,7 @@ extern "C" {
                                      materials: *const MaterialData, n_materials: usize, entries_out: *mut LightPickEntry, entries_capacity: usize,
                                      n_entries_out: *mut usize, n_emissive_out: *mut u32, ms_out: *mut f64) -> c_int;   // build_light_pick_table, src/light_pick.rs:24-122
     pub fn rpt_shadow_order(ctx: *mut rpt_ctx, fixed_out: *mut u32, visits_near_out: *mut f64, visits_fixed_out: *mut f64, probe_rays_out: *mut u32, probe_ms_out: *mut f64) -> c_int;   // which (bit-exact) order the shadow walks use
+    pub fn rpt_last_bounce_order(ctx: *mut rpt_ctx, mode_out: *mut u32, n_emissive_triangles_out: *mut u32, visits_out: *mut f64, probe_rays_out: *mut u32, probe_ms_out: *mut f64) -> c_int;   // how the last extension rays of a batch without NEE are walked
 
     // --- one GPU: what trace_gpu needs (each line: the reference call it replaces) -------------------------------
     pub fn rpt_create(device_id: c_int, out: *mut *mut rpt_ctx) -> c_int;          // FW / adaptor creation, trace.rs:3-6,25-38

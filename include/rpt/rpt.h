@@ -253,6 +253,15 @@ int rpt_device_info(int device_id, uint32_t *compute_units_out, uint32_t *clock_
  * so the library may choose: fixed_out = 0 the reference's near-first order, 1 a fixed opaque-first order over a flipped copy of the tree —
  * chosen at rpt_upload_scene by the node visits of synthetic shadow rays under both (csrc/shadow_order.h).  The image is the same either way. */
 int rpt_shadow_order(rpt_ctx *ctx, uint32_t *fixed_out, double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out, double *probe_ms_out);
+/* How the LAST extension rays of a batch of known length are walked when the configuration has no NEE.  At bounce max_bounces - 1 the reference reads three
+ * things off intersect_nearest (kernels/src/lib.rs:62-109): a miss adds the sky, a hit on the front of an emissive triangle adds its emission, any other hit
+ * adds nothing — so a ray that passes the Moller-Trumbore test of no emissive triangle only has to answer "hit or miss", which the reference's own walk
+ * answers at its FIRST accepted triangle (intersection.rs:195-203), in any visiting order.  mode_out: 0 the plain walk (more than four emissive triangles, a
+ * scene that does not live in LDS, RPT_LAST_BOUNCE_HIT_OR_MISS=0); 1 those rays stop at their first accept, near child first; 2 / 3 / 4 fixed order over a
+ * copy flipped so that the more opaque / the smaller / the more-opaque-per-node child comes first — chosen at rpt_upload_scene by the node visits of
+ * synthetic rays (visits_out[4]: near first, then the three rules; csrc/shadow_order.h choose_last_order).  The image is the same in every mode. */
+int rpt_last_bounce_order(rpt_ctx *ctx, uint32_t *mode_out, uint32_t *n_emissive_triangles_out, double *visits_out /* [4], nullable */, uint32_t *probe_rays_out,
+                          double *probe_ms_out);
 
 /* --- scene preparation on the device ---------------------- */
 /* BVHBuilder::new(vertices, indices).sah_samples(n).build()  (reference src/bvh.rs:59-324, the call at
@@ -289,6 +298,10 @@ int rpt_debug_shadow_order_host(const rpt_per_vertex_data *vertices, size_t n_ve
                                 const rpt_bvh_node *nodes, size_t n_nodes, const rpt_material_data *materials, size_t n_materials,
                                 const rpt_light_pick_entry *light_pick, size_t n_light_pick, uint32_t *fixed_out, double *visits_near_out,
                                 double *visits_fixed_out, uint32_t *probe_rays_out, uint8_t *flip_out);
+/* The same for the order of the hit-or-miss lanes of the last extension rays (rpt_last_bounce_order): rule_out 0 near child first, 1 / 2 / 3 the fixed rules. */
+int rpt_debug_last_order_host(const rpt_per_vertex_data *vertices, size_t n_vertices, const rpt_triangle *indices, size_t n_triangles,
+                              const rpt_bvh_node *nodes, size_t n_nodes, const rpt_material_data *materials, size_t n_materials,
+                              uint32_t *rule_out, double *visits_out /* [4] */, uint32_t *probe_rays_out, uint8_t *flip_out);
 /* Exhaustive device-side check of a cheap exact operation of rpt_math.h against its IEEE form over the float bit patterns
  * [lo_bits, lo_bits + count): op 0 sqrtr vs the correctly rounded sqrtf, op 1 div_const_nontiny(x, y, RN(1/y)) vs x / y.  Returns the
  * number of arguments whose results differ in any bit (NaN == NaN) and the smallest such bit pattern (0xffffffff if none). */

@@ -80,6 +80,7 @@ struct DevImage {
  * predicate as 0/1 in a VGPR and compares it again (two extra VALU instructions per ballot). */
 __device__ __forceinline__ unsigned long long rpt_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 
+#define RPT_LAST_EMIT_MAX 4
 struct DevScene {
     const float4 *nodes;           /* 2 x float4 per rpt_bvh_node, reference layout */
     const float4 *tri_geom;        /* 3 x float4 per triangle: (a | d00), (e1 = b-a | d01), (e2 = c-a | d11);
@@ -106,6 +107,12 @@ struct DevScene {
     const float4 *lds_image_shadow;
     const float4 *gpairs_shadow;
     const uint32_t *glinks_shadow;
+    /* the last extension rays of a batch without NEE (k_traverse.h k_traverse_nearest_stream LAST): the triangles whose material emits, when there are at most
+     * RPT_LAST_EMIT_MAX of them (last_emit_n > RPT_LAST_EMIT_MAX: too many, the launch is the plain one), and the size of the flipped copy's pair records
+     * staged behind the LDS image (0: not staged) */
+    uint32_t last_emit_n, last_emit_tri[RPT_LAST_EMIT_MAX];
+    uint32_t last_flip_vecs;
+    const float4 *lds_image_last;  /* those pair records (6 x lds_pairs plane float4 + the child descriptors), flipped by the rule shadow_order.h choose_last_order picked */
     uint32_t no_lights;            /* light_pick[0].ratio < 0 */
     uint32_t fastdiv_ok;           /* every node bound is 0 or in [2^-60, 2^40): exact fast division allowed */
     uint32_t textured;             /* some material has a texture flag set */

@@ -650,16 +650,24 @@ __device__ __forceinline__ void lds_walk_begin(const SceneViewLds &view, LdsWalk
 
 /* At most `budget` trips of the deferred-leaf loop (see traverse_loop) for the lanes of this wave; returns early when
  * no lane has anything left.  Per ray the visiting order and every comparison are the reference's. */
-template <int STACK, bool ANY_HIT, bool SIGNED, bool FIXED = false>
+/* MIXED (the last extension rays of a batch without NEE, k_traverse_nearest_stream<.., LAST = true>): a nearest-hit walk in which SOME lanes only have to
+ * answer "hit or miss" — `stop_first` lanes leave at their first accepted triangle, which is where the reference's walk makes result.hit true for good
+ * (intersection.rs:195-203), and because nothing was accepted before, result.t was 1e6 at every box test up to there: the part of the walk they run is an
+ * any-hit walk, whose answer does not depend on the visiting order (header).  They read the planes and child descriptors of `img_lane` — the flipped copy
+ * of the pair records when the workgroup staged one, then with order_bias = +inf (tl > tr + inf is never true: the left child first, the fixed order of
+ * shadow_order.h choose_last_order); the other lanes read the primary image with order_bias = 0 (tr + 0 compares like tr) and are the reference's walk to its end. */
+template <int STACK, bool ANY_HIT, bool SIGNED, bool FIXED = false, bool MIXED = false>
 __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &w, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack,
-                                             int budget) {
+                                             int budget, const float4 *img_lane = nullptr, uint32_t stop_first = 0u, float order_bias = 0.0f) {
     static_assert(!FIXED || ANY_HIT, "only the any-hit walk may choose its order");
+    static_assert(!MIXED || (!ANY_HIT && !FIXED), "MIXED is the nearest-hit walk with per-lane early exits");
     const uint32_t P = view.pairs;
+    const float4 *img = MIXED ? img_lane : view.img;
     /* per-ray plane-record bases (float4 units): x | y | z, A or B variant by the sign of the direction */
-    const float4 *px = view.img + ((SIGNED && rd.x < 0.0f) ? P : 0u);
-    const float4 *py = view.img + 2u * P + ((SIGNED && rd.y < 0.0f) ? P : 0u);
-    const float4 *pz = view.img + 4u * P + ((SIGNED && rd.z < 0.0f) ? P : 0u);
-    const uint32_t *descs = reinterpret_cast<const uint32_t *>(view.img + 6u * P);
+    const float4 *px = img + ((SIGNED && rd.x < 0.0f) ? P : 0u);
+    const float4 *py = img + 2u * P + ((SIGNED && rd.y < 0.0f) ? P : 0u);
+    const float4 *pz = img + 4u * P + ((SIGNED && rd.z < 0.0f) ? P : 0u);
+    const uint32_t *descs = reinterpret_cast<const uint32_t *>(img + 6u * P);
     uint32_t cur = w.cur;
     int sp = w.sp;
     HitRecord res = w.res;
@@ -684,7 +692,9 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
             float tl, tr;
             const bool hit_l = slab_pair_lds<SIGNED>(X.x, Y.x, Z.x, X.z, Y.z, Z.z, ro, rd, ird, res.t, tl);
             const bool hit_r = slab_pair_lds<SIGNED>(X.y, Y.y, Z.y, X.w, Y.w, Z.w, ro, rd, ird, res.t, tr);
-            const bool swap = FIXED ? (hit_r && !hit_l) : (hit_r && (!hit_l || tl > tr));     /* strict: ties keep left first */
+            const bool swap = FIXED ? (hit_r && !hit_l)
+                            : MIXED ? (hit_r && (!hit_l || tl > tr + order_bias))
+                                    : (hit_r && (!hit_l || tl > tr));     /* strict: ties keep left first */
             if (hit_l || hit_r) {
                 const uint32_t nf = __builtin_amdgcn_alignbit(d, d, swap ? 16u : 0u);    /* near | far << 16 */
                 if (hit_l && hit_r && sp < STACK) {
@@ -717,10 +727,10 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
                     asm volatile("" ::: "memory");
                     res.t = t;
                     res.tri = ti | (bf ? 0x80000000u : 0u);
-                    if (ANY_HIT) { accepted = true; break; }
+                    if (ANY_HIT || (MIXED && stop_first != 0u)) { accepted = true; break; }
                 }
             }
-            if ((ANY_HIT && accepted) || sp == 0) {
+            if (((ANY_HIT || MIXED) && accepted) || sp == 0) {
                 cur = LDS_DESC_DEAD;
             } else {
                 sp -= 1;
@@ -895,7 +905,14 @@ __device__ __forceinline__ uint32_t wg_pool_take(WgPool *pool, uint32_t *global_
  * show (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES 32 instead of 63).  Measured: the shadow walk 48.3 ms per four batches at 78 SGPRs, 61.2 at
  * 82 (profiles/r03_slp.txt).  So the compiler is held to 80 (it spills nothing: the excess was address arithmetic it can redo). */
 #define RPT_LDS_WALK_SGPRS 80
-template <int STACK, int THREADS>
+/* LAST: the launch that traces the last extension ray of every path of a batch of known length WITHOUT NEE (the host's choice, rpt_hip.hip launch_iteration:
+ * the same condition as the shade stage's last_iteration).  At that bounce the reference reads three things off the walk's result (kernels/src/lib.rs:62-109):
+ * a miss adds the sky; a hit on the front of a triangle whose material emits adds its emission; any other hit adds nothing and ends the sample.  A ray that
+ * passes the Moller-Trumbore test of NO emissive triangle (sc.last_emit_tri, at most RPT_LAST_EMIT_MAX of them, tested when the lane takes the ray) cannot
+ * end on one, so "hit or miss" is all its walk has to say: it stops at its first accepted triangle (lds_walk_run MIXED) — in a closed scene about half of
+ * the node visits of the bounce (tools/last_bounce_sim.py).  Its hit record names THAT triangle: not the nearest one, but like the nearest one not an
+ * emitter, which is all the shade stage's last iteration looks at.  A ray that does pass such a test runs the reference's walk to its end. */
+template <int STACK, int THREADS, bool LAST = false>
 __attribute__((amdgpu_num_sgpr(RPT_LDS_WALK_SGPRS)))
 __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
                                                                        uint32_t SPAN /* slots a workgroup fetches at a time */) {
@@ -918,7 +935,14 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
     }
     __syncthreads();
     if ((uint32_t)(pool.word >> 32) == 0u) return;             /* block-uniform: a late workgroup, nothing left */
+    /* LAST: behind the image, the pair records (planes + child descriptors) of the flipped copy the hit-or-miss lanes walk in fixed order, when the
+     * scene has one and the host found room for it (sc.last_flip_vecs float4; 0: those lanes walk the primary image near child first) */
+    if (LAST)
+        for (uint32_t k = threadIdx.x; k < sc.last_flip_vecs; k += THREADS) lds_scene[sc.lds_vecs + k] = sc.lds_image_last[k];
     const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);
+    const float4 *img_lane = view.img;                         /* (per lane, LAST only) */
+    uint32_t stop_first = 0u;
+    float order_bias = 0.0f;
     uint16_t *stack = &lds_stack[wave][0][lane];
     F3 ro = f3(0, 0, 0), rd = f3(1, 1, 1), ird = f3(1, 1, 1);
     LdsWalk w;
@@ -957,6 +981,18 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
                             ird = f3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                             lds_walk_begin(view, w);
                             have = true;
+                            if (LAST) {
+                                bool may_emit = false;
+                                for (uint32_t e = 0; e < sc.last_emit_n; ++e) {
+                                    float t_e;
+                                    bool bf_e;
+                                    may_emit = moller_trumbore_view(view, sc.last_emit_tri[e], ro, rd, t_e, bf_e) || may_emit;
+                                }
+                                stop_first = may_emit ? 0u : 1u;
+                                const bool flipped = !may_emit && sc.last_flip_vecs != 0u;
+                                img_lane = flipped ? view.img + sc.lds_vecs : view.img;
+                                order_bias = flipped ? __builtin_inff() : 0.0f;
+                            }
                         } else {
                             /* outside the exact-division guard (a zero / denormal-small direction component): walked here, alone */
                             HitRecord h = traverse_loop_lds<STACK, false, false>(view, ro, rd, rd, 0.0f, stack);
@@ -973,7 +1009,8 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
             if (!pool_open) break;                             /* nothing in flight and nothing left to hand out */
             continue;
         }
-        lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
+        if (LAST) lds_walk_run<STACK, false, true, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff, img_lane, stop_first, order_bias);
+        else lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
     }
     if (have) st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
     /* ray accounting + the alive flag, once per wave */

@@ -75,6 +75,8 @@ struct rpt_ctx {
     DevBuf<float4> lds_image_shadow, gpairs_shadow;   /* the same tree with its pairs flipped for the fixed-order any-hit walks (shadow_order.h) */
     DevBuf<uint32_t> glinks_shadow;
     ShadowOrder shadow_order;
+    DevBuf<float4> lds_image_last;                    /* pair records of the copy flipped for the hit-or-miss lanes of the last extension rays (choose_last_order) */
+    LastOrder last_order;
     DevBuf<rpt_light_pick_entry> light_pick;
     DevBuf<uchar4> atlas;
     DevBuf<float4> skybox;

@@ -275,7 +275,7 @@ static uint32_t gstream_span(const rpt_ctx *c, uint32_t most) {
 /* The nearest-hit traversal stage for the context's scene and state: which kernel, which grid.  Used by every iteration of a
  * render call and by rpt_debug_trace_rays_production (per-ray parity of exactly these kernels). */
 template <int STACK>
-void launch_nearest(rpt_ctx *c, uint32_t iteration) {
+void launch_nearest(rpt_ctx *c, uint32_t iteration, bool last_without_nee = false /* the last extension rays of a batch of known length, no NEE */) {
     hipStream_t s = c->stream;
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
@@ -291,7 +291,9 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration) {
         span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
         span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
         const uint32_t n_spans = (c->n_slots + span - 1) / span;
-        k_traverse_nearest_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span);
+        if (last_without_nee && c->scene.last_emit_n <= RPT_LAST_EMIT_MAX)
+            k_traverse_nearest_stream<16, LDS_THREADS, true><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes + (size_t)c->scene.last_flip_vecs * sizeof(float4), s>>>(c->scene, c->state, c->queues, iteration, span);
+        else k_traverse_nearest_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span);
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else if (c->gstream && (!RPT_GSTREAM_PAIRS || c->scene.gpairs)) {
@@ -325,7 +327,8 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     const uint32_t blocks_lds = (q_positions + LDS_THREADS - 1) / LDS_THREADS;
     const int stack_width = gstream_stack_width(c);
     const uint32_t gspan = gstream_span(c, (uint32_t)RPT_GSTREAM_RAYS), gblocks = (q_positions + gspan - 1) / gspan;            /* any-hit walk */
-    launch_nearest<STACK>(c, iteration);
+    /* (the shade stage's last_iteration, k_shade.h: in a batch of known length iteration k is bounce k of every path) */
+    launch_nearest<STACK>(c, iteration, NEE == RPT_NEE_NONE && c->queues.known_length != 0u && iteration != 0u && iteration + 1u >= c->cfg.c.max_bounces);
     mark(true);
     if (c->shade_compact) k_shade<NEE, TEXTURED, true><<<(c->n_slots + RPT_BLOCK * RPT_SHADE_ROUNDS - 1) / (RPT_BLOCK * RPT_SHADE_ROUNDS), RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
     else k_shade<NEE, TEXTURED, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
@@ -499,6 +502,18 @@ int rpt_shadow_order(rpt_ctx *c, uint32_t *fixed_out, double *visits_near_out, d
 }
 
 /* the same decision without a device (tests: the probe is host code) */
+int rpt_last_bounce_order(rpt_ctx *c, uint32_t *mode_out, uint32_t *n_emissive_out, double *visits_out, uint32_t *probe_rays_out, double *probe_ms_out) {
+    if (!c) return RPT_EINVAL;
+    if (!c->has_scene) { c->error = "rpt_last_bounce_order: no scene"; return RPT_EINVAL; }
+    const bool on = c->scene.lds_scene != 0u && c->lds_stream && c->scene.last_emit_n <= RPT_LAST_EMIT_MAX;
+    if (mode_out) *mode_out = !on ? 0u : 1u + (uint32_t)c->last_order.rule;
+    if (n_emissive_out) *n_emissive_out = c->scene.last_emit_n;
+    if (visits_out) for (int k = 0; k < 4; ++k) visits_out[k] = c->last_order.visits[k];
+    if (probe_rays_out) *probe_rays_out = c->last_order.probe_rays;
+    if (probe_ms_out) *probe_ms_out = c->last_order.probe_ms;
+    return RPT_OK;
+}
+
 int rpt_debug_shadow_order_host(const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
                                 const rpt_material_data *mats, size_t nm, const rpt_light_pick_entry *lp, size_t nlp, uint32_t *fixed_out,
                                 double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out, uint8_t *flip_out /* (nn - 1) / 2, nullable */) {
@@ -517,6 +532,26 @@ int rpt_debug_shadow_order_host(const rpt_per_vertex_data *pv, size_t nv, const 
     if (visits_fixed_out) *visits_fixed_out = so.visits_fixed;
     if (probe_rays_out) *probe_rays_out = so.probe_rays;
     if (flip_out && !so.flip.empty()) memcpy(flip_out, so.flip.data(), so.flip.size());
+    return RPT_OK;
+}
+
+int rpt_debug_last_order_host(const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
+                              const rpt_material_data *mats, size_t nm, uint32_t *rule_out, double *visits_out /* [4] */, uint32_t *probe_rays_out,
+                              uint8_t *flip_out /* (nn - 1) / 2, nullable */) {
+    if (!pv || !idx || !nodes || !mats || nn == 0) return RPT_EINVAL;
+    bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
+    for (size_t i = 0; i < nn; ++i) {
+        const rpt_bvh_node &n = nodes[i];
+        if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
+        if (n.triangle_count != 0u && (size_t)n.left_or_first + n.triangle_count > nt) return RPT_ESCENE;
+    }
+    for (size_t t = 0; t < nt; ++t)
+        if (idx[t].v0 >= nv || idx[t].v1 >= nv || idx[t].v2 >= nv || idx[t].material >= nm) return RPT_ESCENE;
+    const LastOrder lo = choose_last_order(pv, idx, nt, nodes, nn, mats, pair_shaped);
+    if (rule_out) *rule_out = (uint32_t)lo.rule;
+    if (visits_out) for (int k = 0; k < 4; ++k) visits_out[k] = lo.visits[k];
+    if (probe_rays_out) *probe_rays_out = lo.probe_rays;
+    if (flip_out && !lo.flip.empty()) memcpy(flip_out, lo.flip.data(), lo.flip.size());
     return RPT_OK;
 }
 
@@ -581,7 +616,7 @@ void rpt_destroy(rpt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rpt_comm_release(c);
     release_state(c);
-    c->gpairs.release(); c->glinks.release(); c->lds_image_shadow.release(); c->gpairs_shadow.release(); c->glinks_shadow.release();
+    c->gpairs.release(); c->glinks.release(); c->lds_image_shadow.release(); c->lds_image_last.release(); c->gpairs_shadow.release(); c->glinks_shadow.release();
     c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_isect.release(); c->tri_shade.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->light_rec.release(); c->atlas.release(); c->skybox.release();
@@ -803,6 +838,42 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     sections.mark("shadow_order");
     if (!s.lds_image_shadow) c->lds_image_shadow.release();
     if (!s.gpairs_shadow) { c->gpairs_shadow.release(); c->glinks_shadow.release(); }
+    /* The last extension rays of a batch without NEE only have to say "hit or miss" unless they can end on an emitter (k_traverse.h
+     * k_traverse_nearest_stream LAST): the triangles whose material emits (lib.rs:86: emissive.xyz() != 0, a NaN counts), if they are few enough to test
+     * each ray against; and room behind the LDS image for the flipped copy's pair records (two 1 024-thread workgroups per CU: 80 KB each). */
+    s.last_emit_n = 0u;
+    s.last_flip_vecs = 0u;
+    for (uint32_t k = 0; k < RPT_LAST_EMIT_MAX; ++k) s.last_emit_tri[k] = 0u;
+    for (size_t t = 0; t < nt && s.last_emit_n <= RPT_LAST_EMIT_MAX; ++t) {
+        const float *e = mats[idx[t].material].emissive;
+        if (!(e[0] == 0.0f && e[1] == 0.0f && e[2] == 0.0f)) {
+            if (s.last_emit_n < RPT_LAST_EMIT_MAX) s.last_emit_tri[s.last_emit_n] = (uint32_t)t;
+            s.last_emit_n += 1u;
+        }
+    }
+    if (const char *env = getenv("RPT_LAST_BOUNCE_HIT_OR_MISS"); env && env[0] == '0') s.last_emit_n = RPT_LAST_EMIT_MAX + 1u;      /* A/B and tests: the plain launch */
+    s.lds_image_last = nullptr;
+    c->last_order = LastOrder();
+    if (s.lds_scene && s.last_emit_n <= RPT_LAST_EMIT_MAX) {
+        /* the order those rays walk in (shadow_order.h choose_last_order): near child first over the primary image, or a fixed order over a copy whose pairs
+         * are flipped by the rule that needed the fewest node visits on probe rays of their kind */
+        c->last_order = choose_last_order(pv, idx, nt, nodes, nn, mats, pair_shaped);
+        const size_t flip_vecs = 6 * (size_t)s.lds_pairs + ((size_t)s.lds_pairs + 3) / 4;
+        if (c->last_order.rule != 0 && ((size_t)s.lds_vecs + flip_vecs) * sizeof(float4) + 32 * 1024 + 64 <= 80 * 1024) {
+            const std::vector<rpt_bvh_node> pool = flipped_nodes(nodes, nn, c->last_order.flip);
+            std::vector<float4> image;
+            uint32_t pairs = 0, root = 0;
+            if (build_lds_image(pool.data(), nn, geom, nt, image, pairs, root) && image.size() == (size_t)s.lds_vecs && pairs == s.lds_pairs && root == s.lds_root) {
+                HIP_TRY(c, c->lds_image_last.alloc(std::max<size_t>(1, flip_vecs)));
+                HIP_TRY(c, hipMemcpy(c->lds_image_last.p, image.data(), flip_vecs * sizeof(float4), hipMemcpyHostToDevice));
+                s.lds_image_last = c->lds_image_last.p;
+                s.last_flip_vecs = (uint32_t)flip_vecs;
+            }
+        }
+        if (!s.lds_image_last) c->last_order.rule = 0;
+    }
+    if (!s.lds_image_last) c->lds_image_last.release();
+    sections.mark("last_order");
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
     s.fastdiv_ok = 1u;
     for (size_t i = 0; i < nn && s.fastdiv_ok; ++i)

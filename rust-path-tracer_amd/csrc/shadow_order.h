@@ -226,6 +226,115 @@ inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_
     return so;
 }
 
+/* ---- the hit-or-miss lanes of the last extension rays (k_traverse.h k_traverse_nearest_stream LAST) -------------------------------------------------
+ * Without NEE the last extension ray of a path that cannot end on an emitter only has to say "hit or miss": the part of the reference's walk up to its first
+ * accepted triangle, which is an any-hit walk (result.t is 1e6 throughout) and as free in its order as a shadow query.  These rays are not shadow rays — they
+ * leave a surface in a direction the BSDF drew, and in a closed scene all of them hit — so the order is chosen on rays of their kind: points by area on the
+ * non-emissive triangles, cosine-distributed directions about the shading normal, walked on the host near child first (the primary image: no second copy
+ * needed) and in fixed order under three rules that put into the left slot the child that is (1) more opaque, (2) the smaller subtree, (3) more opaque per
+ * node of its subtree — the classic "most likely per unit of cost first" for a search that stops at its first success.  tools/last_bounce_sim.py and the
+ * replay of the real bounce-3 rays of DarkCornell: 18.9 node visits near first, 15.2 / 12.2 / 11.9 under the three rules (the whole walk: 25.8).  LDS-image scenes only
+ * (the only ones with a LAST kernel): a few hundred nodes, the probe is a fraction of a millisecond. */
+#define LAST_PROBE_RAYS 1024
+struct LastOrder {
+    int rule = 0;                       /* 0: near child first on the primary image; 1..3: fixed order over a copy flipped by that rule */
+    std::vector<uint8_t> flip;
+    double visits[4] = {0.0, 0.0, 0.0, 0.0};   /* node visits per probe ray: near first, rules 1..3 */
+    uint32_t probe_rays = 0, probe_hits = 0;
+    double probe_ms = 0.0;
+};
+
+inline LastOrder choose_last_order(const rpt_per_vertex_data *pv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
+                                   const rpt_material_data *mats, bool pair_shaped) {
+    using namespace shadow_order_detail;
+    LastOrder lo;
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Stamp { LastOrder &lo; std::chrono::steady_clock::time_point t0; ~Stamp() { lo.probe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } stamp{lo, t_begin};
+    if (!pair_shaped || nn < 3 || nt == 0) return lo;
+    std::vector<double> area(nn, 0.0), tri_area(nt, 0.0), count(nn, 1.0);
+    for (size_t t = 0; t < nt; ++t) {
+        V a = vtx(pv[idx[t].v0]);
+        V x = cross(sub(vtx(pv[idx[t].v1]), a), sub(vtx(pv[idx[t].v2]), a));
+        tri_area[t] = 0.5 * std::sqrt((double)dot(x, x));
+    }
+    {
+        std::vector<uint32_t> order;
+        order.reserve(nn);
+        std::vector<uint32_t> st(1, 0u);
+        while (!st.empty()) {
+            uint32_t n = st.back(); st.pop_back();
+            order.push_back(n);
+            if (nodes[n].triangle_count == 0u) { st.push_back(nodes[n].left_or_first); st.push_back(nodes[n].left_or_first + 1u); }
+        }
+        for (size_t i = order.size(); i-- > 0;) {
+            const rpt_bvh_node &n = nodes[order[i]];
+            if (n.triangle_count == 0u) {
+                area[order[i]] = area[n.left_or_first] + area[n.left_or_first + 1u];
+                count[order[i]] = 1.0 + count[n.left_or_first] + count[n.left_or_first + 1u];
+            } else for (uint32_t k = 0; k < n.triangle_count; ++k) area[order[i]] += tri_area[n.left_or_first + k];
+        }
+    }
+    auto opacity = [&](uint32_t n) {
+        const rpt_bvh_node &b = nodes[n];
+        const double ex = (double)b.aabb_max[0] - b.aabb_min[0], ey = (double)b.aabb_max[1] - b.aabb_min[1], ez = (double)b.aabb_max[2] - b.aabb_min[2];
+        return std::min(1.0, area[n] / std::max(ex * ey + ey * ez + ez * ex, 1e-30));
+    };
+    const size_t P = (nn - 1) / 2;
+    std::vector<uint8_t> flips[4];
+    for (int r = 1; r <= 3; ++r) flips[r].assign(P, 0);
+    for (size_t p = 0; p < P; ++p) {
+        const uint32_t L = (uint32_t)(2 * p + 1), R = L + 1u;
+        flips[1][p] = opacity(R) > opacity(L) ? 1 : 0;
+        flips[2][p] = count[R] < count[L] ? 1 : 0;
+        flips[3][p] = opacity(R) / count[R] > opacity(L) / count[L] ? 1 : 0;
+    }
+    std::vector<double> cdf(nt);
+    double total = 0.0;
+    auto emissive = [&](size_t t) { const float *e = mats[idx[t].material].emissive; return e[0] != 0.0f || e[1] != 0.0f || e[2] != 0.0f; };
+    for (size_t t = 0; t < nt; ++t) { total += emissive(t) ? 0.0 : tri_area[t]; cdf[t] = total; }
+    if (!(total > 0.0)) return lo;
+    ProbeRng rng{0x2545f4914f6cdd1dull};
+    uint64_t v[4] = {0, 0, 0, 0};
+    for (int i = 0; i < LAST_PROBE_RAYS; ++i) {
+        const double pick = (double)rng.next() * total;
+        const size_t t0 = std::min((size_t)(std::lower_bound(cdf.begin(), cdf.end(), pick) - cdf.begin()), nt - 1);
+        const V a = vtx(pv[idx[t0].v0]), b = vtx(pv[idx[t0].v1]), c = vtx(pv[idx[t0].v2]);
+        const float s = std::sqrt(rng.next()), r2 = rng.next(), wa = 1.0f - s, wb = s * (1.0f - r2), wc = s * r2;
+        const V p{wa * a.x + wb * b.x + wc * c.x, wa * a.y + wb * b.y + wc * c.y, wa * a.z + wb * b.z + wc * c.z};
+        const float *na = pv[idx[t0].v0].normal, *nb = pv[idx[t0].v1].normal, *nc = pv[idx[t0].v2].normal;
+        V n{na[0] + nb[0] + nc[0], na[1] + nb[1] + nc[1], na[2] + nb[2] + nc[2]};
+        const float nl = std::sqrt(dot(n, n));
+        const float u1 = rng.next(), u2 = rng.next();
+        if (!(nl > 1e-12f)) continue;
+        n = V{n.x / nl, n.y / nl, n.z / nl};
+        /* cosine-distributed direction about n */
+        const V h = std::fabs(n.x) < 0.5f ? V{1, 0, 0} : V{0, 1, 0};
+        V t = cross(n, h);
+        const float tl = std::sqrt(dot(t, t));
+        t = V{t.x / tl, t.y / tl, t.z / tl};
+        const V bt = cross(n, t);
+        const float r = std::sqrt(u1), phi = 6.2831853f * u2, x = r * std::cos(phi), y = r * std::sin(phi), z = std::sqrt(std::fmax(0.0f, 1.0f - u1));
+        const V d{x * t.x + y * bt.x + z * n.x, x * t.y + y * bt.y + z * n.y, x * t.z + y * bt.z + z * n.z};
+        if (d.x == 0.0f || d.y == 0.0f || d.z == 0.0f) continue;
+        const V o{p.x + n.x * 0.001f, p.y + n.y * 0.001f, p.z + n.z * 0.001f};
+        bool hit = false;
+        v[0] += walk<false>(nodes, pv, idx, flips[1], o, d, 1000000.0f, hit);
+        for (int q = 1; q <= 3; ++q) v[q] += walk<true>(nodes, pv, idx, flips[q], o, d, 1000000.0f, hit);
+        lo.probe_rays += 1;
+        lo.probe_hits += hit ? 1u : 0u;
+    }
+    if (lo.probe_rays == 0) return lo;
+    for (int q = 0; q < 4; ++q) lo.visits[q] = (double)v[q] / lo.probe_rays;
+    int best = 1;
+    for (int q = 2; q <= 3; ++q) if (lo.visits[q] < lo.visits[best]) best = q;
+    lo.rule = lo.visits[best] < SHADOW_FIXED_GAIN * lo.visits[0] ? best : 0;
+    if (const char *env = getenv("RPT_LAST_ORDER")) {              /* near | opaque | small | ratio: tests and A/B */
+        if (!strcmp(env, "near")) lo.rule = 0; else if (!strcmp(env, "opaque")) lo.rule = 1; else if (!strcmp(env, "small")) lo.rule = 2; else if (!strcmp(env, "ratio")) lo.rule = 3;
+    }
+    if (lo.rule != 0) lo.flip = flips[lo.rule];
+    return lo;
+}
+
 /* the node pool with the children of every flipped pair exchanged (contents move, pair positions stay: links into pairs remain valid) */
 inline std::vector<rpt_bvh_node> flipped_nodes(const rpt_bvh_node *nodes, size_t nn, const std::vector<uint8_t> &flip) {
     std::vector<rpt_bvh_node> out(nodes, nodes + nn);

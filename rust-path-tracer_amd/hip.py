@@ -23,7 +23,7 @@ EXPORTS = [
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
-    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_build_fingerprint", "rpt_debug_comm_selftest", "rpt_device_info", "rpt_shadow_order", "rpt_debug_shadow_order_host",
+    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_build_fingerprint", "rpt_debug_comm_selftest", "rpt_device_info", "rpt_shadow_order", "rpt_debug_shadow_order_host", "rpt_last_bounce_order", "rpt_debug_last_order_host",
 ]
 COMM_ID_BYTES = 128
 MULTI_ALLOW_SHARED_DEVICE = 1
@@ -83,6 +83,7 @@ def lib():
         L.rpt_comm_init_local.argtypes = [C.c_void_p]
         L.rpt_device_info.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rpt_shadow_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        L.rpt_last_bounce_order.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         L.rpt_debug_comm_selftest.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
         L.rpt_comm_world.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.rpt_gather_async.argtypes = [C.c_void_p]
@@ -275,6 +276,18 @@ class Renderer:
         self._check(lib().rpt_shadow_order(self._h, C.byref(f), C.byref(vn), C.byref(vf), C.byref(n), C.byref(ms)))
         return {"fixed": bool(f.value), "visits_near": vn.value, "visits_fixed": vf.value, "probe_rays": n.value, "probe_ms": ms.value}
 
+    LAST_BOUNCE_MODES = ("whole walk", "hit or miss, near child first", "hit or miss, more opaque child first", "hit or miss, smaller subtree first",
+                         "hit or miss, more opaque per node first")
+
+    def last_bounce_order(self):
+        """rpt_last_bounce_order: how the last extension rays of a batch without NEE are walked on the uploaded scene (every mode gives the same image)."""
+        m, ne, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        v = (C.c_double * 4)()
+        ms = C.c_double()
+        self._check(lib().rpt_last_bounce_order(self._h, C.byref(m), C.byref(ne), v, C.byref(n), C.byref(ms)))
+        return {"mode": m.value, "mode_is": self.LAST_BOUNCE_MODES[m.value], "emissive_triangles": ne.value, "probe_rays": n.value, "probe_ms": ms.value,
+                "probe_node_visits": {"near child first": v[0], "more opaque first": v[1], "smaller subtree first": v[2], "more opaque per node first": v[3]}}
+
     def comm_world(self):
         r, w = C.c_uint32(), C.c_uint32()
         self._check(lib().rpt_comm_world(self._h, C.byref(r), C.byref(w)))
@@ -463,6 +476,21 @@ def tile_order(width, height, rank, world_size):
     if rc != 0:
         raise RptError(rc, "rpt_tile_order")
     return out
+
+
+def last_order_host(world):
+    """rpt_debug_last_order_host: the upload-time decision about the order of the hit-or-miss lanes of the last extension rays, without a GPU."""
+    r, n = C.c_uint32(), C.c_uint32()
+    v = (C.c_double * 4)()
+    flip = np.zeros(max(1, (len(world.nodes) - 1) // 2), np.uint8)
+    L = lib()
+    L.rpt_debug_last_order_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_void_p]
+    rc = L.rpt_debug_last_order_host(ptr(world.per_vertex), len(world.per_vertex), ptr(world.indices), len(world.indices), ptr(world.nodes), len(world.nodes),
+                                     ptr(world.materials), len(world.materials), C.byref(r), v, C.byref(n), ptr(flip))
+    if rc != 0:
+        raise RptError(rc, "rpt_debug_last_order_host")
+    return {"rule": r.value, "visits": [v[k] for k in range(4)], "probe_rays": n.value, "flip": flip}
 
 
 def shadow_order_host(world):
