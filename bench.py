@@ -328,7 +328,7 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
         pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
         roofline, whole = stage_roofline(hip, name, s0, s1, steps, elapsed, cus, clock_mhz, pipeline_bytes)
         pgbs = pipeline_bytes / elapsed / 1e9
-        order = shadow_order_label(r)
+        order, last_order = shadow_order_label(r), last_bounce_label(r)
         par = None
         if parity:
             image, image_spp = r.read_accum()
@@ -352,7 +352,7 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
             "data": ("fixtures/" + scene + ".glb (reference scene file)" if not scene.startswith("procedural:")
                      else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
             "config": {"workload": workload_label(scene, W, H, steps, spp_per_step, total_spp, cfg), "spp_per_step": spp_per_step,
-                       "shadow_order": order},
+                       "shadow_order": order, "last_bounce_order": last_order},
             "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "shadow_elided": int(n_elided), "sky_evals": int(n_sky),
                      "per_sample": round((n_ext + n_shadow) / max(n_samples, 1), 4),
                      "per_sample_as_the_reference_counts": round((n_ext + n_shadow + n_elided) / max(n_samples, 1), 4)},
@@ -364,6 +364,13 @@ def shadow_order_label(r):
     so = r.shadow_order()
     return {"order": "fixed, more opaque child first" if so["fixed"] else "near child first", "probe_rays": so["probe_rays"],
             "probe_node_visits_near_first": round(so["visits_near"], 2), "probe_node_visits_fixed": round(so["visits_fixed"], 2)}
+
+
+def last_bounce_label(r):
+    """How the last extension rays of a batch without NEE are walked on this scene (rpt_last_bounce_order; every mode gives the same image)."""
+    lo = r.last_bounce_order()
+    return {"mode": lo["mode_is"], "emissive_triangles": lo["emissive_triangles"], "probe_rays": lo["probe_rays"],
+            "probe_node_visits": {k: round(v, 2) for k, v in lo["probe_node_visits"].items()}}
 
 
 def launch_ranks(n, argv):
@@ -684,7 +691,7 @@ def main():
 
     # --- parity inside the benchmark run: windows of the image the timed loop rendered vs the CPU oracle at the same sample
     # count; a mismatch fails the bench.
-    order = shadow_order_label(r)
+    order, last_order = shadow_order_label(r), last_bounce_label(r)
     parity = None
     if bench_image is not None:
         parity = parity_windows(world, cfg, seeds, bench_image, bench_image_spp, args.spp_per_step * (args.warmup + args.steps), W, H)
@@ -716,7 +723,7 @@ def main():
         "config": {"workload": workload_label(scene, W, H, args.steps, args.spp_per_step, total_spp, cfg),
                    "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU",
                    "kernel_sources": hip.build_fingerprint(), "gather": gather_impl, "collective_library": hip.comm_library() or None,
-                   "rpt_comm_world": comm_world_seen, "shadow_order": order},
+                   "rpt_comm_world": comm_world_seen, "shadow_order": order, "last_bounce_order": last_order},
         "samples_per_s": round(n_samples / elapsed_max, 1),
         "value_as_the_reference_counts": round((rays + n_elided) / elapsed_max / 1e6, 3),
         "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "shadow_elided": int(n_elided), "sky_evals": int(n_sky),

@@ -505,7 +505,7 @@ int rpt_shadow_order(rpt_ctx *c, uint32_t *fixed_out, double *visits_near_out, d
 int rpt_last_bounce_order(rpt_ctx *c, uint32_t *mode_out, uint32_t *n_emissive_out, double *visits_out, uint32_t *probe_rays_out, double *probe_ms_out) {
     if (!c) return RPT_EINVAL;
     if (!c->has_scene) { c->error = "rpt_last_bounce_order: no scene"; return RPT_EINVAL; }
-    const bool on = c->scene.lds_scene != 0u && c->lds_stream && c->scene.last_emit_n <= RPT_LAST_EMIT_MAX;
+    const bool on = c->scene.lds_scene != 0u && c->lds_stream && c->stack_cap == 16 && c->scene.last_emit_n <= RPT_LAST_EMIT_MAX;
     if (mode_out) *mode_out = !on ? 0u : 1u + (uint32_t)c->last_order.rule;
     if (n_emissive_out) *n_emissive_out = c->scene.last_emit_n;
     if (visits_out) for (int k = 0; k < 4; ++k) visits_out[k] = c->last_order.visits[k];

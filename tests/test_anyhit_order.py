@@ -100,3 +100,60 @@ def test_a_flipped_tree_is_the_same_tree(sim, hipmod, oracle, rpt, world):
     sim.sim_any_hit_order(C.byref(sc), C.c_size_t(n), _p(o), _p(d), _p(max_t), 0, C.c_uint32(0), _p(a))
     sim.sim_any_hit_order(C.byref(sc2), C.c_size_t(n), _p(o), _p(d), _p(max_t), 1, C.c_uint32(0), _p(b))          # left first = the preferred child first
     assert np.array_equal(a, b) and 0 < a.sum() < n
+
+
+@pytest.mark.parametrize("scene", ["DarkCornell", "PBRTest"])
+def test_the_nearest_walk_says_hit_at_its_first_accept_in_any_order(sim, oracle, rpt, world, scene):
+    """What the last extension rays of a batch without NEE rest on (k_traverse.h k_traverse_nearest_stream LAST): intersect_nearest's `.hit`
+    (intersection.rs:169-171) is decided at the first triangle its walk accepts — result.t is 1e6 until then, exactly the any-hit walk with
+    max_t = 1e6 — so it equals the any-hit answer under EVERY visiting order; and a ray whose nearest hit is an emissive triangle passes that
+    triangle's Moller-Trumbore test (so a ray that passes none cannot end on one)."""
+    w = world(scene)
+    sc = oracle.scene(w)
+    rng = np.random.default_rng(47)
+    n = 200_000
+    o, d, _ = _shadow_like_rays(rng, n, w)
+    t, tri, flags, _ = oracle.trace_rays(sc, 0, o, d)                           # intersect_front_to_back<true>
+    hit = (flags & 1).astype(np.uint8)
+    assert 0.02 * n < hit.sum() < 0.999 * n
+    far = np.full(n, 1000000.0, np.float32)
+    for mode, seed in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 1), (5, 0)):
+        got = np.zeros(n, np.uint8)
+        sim.sim_any_hit_order(C.byref(sc), C.c_size_t(n), _p(o), _p(d), _p(far), mode, C.c_uint32(seed), _p(got))
+        assert np.array_equal(got, hit), (scene, mode, int((got != hit).sum()))
+    em = w.materials["emissive"][:, :3]
+    em_tris = np.nonzero(np.isin(w.indices["material"], [m for m in range(len(em)) if np.any(em[m] != 0)]))[0]
+    if len(em_tris):
+        # rays aimed at the emitters: the ones whose walk ends on one are accepted by that triangle in the brute-force walk too (mode 2 tests every
+        # triangle on its own: the Moller-Trumbore test of the emitter passed)
+        m = 40_000
+        v = w.per_vertex["vertex"][:, :3]
+        lo, hi = v.min(axis=0), v.max(axis=0)
+        o2 = (lo + (hi - lo) * rng.random((m, 3))).astype(np.float32)
+        tr = w.indices[em_tris[rng.integers(0, len(em_tris), m)]]
+        bary = rng.dirichlet((1.0, 1.0, 1.0), m).astype(np.float32)
+        target = bary[:, :1] * v[tr["v0"]] + bary[:, 1:2] * v[tr["v1"]] + bary[:, 2:] * v[tr["v2"]]
+        d2 = (target - o2).astype(np.float32)
+        d2 /= np.maximum(np.linalg.norm(d2, axis=1), 1e-6)[:, None].astype(np.float32)
+        o2, d2 = np.ascontiguousarray(o2), np.ascontiguousarray(d2.astype(np.float32))
+        _, tri2, flags2, _ = oracle.trace_rays(sc, 0, o2, d2)
+        ends_on_emitter = ((flags2 & 1) == 1) & np.isin(tri2, em_tris)
+        assert ends_on_emitter.sum() > 1000          # (the light is occluded from most of the box by its own housing)
+        _, tri_b, flags_b, _ = oracle.trace_rays(sc, 2, o2[ends_on_emitter], d2[ends_on_emitter])
+        assert np.all(flags_b & 1)
+
+
+def test_the_upload_time_choice_of_the_last_rays_order(hipmod, rpt, world, monkeypatch):
+    """csrc/shadow_order.h choose_last_order through rpt_debug_last_order_host (host code, no GPU): on the closed box every fixed rule finds a first hit
+    in fewer node visits than the reference's near-first order and the best one is taken; deterministic; RPT_LAST_ORDER overrides; the flip it hands
+    out is a proper subset of the pairs."""
+    monkeypatch.delenv("RPT_LAST_ORDER", raising=False)
+    dc = hipmod.last_order_host(world("DarkCornell"))
+    assert dc["rule"] in (1, 2, 3) and dc["probe_rays"] > 500
+    assert dc["visits"][dc["rule"]] == min(dc["visits"][1:]) < 0.95 * dc["visits"][0]
+    assert 0 < dc["flip"].sum() < len(dc["flip"])
+    again = hipmod.last_order_host(world("DarkCornell"))
+    assert again["visits"] == dc["visits"] and np.array_equal(again["flip"], dc["flip"])
+    for name, rule in (("near", 0), ("opaque", 1), ("small", 2), ("ratio", 3)):
+        monkeypatch.setenv("RPT_LAST_ORDER", name)
+        assert hipmod.last_order_host(world("DarkCornell"))["rule"] == rule

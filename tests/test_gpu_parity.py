@@ -253,6 +253,101 @@ def test_the_library_chooses_the_shadow_order_per_scene(monkeypatch, hipmod, rpt
         r.close()
 
 
+def _with_emissive_materials(rpt, w, how_many_triangles):
+    """a copy of the world in which the materials of the first few non-emissive triangles (in material order) emit as well: nee = 0 reads no light table"""
+    import copy
+    w2 = copy.copy(w)
+    w2.materials = w.materials.copy()
+    em = w2.materials["emissive"]
+    tri_mat = w.indices["material"]
+    have = int(sum((tri_mat == m).sum() for m in range(len(em)) if np.any(em[m, :3] != 0)))
+    for m in np.argsort([int((tri_mat == m).sum()) for m in range(len(em))]):
+        n = int((tri_mat == m).sum())
+        if n == 0 or np.any(em[m, :3] != 0):
+            continue
+        if have + n > how_many_triangles:
+            continue
+        em[m] = (1.5, 0.25, 4.0, 0.0)
+        have += n
+    return w2, have
+
+
+LAST_MODES = {"off": ("RPT_LAST_BOUNCE_HIT_OR_MISS", "0", 0), "near": ("RPT_LAST_ORDER", "near", 1), "opaque": ("RPT_LAST_ORDER", "opaque", 2),
+              "small": ("RPT_LAST_ORDER", "small", 3), "ratio": ("RPT_LAST_ORDER", "ratio", 4)}
+
+
+@pytest.mark.parametrize("mode", sorted(LAST_MODES))
+@pytest.mark.parametrize("case", ["cornell", "cornell_two_bounces", "cornell_roulette", "cornell_more_emitters", "cornell_too_many_emitters", "textured_open"])
+def test_last_extension_rays_may_stop_at_their_first_hit(monkeypatch, hipmod, oracle, rpt, world, case, mode):
+    """Without NEE the last extension ray of a path adds the sky on a miss, the emission of an emitter's front, and nothing otherwise (kernels/src/lib.rs:62-109):
+    in a batch of known length the rays of that launch which pass the Moller-Trumbore test of no emissive triangle stop at their first accepted triangle
+    (k_traverse_nearest_stream LAST), near child first or in one of three fixed orders over a flipped copy of the pair records — and with more than four
+    emissive triangles, or switched off, they walk to the end.  Every mode gives the oracle's accumulators bit for bit: closed box, open textured scene
+    with an image skybox, two bounces (the last ray is the second), roulette from the first bounce on, more emitters to test against."""
+    var, val, expect = LAST_MODES[mode]
+    monkeypatch.delenv("RPT_LAST_ORDER", raising=False)
+    monkeypatch.delenv("RPT_LAST_BOUNCE_HIT_OR_MISS", raising=False)
+    monkeypatch.setenv(var, val)
+    skybox = None
+    over = {}
+    W, H, spp = 160, 96, 8
+    if case == "textured_open":
+        from scenes import textured_scene
+        w, skybox = textured_scene()
+        over = {"has_skybox": 1, "cam_position": (0.0, 1.6, -4.0, 0.0), "cam_rotation": (0.05, 0.1, 0.0, 0.0)}
+    else:
+        w = world("DarkCornell")
+        if case == "cornell_two_bounces":
+            over = {"min_bounces": 1, "max_bounces": 2}
+        elif case == "cornell_roulette":
+            over = {"min_bounces": 0, "max_bounces": 5}
+        elif case == "cornell_more_emitters":
+            w, n_em = _with_emissive_materials(rpt, w, 4)
+            assert 2 < n_em <= 4
+        elif case == "cornell_too_many_emitters":
+            w, n_em = _with_emissive_materials(rpt, w, 40)
+            assert n_em > 4
+            expect = 0
+    cfg = rpt.default_config(W, H, nee=0, **over)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    try:
+        r.upload_scene(w, skybox_f32=skybox)
+        lo = r.last_bounce_order()
+        if lo["mode"] != 0 or expect == 0:
+            assert lo["mode"] == expect, lo
+        r.set_config(cfg); r.reset(seeds)
+        r.render(spp)
+        acc_g, _ = r.read_accum()
+        st_g = r.stats()
+    finally:
+        r.close()
+    acc_c, _, st_c = oracle.trace_cpu(cfg, oracle.scene(w, skybox_f32=skybox), seeds, spp)
+    assert st_g["extension_rays"] == st_c.extension_rays and st_g["sky_evals"] == st_c.sky_evals
+    assert np.array_equal(acc_g.view(np.uint32), acc_c.view(np.uint32))
+
+
+def test_the_library_chooses_the_order_of_the_last_rays_per_scene(monkeypatch, hipmod, rpt, world):
+    """rpt_last_bounce_order after rpt_upload_scene: DarkCornell (two emissive triangles, lives in LDS) walks those rays in a fixed order its probe favoured;
+    a scene that does not live in LDS keeps the whole walk; the decision is the host probe's (rpt_debug_last_order_host) and is re-taken on every upload."""
+    monkeypatch.delenv("RPT_LAST_ORDER", raising=False)
+    monkeypatch.delenv("RPT_LAST_BOUNCE_HIT_OR_MISS", raising=False)
+    r = hipmod.Renderer(0)
+    try:
+        r.upload_scene(world("DarkCornell"))
+        lo = r.last_bounce_order()
+        host = hipmod.last_order_host(world("DarkCornell"))
+        assert lo["mode"] == 1 + host["rule"] >= 2 and lo["emissive_triangles"] == 2 and lo["probe_rays"] == host["probe_rays"] > 500
+        v = lo["probe_node_visits"]
+        assert list(v.values()) == host["visits"] and min(list(v.values())[1:]) < 0.95 * v["near child first"]
+        r.upload_scene(world("PBRTest"))
+        assert r.last_bounce_order()["mode"] == 0
+        r.upload_scene(world("DarkCornell"))
+        assert r.last_bounce_order()["mode"] == lo["mode"]
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("nee,has_skybox", [(0, 1), (1, 1), (2, 0), (1, 0)])
 def test_textured_scene_and_image_skybox_parity(renderer, oracle, rpt, nee, has_skybox):
     """Atlas sampling (CPU-polyfill semantics, image_polyfill.rs:32-55), normal mapping (lib.rs:132-141), uv wrap
