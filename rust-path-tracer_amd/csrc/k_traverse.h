@@ -952,6 +952,12 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
     bool have = false;                                         /* this lane holds a ray whose result is not written yet */
     bool pool_open = true;                                     /* wave-uniform: the launch may still have slots */
     uint32_t traced = 0u;                                      /* wave-uniform */
+    /* LAST: a hit-or-miss lane that hit knows what the shade stage's last iteration would find out from the triangle's material — not an emitter, the sample
+     * is finished with the radiance it has — and with several slots per pixel says so itself (HIT_DONE: k_shade.h, the `else` of the last iteration) */
+    const bool done_here = LAST && st.group_shift != 0u;
+    auto last_word = [&](const HitRecord &r, uint32_t stopped) {
+        return (done_here && stopped != 0u && r.tri != HIT_MISS) ? make_float2(0.0f, __uint_as_float(HIT_DONE)) : make_float2(r.t, __uint_as_float(r.tri));
+    };
     for (;;) {
         const unsigned long long idle_m = rpt_ballot(w.cur == LDS_DESC_DEAD);
         const uint32_t n_idle = (uint32_t)__popcll(idle_m);
@@ -965,7 +971,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
             bool took = false;
             if (w.cur == LDS_DESC_DEAD) {
                 if (have) {
-                    st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
+                    st.hit[slot] = last_word(w.res, stop_first);
                     have = false;
                 }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
@@ -1012,7 +1018,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
         if (LAST) lds_walk_run<STACK, false, true, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff, img_lane, stop_first, order_bias);
         else lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
     }
-    if (have) st.hit[slot] = make_float2(w.res.t, __uint_as_float(w.res.tri));
+    if (have) st.hit[slot] = last_word(w.res, stop_first);
     /* ray accounting + the alive flag, once per wave */
     if (lane == 0u && traced != 0u) {
         raise_flag(&q.count[Q_ALIVE0 + (iteration & 1u) * Q_LINE]);
