@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from oracle_ffi import Oracle, _p  # noqa: E402
 
 rpt = importlib.import_module("rust-path-tracer_amd")
@@ -92,6 +93,38 @@ def main():
                   + ("   <- the last bounce" if b == last else ""))
         n, full, first, mixed, me = tot[last]
         print(f"  all bounces: node visits {allfull} -> {allfull - full + mixed} ({100.0 * ((allfull - full + mixed) / allfull - 1):+.1f} %) with the last bounce cut at its first accept")
+        replay_orders(orc, sc, cfg, name, W, H, last)
+
+
+def replay_orders(orc, sc, cfg, name, W, H, bounce):
+    """The part of the walk up to the first accept is an any-hit walk (result.t = 1e6 throughout): free in its visiting order like a shadow query.  The rays of
+    the last bounce through the streamed LDS kernel's replay (tools/anyhit_order_sim.cpp: waves of 64 lanes over spans of 512 rays, 16 trips between refills)
+    under the reference's near-first order and the static orders csrc/shadow_order.h choose_last_order picks from."""
+    import anyhit_order_sim as A
+    sim = A.build()
+    seeds = rpt.blue_noise_seeds(W, H)
+    rays = np.zeros((W * H, 6), np.float32)
+    valid = np.zeros(W * H, np.uint8)
+    orc.lib.oracle_dump_rays(C.byref(cfg), C.byref(sc), _p(seeds), C.c_uint32(bounce), _p(rays), _p(valid))
+    idx = np.array([(by * 8 + y) * W + bx * 8 + x for by in range(H // 8) for bx in range(W // 8) for y in range(8) for x in range(8)])   # a wave = an 8 x 8 pixel block
+    r = rays[idx][valid[idx] == 1]
+    sh = np.zeros((len(r), 8), np.float32)
+    sh[:, :6] = r
+    sh[:, 6] = 1e6
+    f = {k: i for i, k in enumerate(A.FIELDS)}
+    print(f"  the rays of bounce {bounce} as any-hit walks (max_t = 1e6), per visiting order:")
+    for oname, code in (("near child first (the reference's)", 0), ("larger box first", 20), ("more opaque child first (rule 1)", 21), ("smaller subtree first (rule 2)", 22),
+                        ("more opaque per node first (rule 3)", 23), ("opaque area per node first", 24)):
+        acc = np.zeros(24, np.float64)
+        for at in range(0, len(sh) - 511, 512):
+            span = np.ascontiguousarray(sh[at:at + 512])
+            out = np.zeros(24, np.uint64)
+            hit = np.zeros(512, np.uint8)
+            sim.sim_wave(C.byref(sc), _p(span), C.c_uint32(512), code, 16, 16, _p(out), _p(hit))
+            acc += out
+        n = acc[f["rays"]]
+        print(f"      {oname:38s} node visits per ray that hits {acc[f['visits_occluded']] / max(acc[f['occluded']], 1):6.2f}   inner trips per ray {acc[f['inner_trips']] / n:.3f}   "
+              f"leaf trips {acc[f['leaf_trips']] / n:.3f}   triangle iterations {acc[f['leaf_iters']] / n:.3f}   lanes per inner trip {acc[f['inner_lanes']] / max(acc[f['inner_trips']], 1):.1f}")
 
 
 if __name__ == "__main__":
