@@ -656,11 +656,15 @@ __device__ __forceinline__ void lds_walk_begin(const SceneViewLds &view, LdsWalk
  * any-hit walk, whose answer does not depend on the visiting order (header).  They read the planes and child descriptors of `img_lane` — the flipped copy
  * of the pair records when the workgroup staged one, then with order_bias = +inf (tl > tr + inf is never true: the left child first, the fixed order of
  * shadow_order.h choose_last_order); the other lanes read the primary image with order_bias = 0 (tr + 0 compares like tr) and are the reference's walk to its end. */
-template <int STACK, bool ANY_HIT, bool SIGNED, bool FIXED = false, bool MIXED = false>
+/* PRESUB (the camera rays of a call's first iteration, k_traverse_nearest_stream FIRST): every ray of the launch has the SAME origin, and the workgroup
+ * staged the plane records with that origin already subtracted — the very `plane - ro` (one IEEE subtraction of the same two floats) each lane would
+ * compute at each of the twelve planes of a node pair.  The slab test then divides the staged value directly; the triangle test keeps the true origin. */
+template <int STACK, bool ANY_HIT, bool SIGNED, bool FIXED = false, bool MIXED = false, bool PRESUB = false>
 __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &w, F3 ro, F3 rd, F3 ird, float max_t, uint16_t *stack,
                                              int budget, const float4 *img_lane = nullptr, uint32_t stop_first = 0u, float order_bias = 0.0f) {
     static_assert(!FIXED || ANY_HIT, "only the any-hit walk may choose its order");
     static_assert(!MIXED || (!ANY_HIT && !FIXED), "MIXED is the nearest-hit walk with per-lane early exits");
+    const F3 ro_slab = PRESUB ? f3(0.0f, 0.0f, 0.0f) : ro;         /* x - (+0) is x, bit for bit: the subtraction folds away */
     const uint32_t P = view.pairs;
     const float4 *img = MIXED ? img_lane : view.img;
     /* per-ray plane-record bases (float4 units): x | y | z, A or B variant by the sign of the direction */
@@ -690,8 +694,8 @@ __device__ __forceinline__ void lds_walk_run(const SceneViewLds &view, LdsWalk &
             const float4 X = px[cur], Y = py[cur], Z = pz[cur];     /* (L.near, R.near, L.far, R.far) per axis */
             const uint32_t d = descs[cur];
             float tl, tr;
-            const bool hit_l = slab_pair_lds<SIGNED>(X.x, Y.x, Z.x, X.z, Y.z, Z.z, ro, rd, ird, res.t, tl);
-            const bool hit_r = slab_pair_lds<SIGNED>(X.y, Y.y, Z.y, X.w, Y.w, Z.w, ro, rd, ird, res.t, tr);
+            const bool hit_l = slab_pair_lds<SIGNED>(X.x, Y.x, Z.x, X.z, Y.z, Z.z, ro_slab, rd, ird, res.t, tl);
+            const bool hit_r = slab_pair_lds<SIGNED>(X.y, Y.y, Z.y, X.w, Y.w, Z.w, ro_slab, rd, ird, res.t, tr);
             const bool swap = FIXED ? (hit_r && !hit_l)
                             : MIXED ? (hit_r && (!hit_l || tl > tr + order_bias))
                                     : (hit_r && (!hit_l || tl > tr));     /* strict: ties keep left first */
@@ -912,10 +916,17 @@ __device__ __forceinline__ uint32_t wg_pool_take(WgPool *pool, uint32_t *global_
  * end on one, so "hit or miss" is all its walk has to say: it stops at its first accepted triangle (lds_walk_run MIXED) — in a closed scene about half of
  * the node visits of the bounce (tools/last_bounce_sim.py).  Its hit record names THAT triangle: not the nearest one, but like the nearest one not an
  * emitter, which is all the shade stage's last iteration looks at.  A ray that does pass such a test runs the reference's walk to its end. */
-template <int STACK, int THREADS, bool LAST = false>
+/* FIRST: the launch of a render call's first iteration, where every ray is a camera ray and leaves cfg.cam_position (k_path.h camera_ray; lib.rs:36-60):
+ * the workgroup stages the plane records with that origin subtracted (lds_walk_run PRESUB) — twelve of the ~ 98 instructions of a node-pair step. */
+#define RPT_NEAREST_PLAIN 0
+#define RPT_NEAREST_LAST 1
+#define RPT_NEAREST_FIRST 2
+template <int STACK, int THREADS, int MODE = RPT_NEAREST_PLAIN>
 __attribute__((amdgpu_num_sgpr(RPT_LDS_WALK_SGPRS)))
 __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc, DevState st, DevQueues q, uint32_t iteration,
-                                                                       uint32_t SPAN /* slots a workgroup fetches at a time */) {
+                                                                       uint32_t SPAN /* slots a workgroup fetches at a time */,
+                                                                       float cam_x, float cam_y, float cam_z /* FIRST: the origin of every ray of the launch */) {
+    constexpr bool LAST = MODE == RPT_NEAREST_LAST, FIRST = MODE == RPT_NEAREST_FIRST;
     constexpr uint32_t NW = THREADS / RPT_WAVE;
     __shared__ uint16_t lds_stack[NW][STACK][RPT_WAVE];
     __shared__ WgPool pool;
@@ -939,7 +950,17 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
      * scene has one and the host found room for it (sc.last_flip_vecs float4; 0: those lanes walk the primary image near child first) */
     if (LAST)
         for (uint32_t k = threadIdx.x; k < sc.last_flip_vecs; k += THREADS) lds_scene[sc.lds_vecs + k] = sc.lds_image_last[k];
-    const SceneViewLds view = stage_scene_lds<THREADS>(sc, lds_scene);
+    if (FIRST) {
+        const uint32_t P2 = 2u * sc.lds_pairs;                 /* image layout (rpt_hip.hip build_lds_image): 2 P plane records per axis, x | y | z */
+        for (uint32_t k = threadIdx.x; k < 3u * P2; k += THREADS) {
+            const float4 v = sc.lds_image[k];
+            const float o = k < P2 ? cam_x : (k < 2u * P2 ? cam_y : cam_z);
+            lds_scene[k] = make_float4(v.x - o, v.y - o, v.z - o, v.w - o);
+        }
+        for (uint32_t k = 3u * P2 + threadIdx.x; k < sc.lds_vecs; k += THREADS) lds_scene[k] = sc.lds_image[k];
+        __syncthreads();
+    }
+    const SceneViewLds view = FIRST ? SceneViewLds{lds_scene, sc.lds_pairs, sc.n_triangles, sc.lds_root} : stage_scene_lds<THREADS>(sc, lds_scene);
     const float4 *img_lane = view.img;                         /* (per lane, LAST only) */
     uint32_t stop_first = 0u;
     float order_bias = 0.0f;
@@ -1001,8 +1022,10 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
                             }
                         } else {
                             /* outside the exact-division guard (a zero / denormal-small direction component): walked here, alone */
-                            HitRecord h = traverse_loop_lds<STACK, false, false>(view, ro, rd, rd, 0.0f, stack);
-                            st.hit[cand] = make_float2(h.t, __uint_as_float(h.tri));
+                            LdsWalk alone;
+                            lds_walk_begin(view, alone);
+                            lds_walk_run<STACK, false, false, false, false, FIRST>(view, alone, ro, rd, rd, 0.0f, stack, 0x7fffffff);
+                            st.hit[cand] = make_float2(alone.res.t, __uint_as_float(alone.res.tri));
                         }
                     }
                 }
@@ -1016,7 +1039,7 @@ __global__ __launch_bounds__(THREADS) void k_traverse_nearest_stream(DevScene sc
             continue;
         }
         if (LAST) lds_walk_run<STACK, false, true, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff, img_lane, stop_first, order_bias);
-        else lds_walk_run<STACK, false, true>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
+        else lds_walk_run<STACK, false, true, false, false, FIRST>(view, w, ro, rd, ird, 0.0f, stack, pool_open ? RPT_STREAM_TRIPS : 0x7fffffff);
     }
     if (have) st.hit[slot] = last_word(w.res, stop_first);
     /* ray accounting + the alive flag, once per wave */

@@ -50,6 +50,7 @@ struct rpt_ctx {
     std::string error;
     uint32_t rank = 0, world = 1;
     bool lds_stream = true;
+    bool first_presub = true;            /* iteration 0 walks plane records with the camera position already subtracted (k_traverse.h FIRST); RPT_FIRST_PRESUB=0: the plain launch */
     bool shade_compact = false;          /* shade stage variant in use: traversed slots packed per workgroup before shading (k_shade<.., COMPACT>) */
     int shade_compact_mode = -1;         /* -1 automatic (refresh_device_stats), 0 / 1 forced by RPT_SHADE_COMPACT */
     double shade_compact_at = 0.7;       /* automatic: on when more than this share of the samples ends in the sky */

@@ -275,7 +275,8 @@ static uint32_t gstream_span(const rpt_ctx *c, uint32_t most) {
 /* The nearest-hit traversal stage for the context's scene and state: which kernel, which grid.  Used by every iteration of a
  * render call and by rpt_debug_trace_rays_production (per-ray parity of exactly these kernels). */
 template <int STACK>
-void launch_nearest(rpt_ctx *c, uint32_t iteration, bool last_without_nee = false /* the last extension rays of a batch of known length, no NEE */) {
+void launch_nearest(rpt_ctx *c, uint32_t iteration, bool last_without_nee = false /* the last extension rays of a batch of known length, no NEE */,
+                    bool camera_rays = false /* iteration 0 of a render call: every ray leaves cfg.cam_position */) {
     hipStream_t s = c->stream;
     const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
@@ -291,9 +292,12 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration, bool last_without_nee = fals
         span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
         span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
         const uint32_t n_spans = (c->n_slots + span - 1) / span;
+        const float *cam = c->cfg.c.cam_position;
         if (last_without_nee && c->scene.last_emit_n <= RPT_LAST_EMIT_MAX)
-            k_traverse_nearest_stream<16, LDS_THREADS, true><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes + (size_t)c->scene.last_flip_vecs * sizeof(float4), s>>>(c->scene, c->state, c->queues, iteration, span);
-        else k_traverse_nearest_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span);
+            k_traverse_nearest_stream<16, LDS_THREADS, RPT_NEAREST_LAST><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes + (size_t)c->scene.last_flip_vecs * sizeof(float4), s>>>(c->scene, c->state, c->queues, iteration, span, 0.0f, 0.0f, 0.0f);
+        else if (camera_rays && c->first_presub)
+            k_traverse_nearest_stream<16, LDS_THREADS, RPT_NEAREST_FIRST><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span, cam[0], cam[1], cam[2]);
+        else k_traverse_nearest_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span, 0.0f, 0.0f, 0.0f);
     } else if (STACK == 16 && c->scene.lds_scene)
         k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
     else if (c->gstream && (!RPT_GSTREAM_PAIRS || c->scene.gpairs)) {
@@ -328,7 +332,8 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     const int stack_width = gstream_stack_width(c);
     const uint32_t gspan = gstream_span(c, (uint32_t)RPT_GSTREAM_RAYS), gblocks = (q_positions + gspan - 1) / gspan;            /* any-hit walk */
     /* (the shade stage's last_iteration, k_shade.h: in a batch of known length iteration k is bounce k of every path) */
-    launch_nearest<STACK>(c, iteration, NEE == RPT_NEE_NONE && c->queues.known_length != 0u && iteration != 0u && iteration + 1u >= c->cfg.c.max_bounces);
+    launch_nearest<STACK>(c, iteration, NEE == RPT_NEE_NONE && c->queues.known_length != 0u && iteration != 0u && iteration + 1u >= c->cfg.c.max_bounces,
+                          iteration == 0u);
     mark(true);
     if (c->shade_compact) k_shade<NEE, TEXTURED, true><<<(c->n_slots + RPT_BLOCK * RPT_SHADE_ROUNDS - 1) / (RPT_BLOCK * RPT_SHADE_ROUNDS), RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
     else k_shade<NEE, TEXTURED, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
@@ -587,6 +592,7 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (c->timing_level < 0 || c->timing_level > 2) c->timing_level = 0;
     c->stage_timing = c->timing_level != 0;
     if (const char *e2 = getenv("RPT_LDS_STREAM")) c->lds_stream = e2[0] != '0';
+    if (const char *e2 = getenv("RPT_FIRST_PRESUB")) c->first_presub = e2[0] != '0';
     if (const char *e10 = getenv("RPT_MAX_SLOTS")) c->max_slots_budget = (uint64_t)std::max(1ll, atoll(e10));
     if (const char *e6 = getenv("RPT_GSTREAM")) c->gstream = e6[0] != '0';
     if (const char *e11 = getenv("RPT_SHADE_COMPACT")) { c->shade_compact_mode = e11[0] != '0' ? 1 : 0; c->shade_compact = c->shade_compact_mode == 1; }

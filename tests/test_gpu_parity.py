@@ -327,6 +327,39 @@ def test_last_extension_rays_may_stop_at_their_first_hit(monkeypatch, hipmod, or
     assert np.array_equal(acc_g.view(np.uint32), acc_c.view(np.uint32))
 
 
+@pytest.mark.parametrize("presub", ["0", "1"])
+@pytest.mark.parametrize("scene,nee,over", [("DarkCornell", 0, {}), ("DarkCornell", 1, {"cam_position": (-0.0, 1.0, -3.5, 0.0)}), ("textured", 2, {"cam_position": (0.0, 1.6, -4.0, 0.0)}),
+                                            ("DarkCornell", 0, {"cam_position": (0.0, 1e6, -3e7, 0.0)})])
+def test_camera_rays_walk_planes_with_the_origin_already_subtracted(monkeypatch, hipmod, oracle, rpt, world, scene, nee, over, presub):
+    """Iteration 0 of a render call traces camera rays only, all from cfg.cam_position: the streamed LDS walk of that launch stages `plane - origin`
+    once per workgroup instead of computing it per lane and node (k_traverse_nearest_stream FIRST).  On or off (RPT_FIRST_PRESUB), the image is the
+    oracle's — with NEE, with a zero of either sign and with a far-away value in the camera position (the exact-division guard's other path), and for a
+    call whose slots take more than one sample (only its first iteration is such a launch)."""
+    monkeypatch.setenv("RPT_FIRST_PRESUB", presub)
+    skybox = None
+    if scene == "textured":
+        from scenes import textured_scene
+        w, skybox = textured_scene()
+    else:
+        w = world(scene)
+    W, H, spp = 136, 72, 40
+    cfg = rpt.default_config(W, H, nee=nee, **over)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    try:
+        r.upload_scene(w, skybox_f32=skybox)
+        r.set_config(cfg); r.reset(seeds)
+        r.render(8)                      # a batch of known length
+        r.render(spp - 8)                # slots take a second sample: regenerated paths share later launches with bounced ones
+        acc_g, _ = r.read_accum()
+        st_g = r.stats()
+    finally:
+        r.close()
+    acc_c, _, st_c = oracle.trace_cpu(cfg, oracle.scene(w, skybox_f32=skybox), seeds, spp)
+    assert st_g["extension_rays"] == st_c.extension_rays and st_g["shadow_rays"] == st_c.shadow_rays
+    assert np.array_equal(acc_g.view(np.uint32), acc_c.view(np.uint32))
+
+
 def test_the_library_chooses_the_order_of_the_last_rays_per_scene(monkeypatch, hipmod, rpt, world):
     """rpt_last_bounce_order after rpt_upload_scene: DarkCornell (two emissive triangles, lives in LDS) walks those rays in a fixed order its probe favoured;
     a scene that does not live in LDS keeps the whole walk; the decision is the host probe's (rpt_debug_last_order_host) and is re-taken on every upload."""

@@ -35,7 +35,7 @@ def _find(table, prefix):
     return hits
 
 
-@pytest.mark.parametrize("kernel", ["void k_traverse_nearest_stream<16, 1024, false>", "void k_traverse_nearest_stream<16, 1024, true>", "void k_traverse_shadow_stream<16, 1024, false>", "void k_traverse_shadow_stream<16, 1024, true>"])
+@pytest.mark.parametrize("kernel", ["void k_traverse_nearest_stream<16, 1024, 0>", "void k_traverse_nearest_stream<16, 1024, 1>", "void k_traverse_nearest_stream<16, 1024, 2>", "void k_traverse_shadow_stream<16, 1024, false>", "void k_traverse_shadow_stream<16, 1024, true>"])
 def test_streamed_lds_walks_fit_two_workgroups_per_cu(resources, kernel):
     for vgpr, sgpr, scratch, lds in _find(resources, kernel):
         assert vgpr <= 64 and scratch == 0
