@@ -35,6 +35,10 @@ WORKLOADS = {
     "darkcornell_mis": ("DarkCornell", 1024, 1024, 256, {"nee": 1}),
     "veachmis": ("VeachMIS", 1920, 1080, 1024, {"nee": 1}),
     "pbrtest": ("PBRTest", 2048, 2048, 512, {}),
+    # BASELINE config 4 AS IT IS WRITTEN ("PBRTest.glb with albedo/normal/rough/metal textures 2048x2048"): the shipped file carries no
+    # texture, so its own buffers + a labelled SYNTHETIC 4096^2 RGBA8 atlas laid out by the reference's packer (tests/scenes.py
+    # pbrtest_textured_scene: four maps per material through the reference's own uvst fields)
+    "pbrtest_textured": ("synthetic-textures:PBRTest", 2048, 2048, 512, {}),
     "furnace": ("FurnaceTest", 256, 256, 16, {}),
     # BASELINE config 5 names BreakTime.glb, absent from the reference mount: labelled procedural stand-in
     # (tests/scenes.py: 1 M clustered long thin triangles in a lit room; deep BVH, fat leaves)
@@ -81,7 +85,20 @@ STAGE_MODEL = {
 VALU_ISSUE_CYCLES_FLOOR = 2.1   # SIMD cycles a wave64 v_fma_f32 occupies the issue port (tools/microbench/valu_rates.hip)
 
 
+def data_label(scene):
+    if scene.startswith("synthetic-textures:"):
+        return ("fixtures/" + scene.split(":")[1] + ".glb (reference scene file: geometry, uvs, BVH, light table) + SYNTHETIC textures: the file has none "
+                "(tests/scenes.py pbrtest_textured_scene: albedo / metallic / roughness / normal map per material in a 4096x4096 RGBA8 atlas)")
+    if scene.startswith("procedural:"):
+        return "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"
+    return "fixtures/" + scene + ".glb (reference scene file)"
+
+
 def build_world(rpt, scene):
+    if scene.startswith("synthetic-textures:"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from scenes import pbrtest_textured_scene
+        return pbrtest_textured_scene()
     if scene.startswith("procedural:"):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from scenes import deep_bvh_scene, scatter_scene
@@ -117,8 +134,9 @@ STAGE_KERNELS = {"shadow": ("shadow", "shadow_resolve")}
 
 def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipeline_bytes, share=1.0):
     """(roofline of the dominant stage, whole-batch traffic / VALU figures) from the HIP events recorded in this run and the kept
-    PMC passes of the same kernel sources.  `share`: the part of the image this rank renders — the kept PMC passes are of
-    whole-image launches on one GPU, so at N > 1 every per-launch counter figure is scaled by it (and says so)."""
+    PMC passes of the same kernel sources.  `share`: the slots one launch of this run covers over the slots a launch of the kept PMC passes
+    covered (whole-image launches of 32-sample batches on one GPU): the part of the image this rank renders x spp_per_step / 32 — every
+    per-launch counter figure is scaled by it (and says so when it is not 1)."""
     kms = {k: s1["kernel_ms"][k] - s0["kernel_ms"][k] for k in s1["kernel_ms"]}
     klaunch = {k: s1["kernel_launches"][k] - s0["kernel_launches"][k] for k in s1["kernel_launches"]}
     dominant = max(kms, key=lambda k: kms[k])
@@ -154,7 +172,7 @@ def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipe
                 "stage_ms": {k: round(v, 3) for k, v in kms.items()},
                 "stage_launches": {k: int(v) for k, v in klaunch.items()}}
     if share != 1.0 and traffic is not None:
-        roofline["traffic_scaled_by"] = round(share, 6)      # whole-image PMC launches -> this rank's part of the image
+        roofline["traffic_scaled_by"] = round(share, 6)      # whole-image 32-sample PMC launches -> the slots of this rank's launches
     if ta:
         # the streamed global-memory walks are bound by the CU's texture-address unit, not by HBM: its busy share from the kept TA pass
         roofline["ta"] = ta
@@ -193,7 +211,7 @@ def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipe
         mixed = any("issue_cycles_per_wave_instruction" in rec.get("valu", {}) for rec in stages.values())
         whole = {"traffic": int(tot_bytes / max(steps, 1)), "traffic_over_algorithmic": round(tot_bytes / max(pipeline_bytes, 1), 4),
                  "traffic_is": "HBM bytes per batch, all kernels: (2 x FETCH_SIZE + WRITE_SIZE) per launch of the kept PMC passes x the launches of this run"
-                               + ("" if share == 1.0 else f" x this rank's share of the image ({share:.4f})"),
+                               + ("" if share == 1.0 else f" x the slots of this rank's launches over a whole-image 32-sample launch ({share:.4f})"),
                  "stages_covered": covered_all, "stages_without_counters": missing,
                  "valu": {"wave_instructions_per_batch": int(tot_insts / max(steps, 1)),
                           "simd_cycles_per_wave_instruction": round(avail / tot_insts, 3) if tot_insts else None,
@@ -247,7 +265,9 @@ def parity_ok(parity):
 
 
 def workload_label(scene, W, H, steps, spp_per_step, total_spp, cfg):
-    return (f"{scene}.glb {W}x{H}, {steps}x{spp_per_step} spp (config total {total_spp}), "
+    kind, _, name = scene.rpartition(":")
+    what = {"": name + ".glb", "synthetic-textures": name + ".glb + synthetic textures", "procedural": "procedural:" + name}[kind]
+    return (f"{what} {W}x{H}, {steps}x{spp_per_step} spp (config total {total_spp}), "
             f"nee={cfg.nee}, bounces {cfg.min_bounces}/{cfg.max_bounces}")
 
 
@@ -349,8 +369,7 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
     return {"value": round((n_ext + n_shadow) / elapsed / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
             "value_as_the_reference_counts": round((n_ext + n_shadow + n_elided) / elapsed / 1e6, 3),   # + the shadow rays the reference traces and this build proves irrelevant
             "steps": steps, "warmup": warmup, "samples_per_s": round(n_samples / elapsed, 1),
-            "data": ("fixtures/" + scene + ".glb (reference scene file)" if not scene.startswith("procedural:")
-                     else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
+            "data": data_label(scene),
             "config": {"workload": workload_label(scene, W, H, steps, spp_per_step, total_spp, cfg), "spp_per_step": spp_per_step,
                        "shadow_order": order, "last_bounce_order": last_order},
             "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "shadow_elided": int(n_elided), "sky_evals": int(n_sky),
@@ -373,22 +392,202 @@ def last_bounce_label(r):
             "probe_node_visits": {k: round(v, 2) for k, v in lo["probe_node_visits"].items()}}
 
 
-def launch_ranks(n, argv):
-    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv>` as a child process on a free
-    port of 127.0.0.1, pass its stdout (rank 0's JSON line) and stderr through, return its exit code."""
-    import socket
+HANG_HINTS = ("hints: a communicator bring-up that never returns is usually fabric / IPC configuration — run once with NCCL_DEBUG=INFO (NCCL_DEBUG=WARN is "
+              "set by this launcher), check HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC is the only mode the host driver supports), `rocm-smi --showtopo` for the xGMI "
+              "links, and that every rank sees its own device (HIP_VISIBLE_DEVICES); --launch-timeout raises the watchdog, --driver multi starts the "
+              "one-process driver (rpt_multi_*: ncclCommInitAll) instead of one process per GPU")
+
+
+def run_child(cmd, env, timeout_s, label):
+    """Run one child process under a watchdog: its own session (= its own process group), stdout collected, stderr passed through and its
+    last 50 lines kept.  On expiry the child's WHOLE process group — the group this function created, nothing found by name — is killed.
+    -> (return code or None when killed, stdout lines, last stderr lines, timed out)"""
+    import collections
+    import signal
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    print("bench: no launcher in the environment: starting " + " ".join(cmd[1:8]) + " as a child process", file=sys.stderr)
-    sys.stderr.flush()
-    return subprocess.call(cmd, env=env)
+    import threading
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, text=True, errors="replace")
+    tail, out_lines = collections.deque(maxlen=50), []
+
+    def pump_err():
+        for line in p.stderr:
+            sys.stderr.write(line)
+            sys.stderr.flush()
+            tail.append(line)
+
+    def pump_out():
+        for line in p.stdout:
+            out_lines.append(line)
+    threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in threads:
+        t.start()
+    timed_out = False
+    try:
+        rc = p.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        timed_out, rc = True, None
+        try:
+            os.killpg(p.pid, signal.SIGKILL)              # the session leader's pid is the group id: exactly the processes this call started
+        except ProcessLookupError:
+            pass
+        p.wait()
+    for t in threads:
+        t.join(timeout=10)
+    if timed_out:
+        print(f"bench: {label} did not finish within {timeout_s:.0f} s: its process group was killed.  Last lines of its stderr:", file=sys.stderr)
+        for line in tail:
+            sys.stderr.write("    | " + line)
+        print("bench: " + HANG_HINTS, file=sys.stderr)
+        sys.stderr.flush()
+    return rc, out_lines, list(tail), timed_out
+
+
+def launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment (the driver's plain command; a caller of src/trace.rs:136-224
+    does not bring one either): this process — which has not imported torch nor touched HIP — becomes the launcher.  Every attempt is a CHILD
+    process under a watchdog (--launch-timeout), never an exec:
+      1. one process per GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <argv>` on a free port of 127.0.0.1
+         (rpt_comm_init = ncclCommInitRank per rank);
+      2. only if that failed or hung (or with --driver multi): ONE process driving all N GPUs through rpt_multi_* (ncclCommInitAll — a different
+         RCCL bring-up path); its line says so in config.driver / config.fallback_from.
+    The child's one JSON line and return code are relayed."""
+    import socket
+    n = args.gpus
+    base_env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base_env.setdefault("OMP_NUM_THREADS", "1")
+    base_env.setdefault("NCCL_DEBUG", "WARN")
+    me = os.path.abspath(__file__)
+    why = None
+    if args.driver in ("auto", "ranks"):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), me] + list(argv)
+        print("bench: no launcher in the environment: starting " + " ".join(cmd[1:8]) + f" as a child process (watchdog {args.launch_timeout:.0f} s)", file=sys.stderr)
+        sys.stderr.flush()
+        rc, out, tail, timed_out = run_child(cmd, base_env, args.launch_timeout, f"the {n}-rank run (one process per GPU)")
+        lines = [ln for ln in out if ln.startswith("{")]
+        if rc == 0 and lines:
+            sys.stdout.write(lines[-1])
+            sys.stdout.flush()
+            return 0
+        why = f"the per-process driver {'hung (killed after %.0f s)' % args.launch_timeout if timed_out else 'exited with code %s' % rc}"
+        if args.driver == "ranks":
+            print(f"bench: {why}; --driver ranks: no second attempt", file=sys.stderr)
+            return rc if rc else 1
+        print(f"bench: {why}: second attempt with ONE process driving all {n} GPUs (rpt_multi_*, ncclCommInitAll)", file=sys.stderr)
+    env = dict(base_env, RPT_BENCH_CHILD="multi")
+    if why:
+        env["RPT_BENCH_FALLBACK_FROM"] = why
+    rc, out, tail, timed_out = run_child([sys.executable, me] + list(argv), env, args.launch_timeout, f"the one-process {n}-GPU run (rpt_multi_*)")
+    lines = [ln for ln in out if ln.startswith("{")]
+    if rc == 0 and lines:
+        sys.stdout.write(lines[-1])
+        sys.stdout.flush()
+        return 0
+    print(f"bench: the one-process driver {'hung' if timed_out else 'exited with code %s' % rc}: no scaling line", file=sys.stderr)
+    return rc if rc else 1
+
+
+def run_multi_driver(args):
+    """--driver multi: ONE process drives all N GPUs through rpt_multi_* (ncclCommInitAll inside rpt_multi_create) — the shape of the reference's single
+    render thread (src/trace.rs:136-224).  Same step (one batch on every GPU + the batch's one gather), same bracketing, same JSON line; no
+    torch.distributed (there is one process).  config.driver says which driver produced the line."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)                                           # RCCL's banner goes to C stdout: keep the JSON line's descriptor aside
+    os.environ.setdefault("RPT_STAGE_TIMING", "2")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np                                      # noqa: F401
+    import torch
+    rpt = importlib.import_module("rust-path-tracer_amd")
+    hip = importlib.import_module("rust-path-tracer_amd.hip")
+    n = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    shared = bool(args.rehearsal)
+    if not shared and os.environ.get("RPT_RCCL_LIBRARY"):
+        raise SystemExit("bench.py: RPT_RCCL_LIBRARY is set — that override loads a stand-in for RCCL (tests/fake_rccl); nothing measured with it is a measurement")
+    if not shared and torch.cuda.device_count() < n:
+        raise SystemExit(f"--driver multi --gpus {n}: only {torch.cuda.device_count()} HIP devices visible")
+    scene, W, H, total_spp, over = WORKLOADS[args.workload]
+    world = build_world(rpt, scene)
+    cfg = rpt.default_config(W, H, **over)
+    seeds = rpt.blue_noise_seeds(W, H)
+    m = hip.MultiRenderer([0] * n if shared else list(range(n)), allow_shared_device=shared)
+    m.upload_scene(world)
+    m.set_config(cfg)
+    m.reset(seeds)
+    for _ in range(2):                                      # set-up: pages touched, clocks up
+        m.render(args.spp_per_step)
+    m.wait()
+    m.reset(seeds)
+
+    def sync_all():
+        m.wait()
+        for d in ([0] if shared else range(n)):
+            torch.cuda.synchronize(d)
+    for _ in range(args.warmup):
+        m.render(args.spp_per_step)
+    sync_all()
+    r0 = m.rank_view(0)
+    s0, k0 = m.stats(), r0.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.render(args.spp_per_step)                          # one batch on every GPU + the batch's single gather, enqueued
+    sync_all()                                               # the last batch's image is complete on rank 0 inside the timed region
+    elapsed = time.perf_counter() - t0
+    s1, k1 = m.stats(), r0.stats()
+    n_ext, n_samples = s1["extension_rays"] - s0["extension_rays"], s1["samples"] - s0["samples"]
+    n_elided = s1["shadow_rays_elided"] - s0["shadow_rays_elided"]
+    n_shadow = (s1["shadow_rays"] - s0["shadow_rays"]) - n_elided
+    n_sky = s1["sky_evals"] - s0["sky_evals"]
+    n_mis = (n_shadow + n_elided) if cfg.nee == 1 else 0
+    cus, clock_mhz = hip.device_info(0)
+    pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
+    share = r0.local_pixels() / float(W * H)
+    roofline, whole = stage_roofline(hip, args.workload, k0, k1, args.steps, elapsed, cus, clock_mhz, pipeline_bytes * share, share * args.spp_per_step / 32.0)
+    parity = None
+    if not args.no_parity_check:
+        image, image_spp = m.read_accum()
+        parity = parity_windows(world, cfg, seeds, image, image_spp, args.spp_per_step * (args.warmup + args.steps), W, H)
+    order, last_order = shadow_order_label(r0), last_bounce_label(r0)
+    out = {}
+    if args.rehearsal:
+        out["rehearsal"] = "NOT A MEASUREMENT: all ranks share one GPU (RPT_MULTI_ALLOW_SHARED_DEVICE: device-to-device copies stand in for RCCL)"
+    pgbs = pipeline_bytes / elapsed / 1e9
+    out.update({
+        "metric": "Mrays/s", "value": round((n_ext + n_shadow) / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": data_label(scene) + ("" if ":" in scene else " + blue-noise seeds; no synthetic geometry"),
+        "config": {"workload": workload_label(scene, W, H, args.steps, args.spp_per_step, total_spp, cfg), "spp_per_step": args.spp_per_step,
+                   "tiles": "64x64 round-robin", "kernel_sources": hip.build_fingerprint(),
+                   "driver": "multi: ONE process drives all GPUs through rpt_multi_* (ncclCommInitAll)",
+                   "fallback_from": os.environ.get("RPT_BENCH_FALLBACK_FROM"),
+                   "gather": "rccl-c-abi" if not shared else "device copies (shared-device test aid)", "collective_library": hip.comm_library() or None,
+                   "rpt_comm_world": list(r0.comm_world()), "shadow_order": order, "last_bounce_order": last_order},
+        "samples_per_s": round(n_samples / elapsed, 1),
+        "value_as_the_reference_counts": round((n_ext + n_shadow + n_elided) / elapsed / 1e6, 3),
+        "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "shadow_elided": int(n_elided), "sky_evals": int(n_sky),
+                 "per_sample": round((n_ext + n_shadow) / max(n_samples, 1), 4)},
+        "roofline": roofline,
+        "pipeline_roofline": {"bound": "hbm", "achieved": round(pgbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pgbs / HBM_PEAK_GBS, 6),
+                              "formula": "128*N_ext + 96*N_shadow + 128*N_mis + 40*samples (SURVEY.md 8d)"},
+        "cpu_baseline": None, "parity_check": parity, "readback": None,
+    })
+    if whole:
+        out["pipeline_roofline"].update({k: whole[k] for k in ("traffic", "traffic_over_algorithmic", "traffic_is", "stages_without_counters")})
+    m.close()
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if not parity_ok(parity):
+        print("bench: PARITY CHECK FAILED: " + json.dumps(parity), file=sys.stderr)
+        raise SystemExit(4)
 
 
 def main():
@@ -397,7 +596,13 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3, help="untimed batches first (clocks ramp up over the first ~50 ms)")
     ap.add_argument("--workload", default="darkcornell", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=32, help="samples per batch (reference default sync_rate = 32)")
+    ap.add_argument("--spp-per-step", type=int, default=None,
+                    help="samples per batch; default 32 x N (at most 256): the reference's sync_rate of 32 (src/trace.rs:75) at N = 1, and at N GPUs "
+                         "as many samples of a pixel in flight as make a rank's launches cover the slots the whole image covers at 32")
+    ap.add_argument("--driver", default="auto", choices=["auto", "ranks", "multi"],
+                    help="N > 1 without a launcher: ranks = one process per GPU under torch.distributed.run; multi = ONE process through rpt_multi_* "
+                         "(ncclCommInitAll); auto = ranks, and multi only if that failed or hung")
+    ap.add_argument("--launch-timeout", type=float, default=600.0, help="watchdog (seconds) around each self-launched child")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -411,7 +616,7 @@ def main():
                          "library's gather over the test stand-in for RCCL (RPT_RCCL_LIBRARY).  Exercises every line the scaling run executes; "
                          "the JSON line is marked and its value is not a measurement")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed comparison of windows of the rendered image with the CPU oracle")
-    ap.add_argument("--extra-workloads", default="darkcornell_mis,veachmis,pbrtest,deepbvh",
+    ap.add_argument("--extra-workloads", default="darkcornell_mis,veachmis,pbrtest,pbrtest_textured,deepbvh",
                     help="N = 1, headline workload only: the other single-GPU BASELINE workloads, measured AFTER the headline's timed loop on fresh "
                          "contexts and reported under \"workloads\" (value, roofline, pipeline_roofline, parity_check each); a failed parity check fails the bench")
     ap.add_argument("--no-extra-workloads", action="store_true")
@@ -420,12 +625,14 @@ def main():
     ap.add_argument("--no-readback", action="store_true", help="skip the extra render -> read_accum loop (reference loop shape, src/trace.rs:182-204)")
     args = ap.parse_args()
 
-    # `python bench.py --gpus N` with N > 1 and no launcher (the driver's plain command; a caller of src/trace.rs:136-224 does not
-    # bring one either): this process becomes the launcher.  It has not imported torch nor touched HIP; the N ranks are CHILD
-    # processes (python -m torch.distributed.run, one rank per GPU over RCCL), never an exec; their one JSON line and the return
-    # code are relayed.
-    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1") or "1") <= 1:      # (an inherited WORLD_SIZE=1 is no launcher either)
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.spp_per_step is None:
+        args.spp_per_step = min(256, 32 * max(1, args.gpus))
+    # `python bench.py --gpus N` with N > 1 and no launcher: this process becomes the launcher of watchdog-guarded CHILD processes (launch()).
+    in_launcher = int(os.environ.get("WORLD_SIZE", "1") or "1") > 1      # (an inherited WORLD_SIZE=1 is no launcher either)
+    if os.environ.get("RPT_BENCH_CHILD") == "multi" and args.gpus > 1 and not in_launcher:
+        return run_multi_driver(args)
+    if args.gpus > 1 and not in_launcher:
+        raise SystemExit(launch(args, sys.argv[1:]))
 
     # Rank 0 prints ONE JSON line on stdout.  Libraries print there too (RCCL writes a version banner through C stdio when
     # a communicator is created, and it is flushed at exit — after the JSON line), so for the whole run file descriptor 1
@@ -666,7 +873,8 @@ def main():
     pipeline_bytes = algorithmic_bytes(n_ext, n_shadow, n_mis, n_samples)
     pipeline_gbs = pipeline_bytes / elapsed_max / 1e9
     share = r.local_pixels() / float(W * H)                            # rank 0's part of the image (its kernels are the ones timed)
-    roofline, whole = stage_roofline(hip, args.workload, s0, s1, args.steps, elapsed_max, cus, clock_mhz, pipeline_bytes * share, share)
+    # the kept PMC passes are whole-image launches of 32-sample batches on one GPU: a launch of this run covers share x spp_per_step / 32 as many slots
+    roofline, whole = stage_roofline(hip, args.workload, s0, s1, args.steps, elapsed_max, cus, clock_mhz, pipeline_bytes * share, share * args.spp_per_step / 32.0)
 
     # --- CPU baseline: the oracle (a port of trace_cpu) on this host's cores, bounded sample of the same workload
     cpu = None
@@ -718,13 +926,15 @@ def main():
         "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world_size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-        "data": (f"fixtures/{scene}.glb (reference scene file) + blue-noise seeds; no synthetic geometry"
-                 if not scene.startswith("procedural:") else "synthetic stand-in for the missing BreakTime.glb (tests/scenes.py)"),
+        "data": data_label(scene) + ("" if ":" in scene else " + blue-noise seeds; no synthetic geometry"),
         "config": {"workload": workload_label(scene, W, H, args.steps, args.spp_per_step, total_spp, cfg),
                    "spp_per_step": args.spp_per_step, "tiles": "64x64 round-robin" if world_size > 1 else "single GPU",
-                   "kernel_sources": hip.build_fingerprint(), "gather": gather_impl, "collective_library": hip.comm_library() or None,
+                   "kernel_sources": hip.build_fingerprint(), "driver": "ranks: one process per GPU (rpt_comm_init = ncclCommInitRank)" if world_size > 1 else "single GPU",
+                   "gather": gather_impl, "collective_library": hip.comm_library() or None,
                    "rpt_comm_world": comm_world_seen, "shadow_order": order, "last_bounce_order": last_order},
         "samples_per_s": round(n_samples / elapsed_max, 1),
+        "value_counts": ("extension rays + shadow rays WALKED on the device (since round 5; rounds 1-4 counted one shadow ray per NEE evaluation, walked or not: "
+                         "compare across rounds with value_as_the_reference_counts, samples_per_s or ms_per_step — identical to `value` at nee = 0)"),
         "value_as_the_reference_counts": round((rays + n_elided) / elapsed_max / 1e6, 3),
         "rays": {"extension": int(n_ext), "shadow": int(n_shadow), "shadow_elided": int(n_elided), "sky_evals": int(n_sky),
                  "per_sample": round(rays / max(n_samples, 1), 4),

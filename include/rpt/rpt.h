@@ -278,7 +278,8 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
  * three order-dependent f32 chains (the two sums of :39-64 in index order, the robin-hood fill of :89-104) on the host between the device passes
  * (csrc/rpt_lights.hip: a question of latency per dependent operation, measured).  Same entries, same order, same bits as the sequential builder (tests/test_gpu_light_table.py).  Host pointers, no
  * context; entries_capacity >= the number of emissive triangles (>= 1: a scene without lights yields the one-entry sentinel, ratio = -1).
- * ms_out (nullable): 4 doubles — total, device passes, host chains, transfers.  A NaN probability is refused (RPT_ESCENE). */
+ * ms_out (nullable): 4 doubles — total, device passes, host chains, transfers.  A NaN pick probability — a NaN vertex, a total power of 0 (every emissive
+ * triangle degenerate) or inf — is refused by name (RPT_ESCENE): the reference's answer there depends on its sequential sort, which rpt_light_table_build restates. */
 int rpt_light_table_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertices, const rpt_triangle *triangles, size_t n_triangles,
                               const rpt_material_data *materials, size_t n_materials, rpt_light_pick_entry *entries_out, size_t entries_capacity,
                               size_t *n_entries_out, uint32_t *n_emissive_out, double *ms_out);

@@ -40,6 +40,7 @@
 
 #define RPT_WAVE 64
 #define RPT_BLOCK 256
+#define RPT_MAX_SAMPLES_IN_FLIGHT 256u   /* most slots per pixel (k_path.h k_complete counts a pixel's finished slots; rounds 1-5: a 32-bit mask) */
 
 /* ---- glam-order float3 helpers (device side) ----------------------------- */
 struct F3 { float x, y, z; };
@@ -88,6 +89,8 @@ struct DevScene {
     const float *tri_isect;        /* 9 floats per triangle: e1, e2, a — what the intersection test reads, packed (36 instead of 48 bytes:
                                       the walk of a 1 M-triangle scene is bound by these bytes, profiles/r02_deepbvh_*) */
     const float4 *tri_shade;       /* 4 x float4 per triangle: (na | uva.x) (nb | uva.y) (nc | material) (uvb, uvc) */
+    const float4 *tri_tangent;     /* 3 x float4 per triangle: the three vertex tangents (lib.rs:135-138), only where a material has a normal map — one 48-byte record
+                                      instead of the index record + three 64-byte vertices */
     const float4 *mat_lite;        /* 2 x float4 per material: (emissive.rgb | roughness.x) (albedo.rgb | metallic.x) */
     const uint4 *indices;          /* rpt_triangle */
     const float4 *per_vertex;      /* 4 x float4 per rpt_per_vertex_data */

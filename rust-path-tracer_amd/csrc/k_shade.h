@@ -31,22 +31,38 @@
 #define RPT_PI_F 3.14159265358979323846f
 #define RPT_EPS 0.001f   /* util.rs:5 */
 
-/* ---- CPU-polyfill image sampling ------------------------------------------ */
-template <bool IS_U8>
-__device__ __forceinline__ float4 image_texel(const DevImage &img, int32_t cx, int32_t cy) {
-    /* `coord.x as usize % width as usize`: i32 sign-extends to 64 bits first */
-    uint64_t x = (uint64_t)(int64_t)cx % (uint64_t)img.width;
-    uint64_t y = (uint64_t)(int64_t)cy % (uint64_t)img.height;
-    uint64_t at = y * (uint64_t)img.width + x;
-    if (IS_U8) {
-        /* Vec4(r, g, b, 255) / 255.0 (src/asset.rs:270) */
-        uchar4 t = reinterpret_cast<const uchar4 *>(img.texels)[at];
-        return make_float4((float)t.x / 255.0f, (float)t.y / 255.0f, (float)t.z / 255.0f, 255.0f / 255.0f);
-    }
-    return reinterpret_cast<const float4 *>(img.texels)[at];
+/* ---- CPU-polyfill image sampling (shared_structs/src/image_polyfill.rs:32-55) ----------------------------------------------------------
+ * sample_raw: `coord.x as usize % width as usize` — the i32 sign-extends to 64 bits, then an UNSIGNED 64-bit remainder.  Written out that
+ * is a 64-bit division by a run-time value, ~120 instructions, eight of them per lookup and four lookups per textured hit: rounds 1-5 spent
+ * HALF the textured shade stage there (profiles/r06_texture_sampler.txt).  The same value, cheaply:
+ *   a power-of-two extent (the reference's atlas is always 4096 x 4096, src/asset.rs:177): the remainder of the sign-extended value is its
+ *     low bits — `coord & (extent - 1)`, for negative coordinates too;
+ *   any extent: a coordinate in [0, extent] (every lookup of a uv inside its atlas rectangle: floor / ceil of uv * extent) wraps to itself,
+ *     or to 0 at `extent`; only what is left over divides. */
+__device__ __forceinline__ uint32_t image_wrap(int32_t c, uint32_t extent, bool pow2) {
+    if (pow2) return (uint32_t)c & (extent - 1u);
+    const uint32_t u = (uint32_t)c;
+    if (u < extent) return u;
+    if (u == extent) return 0u;
+    return (uint32_t)((uint64_t)(int64_t)c % (uint64_t)extent);
 }
 __device__ __forceinline__ float4 lerp4(float4 a, float4 b, float s) {
     return make_float4(a.x + ((b.x - a.x) * s), a.y + ((b.y - a.y) * s), a.z + ((b.z - a.z) * s), a.w + ((b.w - a.w) * s));
+}
+/* texel = Vec4(r, g, b, 255) / 255.0 (src/asset.rs:270); rptm::unorm8 is that division, exactly */
+__device__ __forceinline__ float4 texel_of_u8(uint32_t t) {
+    return make_float4(rptm::unorm8((float)(t & 0xffu)), rptm::unorm8((float)((t >> 8) & 0xffu)), rptm::unorm8((float)((t >> 16) & 0xffu)), 1.0f);
+}
+/* The two texels (x0, y) and (x1, y) of a footprint row.  x1 is x0 or its right neighbour (ceil vs floor of one number) unless the footprint wraps, so
+ * both come from ONE 8-byte load of the texel pair that holds x0 — (x0, x0 + 1), or (x0 - 1, x0) in the last column — and only a wrapping footprint
+ * issues a second load: 8 instead of 16 lane-divergent loads per textured hit. */
+__device__ __forceinline__ void u8_row_pair(const uint32_t *texels, uint32_t row /* texel index of the row's first texel: an image has at most 2^30 texels (rpt_upload_scene) */, uint32_t x0, uint32_t x1, uint32_t width, uint32_t &t0, uint32_t &t1) {
+    const bool edge = x0 + 1u >= width;
+    uint2 pair;
+    __builtin_memcpy(&pair, texels + (row + (edge ? x0 - 1u : x0)), sizeof(pair));
+    t0 = edge ? pair.y : pair.x;
+    t1 = x1 == x0 ? t0 : pair.y;
+    if (x1 != x0 && (edge || x1 != x0 + 1u)) t1 = texels[row + x1];
 }
 template <bool IS_U8>
 __device__ __forceinline__ float4 sample_by_lod(const DevImage &img, float u, float v) {
@@ -55,10 +71,26 @@ __device__ __forceinline__ float4 sample_by_lod(const DevImage &img, float u, fl
     float tx = sx - fx, ty = sy - fy;
     int32_t ix0 = rptm::f2i32_sat(fx), iy0 = rptm::f2i32_sat(fy);
     int32_t ix1 = rptm::f2i32_sat(rptm::ceilr(sx)), iy1 = rptm::f2i32_sat(rptm::ceilr(sy));
-    float4 c00 = image_texel<IS_U8>(img, ix0, iy0);
-    float4 c01 = image_texel<IS_U8>(img, ix0, iy1);
-    float4 c10 = image_texel<IS_U8>(img, ix1, iy0);
-    float4 c11 = image_texel<IS_U8>(img, ix1, iy1);
+    const bool pow2 = ((img.width & (img.width - 1u)) | (img.height & (img.height - 1u))) == 0u;       /* (uniform) */
+    const uint32_t x0 = image_wrap(ix0, img.width, pow2), x1 = image_wrap(ix1, img.width, pow2);
+    const uint32_t y0 = image_wrap(iy0, img.height, pow2), y1 = image_wrap(iy1, img.height, pow2);
+    float4 c00, c01, c10, c11;
+    if (IS_U8) {
+        const uint32_t *texels = reinterpret_cast<const uint32_t *>(img.texels);
+        uint32_t t00, t10, t01, t11;
+        if (img.width >= 2u) {                                                                         /* (uniform) */
+            u8_row_pair(texels, y0 * img.width, x0, x1, img.width, t00, t10);
+            u8_row_pair(texels, y1 * img.width, x0, x1, img.width, t01, t11);
+        } else {
+            t00 = t10 = texels[y0];
+            t01 = t11 = texels[y1];
+        }
+        c00 = texel_of_u8(t00); c10 = texel_of_u8(t10); c01 = texel_of_u8(t01); c11 = texel_of_u8(t11);
+    } else {
+        const float4 *texels = reinterpret_cast<const float4 *>(img.texels);
+        c00 = texels[y0 * img.width + x0]; c10 = texels[y0 * img.width + x1];
+        c01 = texels[y1 * img.width + x0]; c11 = texels[y1 * img.width + x1];
+    }
     float4 a = lerp4(c00, c10, tx);
     float4 b = lerp4(c01, c11, tx);
     return lerp4(a, b, ty);
@@ -311,9 +343,8 @@ __device__ __forceinline__ void shade_slot(const DevScene &sc, const DevState &s
                         float su = mat.normals.x + uv_x * mat.normals.z, sv = mat.normals.y + uv_y * mat.normals.w;
                         float4 s = sample_by_lod<true>(sc.atlas, su, sv);
                         F3 nm = f3(s.x * 2.0f - 1.0f, s.y * 2.0f - 1.0f, s.z * 2.0f - 1.0f);
-                        const uint4 tri = sc.indices[tri_index];
-                        F3 tangent = bary.x * xyz4(sc.per_vertex[4u * tri.x + 2u]) + bary.y * xyz4(sc.per_vertex[4u * tri.y + 2u]) +
-                                     bary.z * xyz4(sc.per_vertex[4u * tri.z + 2u]);
+                        const float4 *tt = sc.tri_tangent + 3u * tri_index;                  /* the three vertex tangents, gathered at upload */
+                        F3 tangent = bary.x * xyz4(tt[0]) + bary.y * xyz4(tt[1]) + bary.z * xyz4(tt[2]);
                         F3 bitangent = cross3(tangent, normal);
                         F3 r = tangent * nm.x;
                         r = r + (bitangent * nm.y);

@@ -68,7 +68,7 @@ struct rpt_ctx {
 
     /* scene */
     bool has_scene = false;
-    DevBuf<float4> nodes, tri_geom, tri_shade, mat_lite, per_vertex, materials, lds_image, light_rec;
+    DevBuf<float4> nodes, tri_geom, tri_shade, tri_tangent, mat_lite, per_vertex, materials, lds_image, light_rec;
     DevBuf<uint4> indices;
     DevBuf<float> tri_isect;
     DevBuf<float4> gpairs;                     /* pair records + links of the streamed global-memory walks (k_traverse.h SceneViewPairsT) */

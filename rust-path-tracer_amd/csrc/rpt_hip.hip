@@ -170,40 +170,72 @@ void release_state(rpt_ctx *c) {
  * next render whenever other threads kept that stream busy with their own contexts (lost ray counts in
  * test_contexts_on_different_threads).  Hence: every fill is hipMemsetAsync ON THE CONTEXT'S STREAM; host-to-device copies
  * stay synchronous hipMemcpy (complete when they return) and are only issued after the stream has been drained. */
-int alloc_state(rpt_ctx *c) {
-    size_t n = c->max_slots, np = c->n_pixels;
-    HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n)); HIP_TRY(c, c->hit.alloc(n));
-    HIP_TRY(c, c->thr.alloc(n)); HIP_TRY(c, c->rad.alloc(n));
-    HIP_TRY(c, c->mis_a.alloc(n)); HIP_TRY(c, c->mis_b.alloc(n));
+/* What rpt_set_config allocates: the per-PIXEL state (accumulators, rng, pixel coordinates) and the counters.  The per-SLOT path state is
+ * allocated by the first rpt_render that needs it, at the size it needs (ensure_slot_state): a start-up — the reference's
+ * trace_gpu(scene, 0 samples), benches/benchmark.rs:11-13 — allocates and touches no path state at all, a configuration without NEE no
+ * shadow queue (48 bytes per slot) and no MIS carry (32), and the ceiling of samples in flight can be 256 per pixel without a context
+ * that renders 32-sample batches paying for it (rounds 1-5 allocated up to 160 M slots x 180 bytes = 29 GB in rpt_set_config). */
+int alloc_pixel_state(rpt_ctx *c) {
+    const size_t np = c->n_pixels;
     HIP_TRY(c, c->accum.alloc(np)); HIP_TRY(c, c->rng.alloc(np));
-    HIP_TRY(c, c->q_sky.alloc(n + RPT_Q_SLACK));     /* side queues: positions, not entries (k_common.h: sharded queues) */
     HIP_TRY(c, c->ray_shards.alloc(RPT_STAT_SHARDS * RPT_STAT_STRIDE));
     HIP_TRY(c, hipMemsetAsync(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, c->q_count.alloc(Q_WORDS));
-    HIP_TRY(c, c->sh_o.alloc(n + RPT_Q_SLACK)); HIP_TRY(c, c->sh_d.alloc(n + RPT_Q_SLACK)); HIP_TRY(c, c->sh_c.alloc(n + RPT_Q_SLACK));
     HIP_TRY(c, c->pixel_xy.alloc(np));
     if (np) HIP_TRY(c, hipMemcpy(c->pixel_xy.p, c->pixel_xy_host.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemsetAsync(c->q_count.p, 0, Q_WORDS * sizeof(uint32_t), c->stream));
-    if (n) k_fill_idle<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, c->stream>>>(c->hit.p, (uint32_t)n);   /* nothing in flight */
     DevState &s = c->state;
-    s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.hit = c->hit.p; s.thr = c->thr.p; s.rad = c->rad.p;
-    s.mis_a = c->mis_a.p; s.mis_b = c->mis_b.p;
-    s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = (uint32_t)n;
+    s = DevState{};
+    s.rng = c->rng.p; s.accum = c->accum.p; s.pixel_xy = c->pixel_xy.p; s.n_slots = c->n_slots;
     s.n_pixels = (uint32_t)np; s.group_shift = c->group_shift; s.q_shift = 0;
     DevQueues &q = c->queues;
-    q.sky = c->q_sky.p; q.ray_shards = c->ray_shards.p;
-    q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p; q.count = c->q_count.p;
+    q = DevQueues{};
+    q.ray_shards = c->ray_shards.p; q.count = c->q_count.p;
     q.sky_cnt = c->q_count.p + Q_COUNT; q.shadow_cnt = q.sky_cnt + RPT_Q_SHARDS * RPT_Q_SHARD_STRIDE;
     q.host_ring = c->host_ring_dev; q.ring_mask = RING - 1;
+    /* up to this many queued misses the sky march runs 16 lanes per miss (re-clamped per call to that call's slot count) */
+    c->sky_wide_cfg = 32768u;
+    if (const char *env = getenv("RPT_SKY_WIDE_LIMIT")) c->sky_wide_cfg = (uint32_t)std::max(0, atoi(env));
+    q.sky_wide_limit = (uint32_t)std::min<size_t>(c->n_slots / 16, c->sky_wide_cfg);
     /* 1 = shade misses in the iteration that found them.  Letting them pile up (threshold ~ n/64) removes most
      * of the near-empty sky launches on closed scenes, but the parked pixels finish later and lengthen the tail:
      * measured DarkCornell 3650 Mrays/s deferred vs 3928 eager — so eager is the default. */
-    c->sky_wide_cfg = 32768u;
-    if (const char *env = getenv("RPT_SKY_WIDE_LIMIT")) c->sky_wide_cfg = (uint32_t)std::max(0, atoi(env));
-    q.sky_wide_limit = (uint32_t)std::min<size_t>(n / 16, c->sky_wide_cfg);     /* re-clamped per call to that call's slot count */
     q.sky_threshold = 1u; q.sky_at_end = 0u; q.known_length = 0u;
     if (const char *env = getenv("RPT_SKY_THRESHOLD")) q.sky_threshold = (uint32_t)std::max(1, atoi(env));
     c->has_state = true;
+    return RPT_OK;
+}
+
+/* The per-slot arrays, for a render call over `n` slots: grown (never shrunk) to what the call needs — the path state always, the shadow
+ * queue when the configuration has NEE, the MIS carry when it is MIS.  Growing waits for whatever is in flight, frees the old arrays first
+ * and leaves every slot idle; between render calls every slot IS idle, so nothing is carried over. */
+int ensure_slot_state(rpt_ctx *c, size_t n, bool need_shadow, bool need_mis) {
+    const bool grow = c->hit.n < n, grow_shadow = need_shadow && c->sh_o.n < n + RPT_Q_SLACK, grow_mis = need_mis && c->mis_a.n < n;
+    if (grow || grow_shadow || grow_mis) {
+        if (c->async_pending) { int rc = rpt_wait(c); if (rc) return rc; }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (grow) {
+            c->ray_a.release(); c->ray_b.release(); c->hit.release(); c->thr.release(); c->rad.release(); c->q_sky.release();
+            HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n)); HIP_TRY(c, c->hit.alloc(n));
+            HIP_TRY(c, c->thr.alloc(n)); HIP_TRY(c, c->rad.alloc(n));
+            HIP_TRY(c, c->q_sky.alloc(n + RPT_Q_SLACK));     /* side queues: positions, not entries (k_common.h: sharded queues) */
+            k_fill_idle<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, c->stream>>>(c->hit.p, (uint32_t)n);   /* nothing in flight */
+            HIP_TRY(c, hipGetLastError());
+        }
+        if (grow_shadow) {
+            c->sh_o.release(); c->sh_d.release(); c->sh_c.release();
+            HIP_TRY(c, c->sh_o.alloc(n + RPT_Q_SLACK)); HIP_TRY(c, c->sh_d.alloc(n + RPT_Q_SLACK)); HIP_TRY(c, c->sh_c.alloc(n + RPT_Q_SLACK));
+        }
+        if (grow_mis) {
+            c->mis_a.release(); c->mis_b.release();
+            HIP_TRY(c, c->mis_a.alloc(n)); HIP_TRY(c, c->mis_b.alloc(n));
+        }
+    }
+    DevState &s = c->state;
+    s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.hit = c->hit.p; s.thr = c->thr.p; s.rad = c->rad.p;
+    s.mis_a = c->mis_a.p; s.mis_b = c->mis_b.p;
+    DevQueues &q = c->queues;
+    q.sky = c->q_sky.p; q.sh_o = c->sh_o.p; q.sh_d = c->sh_d.p; q.sh_c = c->sh_c.p;
     return RPT_OK;
 }
 
@@ -317,6 +349,12 @@ void launch_nearest(rpt_ctx *c, uint32_t iteration, bool last_without_nee = fals
     }
 }
 
+/* one wave per chunk of 64 pixels (k_path.h k_complete) */
+static void launch_complete(rpt_ctx *c, uint32_t iteration, uint32_t final_pass) {
+    k_complete<<<padded_pixels(c->n_pixels) / RPT_WAVE, RPT_WAVE, complete_lds_bytes(1u << c->group_shift, c->state.q_shift), c->stream>>>(c->state, c->queues, c->cfg, iteration, final_pass,
+                                                                                                                     c->dev_stats.p);
+}
+
 template <int STACK, int NEE, bool TEXTURED>
 void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vector<hipEvent_t> *ev, size_t &ev_at, bool complete_each, bool sky_now) {
     hipStream_t s = c->stream;
@@ -339,7 +377,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
     else k_shade<NEE, TEXTURED, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
     /* generations are completed (and the next samples started) after every shade stage only where slots take more than one
      * sample in this call; a batch of known length completes them once, after its last iteration (render_impl) */
-    if (complete_each) k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, iteration, 0u, c->dev_stats.p);
+    if (complete_each) launch_complete(c, iteration, 0u);
     mark();
     if (NEE != RPT_NEE_NONE) {
         if (STACK == 16 && c->scene.lds_scene && c->lds_stream && c->lds_shadow_stream) {
@@ -452,7 +490,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_build_pairs(const float4 *nodes, 
  *              with d00 = e1.e1, d01 = e1.e2, d11 = e2.e2 (util.rs:242-244) in the .w lanes — dot = (x x' + y y') + z z', as glam's
  *   tri_isect: e1, e2, a packed in 36 bytes        tri_shade: the three vertex normals, the three uv0 pairs and the material index in 64 bytes */
 __global__ __launch_bounds__(RPT_BLOCK) void k_derive_triangles(const float4 *per_vertex, const uint4 *indices, uint32_t nt, float4 *tri_geom, float *tri_isect,
-                                                                float4 *tri_shade, float *cross_sq) {
+                                                                float4 *tri_shade, float4 *tri_tangent /* nullable */, float *cross_sq) {
     const uint32_t i = blockIdx.x * RPT_BLOCK + threadIdx.x;
     if (i >= nt) return;
     const uint4 t = indices[i];
@@ -470,6 +508,7 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_derive_triangles(const float4 *pe
     tri_shade[4u * (size_t)i + 1u] = make_float4(nb.x, nb.y, nb.z, ua.y);
     tri_shade[4u * (size_t)i + 2u] = make_float4(nc.x, nc.y, nc.z, __uint_as_float(t.w));
     tri_shade[4u * (size_t)i + 3u] = make_float4(ub.x, ub.y, uc.x, uc.y);
+    if (tri_tangent) { tri_tangent[3u * (size_t)i + 0u] = A[2]; tri_tangent[3u * (size_t)i + 1u] = B[2]; tri_tangent[3u * (size_t)i + 2u] = C[2]; }
     const float cx = e1y * e2z - e1z * e2y, cy = e1z * e2x - e1x * e2z, cz = e1x * e2y - e1y * e2x;       /* (the probe's estimate of areas: no part of a result) */
     cross_sq[i] = (cx * cx + cy * cy) + cz * cz;
 }
@@ -523,14 +562,17 @@ int rpt_debug_shadow_order_host(const rpt_per_vertex_data *pv, size_t nv, const 
                                 const rpt_material_data *mats, size_t nm, const rpt_light_pick_entry *lp, size_t nlp, uint32_t *fixed_out,
                                 double *visits_near_out, double *visits_fixed_out, uint32_t *probe_rays_out, uint8_t *flip_out /* (nn - 1) / 2, nullable */) {
     if (!pv || !idx || !nodes || !mats || !lp || nn == 0) return RPT_EINVAL;
+    {   /* the probes walk the pool: the same validation rpt_upload_scene applies first (a child link that points at an ancestor would never end) */
+        rpt_ctx scratch;
+        uint32_t depth = 0;
+        const int rc = validate_scene(&scratch, pv, nv, idx, nt, nodes, nn, mats, nm, lp, nlp, depth);
+        if (rc) { g_create_error = scratch.error; return rc; }
+    }
     bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
     for (size_t i = 0; i < nn; ++i) {
         const rpt_bvh_node &n = nodes[i];
         if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
-        if (n.triangle_count != 0u && (size_t)n.left_or_first + n.triangle_count > nt) return RPT_ESCENE;
     }
-    for (size_t t = 0; t < nt; ++t)
-        if (idx[t].v0 >= nv || idx[t].v1 >= nv || idx[t].v2 >= nv || idx[t].material >= nm) return RPT_ESCENE;
     const ShadowOrder so = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped);
     if (fixed_out) *fixed_out = so.fixed ? 1u : 0u;
     if (visits_near_out) *visits_near_out = so.visits_near;
@@ -544,14 +586,19 @@ int rpt_debug_last_order_host(const rpt_per_vertex_data *pv, size_t nv, const rp
                               const rpt_material_data *mats, size_t nm, uint32_t *rule_out, double *visits_out /* [4] */, uint32_t *probe_rays_out,
                               uint8_t *flip_out /* (nn - 1) / 2, nullable */) {
     if (!pv || !idx || !nodes || !mats || nn == 0) return RPT_EINVAL;
+    {
+        rpt_ctx scratch;
+        uint32_t depth = 0;
+        rpt_light_pick_entry none{};
+        none.ratio = -1.0f;
+        const int rc = validate_scene(&scratch, pv, nv, idx, nt, nodes, nn, mats, nm, &none, 1, depth);
+        if (rc) { g_create_error = scratch.error; return rc; }
+    }
     bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
     for (size_t i = 0; i < nn; ++i) {
         const rpt_bvh_node &n = nodes[i];
         if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
-        if (n.triangle_count != 0u && (size_t)n.left_or_first + n.triangle_count > nt) return RPT_ESCENE;
     }
-    for (size_t t = 0; t < nt; ++t)
-        if (idx[t].v0 >= nv || idx[t].v1 >= nv || idx[t].v2 >= nv || idx[t].material >= nm) return RPT_ESCENE;
     const LastOrder lo = choose_last_order(pv, idx, nt, nodes, nn, mats, pair_shaped);
     if (rule_out) *rule_out = (uint32_t)lo.rule;
     if (visits_out) for (int k = 0; k < 4; ++k) visits_out[k] = lo.visits[k];
@@ -611,7 +658,7 @@ int rpt_create(int device_id, rpt_ctx **out) {
     if (const char *e14 = getenv("RPT_SKY_STRIDED")) { c->sky_strided_mode = e14[0] != '0' ? 1 : 0; c->sky_strided = c->sky_strided_mode == 1; }
     if (const char *e5 = getenv("RPT_STREAM_MAX_BLOCKS")) c->stream_max_blocks = (uint32_t)std::max(1, atoi(e5));
     if (const char *e8 = getenv("RPT_STREAM_SPAN")) c->stream_span = (uint32_t)std::max(0, atoi(e8));
-    if (const char *e3 = getenv("RPT_SAMPLES_IN_FLIGHT")) c->samples_in_flight_request = std::min(32, std::max(0, atoi(e3)));
+    if (const char *e3 = getenv("RPT_SAMPLES_IN_FLIGHT")) c->samples_in_flight_request = std::min((int)RPT_MAX_SAMPLES_IN_FLIGHT, std::max(0, atoi(e3)));
     *out = c;
     return RPT_OK;
 }
@@ -623,7 +670,7 @@ void rpt_destroy(rpt_ctx *c) {
     rpt_comm_release(c);
     release_state(c);
     c->gpairs.release(); c->glinks.release(); c->lds_image_shadow.release(); c->lds_image_last.release(); c->gpairs_shadow.release(); c->glinks_shadow.release();
-    c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_isect.release(); c->tri_shade.release(); c->mat_lite.release();
+    c->nodes.release(); c->lds_image.release(); c->tri_geom.release(); c->tri_isect.release(); c->tri_shade.release(); c->tri_tangent.release(); c->mat_lite.release();
     c->per_vertex.release(); c->materials.release();
     c->indices.release(); c->light_pick.release(); c->light_rec.release(); c->atlas.release(); c->skybox.release();
     c->dev_stats.release();
@@ -665,6 +712,11 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
             c->error = "a material references the texture atlas but no atlas was supplied";
             return RPT_ESCENE;
         }
+    /* texel indices are 32-bit on the device (k_shade.h sample_by_lod): the reference's atlas is 4096 x 4096 (src/asset.rs:177) */
+    if ((atlas && (uint64_t)aw * ah > (1ull << 30)) || (skybox && (uint64_t)sw * sh > (1ull << 28))) {
+        c->error = "atlas larger than 2^30 texels / skybox larger than 2^28 texels";
+        return RPT_ESCENE;
+    }
     SectionTimer sections("rpt_upload_scene");
     sections.mark("validate");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -698,7 +750,9 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         }
     }
     uint32_t textured = 0;
+    bool normal_maps = false;
     for (size_t i = 0; i < nm; ++i) {
+        if (mats[i].has_normal_texture) normal_maps = true;
         lite[2 * i + 0] = make_float4(mats[i].emissive[0], mats[i].emissive[1], mats[i].emissive[2], mats[i].roughness[0]);
         lite[2 * i + 1] = make_float4(mats[i].albedo[0], mats[i].albedo[1], mats[i].albedo[2], mats[i].metallic[0]);
         if (mats[i].has_albedo_texture | mats[i].has_metallic_texture | mats[i].has_roughness_texture | mats[i].has_normal_texture) textured = 1;
@@ -708,6 +762,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, c->tri_geom.alloc(3 * nt));
     HIP_TRY(c, c->tri_shade.alloc(4 * nt));
     HIP_TRY(c, c->tri_isect.alloc(9 * nt));
+    HIP_TRY(c, c->tri_tangent.alloc(normal_maps ? 3 * nt : 0));
     HIP_TRY(c, c->mat_lite.alloc(2 * nm));
     HIP_TRY(c, c->per_vertex.alloc(4 * nv));
     HIP_TRY(c, c->materials.alloc(6 * nm));
@@ -719,7 +774,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, hipMemcpy(c->per_vertex.p, pv, nv * sizeof(rpt_per_vertex_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->indices.p, idx, nt * sizeof(rpt_triangle), hipMemcpyHostToDevice));
     if (nt) k_derive_triangles<<<(unsigned)((nt + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK>>>(c->per_vertex.p, c->indices.p, (uint32_t)nt, c->tri_geom.p, c->tri_isect.p,
-                                                                                         c->tri_shade.p, d_cross_sq.p);
+                                                                                         c->tri_shade.p, c->tri_tangent.p, d_cross_sq.p);
     HIP_TRY(c, hipMemcpy(c->mat_lite.p, lite.data(), lite.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->nodes.p, nodes, nn * sizeof(rpt_bvh_node), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->materials.p, mats, nm * sizeof(rpt_material_data), hipMemcpyHostToDevice));
@@ -764,7 +819,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, hipMemcpy(c->skybox.p, skybox, (size_t)sw * sh * 16, hipMemcpyHostToDevice));
 
     DevScene &s = c->scene;
-    s.nodes = c->nodes.p; s.tri_geom = c->tri_geom.p; s.tri_isect = c->tri_isect.p; s.tri_shade = c->tri_shade.p; s.mat_lite = c->mat_lite.p;
+    s.nodes = c->nodes.p; s.tri_geom = c->tri_geom.p; s.tri_isect = c->tri_isect.p; s.tri_shade = c->tri_shade.p; s.tri_tangent = c->tri_tangent.p; s.mat_lite = c->mat_lite.p;
     s.textured = textured;
     s.indices = c->indices.p; s.per_vertex = c->per_vertex.p;
     s.materials = c->materials.p; s.light_pick = c->light_pick.p; s.light_rec = c->light_rec.p;
@@ -865,7 +920,18 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
          * are flipped by the rule that needed the fewest node visits on probe rays of their kind */
         c->last_order = choose_last_order(pv, idx, nt, nodes, nn, mats, pair_shaped);
         const size_t flip_vecs = 6 * (size_t)s.lds_pairs + ((size_t)s.lds_pairs + 3) / 4;
-        if (c->last_order.rule != 0 && ((size_t)s.lds_vecs + flip_vecs) * sizeof(float4) + 32 * 1024 + 64 <= 80 * 1024) {
+        /* room: two such workgroups per CU (k_traverse.h), i.e. half of what a CU holds — and no more than one workgroup may ask for — minus the kernel's static LDS */
+        size_t lds_room = 0;
+        {
+            hipDeviceProp_t prop;
+            hipFuncAttributes fa;
+            if (hipGetDeviceProperties(&prop, c->device) == hipSuccess &&
+                hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_traverse_nearest_stream<16, RPT_LDS_THREADS, RPT_NEAREST_LAST>)) == hipSuccess) {
+                const size_t per_wg = std::min<size_t>(prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor / 2);
+                lds_room = per_wg > fa.sharedSizeBytes ? per_wg - fa.sharedSizeBytes : 0;
+            }
+        }
+        if (c->last_order.rule != 0 && ((size_t)s.lds_vecs + flip_vecs) * sizeof(float4) <= lds_room) {
             const std::vector<rpt_bvh_node> pool = flipped_nodes(nodes, nn, c->last_order.flip);
             std::vector<float4> image;
             uint32_t pairs = 0, root = 0;
@@ -939,23 +1005,26 @@ int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
          * scanned (16 spp on 32 slots per pixel: 6.0 instead of 8.2 Grays/s).  Up to 32 slots per pixel and 32 M
          * slots: with the reference's default batch of 32 samples (sync_rate, src/trace.rs:75) a rank that owns 1/8
          * of a 1024^2 image then has 4 M paths in flight (7.2 instead of 6.6 Grays/s per GPU). */
+        /* Up to 256 since round 6 (k_path.h k_complete counts the finished slots of a pixel instead of keeping a 32-bit mask): a rank that owns 1/8
+         * of a 1024^2 image runs a 256-sample batch as the same 33 M-slot launches as the whole image runs 32 — the fixed costs of a batch
+         * (11 launches, drain tails) no longer weigh 8 x as much.  The arrays are allocated by the render call that needs them, at its size. */
         uint32_t S = 1;
         if (c->samples_in_flight_request > 0) {
-            while (S < (uint32_t)c->samples_in_flight_request && S < 32u) S <<= 1;
+            while (S < (uint32_t)c->samples_in_flight_request && S < RPT_MAX_SAMPLES_IN_FLIGHT) S <<= 1;
         } else {
-            /* as many as fit in RPT_MAX_SLOTS (160 M slots x ~180 B of path state and queues = 29 GB of the 288 GB).  Round 1
+            /* as many as fit in RPT_MAX_SLOTS (160 M slots x 70 - 150 B of path state and queues).  Round 1
              * stopped at 32 M and used S = 1 from 3 M pixels up, where more slots only cost: with one ray per lane the dead
              * slots of an open scene were walked as empty lanes.  The streamed walks skip them, and measured now (32-spp
              * batches): PBRTest 2048^2 4090 / 4354 / 4505 / 4537 / 4709 Mrays/s for S = 1 / 4 / 8 / 16 / 32, VeachMIS 1080p
              * 4388 / 4757 / 4892 for S = 8 / 16 / 32, the 1 M-triangle stand-in at 2048^2 994 / 1578 for S = 1 / 16. */
-            while (S < 32u && (uint64_t)c->n_pixels * S * 2u <= c->max_slots_budget) S <<= 1;
+            while (S < RPT_MAX_SAMPLES_IN_FLIGHT && (uint64_t)c->n_pixels * S * 2u <= c->max_slots_budget) S <<= 1;
         }
         c->max_group_shift = 0;
         while ((1u << c->max_group_shift) < S) c->max_group_shift += 1;
         c->max_slots = padded_pixels(c->n_pixels) << c->max_group_shift;       /* chunks of 64 pixels x S slots (k_common.h, slot_pix) */
-        c->group_shift = c->max_group_shift;
-        c->n_slots = c->max_slots;
-        int rc = alloc_state(c);
+        c->group_shift = std::min(c->max_group_shift, 5u);                     /* (until the first render call says how many it needs) */
+        c->n_slots = padded_pixels(c->n_pixels) << c->group_shift;
+        int rc = alloc_pixel_state(c);
         if (rc) return rc;
         /* fresh accumulators; seeds must come from rpt_reset */
         if (c->n_pixels) {
@@ -1066,6 +1135,9 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         c->state.q_shift = qs < shift ? qs : shift;
         c->state.n_slots = c->n_slots;
         c->queues.sky_wide_limit = std::min(c->n_slots / 16u, c->sky_wide_cfg);   /* the wide sky pass spends 16 threads of the grid per miss */
+        HIP_TRY(c, hipSetDevice(c->device));
+        int rc = ensure_slot_state(c, c->n_slots, c->cfg.nee_mode != RPT_NEE_NONE, c->cfg.nee_mode == RPT_NEE_MIS);
+        if (rc) return rc;
     }
     /* When no slot gets a second sample in this call (n_samples <= slots per pixel) nothing is regenerated: every path
      * ends within max_bounces iterations (lib.rs:62), its misses and shadow rays inside the iteration that produced
@@ -1150,7 +1222,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         if (it == known_iterations - short_batch) {             /* (no report needed: nothing can be left) */
             /* every path of the batch has ended (max_bounces iterations, side stages included): the one completion of the batch */
             if (c->group_shift != 0) {
-                k_complete<<<(c->n_pixels + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg, (uint32_t)it, 1u, c->dev_stats.p);
+                launch_complete(c, (uint32_t)it, 1u);
                 c->stats.kernel_launches[RPT_STAGE_COMPLETE] += 1;
                 if (time_stages) { HIP_TRY(c, hipEventRecord((*ev)[ev_at++], s)); complete_timed = true; }
             }
@@ -1243,7 +1315,7 @@ int rpt_local_pixels(rpt_ctx *c, uint64_t *n) {
 
 int rpt_set_samples_in_flight(rpt_ctx *c, int s) {
     if (!c) return RPT_EINVAL;
-    if (s < 0 || s > 32) { c->error = "samples in flight must be 0 (automatic) or 1..32"; return RPT_EINVAL; }
+    if (s < 0 || s > (int)RPT_MAX_SAMPLES_IN_FLIGHT) { c->error = "samples in flight must be 0 (automatic) or 1..256"; return RPT_EINVAL; }
     c->samples_in_flight_request = s;
     if (c->has_config) {   /* re-derive the slot count */
         rpt_tracing_config cfg = c->cfg.c;
@@ -1332,13 +1404,14 @@ __global__ void k_debug_math(int op, const float *x, const float *y, float *out,
         case 7: r = rptm::sqrtr(x[i]); break;
         case 9: r = rptm::slab_quotient(x[i], 0.0f, y[i]); break;
         case 10: r = rptm::exp_sky(x[i]); break;
+        case 11: r = rptm::unorm8(x[i]); break;
         default: r = x[i] / y[i]; break;
     }
     out[i] = r;
 }
 
 int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size_t n) {
-    if (op < 0 || op > 10 || !x || !y || !out) return RPT_EINVAL;
+    if (op < 0 || op > 11 || !x || !y || !out) return RPT_EINVAL;
     for (size_t i = 0; i < n; ++i) {
         float r;
         switch (op) {
@@ -1351,7 +1424,8 @@ int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size
             case 6: r = rptm::atan2r(x[i], y[i]); break;
             case 7: r = rptm::sqrtr(x[i]); break;
             case 9: r = rptm::slab_quotient(x[i], 0.0f, y[i]); break;
-        case 10: r = rptm::exp_sky(x[i]); break;
+            case 10: r = rptm::exp_sky(x[i]); break;
+            case 11: r = rptm::unorm8(x[i]); break;
             default: r = x[i] / y[i]; break;
         }
         out[i] = r;
@@ -1360,7 +1434,7 @@ int rpt_debug_math_host(int op, const float *x, const float *y, float *out, size
 }
 
 int rpt_debug_math(rpt_ctx *c, int op, const float *x, const float *y, float *out, size_t n) {
-    if (!c || op < 0 || op > 10 || !x || !y || !out) return RPT_EINVAL;
+    if (!c || op < 0 || op > 11 || !x || !y || !out) return RPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf<float> dx, dy, dout;
     HIP_TRY(c, dx.alloc(n)); HIP_TRY(c, dy.alloc(n)); HIP_TRY(c, dout.alloc(n));
@@ -1377,16 +1451,17 @@ int rpt_debug_math(rpt_ctx *c, int op, const float *x, const float *y, float *ou
 }
 
 /* Exhaustive check of a cheap exact operation against its IEEE form, over the bit patterns [lo_bits, lo_bits + count):
- * op 0: rptm::sqrtr == the compiler's correctly rounded sqrtf (trivially, today: the hook experiments with cheaper roots used); op 1: rptm::div_const_nontiny(x, y, RN(1 / y)) == x / y. */
+ * op 0: rptm::sqrtr == the compiler's correctly rounded sqrtf (trivially, today: the hook experiments with cheaper roots used); op 1: rptm::div_const_nontiny(x, y, RN(1 / y)) == x / y;
+ * op 2: rptm::f2i32_sat (one v_cvt_i32_f32) == Rust's `f32 as i32` written out with its branches (results compared as bit patterns). */
 __global__ void k_debug_math_sweep(int op, uint32_t lo_bits, unsigned long long count, float y, float ry, unsigned long long *out) {
     unsigned long long bad = 0ull;
     uint32_t first = 0xffffffffu;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
         const uint32_t bits = lo_bits + (uint32_t)i;
         const float x = rptm::u2f(bits);
-        const float fast = op == 0 ? rptm::sqrtr(x) : rptm::div_const_nontiny(x, y, ry);
-        const float ieee = op == 0 ? __builtin_sqrtf(x) : x / y;
-        const bool same = rptm::f2u(fast) == rptm::f2u(ieee) || (fast != fast && ieee != ieee);
+        const float fast = op == 0 ? rptm::sqrtr(x) : (op == 1 ? rptm::div_const_nontiny(x, y, ry) : rptm::u2f((uint32_t)rptm::f2i32_sat(x)));
+        const float ieee = op == 0 ? __builtin_sqrtf(x) : (op == 1 ? x / y : rptm::u2f((uint32_t)rptm::f2i32_sat_reference(x)));
+        const bool same = rptm::f2u(fast) == rptm::f2u(ieee) || (op != 2 && fast != fast && ieee != ieee);     /* (op 2 carries integers: bit patterns only) */
         if (!same) { bad += 1ull; first = first < bits ? first : bits; }
     }
     if (bad != 0ull) {
@@ -1396,7 +1471,7 @@ __global__ void k_debug_math_sweep(int op, uint32_t lo_bits, unsigned long long 
 }
 
 int rpt_debug_math_sweep(rpt_ctx *c, int op, uint32_t lo_bits, uint64_t count, float y, uint64_t *mismatches_out, uint32_t *first_bad_bits_out) {
-    if (!c || op < 0 || op > 1 || !mismatches_out || count > 0x100000000ull) return RPT_EINVAL;
+    if (!c || op < 0 || op > 2 || !mismatches_out || count > 0x100000000ull) return RPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf<unsigned long long> d;
     HIP_TRY(c, d.alloc(2));
@@ -1495,6 +1570,8 @@ int rpt_debug_trace_rays_production(rpt_ctx *c, size_t n, const float *origins, 
     int rc = rpt_wait(c);
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_slot_state(c, c->n_slots, false, false);
+    if (rc) return rc;
     DevBuf<float> d_o, d_d;
     HIP_TRY(c, d_o.alloc(3 * n)); HIP_TRY(c, d_d.alloc(3 * n));
     HIP_TRY(c, hipMemcpy(d_o.p, origins, 12 * n, hipMemcpyHostToDevice));

@@ -128,6 +128,14 @@ class Renderer:
             self._check(lib().rpt_set_partition(self._h, rank, world_size))
         self.config = None
 
+    @classmethod
+    def borrowed(cls, handle, config=None, rank=0, world_size=1):
+        """A view of an rpt_ctx somebody else owns (rpt_multi_ctx): every method works, close() / garbage collection leave the context alone."""
+        self = cls.__new__(cls)
+        self._h, self._borrowed = handle, True
+        self.rank, self.world_size, self.config = rank, world_size, config
+        return self
+
     def _check(self, rc):
         if rc != 0:
             raise RptError(rc, lib().rpt_last_error(self._h).decode())
@@ -139,7 +147,8 @@ class Renderer:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().rpt_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                lib().rpt_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -414,6 +423,10 @@ class MultiRenderer:
 
     def size(self):
         return lib().rpt_multi_size(self._h)
+
+    def rank_view(self, rank):
+        """The rpt_ctx of one rank as a (borrowed) Renderer: per-GPU statistics, stage times, partition queries."""
+        return Renderer.borrowed(self.ctx_handle(rank), self.config, rank, self.size())
 
     def ctx_handle(self, rank):
         """rpt_multi_ctx: the borrowed rpt_ctx of one rank (for rpt_set_samples_in_flight / rpt_get_stats per GPU)."""

@@ -69,6 +69,73 @@ def textured_scene(seed=7):
     return w, skybox
 
 
+def pbrtest_textured_scene():
+    """BASELINE config[3] as it is written — "PBRTest.glb with albedo/normal/rough/metal textures" — on the shipped file, which carries
+    NO texture: the file's own buffers (vertices, uvs, BVH, light table) + SYNTHETIC textures, labelled as such.
+    Every one of the 26 materials gets the four maps get_pbr_bsdf / the normal-map branch read (bsdf.rs:354-387, lib.rs:132-141), in the
+    order World::from_path pushes them (albedo, metallic, roughness, normals: src/asset.rs:138-160), each in the rectangle of the
+    4096 x 4096 RGBA8 atlas the reference's own packer gives 104 textures (pack_rects = src/atlas.rs:26-71; uvst = atlas.rs:16-23):
+    40 rectangles of 512^2 and 64 of 256^2 texels.  Contents: a two-colour checker with a gradient inside each square (albedo), a rippled
+    tangent-space normal, roughness / metallic ramps around the material's own factor.  PBRTest.glb has no TANGENT attribute (the
+    reference would get assimp's CalculateTangentSpace, asset.rs:65): tangents are a unit vector perpendicular to the vertex normal."""
+    rpt = importlib.import_module("rust-path-tracer_amd")
+    w = rpt.World.from_path(rpt.fixture("PBRTest.glb"))
+    A = 4096
+    n_mat = len(w.materials)
+    rects = pack_rects(4 * n_mat, A)
+    atlas = np.zeros((A, A, 4), np.uint8)
+    atlas[..., 3] = 255
+    m = w.materials.copy()
+
+    def uvst(r):
+        x, y, rw, rh = r
+        return [np.float32(x) / np.float32(A), np.float32(y) / np.float32(A), np.float32(rw) / np.float32(A), np.float32(rh) / np.float32(A)]
+
+    def grid(rw, rh):
+        yy, xx = np.mgrid[0:rh, 0:rw].astype(np.float32)
+        return xx, yy, xx / np.float32(rw), yy / np.float32(rh)
+
+    def put(r, rgb):
+        x, y, rw, rh = r
+        atlas[y:y + rh, x:x + rw, :3] = np.clip(np.rint(rgb * 255.0), 0, 255).astype(np.uint8)
+
+    for i in range(n_mat):
+        base_rough, base_metal = float(m["roughness"][i][0]), float(m["metallic"][i][0])
+        r_alb, r_met, r_rough, r_nrm = rects[4 * i: 4 * i + 4]
+        # albedo: checker of 32-texel squares between two colours of the material's own hue, a gradient inside every square
+        xx, yy, u, v = grid(r_alb[2], r_alb[3])
+        hue = (i * 0.61803398875) % 1.0
+        c0 = np.array([0.5 + 0.5 * np.cos(2 * np.pi * (hue + k / 3.0)) for k in range(3)], np.float32) * 0.7 + 0.15
+        c1 = 1.0 - 0.6 * c0
+        check = ((xx // 32 + yy // 32) % 2)[..., None]
+        shade = (0.75 + 0.25 * ((xx % 32) / 32.0))[..., None]
+        put(r_alb, (check * c0 + (1 - check) * c1) * shade)
+        m["albedo"][i] = uvst(r_alb); m["has_albedo_texture"][i] = 1
+        # metallic: vertical ramp around the factor; roughness: horizontal ramp around the factor (the kernels read .x)
+        xx, yy, u, v = grid(r_met[2], r_met[3])
+        put(r_met, np.repeat(np.clip(base_metal + 0.5 * (v - 0.5), 0.0, 1.0)[..., None], 3, 2))
+        m["metallic"][i] = uvst(r_met); m["has_metallic_texture"][i] = 1
+        xx, yy, u, v = grid(r_rough[2], r_rough[3])
+        put(r_rough, np.repeat(np.clip(base_rough + 0.4 * (u - 0.5), 0.03, 1.0)[..., None], 3, 2))
+        m["roughness"][i] = uvst(r_rough); m["has_roughness_texture"][i] = 1
+        # normal map: ripples of 64 texels, at most ~17 degrees off +z
+        xx, yy, u, v = grid(r_nrm[2], r_nrm[3])
+        nx = 0.3 * np.sin(2 * np.pi * xx / 64.0)
+        ny = 0.3 * np.cos(2 * np.pi * yy / 48.0)
+        nz = np.sqrt(np.maximum(1.0 - nx * nx - ny * ny, 0.0))
+        put(r_nrm, np.stack([nx, ny, nz], -1) * 0.5 + 0.5)
+        m["normals"][i] = uvst(r_nrm); m["has_normal_texture"][i] = 1
+    w.materials = m
+    n = w.per_vertex["normal"][:, :3]
+    t = np.cross(n, np.array([0.0, 1.0, 0.0], np.float32))
+    bad = np.linalg.norm(t, axis=1) < 1e-3
+    t[bad] = np.cross(n[bad], np.array([1.0, 0.0, 0.0], np.float32))
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    w.per_vertex["tangent"][:, :3] = t.astype(np.float32)
+    w.atlas = atlas
+    return w
+
+
 def deep_bvh_scene(n_triangles=200_000, seed=1):
     """Stand-in for the missing BreakTime.glb (BASELINE config 5): clustered long thin triangles
     inside a closed room, a few emissive panels.  Long thin primitives overlap heavily, which makes the binned-SAH

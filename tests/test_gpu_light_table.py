@@ -83,3 +83,42 @@ def test_nan_probabilities_are_refused(hipmod, world):
     v[t["v0"][np.nonzero(np.any(m["emissive"][t["material"], :3] != 0, axis=1))[0][0]], 0] = np.nan
     with pytest.raises(hipmod.RptError, match="NaN"):
         hipmod.light_table_build_gpu(v, t, m)
+
+
+def test_inputs_without_a_defined_table_are_refused_by_name_never_answered_differently(hipmod, oracle, rpt):
+    """Where src/light_pick.rs has no defined answer the device builder must not hand out a table that differs from the sequential one:
+    EVERY emissive triangle degenerate -> total power 0 -> every pick probability 0 / 0 = NaN (the reference carries the NaNs through an order-dependent
+    sort and a robin-hood loop that never terminates its donor: the sequential builders — host mirror, oracle — reproduce that table, NaN for NaN);
+    the device builder refuses the input BY NAME (RPT_ESCENE, "NaN") and the caller keeps the host builder.  A scene whose emissive triangles are only
+    PARTLY degenerate is the defined case of test_ties_zero_areas_and_negative_emission."""
+    from scenes import textured_scene
+    w, _ = textured_scene()
+    v, t, m = _inputs(w)
+    v = v.copy()
+    em = np.nonzero(np.any(m["emissive"][t["material"], :3] != 0, axis=1))[0]
+    assert len(em) >= 1
+    for k in em:                                            # collapse every emissive triangle onto its first corner
+        v[t["v1"][k]] = v[t["v0"][k]]
+        v[t["v2"][k]] = v[t["v0"][k]]
+    with pytest.raises(hipmod.RptError, match="NaN"):
+        hipmod.light_table_build_gpu(v, t, m)
+    ht = _host_builder(rpt)(v, t, m)                        # the host mirror through its C entry point: the reference's NaN table, as the oracle restates it
+    assert len(ht) == len(t) and np.isnan(ht["ratio"]).all()
+    assert _same(ht, oracle.light_table(v, t, m))
+
+
+def _host_builder(rpt):
+    """rpt_light_table_build of librpt_host.so (include/rpt/rpt_host.h) as a function of (vertices, triangles, materials) -> table"""
+    from importlib import import_module
+    ffi = import_module("rust-path-tracer_amd._ffi")
+    L = rpt.host.lib()
+
+    def build(v, t, m):
+        out = np.zeros(max(1, len(t)), ffi.LIGHT_PICK_DTYPE)
+        n = C.c_size_t(0)
+        L.rpt_light_table_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        rc = L.rpt_light_table_build(v.ctypes.data, len(v), np.ascontiguousarray(t).ctypes.data, len(t), np.ascontiguousarray(m).ctypes.data, len(m),
+                                     out.ctypes.data, len(out), C.byref(n))
+        assert rc == 0
+        return out[: n.value]
+    return build

@@ -16,6 +16,14 @@ def test_division_by_a_constant_is_the_ieee_quotient_on_its_whole_domain(rendere
         assert bad == 0, (c, hex(first), bad, hex(where))
 
 
+def test_float_to_int_conversion_is_rusts_as_i32_for_every_float(renderer):
+    """rptm::f2i32_sat on the device is ONE v_cvt_i32_f32 (image_polyfill.rs:41-42 `as_ivec2`: 16 conversions per textured hit): equal to the written-out
+    saturating cast — NaN -> 0, truncation, i32::MIN / MAX beyond the range — on all 2^32 bit patterns."""
+    for first in (0, 0x80000000):
+        bad, where = renderer.debug_math_sweep(2, first, 0x80000000, 1.0)
+        assert bad == 0, (hex(first), bad, hex(where))
+
+
 def test_the_sweep_sees_a_difference_where_there_is_one(renderer):
     """Below the contract's range the three-step quotient does lose bits (denormal residuals): the checker is not blind."""
     bad, _ = renderer.debug_math_sweep(1, 1, 0x00800000, 8e3)

@@ -112,15 +112,16 @@ def test_overlapped_reads_see_batch_k_while_batch_k_plus_1_renders(hipmod, rpt, 
     assert sum(i["samples"] for i in infos) == W * H * sum(batches)
 
 
-@pytest.mark.parametrize("ranks,launcher", [(2, "torchrun"), (8, "torchrun"), (2, "plain"), (4, "plain")])
+@pytest.mark.parametrize("ranks,launcher", [(2, "torchrun"), (8, "torchrun"), (2, "plain"), (4, "plain"), (2, "multi"), (4, "multi")])
 def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks, launcher):
     """`bench.py --gpus N` exactly as the driver's scaling run starts it — under torch.distributed.run (one process per rank) AND as
-    the plain `python bench.py --gpus N` with no launcher in the environment, where bench.py starts its ranks itself as child
+    the plain `python bench.py --gpus N` with no launcher in the environment, where bench.py starts its ranks itself as watchdog-guarded child
     processes — except that every rank sits on the one GPU of this box (--rehearsal: gloo for torch.distributed, the stand-in for
     RCCL inside the library).  Every line the 2 / 4 / 8-GPU run executes runs here: unique id broadcast, rpt_comm_init, render +
     gather per step, drain, barriers, statistics reduction, rank 0's JSON line — whose image (gathered from all ranks) must pass
-    the bitwise parity check against the oracle, with the gather reported as the library's.  The number itself is not a
-    measurement and says so."""
+    the bitwise parity check against the oracle, with the gather reported as the library's.  `multi`: the second driver (`--driver multi`:
+    ONE child process, rpt_multi_* — what the launcher falls back to when the per-process run fails or hangs), same line, same parity.
+    A batch is 32 x N samples (N x as many samples of a pixel in flight on 1 / N of the image).  The number itself is not a measurement and says so."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -129,6 +130,8 @@ def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks, launcher):
     if launcher == "torchrun":
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + bench_args
+    elif launcher == "multi":
+        cmd = [sys.executable] + bench_args + ["--driver", "multi"]
     else:
         cmd = [sys.executable] + bench_args
     env = _env()
@@ -140,17 +143,25 @@ def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks, launcher):
     assert len(lines) == 1, p.stdout[-2000:]
     out = json.loads(lines[0])
     assert "rehearsal" in out and out["n_gpus"] == ranks and out["steps"] == 2 and out["warmup"] == 1
-    assert out["config"]["gather"] == "rccl-c-abi" and out["config"]["collective_library"] == FAKE
+    assert out["config"]["spp_per_step"] == 32 * ranks
     assert out["config"]["rpt_comm_world"] == [0, ranks]
-    assert out["parity_check"]["bitwise"] is True and out["parity_check"]["windows"] >= 2 and out["parity_check"]["image_spp"] == 96
-    assert out["rays"]["extension"] > 1024 * 1024 * 64 and out["roofline"]["kernel"] == "k_traverse"
-    # counter-derived per-launch figures are the kept whole-image passes scaled to rank 0's part of the image, or absent — never N x too high
+    assert out["parity_check"]["bitwise"] is True and out["parity_check"]["windows"] >= 2 and out["parity_check"]["image_spp"] == 96 * ranks
+    assert out["rays"]["extension"] > 1024 * 1024 * 64 * ranks and out["roofline"]["kernel"] == "k_traverse"
+    if launcher == "multi":
+        assert out["config"]["driver"].startswith("multi") and out["config"]["fallback_from"] is None
+        assert "starting -m torch.distributed.run" not in p.stderr
+    else:
+        assert out["config"]["driver"].startswith("ranks")
+        assert out["config"]["gather"] == "rccl-c-abi" and out["config"]["collective_library"] == FAKE
+    # counter-derived per-launch figures are the kept whole-image passes scaled to the slots of rank 0's launches (1 / N of the image x N x the samples:
+    # the same launch as the whole image at 32), or absent — never N x too high or too low
     rf = out["roofline"]
     if rf["traffic"] is not None:
-        assert abs(rf["traffic_scaled_by"] - 1.0 / ranks) < 0.02 and 0.9 < rf["traffic_over_algorithmic"] < 1.6
+        assert abs(rf.get("traffic_scaled_by", 1.0) - 1.0) < 0.02 and 0.9 < rf["traffic_over_algorithmic"] < 1.6
         assert 0.9 < out["pipeline_roofline"]["traffic_over_algorithmic"] < 1.6
     if launcher == "plain":
         assert "starting -m torch.distributed.run" in p.stderr
+    if launcher != "torchrun":
         return
     # and WITHOUT the rehearsal flag the stand-in is refused: a scaling number can only come from RCCL
     cmd_real = [c for c in cmd if c != "--rehearsal"]

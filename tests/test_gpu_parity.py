@@ -57,6 +57,13 @@ def test_math_two_operand_bitwise(renderer, oracle):
     assert np.array_equal(q_dev.view(np.uint32)[~both_nan], q_cpu.view(np.uint32)[~both_nan])
 
 
+def test_texel_channels_are_divided_by_255_exactly_on_the_device(renderer):
+    """rptm::unorm8 == u8 / 255.0f for all 256 channel values (the textured shade stage converts up to 48 per hit)."""
+    x = np.arange(256, dtype=np.float32)
+    got = renderer.debug_math(11, x)
+    assert np.array_equal(got.view(np.uint32), (x / np.float32(255.0)).view(np.uint32))
+
+
 def test_fast_division_on_device_equals_ieee(renderer):
     """rpt_fastdiv.h on gfx950: guarded reciprocal division == IEEE division (modulo the sign of a zero quotient)."""
     rng = np.random.default_rng(23)
@@ -196,6 +203,29 @@ def test_image_parity_with_oracle(renderer, oracle, rpt, world, scene, W, H, spp
     print(f"{scene} {W}x{H} spp={spp} nee={nee}: relL2={err:.3e} pixels differing bitwise={n_diff}")
     assert err <= TOL_REL_L2
     assert n_diff == 0, "accumulators are expected to be bit-identical to the oracle"
+
+
+@pytest.mark.parametrize("scene,W,H,nee,spp", [("DarkCornell", 1024, 1024, 1, 2), ("VeachMIS", 1920, 1080, 1, 1)])
+def test_elided_shadow_rays_equal_the_oracles_count_at_full_size(hipmod, oracle, rpt, world, scene, W, H, nee, spp):
+    """The NEE evaluations whose shadow ray decides nothing (k_shade.h; light_pick.rs:141-172 + lib.rs:164) at the BASELINE configurations' own resolutions:
+    the device elides exactly the evaluations the oracle's analysis hook identifies, walks exactly the others, and the image is the oracle's, whole."""
+    w = world(scene)
+    cfg = rpt.default_config(W, H, nee=nee)
+    seeds = rpt.blue_noise_seeds(W, H)
+    r = hipmod.Renderer(0)
+    try:
+        r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+        r.render(spp)
+        acc, _ = r.read_accum()
+        st = r.stats()
+    finally:
+        r.close()
+    sc = oracle.scene(w)
+    ref, _, st_c = oracle.trace_cpu(cfg, sc, seeds, spp)
+    n_all, n_dead, _, _ = oracle.dead_shadow_rays(cfg, sc, seeds, spp)
+    assert n_all == st_c.shadow_rays == st["shadow_rays"] and st["shadow_rays_elided"] == n_dead and st["shadow_rays_traced"] == n_all - n_dead
+    assert 0.2 * n_all < n_dead < 0.8 * n_all and st["extension_rays"] == st_c.extension_rays
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
 
 
 @pytest.mark.parametrize("order", ["near", "fixed"])
@@ -515,7 +545,7 @@ def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp
     cfg = rpt.default_config(W, H, nee=nee)
     seeds = rpt.blue_noise_seeds(W, H)
     ref, rng_ref, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
-    for s_in_flight in (1, 2, 4, 16, 32, 0):
+    for s_in_flight in (1, 2, 4, 16, 32, 256, 0):
         r = hipmod.Renderer(0)
         r.set_samples_in_flight(s_in_flight)
         r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
@@ -528,6 +558,45 @@ def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp
         assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays
         assert np.array_equal(r.read_rng()["n"], rng_ref["n"])
         r.close()
+
+
+@pytest.mark.parametrize("q_shift", [None, 5, 3])
+@pytest.mark.parametrize("scene,nee", [("DarkCornell", 0), ("VeachMIS", 1)])
+def test_up_to_256_samples_of_a_pixel_in_flight(monkeypatch, hipmod, oracle, rpt, world, scene, nee, q_shift):
+    """More than 32 slots per pixel (round 6: k_complete counts a pixel's finished slots — a prefix — instead of keeping a 32-bit mask): 64, 128 and
+    256 samples in flight give the sequential sample-order sum bit for bit (kernels/src/lib.rs:225-226), as batches of known length (n <= S),
+    as calls whose slots take several samples (n > S), with sample counts that are no multiple of anything, under both slot layouts, and a
+    context may move between them (the path state grows on demand)."""
+    if q_shift is not None:
+        monkeypatch.setenv("RPT_SLOT_Q_SHIFT", str(q_shift))
+    w = world(scene)
+    W, H = 56, 44                                                   # (2 464 pixels: not a multiple of 64)
+    cfg = rpt.default_config(W, H, nee=nee)
+    seeds = rpt.blue_noise_seeds(W, H)
+    calls = (256, 37, 130, 64, 200)                                 # 256 / 64 / 256 / 64 / 256 slots per pixel under S = 256
+    ref, rng_ref, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, sum(calls))
+    for s_in_flight in (256, 128, 64):
+        r = hipmod.Renderer(0)
+        try:
+            r.set_samples_in_flight(s_in_flight)
+            r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
+            for k, n in enumerate(calls):
+                (r.render_async if k % 2 == 0 else r.render)(n)
+            r.wait()
+            acc, n = r.read_accum()
+            assert n == sum(calls)
+            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"samples in flight = {s_in_flight}"
+            g = r.stats()
+            assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays
+            assert np.array_equal(r.read_rng()["n"], rng_ref["n"])
+        finally:
+            r.close()
+    with pytest.raises(hipmod.RptError):
+        r = hipmod.Renderer(0)
+        try:
+            r.set_samples_in_flight(257)
+        finally:
+            r.close()
 
 
 def test_sky_stage_per_iteration_or_once_per_batch(monkeypatch, hipmod, oracle, rpt, world):

@@ -68,9 +68,25 @@ def test_registers_of_the_nee_and_packed_shade_variants_do_not_creep(resources, 
         assert vgpr <= vgpr_max and scratch == 0
 
 
+@pytest.mark.parametrize("kernel,vgpr_max", [("void k_shade<0, true, false>", 96), ("void k_shade<0, true, true>", 128), ("void k_shade<1, true, false>", 96),
+                                             ("void k_shade<1, true, true>", 128), ("void k_shade<2, true, false>", 96), ("void k_shade<2, true, true>", 128)])
+def test_registers_of_the_textured_shade_variants(resources, kernel, vgpr_max):
+    """The TEXTURED variants (BASELINE config[3] as written; round 6: first counters): 84 / 119 / 82 / 123 / 82 / 123 VGPRs, 5 and 4 waves per SIMD, no scratch,
+    the packed variants' 8 KB of list + a few words of LDS."""
+    for vgpr, sgpr, scratch, lds in _find(resources, kernel):
+        assert vgpr <= vgpr_max and scratch == 0 and lds <= 8472
+
+
+def test_completion_kernel(resources):
+    """k_complete (k_path.h): one wave per chunk, its LDS tile is dynamic (0 at q_shift = 0, up to 35 KB otherwise), eight radiance rows in flight
+    in scalars — an array of float4 there stays in scratch behind its 16-byte copies (found in round 6)."""
+    for vgpr, sgpr, scratch, lds in _find(resources, "k_complete"):
+        assert vgpr <= 96 and scratch == 0 and lds == 0
+
+
 def test_no_stage_kernel_of_the_shipped_scenes_spills(resources):
     """every kernel a shipped scene (or the two stand-ins) launches: no scratch"""
-    for prefix in ("void k_shade<0, false, ", "void k_shade<1, false, ", "void k_shade<2, false, ", "void k_sky<", "k_generate_first", "k_complete",
+    for prefix in ("void k_shade<0, false, ", "void k_shade<1, false, ", "void k_shade<2, false, ", "void k_shade<0, true, ", "void k_shade<1, true, ", "void k_shade<2, true, ", "void k_sky<", "k_generate_first", "k_complete",
                    "k_shadow_resolve", "void k_traverse_nearest_gstream<32, 16, true>", "void k_traverse_shadow_gstream<32, 16, true, "):
         for vgpr, sgpr, scratch, lds in _find(resources, prefix):
             assert scratch == 0, prefix

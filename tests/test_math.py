@@ -82,3 +82,12 @@ def test_exp_sky_specials_without_branches(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-mfma", "-pthread", "-I" + ROOT, "-o", str(exe), os.path.join(ROOT, "tools", "exp_sky_check.cpp")], check=True)
     out = subprocess.run([str(exe), "64"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-500:]
+
+
+def test_texel_channels_are_divided_by_255_exactly(hipmod):
+    """rptm::unorm8 (an atlas texel channel, src/asset.rs:270 `Vec4(r, g, b, 255) / 255.0`): three instructions instead of an IEEE division, the correctly
+    rounded quotient for EVERY channel value — the host build here, the device in tests/test_gpu_parity.py."""
+    x = np.arange(256, dtype=np.float32)
+    got = hipmod.debug_math_host(11, x)
+    assert np.array_equal(got.view(np.uint32), (x / np.float32(255.0)).view(np.uint32))
+    assert got[0] == 0.0 and not np.signbit(got[0]) and got[255] == 1.0
