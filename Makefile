@@ -12,7 +12,8 @@ CXX      ?= g++
 
 HOST_SRCS := $(CSRC)/host/host_api.cpp $(CSRC)/host/glb_scene.cpp $(CSRC)/host/bvh_build.cpp \
              $(CSRC)/host/light_table.cpp $(CSRC)/host/bluenoise.cpp $(CSRC)/host/image_io.cpp $(CSRC)/host/textures.cpp $(CSRC)/host/obj_scene.cpp $(CSRC)/host/jpeg_decode.cpp
-HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_comm.hip $(CSRC)/rpt_lights.hip
+HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_traverse.hip $(CSRC)/rpt_comm.hip $(CSRC)/rpt_lights.hip
+HIP_OBJS  := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 HIP_DEPS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hip) $(wildcard include/rpt/*.h)
 
 CXXFLAGS_COMMON := -std=c++20 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unknown-pragmas
@@ -43,9 +44,16 @@ oracle/liboracle_libm.so: oracle/rpt_oracle.cpp oracle/bvh_oracle.cpp $(CSRC)/rp
 
 # the fingerprint of the device-side sources is compiled in (rpt_build_fingerprint): bench.py reports PMC-derived figures only for the
 # sources the LOADED library was built from, and says so when the library is older than the source tree
-$(LIBDIR)/librpt_hip.so: $(HIP_DEPS) tools/source_fingerprint.py Makefile
+# one object per translation unit, built in PARALLEL (the recipe below re-invokes make with -j): the walk kernels (rpt_traverse.hip) and the
+# shade / sky / set-up kernels (rpt_hip.hip) each take about 20 s, one after the other they were 50 s
+build/%.o: $(CSRC)/%.hip $(HIP_DEPS) tools/source_fingerprint.py Makefile
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DRPT_BUILD_FINGERPRINT=\"$$(python3 tools/source_fingerprint.py)\" -c -o $@ $<
+
+$(LIBDIR)/librpt_hip.so: $(HIP_SRCS) $(HIP_DEPS) tools/source_fingerprint.py Makefile
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DRPT_BUILD_FINGERPRINT=\"$$(python3 tools/source_fingerprint.py)\" -shared -o $@ $(HIP_SRCS) -ldl
+	$(MAKE) -j4 $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(HIP_OBJS) -ldl
 
 # test infrastructure: a stand-in for RCCL's point-to-point calls over shared memory, so that N PROCESSES on a one-GPU test box run
 # the product's gather unchanged (tests/test_gpu_multiprocess.py; selected with RPT_RCCL_LIBRARY, never linked by the product)

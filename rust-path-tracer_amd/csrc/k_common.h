@@ -12,7 +12,7 @@
  * tiles still fills its 256 CUs.  Slot k takes samples k, k+S, k+2S, ...; the S samples
  * of a "generation" are summed into the accumulator in k order by the pixel's thread once
  * all of them have finished, which reproduces the reference's sample-order f32 sum
- * bit for bit whatever S is (k_path.h: k_complete).
+ * bit for bit whatever S is (k_complete.h).
  *
  * Extension rays need no queue: a finished path is regenerated in place, so
  * (except in the last few iterations of a render call) every slot always has
@@ -40,7 +40,7 @@
 
 #define RPT_WAVE 64
 #define RPT_BLOCK 256
-#define RPT_MAX_SAMPLES_IN_FLIGHT 256u   /* most slots per pixel (k_path.h k_complete counts a pixel's finished slots; rounds 1-5: a 32-bit mask) */
+#define RPT_MAX_SAMPLES_IN_FLIGHT 256u   /* most slots per pixel (k_complete.h counts a pixel's finished slots; rounds 1-5: a 32-bit mask) */
 
 /* ---- glam-order float3 helpers (device side) ----------------------------- */
 struct F3 { float x, y, z; };
@@ -121,6 +121,12 @@ struct DevScene {
     uint32_t textured;             /* some material has a texture flag set */
     DevImage atlas, skybox;
 };
+
+/* constants of the traversal structures that the upload code (rpt_hip.hip) and the walk kernels (k_traverse.h, compiled in rpt_traverse.hip) share */
+#define LDS_DESC_DEAD 0x4000u      /* 16-bit child descriptor of the LDS image (k_traverse.h SceneViewLds): pair index, or LEAF | count << 9 | first triangle */
+#define LDS_DESC_LEAF 0x8000u
+#define RPT_LDS_SCENE_BYTES 32768  /* a traversal image up to this size lives in LDS (+ 32 KB of 16-bit stacks = the 64 KB of one of two workgroups per CU) */
+#define RPT_COOP_LEAF_MIN 6        /* leaves with more triangles than this are tested by the whole wave (global-memory scenes) */
 
 /* ---- per-slot path state (SoA of float4 records) -------------------------- */
 struct DevState {
@@ -305,7 +311,7 @@ __device__ __forceinline__ uint32_t block_push(uint32_t *counter, bool pred, uin
 }
 
 /* ---- stateless LDS sequence (kernels/src/rng.rs:20-32) --------------------- */
-__device__ __constant__ uint32_t c_lds_primes[32] = {
+static __device__ __constant__ uint32_t c_lds_primes[32] = {
     0x6a09e667u, 0xbb67ae84u, 0x3c6ef372u, 0xa54ff539u, 0x510e527fu, 0x9b05688au, 0x1f83d9abu, 0x5be0cd18u,
     0xcbbb9d5cu, 0x629a2929u, 0x91590159u, 0x452fecd8u, 0x67332667u, 0x8eb44a86u, 0xdb0c2e0bu, 0x47b5481du,
     0xae5f9155u, 0xcf6c85d1u, 0x2f73477du, 0x6d1826cau, 0x8b43d455u, 0xe360b595u, 0x1c456002u, 0x6f196330u,

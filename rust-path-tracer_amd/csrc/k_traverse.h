@@ -278,8 +278,6 @@ template <bool COOP> struct GstreamView { typedef SceneViewGlobalT<COOP> type; }
  * LDS cycle spread over all 64 banks instead of the 4 bank groups an array-of-nodes layout allows.
  * A node array that is not pair-shaped, has an empty/inverted box, or a leaf of 64+ triangles gets no image and
  * is traversed from global memory by the generic loop. */
-#define LDS_DESC_DEAD 0x4000u
-#define LDS_DESC_LEAF 0x8000u
 struct SceneViewLds {
     static constexpr bool kCoopLeaves = false;
     const float4 *img;
@@ -355,7 +353,6 @@ __device__ __forceinline__ bool moller_trumbore_regs(F3 edge1, F3 edge2, F3 corn
                                             Measured (K = 8 rule / 100 / 60): VeachMIS 5175 / 5506 / 5453 Mrays/s, PBRTest 4915 / 5027 / 5011 */
 #endif
 #ifndef RPT_COOP_LEAF_MIN
-#define RPT_COOP_LEAF_MIN 6        /* leaves with more triangles than this are tested by the whole wave (global-memory scenes) */
 #endif
 __device__ __forceinline__ float rpt_readlane(float v, int lane) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane)); }
 __device__ __forceinline__ uint32_t rpt_readlane_u(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
@@ -774,7 +771,6 @@ __device__ __forceinline__ HitRecord traverse_one(const SceneViewLds &view, uint
  * (ds_read_b128, ~64-cycle latency, no pressure on the CU's single vector-memory address
  * unit — the measured limiter once the divisions were gone: ~380 divergent 16-byte
  * wave-loads per wave through one TA per CU).  Larger scenes read through L1/L2. */
-#define RPT_LDS_SCENE_BYTES 32768
 extern __shared__ __attribute__((aligned(16))) float4 rpt_lds_dyn[];   /* sized at launch to the scene (LDS variants only) */
 template <bool LDS_SCENE> struct SceneViewOf { typedef SceneViewGlobal type; };
 template <> struct SceneViewOf<true> { typedef SceneViewLds type; };

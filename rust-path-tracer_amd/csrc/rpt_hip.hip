@@ -29,8 +29,7 @@ struct SectionTimer {
     std::chrono::steady_clock::time_point last;
     std::string line;
     explicit SectionTimer(const char *t) : on(false), title(t) {
-        const char *e = getenv("RPT_UPLOAD_TIMING");
-        on = e && e[0] == '1';
+        on = rpt_read_knobs().upload_timing;
         last = std::chrono::steady_clock::now();
     }
     void mark(const char *name) {
@@ -43,9 +42,10 @@ struct SectionTimer {
     }
     ~SectionTimer() { if (on) fprintf(stderr, "%s (ms):%s\n", title, line.c_str()); }
 };
-#include "k_traverse.h"
+#include "rpt_fastdiv.h"      /* (the walk kernels of k_traverse.h are compiled in rpt_traverse.hip) */
 #include "k_bvh_build.h"
 #include "k_shade.h"
+#include "k_complete.h"
 #include "k_sky_generate.h"
 #include "k_bsdf_extra.h"
 
@@ -55,6 +55,28 @@ constexpr int LAG = RPT_RING_LAG;
 constexpr int RING = RPT_RING;
 
 }  // namespace
+
+/* (read afresh by every rpt_create / scene-preparation call: a test process changes its environment between contexts) */
+rpt_knobs rpt_read_knobs() {
+    {
+        rpt_knobs k;
+        auto num = [](const char *name, int lo, int hi, int otherwise) { const char *e = getenv(name); if (!e || !e[0]) return otherwise; const int v = atoi(e); return v < lo ? lo : (v > hi ? hi : v); };
+        auto word = [](const char *name) { const char *e = getenv(name); return std::string(e ? e : ""); };
+        k.stage_timing = num("RPT_STAGE_TIMING", 0, 2, 0);
+        k.upload_timing = num("RPT_UPLOAD_TIMING", 0, 1, 0) == 1;
+        k.slot_q_shift = num("RPT_SLOT_Q_SHIFT", 0, 5, -1);
+        const std::string so = word("RPT_SHADOW_ORDER"), lo = word("RPT_LAST_ORDER");
+        k.shadow_order = so == "near" ? 0 : (so == "fixed" ? 1 : -1);
+        k.last_order = lo == "off" ? 4 : (lo == "near" ? 0 : (lo == "opaque" ? 1 : (lo == "small" ? 2 : (lo == "ratio" ? 3 : -1))));
+        k.shade_compact = num("RPT_SHADE_COMPACT", 0, 1, -1);
+        k.sky_strided = num("RPT_SKY_STRIDED", 0, 1 << 20, -1);
+        k.stack_bits = num("RPT_STACK_BITS", 16, 32, 16);
+        k.coop_leaves = num("RPT_COOP_LEAVES", 0, 1, -1);
+        k.no_lds_scene = num("RPT_NO_LDS_SCENE", 0, 1, 0) == 1;
+        k.bvh_team_min = num("RPT_BVH_TEAM_MIN", 2, 1 << 30, 0);
+        return k;
+    }
+}
 
 thread_local std::string g_create_error;
 std::string &rpt_create_error() { return g_create_error; }
@@ -66,18 +88,24 @@ namespace {
  * outside the image are skipped.  One wave = one 8x8 block on full tiles, so
  * primary rays of a wave are coherent. */
 void build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, std::vector<uint32_t> &out) {
-    out.clear();
     const uint32_t T = RPT_TILE, B = 8;
     uint32_t tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+    /* (count first, then plain stores: four million push_backs were 10 ms of rpt_set_config at 2048^2) */
+    size_t total = 0;
+    for (uint32_t t = rank; t < tiles_x * tiles_y; t += world) {
+        const uint32_t tx = (t % tiles_x) * T, ty = (t / tiles_x) * T;
+        total += (size_t)std::min(T, W - tx) * std::min(T, H - ty);
+    }
+    out.resize(total);
+    uint32_t *at = out.data();
     for (uint32_t t = rank; t < tiles_x * tiles_y; t += world) {
         uint32_t tx = (t % tiles_x) * T, ty = (t / tiles_x) * T;
-        for (uint32_t by = 0; by < T; by += B)
-            for (uint32_t bx = 0; bx < T; bx += B)
-                for (uint32_t y = 0; y < B; ++y)
-                    for (uint32_t x = 0; x < B; ++x) {
-                        uint32_t px = tx + bx + x, py = ty + by + y;
-                        if (px < W && py < H) out.push_back(px | (py << 16));
-                    }
+        for (uint32_t by = 0; by < T && ty + by < H; by += B)
+            for (uint32_t bx = 0; bx < T && tx + bx < W; bx += B) {
+                const uint32_t xs = std::min(B, W - (tx + bx)), ys = std::min(B, H - (ty + by));
+                for (uint32_t y = 0; y < ys; ++y)
+                    for (uint32_t x = 0; x < xs; ++x) *at++ = (tx + bx + x) | ((ty + by + y) << 16);
+            }
     }
 }
 
@@ -194,14 +222,10 @@ int alloc_pixel_state(rpt_ctx *c) {
     q.sky_cnt = c->q_count.p + Q_COUNT; q.shadow_cnt = q.sky_cnt + RPT_Q_SHARDS * RPT_Q_SHARD_STRIDE;
     q.host_ring = c->host_ring_dev; q.ring_mask = RING - 1;
     /* up to this many queued misses the sky march runs 16 lanes per miss (re-clamped per call to that call's slot count) */
-    c->sky_wide_cfg = 32768u;
-    if (const char *env = getenv("RPT_SKY_WIDE_LIMIT")) c->sky_wide_cfg = (uint32_t)std::max(0, atoi(env));
     q.sky_wide_limit = (uint32_t)std::min<size_t>(c->n_slots / 16, c->sky_wide_cfg);
-    /* 1 = shade misses in the iteration that found them.  Letting them pile up (threshold ~ n/64) removes most
-     * of the near-empty sky launches on closed scenes, but the parked pixels finish later and lengthen the tail:
-     * measured DarkCornell 3650 Mrays/s deferred vs 3928 eager — so eager is the default. */
+    /* 1 = shade misses in the iteration that found them.  (Letting them pile up removed most of the near-empty sky launches on closed scenes, but the
+     * parked pixels finish later and lengthen the tail: DarkCornell 3650 Mrays/s deferred vs 3928 eager in round 1; the knob went in round 6.) */
     q.sky_threshold = 1u; q.sky_at_end = 0u; q.known_length = 0u;
-    if (const char *env = getenv("RPT_SKY_THRESHOLD")) q.sky_threshold = (uint32_t)std::max(1, atoi(env));
     c->has_state = true;
     return RPT_OK;
 }
@@ -212,13 +236,16 @@ int alloc_pixel_state(rpt_ctx *c) {
 int ensure_slot_state(rpt_ctx *c, size_t n, bool need_shadow, bool need_mis) {
     const bool grow = c->hit.n < n, grow_shadow = need_shadow && c->sh_o.n < n + RPT_Q_SLACK, grow_mis = need_mis && c->mis_a.n < n;
     if (grow || grow_shadow || grow_mis) {
+        SectionTimer sections("path state");
         if (c->async_pending) { int rc = rpt_wait(c); if (rc) return rc; }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        sections.mark("drain");
         if (grow) {
             c->ray_a.release(); c->ray_b.release(); c->hit.release(); c->thr.release(); c->rad.release(); c->q_sky.release();
             HIP_TRY(c, c->ray_a.alloc(n)); HIP_TRY(c, c->ray_b.alloc(n)); HIP_TRY(c, c->hit.alloc(n));
             HIP_TRY(c, c->thr.alloc(n)); HIP_TRY(c, c->rad.alloc(n));
             HIP_TRY(c, c->q_sky.alloc(n + RPT_Q_SLACK));     /* side queues: positions, not entries (k_common.h: sharded queues) */
+            sections.mark("alloc_path_state");
             k_fill_idle<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, c->stream>>>(c->hit.p, (uint32_t)n);   /* nothing in flight */
             HIP_TRY(c, hipGetLastError());
         }
@@ -230,6 +257,7 @@ int ensure_slot_state(rpt_ctx *c, size_t n, bool need_shadow, bool need_mis) {
             c->mis_a.release(); c->mis_b.release();
             HIP_TRY(c, c->mis_a.alloc(n)); HIP_TRY(c, c->mis_b.alloc(n));
         }
+        sections.mark("alloc_queues_carries");
     }
     DevState &s = c->state;
     s.ray_a = c->ray_a.p; s.ray_b = c->ray_b.p; s.hit = c->hit.p; s.thr = c->thr.p; s.rad = c->rad.p;
@@ -283,73 +311,9 @@ bool build_lds_image(const rpt_bvh_node *nodes, size_t nn, const std::vector<flo
     return true;
 }
 
-#ifndef RPT_GLOBAL_THREADS
-#define RPT_GLOBAL_THREADS 64      /* one wave: no scene staging to share, and a finished wave frees its stack at once (PBRTest traverse -5 %) */
-#endif
-constexpr int GLOBAL_THREADS = RPT_GLOBAL_THREADS;   /* workgroup size of the global-memory traversal variants */
-constexpr int LDS_THREADS = RPT_LDS_THREADS;     /* (rpt_ctx.h) */
-
 static uint32_t padded_pixels(uint32_t n_pixels) { return (n_pixels + 63u) & ~63u; }      /* whole chunks of 64 pixels (k_common.h, slot_pix) */
 
-/* streamed global-memory walks: width of a stack entry for the scene, and slots per wave — as many as keep >= gstream_min_waves
- * waves in the launch, at most `most` per lane */
-static int gstream_stack_width(const rpt_ctx *c) {
-    return (c->scene.n_nodes < 65536u && c->stack_bits_min <= 16) ? 16
-         : (c->scene.n_nodes < (1u << 21) && c->stack_bits_min <= 21) ? 21
-         : (c->scene.n_nodes < (1u << 24) && c->stack_bits_min <= 24) ? 24 : 32;
-}
-static uint32_t gstream_span(const rpt_ctx *c, uint32_t most) {
-    const uint32_t wanted = c->n_slots / (c->gstream_min_waves * RPT_WAVE);
-    const uint32_t g = wanted < 1u ? 1u : (wanted > most ? most : wanted);
-    return g * RPT_WAVE;
-}
-
-/* The nearest-hit traversal stage for the context's scene and state: which kernel, which grid.  Used by every iteration of a
- * render call and by rpt_debug_trace_rays_production (per-ray parity of exactly these kernels). */
-template <int STACK>
-void launch_nearest(rpt_ctx *c, uint32_t iteration, bool last_without_nee = false /* the last extension rays of a batch of known length, no NEE */,
-                    bool camera_rays = false /* iteration 0 of a render call: every ray leaves cfg.cam_position */) {
-    hipStream_t s = c->stream;
-    const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
-    const uint32_t blocks_lds = (c->n_slots + LDS_THREADS - 1) / LDS_THREADS;
-    const int stack_width = gstream_stack_width(c);
-    const uint32_t gspan_n = gstream_span(c, (uint32_t)gstream_rays_nearest(STACK, stack_width)), gblocks_n = (c->n_slots + gspan_n - 1) / gspan_n;
-    if (STACK == 16 && c->scene.lds_scene && c->lds_stream) {
-        /* persistent workgroups (as many as stay resident: 2 per CU) that fetch spans of slots from a launch-wide counter:
-         * a span = 1/32 of a workgroup's share, between 1 and 8 slots per lane (measured at 33 M slots: 8192 / 4096 / 2048 / 1024
-         * slots per span: DarkCornell 9 995 / 10 160 / 10 255 / 10 200 Mrays/s with 64 pixels per wave; rounds 1-2, two pixels
-         * per wave, preferred 4096) */
-        const uint32_t wgs = c->stream_max_blocks;
-        uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 32u);
-        span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
-        span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
-        const uint32_t n_spans = (c->n_slots + span - 1) / span;
-        const float *cam = c->cfg.c.cam_position;
-        if (last_without_nee && c->scene.last_emit_n <= RPT_LAST_EMIT_MAX)
-            k_traverse_nearest_stream<16, LDS_THREADS, RPT_NEAREST_LAST><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes + (size_t)c->scene.last_flip_vecs * sizeof(float4), s>>>(c->scene, c->state, c->queues, iteration, span, 0.0f, 0.0f, 0.0f);
-        else if (camera_rays && c->first_presub)
-            k_traverse_nearest_stream<16, LDS_THREADS, RPT_NEAREST_FIRST><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span, cam[0], cam[1], cam[2]);
-        else k_traverse_nearest_stream<16, LDS_THREADS><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration, span, 0.0f, 0.0f, 0.0f);
-    } else if (STACK == 16 && c->scene.lds_scene)
-        k_traverse_nearest<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, iteration);
-    else if (c->gstream && (!RPT_GSTREAM_PAIRS || c->scene.gpairs)) {
-#define RPT_LAUNCH_NEAREST(W, COOP) k_traverse_nearest_gstream<STACK, W, COOP><<<gblocks_n, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, iteration, gspan_n)
-        if (c->fat_leaves) {
-            if (stack_width == 16) RPT_LAUNCH_NEAREST(16, true); else if (stack_width == 21) RPT_LAUNCH_NEAREST(21, true);
-            else if (stack_width == 24) RPT_LAUNCH_NEAREST(24, true); else RPT_LAUNCH_NEAREST(32, true);
-        } else {
-            if (stack_width == 16) RPT_LAUNCH_NEAREST(16, false); else if (stack_width == 21) RPT_LAUNCH_NEAREST(21, false);
-            else if (stack_width == 24) RPT_LAUNCH_NEAREST(24, false); else RPT_LAUNCH_NEAREST(32, false);
-        }
-#undef RPT_LAUNCH_NEAREST
-    } else {
-        const uint32_t nb = (c->n_slots + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
-        if (c->scene.n_nodes < 65536u) k_traverse_nearest<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
-        else k_traverse_nearest<STACK, false, GLOBAL_THREADS><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, iteration);
-    }
-}
-
-/* one wave per chunk of 64 pixels (k_path.h k_complete) */
+/* one wave per chunk of 64 pixels (k_complete.h) */
 static void launch_complete(rpt_ctx *c, uint32_t iteration, uint32_t final_pass) {
     k_complete<<<padded_pixels(c->n_pixels) / RPT_WAVE, RPT_WAVE, complete_lds_bytes(1u << c->group_shift, c->state.q_shift), c->stream>>>(c->state, c->queues, c->cfg, iteration, final_pass,
                                                                                                                      c->dev_stats.p);
@@ -363,15 +327,11 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
         if (ev && (!only_traverse || traverse_edge)) (void)hipEventRecord((*ev)[ev_at++], s);
     };
     if (only_traverse) mark(true);
-    const size_t lds_bytes = (size_t)c->scene.lds_vecs * sizeof(float4);
     /* the consumers of a side queue cover its POSITIONS: up to RPT_Q_SLACK more than there are slots (k_common.h) */
     const uint32_t q_positions = c->n_slots + RPT_Q_SLACK, blocks_q = (q_positions + RPT_BLOCK - 1) / RPT_BLOCK;
-    const uint32_t blocks_lds = (q_positions + LDS_THREADS - 1) / LDS_THREADS;
-    const int stack_width = gstream_stack_width(c);
-    const uint32_t gspan = gstream_span(c, (uint32_t)RPT_GSTREAM_RAYS), gblocks = (q_positions + gspan - 1) / gspan;            /* any-hit walk */
     /* (the shade stage's last_iteration, k_shade.h: in a batch of known length iteration k is bounce k of every path) */
-    launch_nearest<STACK>(c, iteration, NEE == RPT_NEE_NONE && c->queues.known_length != 0u && iteration != 0u && iteration + 1u >= c->cfg.c.max_bounces,
-                          iteration == 0u);
+    rpt_launch_nearest(c, iteration, NEE == RPT_NEE_NONE && c->queues.known_length != 0u && iteration != 0u && iteration + 1u >= c->cfg.c.max_bounces,
+                       iteration == 0u);
     mark(true);
     if (c->shade_compact) k_shade<NEE, TEXTURED, true><<<(c->n_slots + RPT_BLOCK * RPT_SHADE_ROUNDS - 1) / (RPT_BLOCK * RPT_SHADE_ROUNDS), RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
     else k_shade<NEE, TEXTURED, false><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p, c->call_samples);
@@ -379,38 +339,7 @@ void launch_iteration(rpt_ctx *c, uint32_t iteration, uint32_t blocks, std::vect
      * sample in this call; a batch of known length completes them once, after its last iteration (render_impl) */
     if (complete_each) launch_complete(c, iteration, 0u);
     mark();
-    if (NEE != RPT_NEE_NONE) {
-        if (STACK == 16 && c->scene.lds_scene && c->lds_stream && c->lds_shadow_stream) {
-            const uint32_t wgs = c->stream_max_blocks;
-            uint32_t span = c->stream_span ? c->stream_span : c->n_slots / (wgs * 32u);
-            span = span < (uint32_t)LDS_THREADS ? (uint32_t)LDS_THREADS : (span > 8u * LDS_THREADS ? 8u * LDS_THREADS : span);
-            span = (span + LDS_THREADS - 1) / LDS_THREADS * LDS_THREADS;
-            const uint32_t n_spans = (c->n_slots + span - 1) / span;
-            if (c->scene.lds_image_shadow) k_traverse_shadow_stream<16, LDS_THREADS, true><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
-            else k_traverse_shadow_stream<16, LDS_THREADS, false><<<n_spans < wgs ? n_spans : wgs, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->dev_stats.p, span);
-            k_shadow_resolve<<<blocks_q, RPT_BLOCK, 0, s>>>(c->state, c->queues, c->cfg);
-        } else if (STACK == 16 && c->scene.lds_scene)
-            k_traverse_shadow<16, true, LDS_THREADS><<<blocks_lds, LDS_THREADS, lds_bytes, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
-        else if (c->gstream && (!RPT_GSTREAM_PAIRS || c->scene.gpairs)) {
-#define RPT_LAUNCH_SHADOW(W, COOP)                                                                                                                         \
-    do {                                                                                                                                                   \
-        if (RPT_GSTREAM_PAIRS && c->scene.gpairs_shadow) k_traverse_shadow_gstream<STACK, W, COOP, true><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan); \
-        else k_traverse_shadow_gstream<STACK, W, COOP, false><<<gblocks, RPT_WAVE, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p, gspan);   \
-    } while (0)
-            if (c->fat_leaves) {
-                if (stack_width == 16) RPT_LAUNCH_SHADOW(16, true); else if (stack_width == 21) RPT_LAUNCH_SHADOW(21, true);
-                else if (stack_width == 24) RPT_LAUNCH_SHADOW(24, true); else RPT_LAUNCH_SHADOW(32, true);
-            } else {
-                if (stack_width == 16) RPT_LAUNCH_SHADOW(16, false); else if (stack_width == 21) RPT_LAUNCH_SHADOW(21, false);
-                else if (stack_width == 24) RPT_LAUNCH_SHADOW(24, false); else RPT_LAUNCH_SHADOW(32, false);
-            }
-#undef RPT_LAUNCH_SHADOW
-        } else {
-            const uint32_t nb = (q_positions + GLOBAL_THREADS - 1) / GLOBAL_THREADS;
-            if (c->scene.n_nodes < 65536u) k_traverse_shadow<STACK, false, GLOBAL_THREADS, true><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
-            else k_traverse_shadow<STACK, false, GLOBAL_THREADS><<<nb, GLOBAL_THREADS, 0, s>>>(c->scene, c->state, c->queues, c->cfg, c->dev_stats.p);
-        }
-    }
+    if (NEE != RPT_NEE_NONE) rpt_launch_shadow(c);          /* the any-hit walk of the queued shadow rays (+ k_shadow_resolve behind the streamed LDS walk) */
     mark();
     if (c->queues.sky_at_end == 0u || sky_now) {
         if (c->sky_strided && blocks > c->sky_blocks) k_sky<true><<<c->sky_blocks, RPT_BLOCK, 0, s>>>(c->scene, c->state, c->queues, c->cfg, iteration, c->dev_stats.p);
@@ -466,6 +395,17 @@ static void timing_accumulate(rpt_ctx *c, const std::vector<hipEvent_t> &ev, uin
 
 }  // namespace
 
+/* rpt_reset: the caller's row-major seeds (and accumulators, when a render resumes) into the rank's tile-major pixel order */
+__global__ __launch_bounds__(RPT_BLOCK) void k_reset_gather(const uint32_t *pixel_xy, uint32_t n_pixels, uint32_t width, const uint2 *seed, const float4 *accum_init /* nullable */,
+                                                            uint2 *rng, float4 *accum) {
+    const uint32_t s = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (s >= n_pixels) return;
+    const uint32_t pxy = pixel_xy[s];
+    const size_t i = (size_t)(pxy >> 16) * width + (pxy & 0xffffu);
+    rng[s] = seed[i];
+    accum[s] = accum_init ? accum_init[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 /* The 64-byte pair records + per-node links of the streamed global-memory walks (k_traverse.h SceneViewPairsT) from the uploaded node pool; with `flip`
  * (shadow_order.h) the two nodes of a flipped pair exchange slots: the copy the fixed-order shadow walks read.  (On the host this loop took 27 ms for 2 M nodes.) */
 __global__ __launch_bounds__(RPT_BLOCK) void k_build_pairs(const float4 *nodes, const uint8_t *flip, uint32_t n_pairs, float4 *pairs, uint32_t *links) {
@@ -513,6 +453,159 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_derive_triangles(const float4 *pe
     cross_sq[i] = (cx * cx + cy * cy) + cz * cz;
 }
 
+/* what the pair records of the streamed global-memory walks (k_traverse.h SceneViewPairsT) and the flipped copies can express: children of every inner node
+ * are the nodes (2p + 1, 2p + 2) of one pair — every pool the reference's builder makes (src/bvh.rs:296-320) —, leaves of fewer than 255 triangles, links in 24 bits */
+static bool pool_is_pair_shaped(const rpt_bvh_node *nodes, size_t nn) {
+    if ((nn & 1u) != 1u || nn < 3 || nodes[0].triangle_count != 0u) return false;
+    for (size_t i = 0; i < nn; ++i) {
+        const rpt_bvh_node &n = nodes[i];
+        if (n.triangle_count >= 255u || n.left_or_first >= (1u << 24)) return false;
+        if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) return false;
+    }
+    return true;
+}
+
+/* ---- the order probes as kernels (shadow_order.h: the core is shared with the host driver) ---------------------------------------------------------------- */
+namespace order_probe {
+
+constexpr uint32_t LEVEL_UNSET = 0xffffffffu;
+struct DevStack {
+    uint32_t *column;                                   /* LDS [entry][lane] */
+    __device__ __forceinline__ uint32_t &operator()(int k) const { return column[k * RPT_WAVE]; }
+};
+
+__global__ __launch_bounds__(RPT_BLOCK) void k_probe_tri_area(const float *cross_sq, uint32_t nt, double *tri_area) {
+    const uint32_t t = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (t < nt) tri_area[t] = area_of_cross_sq(cross_sq[t]);
+}
+/* leaves: the sums over their own triangles, in index order (as host_sums adds them); inner nodes wait for their children */
+__global__ __launch_bounds__(RPT_BLOCK) void k_probe_leaves(View s, double *area_all, double *area_ne, double *count, uint32_t *level) {
+    const uint32_t n = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (n >= s.nn) return;
+    const rpt_bvh_node &node = s.nodes[n];
+    count[n] = 1.0;
+    if (node.triangle_count == 0u) { level[n] = LEVEL_UNSET; return; }
+    double a = 0.0, ne = 0.0;
+    for (uint32_t k = 0; k < node.triangle_count; ++k) {
+        const uint32_t t = node.left_or_first + k;
+        a += s.tri_area[t];
+        if (!emissive(s, t)) ne += s.tri_area[t];
+    }
+    area_all[n] = a; area_ne[n] = ne; level[n] = 0u;
+}
+/* pass p: the inner nodes whose children were both finished by EARLIER launches (level < p: nothing read here is written by this launch) */
+__global__ __launch_bounds__(RPT_BLOCK) void k_probe_inner(View s, double *area_all, double *area_ne, double *count, uint32_t *level, uint32_t pass) {
+    const uint32_t n = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (n >= s.nn || level[n] != LEVEL_UNSET) return;
+    const uint32_t L = s.nodes[n].left_or_first, R = L + 1u;
+    if (level[L] >= pass || level[R] >= pass) return;
+    area_all[n] = area_all[L] + area_all[R];
+    area_ne[n] = area_ne[L] + area_ne[R];
+    count[n] = 1.0 + count[L] + count[R];
+    level[n] = pass;
+}
+__global__ __launch_bounds__(RPT_BLOCK) void k_probe_flips(View s, uint32_t n_pairs, uint8_t *flip1, uint8_t *flip2, uint8_t *flip3) {
+    const uint32_t p = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    if (p >= n_pairs) return;
+    flip1[p] = prefers_right(s, p, 1) ? 1 : 0;
+    if (flip2) { flip2[p] = prefers_right(s, p, 2) ? 1 : 0; flip3[p] = prefers_right(s, p, 3) ? 1 : 0; }
+}
+/* one thread per (probe ray, order): lane 2i walks ray i near child first, lane 2i + 1 in the fixed order; counters: node visits near first, fixed, rays, occluded */
+__global__ __launch_bounds__(RPT_WAVE) void k_probe_shadow(View s, const uint8_t *flip, unsigned long long *counters) {
+    __shared__ uint32_t stacks[ORDER_PROBE_STACK * RPT_WAVE];
+    const uint32_t job = blockIdx.x * RPT_WAVE + threadIdx.x, i = job >> 1;
+    const bool all = !(s.area_ne[0] > 0.0);
+    if (i >= SHADOW_PROBE_RAYS || (all && !(s.area_all[0] > 0.0))) return;
+    V o, d;
+    float max_t;
+    if (!shadow_probe_ray(s, all, i, o, d, max_t)) return;
+    bool occluded = false;
+    const DevStack stack{stacks + threadIdx.x};
+    if ((job & 1u) == 0u) {
+        atomicAdd(&counters[0], (unsigned long long)walk<false>(s, flip, o, d, max_t, stack, occluded));
+        atomicAdd(&counters[2], 1ull);
+        if (occluded) atomicAdd(&counters[3], 1ull);
+    } else {
+        atomicAdd(&counters[1], (unsigned long long)walk<true>(s, flip, o, d, max_t, stack, occluded));
+    }
+}
+/* one thread per (probe ray, order 0..3); counters 4..7: node visits near first and under rules 1..3; 8: rays; 9: hits */
+__global__ __launch_bounds__(RPT_WAVE) void k_probe_last(View s, const uint8_t *flip1, const uint8_t *flip2, const uint8_t *flip3, unsigned long long *counters) {
+    __shared__ uint32_t stacks[ORDER_PROBE_STACK * RPT_WAVE];
+    const uint32_t job = blockIdx.x * RPT_WAVE + threadIdx.x, i = job >> 2, q = job & 3u;
+    if (i >= LAST_PROBE_RAYS || !(s.area_ne[0] > 0.0)) return;
+    V o, d;
+    if (!last_probe_ray(s, i, o, d)) return;
+    bool hit = false;
+    const DevStack stack{stacks + threadIdx.x};
+    const uint8_t *flip = q == 1u ? flip1 : (q == 2u ? flip2 : flip3);
+    const uint32_t visits = q == 0u ? walk<false>(s, nullptr, o, d, 1000000.0f, stack, hit) : walk<true>(s, flip, o, d, 1000000.0f, stack, hit);
+    atomicAdd(&counters[4u + q], (unsigned long long)visits);
+    if (q == 3u) {                                        /* (the host loop reports the hit flag of its last walk: rule 3) */
+        atomicAdd(&counters[8], 1ull);
+        if (hit) atomicAdd(&counters[9], 1ull);
+    }
+}
+
+}  // namespace order_probe
+
+/* Both decisions of shadow_order.h for the scene just uploaded into `c`, on the device: the same rays, the same node visits and therefore the same decision
+ * as choose_shadow_order / choose_last_order make on the host (tests/test_gpu_parity.py compares them to the last digit).  d_cross_sq: what k_derive_triangles
+ * left.  Kernels on the null stream, like the other upload-time kernels. */
+static int device_order_probes(rpt_ctx *c, const float *d_cross_sq, uint32_t depth, bool pair_shaped, bool lights, bool want_last, ShadowOrder &so, LastOrder &lo) {
+    using namespace order_probe;
+    const Clock clock;
+    so = ShadowOrder();
+    lo = LastOrder();
+    const uint32_t nt = c->scene.n_triangles, nn = c->scene.n_nodes, P = nn >= 3u ? (nn - 1u) / 2u : 0u;
+    if (nt == 0u || (!lights && !want_last)) { so.probe_ms = lo.probe_ms = clock.ms(); return RPT_OK; }
+    if (!pair_shaped || nn < 3u) { if (lights) so.why = "node pool is not pair-shaped"; so.probe_ms = lo.probe_ms = clock.ms(); return RPT_OK; }
+    DevBuf<double> tri_area, sums;
+    DevBuf<uint32_t> level;
+    DevBuf<uint8_t> flips;
+    DevBuf<unsigned long long> counters;
+    auto release = [&]() { tri_area.release(); sums.release(); level.release(); flips.release(); counters.release(); };
+#define PROBE_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { release(); c->error = std::string("order probes: ") + hipGetErrorString(e_); return RPT_EHIP; } } while (0)
+    PROBE_TRY(tri_area.alloc(nt));
+    PROBE_TRY(sums.alloc(3 * (size_t)nn));
+    PROBE_TRY(level.alloc(nn));
+    PROBE_TRY(flips.alloc(3 * (size_t)P));
+    PROBE_TRY(counters.alloc(10));
+    PROBE_TRY(hipMemset(counters.p, 0, 10 * sizeof(unsigned long long)));
+    double *area_all = sums.p, *area_ne = sums.p + nn, *count = sums.p + 2 * (size_t)nn;
+    const View s{reinterpret_cast<const rpt_per_vertex_data *>(c->per_vertex.p), reinterpret_cast<const rpt_triangle *>(c->indices.p),
+                 reinterpret_cast<const rpt_bvh_node *>(c->nodes.p), reinterpret_cast<const rpt_material_data *>(c->materials.p), c->light_pick.p, nt, nn,
+                 c->scene.n_light_pick, tri_area.p, area_all, area_ne, count, reinterpret_cast<const float4_like *>(c->tri_geom.p)};
+    const unsigned node_blocks = (nn + RPT_BLOCK - 1) / RPT_BLOCK;
+    k_probe_tri_area<<<(nt + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK>>>(d_cross_sq, nt, tri_area.p);
+    k_probe_leaves<<<node_blocks, RPT_BLOCK>>>(s, area_all, area_ne, count, level.p);
+    for (uint32_t pass = 1; pass <= depth; ++pass) k_probe_inner<<<node_blocks, RPT_BLOCK>>>(s, area_all, area_ne, count, level.p, pass);
+    uint8_t *flip1 = flips.p, *flip2 = want_last ? flips.p + P : nullptr, *flip3 = want_last ? flips.p + 2 * (size_t)P : nullptr;
+    k_probe_flips<<<(P + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK>>>(s, P, flip1, flip2, flip3);
+    if (lights) k_probe_shadow<<<2 * SHADOW_PROBE_RAYS / RPT_WAVE, RPT_WAVE>>>(s, flip1, counters.p);
+    if (want_last) k_probe_last<<<4 * LAST_PROBE_RAYS / RPT_WAVE, RPT_WAVE>>>(s, flip1, flip2, flip3, counters.p);
+    unsigned long long h[10];
+    PROBE_TRY(hipMemcpy(h, counters.p, sizeof(h), hipMemcpyDeviceToHost));       /* (waits for the kernels) */
+    PROBE_TRY(hipGetLastError());
+    if (lights) {
+        decide_shadow(so, h[0], h[1], (uint32_t)h[2], (uint32_t)h[3], c->knobs.shadow_order);
+        so.flip.assign(P, 0);
+        if (so.fixed) PROBE_TRY(hipMemcpy(so.flip.data(), flip1, P, hipMemcpyDeviceToHost));
+    }
+    if (want_last) {
+        const uint64_t v[4] = {h[4], h[5], h[6], h[7]};
+        decide_last(lo, v, (uint32_t)h[8], (uint32_t)h[9], c->knobs.last_order);
+        if (lo.rule != 0) {
+            lo.flip.assign(P, 0);
+            PROBE_TRY(hipMemcpy(lo.flip.data(), flips.p + (size_t)(lo.rule - 1) * P, P, hipMemcpyDeviceToHost));
+        }
+    }
+#undef PROBE_TRY
+    release();
+    so.probe_ms = lo.probe_ms = clock.ms();
+    return RPT_OK;
+}
+
 extern "C" {
 
 int rpt_abi_version(void) { return RPT_ABI_VERSION; }
@@ -549,7 +642,7 @@ int rpt_shadow_order(rpt_ctx *c, uint32_t *fixed_out, double *visits_near_out, d
 int rpt_last_bounce_order(rpt_ctx *c, uint32_t *mode_out, uint32_t *n_emissive_out, double *visits_out, uint32_t *probe_rays_out, double *probe_ms_out) {
     if (!c) return RPT_EINVAL;
     if (!c->has_scene) { c->error = "rpt_last_bounce_order: no scene"; return RPT_EINVAL; }
-    const bool on = c->scene.lds_scene != 0u && c->lds_stream && c->stack_cap == 16 && c->scene.last_emit_n <= RPT_LAST_EMIT_MAX;
+    const bool on = c->scene.lds_scene != 0u && c->stack_cap == 16 && c->scene.last_emit_n <= RPT_LAST_EMIT_MAX;
     if (mode_out) *mode_out = !on ? 0u : 1u + (uint32_t)c->last_order.rule;
     if (n_emissive_out) *n_emissive_out = c->scene.last_emit_n;
     if (visits_out) for (int k = 0; k < 4; ++k) visits_out[k] = c->last_order.visits[k];
@@ -568,12 +661,8 @@ int rpt_debug_shadow_order_host(const rpt_per_vertex_data *pv, size_t nv, const 
         const int rc = validate_scene(&scratch, pv, nv, idx, nt, nodes, nn, mats, nm, lp, nlp, depth);
         if (rc) { g_create_error = scratch.error; return rc; }
     }
-    bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
-    for (size_t i = 0; i < nn; ++i) {
-        const rpt_bvh_node &n = nodes[i];
-        if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
-    }
-    const ShadowOrder so = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped);
+    const bool pair_shaped = pool_is_pair_shaped(nodes, nn);
+    const ShadowOrder so = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped, nullptr, rpt_read_knobs().shadow_order);
     if (fixed_out) *fixed_out = so.fixed ? 1u : 0u;
     if (visits_near_out) *visits_near_out = so.visits_near;
     if (visits_fixed_out) *visits_fixed_out = so.visits_fixed;
@@ -594,12 +683,8 @@ int rpt_debug_last_order_host(const rpt_per_vertex_data *pv, size_t nv, const rp
         const int rc = validate_scene(&scratch, pv, nv, idx, nt, nodes, nn, mats, nm, &none, 1, depth);
         if (rc) { g_create_error = scratch.error; return rc; }
     }
-    bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
-    for (size_t i = 0; i < nn; ++i) {
-        const rpt_bvh_node &n = nodes[i];
-        if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
-    }
-    const LastOrder lo = choose_last_order(pv, idx, nt, nodes, nn, mats, pair_shaped);
+    const bool pair_shaped = pool_is_pair_shaped(nodes, nn);
+    const LastOrder lo = choose_last_order(pv, idx, nt, nodes, nn, mats, pair_shaped, rpt_read_knobs().last_order);
     if (rule_out) *rule_out = (uint32_t)lo.rule;
     if (visits_out) for (int k = 0; k < 4; ++k) visits_out[k] = lo.visits[k];
     if (probe_rays_out) *probe_rays_out = lo.probe_rays;
@@ -634,31 +719,20 @@ int rpt_create(int device_id, rpt_ctx **out) {
         rpt_destroy(c);
         return RPT_ENOMEM;
     }
-    const char *env = getenv("RPT_STAGE_TIMING");
-    c->timing_level = env ? atoi(env) : 0;
-    if (c->timing_level < 0 || c->timing_level > 2) c->timing_level = 0;
+    c->knobs = rpt_read_knobs();
+    c->timing_level = c->knobs.stage_timing;
     c->stage_timing = c->timing_level != 0;
-    if (const char *e2 = getenv("RPT_LDS_STREAM")) c->lds_stream = e2[0] != '0';
-    if (const char *e2 = getenv("RPT_FIRST_PRESUB")) c->first_presub = e2[0] != '0';
-    if (const char *e10 = getenv("RPT_MAX_SLOTS")) c->max_slots_budget = (uint64_t)std::max(1ll, atoll(e10));
-    if (const char *e6 = getenv("RPT_GSTREAM")) c->gstream = e6[0] != '0';
-    if (const char *e11 = getenv("RPT_SHADE_COMPACT")) { c->shade_compact_mode = e11[0] != '0' ? 1 : 0; c->shade_compact = c->shade_compact_mode == 1; }
-    if (const char *e12 = getenv("RPT_SHADE_COMPACT_AT")) c->shade_compact_at = atof(e12);
-    if (const char *e9 = getenv("RPT_LDS_SHADOW_STREAM")) c->lds_shadow_stream = e9[0] != '0';
-    if (const char *e7 = getenv("RPT_GSTREAM_MIN_WAVES")) c->gstream_min_waves = (uint32_t)std::max(1, atoi(e7));
-    if (const char *e17 = getenv("RPT_STACK_BITS")) c->stack_bits_min = atoi(e17);      /* test aid: wider stack entries than the scene needs */
-    if (const char *e19 = getenv("RPT_SKY_AT_END")) c->sky_at_end_ok = e19[0] != '0';
-    if (const char *e18 = getenv("RPT_SLOT_Q_SHIFT")) c->slot_q_shift_mode = std::max(0, std::min(5, atoi(e18)));   /* test aid: log2 of the samples of a pixel per wave */
+    if (c->knobs.shade_compact >= 0) { c->shade_compact_mode = c->knobs.shade_compact; c->shade_compact = c->shade_compact_mode == 1; }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->stream_max_blocks = 2u * (uint32_t)prop.multiProcessorCount;
     }
     c->sky_blocks = 16u * c->stream_max_blocks / 2u;       /* 16 workgroups of 256 per CU: the sky stage strides over its queue */
-    if (const char *e13 = getenv("RPT_SKY_BLOCKS")) c->sky_blocks = (uint32_t)std::max(1, atoi(e13));
-    if (const char *e14 = getenv("RPT_SKY_STRIDED")) { c->sky_strided_mode = e14[0] != '0' ? 1 : 0; c->sky_strided = c->sky_strided_mode == 1; }
-    if (const char *e5 = getenv("RPT_STREAM_MAX_BLOCKS")) c->stream_max_blocks = (uint32_t)std::max(1, atoi(e5));
-    if (const char *e8 = getenv("RPT_STREAM_SPAN")) c->stream_span = (uint32_t)std::max(0, atoi(e8));
-    if (const char *e3 = getenv("RPT_SAMPLES_IN_FLIGHT")) c->samples_in_flight_request = std::min((int)RPT_MAX_SAMPLES_IN_FLIGHT, std::max(0, atoi(e3)));
+    if (c->knobs.sky_strided >= 0) {
+        c->sky_strided_mode = c->knobs.sky_strided != 0 ? 1 : 0;
+        c->sky_strided = c->sky_strided_mode == 1;
+        if (c->knobs.sky_strided > 1) c->sky_blocks = (uint32_t)c->knobs.sky_strided;
+    }
     *out = c;
     return RPT_OK;
 }
@@ -703,6 +777,10 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     if (!c) return RPT_EINVAL;
     if (!pv || !idx || !nodes || !mats || !lp) { c->error = "null scene buffer"; return RPT_EINVAL; }
     HIP_TRY(c, hipSetDevice(c->device));
+    {   /* the knobs that act at upload (orders, leaf build, LDS residency) are read again: a test process changes them between scenes of one context */
+        const rpt_knobs now = rpt_read_knobs();
+        c->knobs.shadow_order = now.shadow_order; c->knobs.last_order = now.last_order; c->knobs.coop_leaves = now.coop_leaves; c->knobs.no_lds_scene = now.no_lds_scene;
+    }
     uint32_t depth = 0;
     int rc = validate_scene(c, pv, nv, idx, nt, nodes, nn, mats, nm, lp, nlp, depth);
     if (rc) return rc;
@@ -724,7 +802,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     c->fat_leaves = false;
     for (size_t i = 0; i < nn; ++i)
         if (nodes[i].triangle_count > (uint32_t)RPT_COOP_LEAF_MIN) c->fat_leaves = true;
-    if (const char *env = getenv("RPT_COOP_LEAVES")) c->fat_leaves = env[0] != '0';
+    if (c->knobs.coop_leaves >= 0) c->fat_leaves = c->knobs.coop_leaves != 0;
 
     /* derived per-triangle records, computed with the very f32 operations the reference performs per hit:
      *   tri_geom : a, e1 = b - a, e2 = c - a (muller_trumbore, intersection.rs:13-14; barycentric v0, v1, util.rs:239-240)
@@ -768,8 +846,8 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, c->materials.alloc(6 * nm));
     HIP_TRY(c, c->indices.alloc(nt));
     HIP_TRY(c, c->light_pick.alloc(nlp));
-    DevBuf<float> d_cross_sq;
-    std::vector<float> cross_sq(nt);
+    DevBuf<float> d_cross_sq;              /* |e1 x e2|^2 per triangle: the order probes' triangle areas (released on every return path below: see CrossSqGuard) */
+    struct CrossSqGuard { DevBuf<float> &b; ~CrossSqGuard() { b.release(); } } cross_sq_guard{d_cross_sq};
     HIP_TRY(c, d_cross_sq.alloc(nt));
     HIP_TRY(c, hipMemcpy(c->per_vertex.p, pv, nv * sizeof(rpt_per_vertex_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->indices.p, idx, nt * sizeof(rpt_triangle), hipMemcpyHostToDevice));
@@ -779,12 +857,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     HIP_TRY(c, hipMemcpy(c->nodes.p, nodes, nn * sizeof(rpt_bvh_node), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->materials.p, mats, nm * sizeof(rpt_material_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->light_pick.p, lp, nlp * sizeof(rpt_light_pick_entry), hipMemcpyHostToDevice));
-    {
-        const hipError_t e_cs = nt ? hipMemcpy(cross_sq.data(), d_cross_sq.p, nt * sizeof(float), hipMemcpyDeviceToHost) : hipSuccess;   /* (also waits for the kernel) */
-        d_cross_sq.release();
-        HIP_TRY(c, e_cs);
-        HIP_TRY(c, hipGetLastError());
-    }
+    HIP_TRY(c, hipGetLastError());
     sections.mark("h2d_derive_device");
     {
         /* per light-pick entry, for its two triangles: corners, the mean of the three vertex normals exactly as
@@ -839,15 +912,10 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         }
     }
     sections.mark("atlas_lds_image");
-    if (const char *env = getenv("RPT_NO_LDS_SCENE"); env && env[0] == '1') s.lds_scene = 0u;
+    if (c->knobs.no_lds_scene) s.lds_scene = 0u;
     /* pair records for the streamed global-memory walks (k_traverse.h SceneViewPairsT); a pool they cannot express keeps the one-shot walks */
     s.gpairs = nullptr; s.glinks = nullptr;
-    bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u;
-    for (size_t i = 0; i < nn && pair_shaped; ++i) {
-        const rpt_bvh_node &n = nodes[i];
-        if (n.triangle_count >= 255u || n.left_or_first >= (1u << 24)) pair_shaped = false;
-        else if (n.triangle_count == 0u && ((n.left_or_first & 1u) == 0u || (size_t)n.left_or_first + 1 >= nn)) pair_shaped = false;
-    }
+    const bool pair_shaped = pool_is_pair_shaped(nodes, nn);
     const uint32_t n_pairs = pair_shaped ? (uint32_t)((nn - 1) / 2) : 0u;
     if (pair_shaped) {
         HIP_TRY(c, c->gpairs.alloc(std::max<size_t>(1, 4 * (size_t)n_pairs)));
@@ -865,7 +933,25 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
      * that the preferred child is the LEFT one: a second LDS image / pair array, read by the shadow kernels only. */
     sections.mark("pairs");
     s.shadow_fixed = 0u; s.lds_image_shadow = nullptr; s.gpairs_shadow = nullptr; s.glinks_shadow = nullptr;
-    c->shadow_order = choose_shadow_order(pv, idx, nt, nodes, nn, mats, lp, nlp, pair_shaped, cross_sq.data());
+    /* The last extension rays of a batch without NEE only have to say "hit or miss" unless they can end on an emitter (k_traverse.h
+     * k_traverse_nearest_stream LAST): the triangles whose material emits (lib.rs:86: emissive.xyz() != 0, a NaN counts), if they are few enough to test
+     * each ray against; and room behind the LDS image for the flipped copy's pair records (two 1 024-thread workgroups per CU). */
+    s.last_emit_n = 0u;
+    s.last_flip_vecs = 0u;
+    for (uint32_t k = 0; k < RPT_LAST_EMIT_MAX; ++k) s.last_emit_tri[k] = 0u;
+    for (size_t t = 0; t < nt && s.last_emit_n <= RPT_LAST_EMIT_MAX; ++t) {
+        const float *e = mats[idx[t].material].emissive;
+        if (!(e[0] == 0.0f && e[1] == 0.0f && e[2] == 0.0f)) {
+            if (s.last_emit_n < RPT_LAST_EMIT_MAX) s.last_emit_tri[s.last_emit_n] = (uint32_t)t;
+            s.last_emit_n += 1u;
+        }
+    }
+    if (c->knobs.last_order == 4) s.last_emit_n = RPT_LAST_EMIT_MAX + 1u;      /* RPT_LAST_ORDER=off (A/B and tests): the plain launch */
+    const bool want_last = s.lds_scene && s.last_emit_n <= RPT_LAST_EMIT_MAX;
+    /* both decisions by probe rays, as kernels over the buffers just uploaded (shadow_order.h; round 5 walked the rays on the host: 17 - 40 ms of a 1 M-triangle upload) */
+    rc = device_order_probes(c, d_cross_sq.p, depth, pair_shaped, !(lp[0].ratio < 0.0f), want_last, c->shadow_order, c->last_order);
+    if (rc) return rc;
+    d_cross_sq.release();
     if (c->shadow_order.fixed) {
         bool built = false;
         if (s.lds_scene) {
@@ -899,35 +985,20 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     sections.mark("shadow_order");
     if (!s.lds_image_shadow) c->lds_image_shadow.release();
     if (!s.gpairs_shadow) { c->gpairs_shadow.release(); c->glinks_shadow.release(); }
-    /* The last extension rays of a batch without NEE only have to say "hit or miss" unless they can end on an emitter (k_traverse.h
-     * k_traverse_nearest_stream LAST): the triangles whose material emits (lib.rs:86: emissive.xyz() != 0, a NaN counts), if they are few enough to test
-     * each ray against; and room behind the LDS image for the flipped copy's pair records (two 1 024-thread workgroups per CU: 80 KB each). */
-    s.last_emit_n = 0u;
-    s.last_flip_vecs = 0u;
-    for (uint32_t k = 0; k < RPT_LAST_EMIT_MAX; ++k) s.last_emit_tri[k] = 0u;
-    for (size_t t = 0; t < nt && s.last_emit_n <= RPT_LAST_EMIT_MAX; ++t) {
-        const float *e = mats[idx[t].material].emissive;
-        if (!(e[0] == 0.0f && e[1] == 0.0f && e[2] == 0.0f)) {
-            if (s.last_emit_n < RPT_LAST_EMIT_MAX) s.last_emit_tri[s.last_emit_n] = (uint32_t)t;
-            s.last_emit_n += 1u;
-        }
-    }
-    if (const char *env = getenv("RPT_LAST_BOUNCE_HIT_OR_MISS"); env && env[0] == '0') s.last_emit_n = RPT_LAST_EMIT_MAX + 1u;      /* A/B and tests: the plain launch */
     s.lds_image_last = nullptr;
-    c->last_order = LastOrder();
-    if (s.lds_scene && s.last_emit_n <= RPT_LAST_EMIT_MAX) {
-        /* the order those rays walk in (shadow_order.h choose_last_order): near child first over the primary image, or a fixed order over a copy whose pairs
+    if (want_last) {
+        /* the order those rays walk in (shadow_order.h): near child first over the primary image, or a fixed order over a copy whose pairs
          * are flipped by the rule that needed the fewest node visits on probe rays of their kind */
-        c->last_order = choose_last_order(pv, idx, nt, nodes, nn, mats, pair_shaped);
         const size_t flip_vecs = 6 * (size_t)s.lds_pairs + ((size_t)s.lds_pairs + 3) / 4;
-        /* room: two such workgroups per CU (k_traverse.h), i.e. half of what a CU holds — and no more than one workgroup may ask for — minus the kernel's static LDS */
+        /* room: two such workgroups per CU (k_traverse.h), i.e. half of what THIS device's CU holds (160 KB on MI355X; a partitioned or older device
+         * reports less and simply gets no flipped copy), minus the kernel's static LDS as the code object states it */
         size_t lds_room = 0;
         {
             hipDeviceProp_t prop;
             hipFuncAttributes fa;
-            if (hipGetDeviceProperties(&prop, c->device) == hipSuccess &&
-                hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_traverse_nearest_stream<16, RPT_LDS_THREADS, RPT_NEAREST_LAST>)) == hipSuccess) {
-                const size_t per_wg = std::min<size_t>(prop.sharedMemPerBlock, prop.maxSharedMemoryPerMultiProcessor / 2);
+            if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.maxSharedMemoryPerMultiProcessor != 0 &&
+                rpt_last_walk_attributes(&fa) == hipSuccess) {
+                const size_t per_wg = prop.maxSharedMemoryPerMultiProcessor / 2;
                 lds_room = per_wg > fa.sharedSizeBytes ? per_wg - fa.sharedSizeBytes : 0;
             }
         }
@@ -951,7 +1022,6 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     for (size_t i = 0; i < nn && s.fastdiv_ok; ++i)
         for (int k = 0; k < 3; ++k)
             if (!rptm::fastdiv_operand_ok(nodes[i].aabb_min[k]) || !rptm::fastdiv_operand_ok(nodes[i].aabb_max[k])) s.fastdiv_ok = 0u;
-    if (const char *env = getenv("RPT_NO_FASTDIV"); env && env[0] == '1') s.fastdiv_ok = 0u;
     s.atlas = DevImage{c->atlas.p, aw, ah};
     s.skybox = DevImage{c->skybox.p, sw, sh};
     sections.mark("fastdiv_check");
@@ -1005,7 +1075,7 @@ int rpt_set_config(rpt_ctx *c, const rpt_tracing_config *cfg) {
          * scanned (16 spp on 32 slots per pixel: 6.0 instead of 8.2 Grays/s).  Up to 32 slots per pixel and 32 M
          * slots: with the reference's default batch of 32 samples (sync_rate, src/trace.rs:75) a rank that owns 1/8
          * of a 1024^2 image then has 4 M paths in flight (7.2 instead of 6.6 Grays/s per GPU). */
-        /* Up to 256 since round 6 (k_path.h k_complete counts the finished slots of a pixel instead of keeping a 32-bit mask): a rank that owns 1/8
+        /* Up to 256 since round 6 (k_complete.h counts the finished slots of a pixel instead of keeping a 32-bit mask): a rank that owns 1/8
          * of a 1024^2 image runs a 256-sample batch as the same 33 M-slot launches as the whole image runs 32 — the fixed costs of a batch
          * (11 launches, drain tails) no longer weigh 8 x as much.  The arrays are allocated by the render call that needs them, at its size. */
         uint32_t S = 1;
@@ -1043,19 +1113,26 @@ int rpt_reset(rpt_ctx *c, const rpt_rng_state *seed, const float *accum_init, ui
     if (!seed) { c->error = "null seed buffer"; return RPT_EINVAL; }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint32_t W = c->cfg.c.width;
-    size_t n = c->n_pixels;
-    std::vector<uint2> rng(n);
-    std::vector<float4> acc(n, make_float4(0, 0, 0, 0));
-    for (size_t s = 0; s < n; ++s) {
-        uint32_t pxy = c->pixel_xy_host[s];
-        size_t i = (size_t)(pxy >> 16) * W + (pxy & 0xffffu);
-        rng[s] = make_uint2(seed[i].n, seed[i].offset);
-        if (accum_init) acc[s] = make_float4(accum_init[4 * i], accum_init[4 * i + 1], accum_init[4 * i + 2], accum_init[4 * i + 3]);
-    }
+    /* The caller's row-major buffers go up as they are; a kernel gathers them into this rank's tile-major pixel order (rounds 1-5 gathered on the host:
+     * two loops over every pixel and 24 bytes per pixel of staging, 20 ms of a 2048^2 reset).  No accum_init: the accumulators are simply zeroed. */
+    const uint32_t W = c->cfg.c.width, H = c->cfg.c.height;
+    const size_t n = c->n_pixels, whole = (size_t)W * H;
     if (n) {
-        HIP_TRY(c, hipMemcpy(c->rng.p, rng.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->accum.p, acc.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        DevBuf<uint2> d_seed;
+        DevBuf<float4> d_acc;
+        HIP_TRY(c, d_seed.alloc(whole));
+        hipError_t e = hipMemcpy(d_seed.p, seed, whole * sizeof(uint2), hipMemcpyHostToDevice);
+        if (e == hipSuccess && accum_init) {
+            e = d_acc.alloc(whole);
+            if (e == hipSuccess) e = hipMemcpy(d_acc.p, accum_init, whole * sizeof(float4), hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) {
+            k_reset_gather<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, c->stream>>>(c->pixel_xy.p, (uint32_t)n, W, d_seed.p, d_acc.p, c->rng.p, c->accum.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);             /* (the staging buffers go out of scope) */
+        d_seed.release(); d_acc.release();
+        HIP_TRY(c, e);
     }
     HIP_TRY(c, hipMemsetAsync(c->dev_stats.p, 0, sizeof(DevStats), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->ray_shards.p, 0, RPT_STAT_SHARDS * RPT_STAT_STRIDE * sizeof(unsigned long long), c->stream));
@@ -1131,7 +1208,7 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
         c->n_slots = padded_pixels(c->n_pixels) << shift;
         c->state.group_shift = shift;
         /* samples of one pixel per wave (k_common.h, slot_pix): 1 unless the scene is a large one */
-        const uint32_t qs = c->slot_q_shift_mode >= 0 ? (uint32_t)c->slot_q_shift_mode : (c->scene.n_triangles >= RPT_BIG_SCENE_TRIANGLES ? 5u : 0u);
+        const uint32_t qs = c->knobs.slot_q_shift >= 0 ? (uint32_t)c->knobs.slot_q_shift : (c->scene.n_triangles >= RPT_BIG_SCENE_TRIANGLES ? 5u : 0u);
         c->state.q_shift = qs < shift ? qs : shift;
         c->state.n_slots = c->n_slots;
         c->queues.sky_wide_limit = std::min(c->n_slots / 16u, c->sky_wide_cfg);   /* the wide sky pass spends 16 threads of the grid per miss */
@@ -1160,8 +1237,8 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
     if (!async) for (int k = 0; k < RING; ++k) __atomic_store_n(&c->host_ring[k], 0ull, __ATOMIC_RELAXED);
     c->call_samples = n_samples;
     /* A miss ends its path (lib.rs:79) and in a batch of known length nothing is started in its place: the misses of all iterations
-     * wait in the queue for ONE sky launch after the last iteration (three launches less per batch; RPT_SKY_AT_END=0: every iteration) */
-    c->queues.sky_at_end = (known_iterations != 0 && c->sky_at_end_ok) ? 1u : 0u;
+     * wait in the queue for ONE sky launch after the last iteration (three launches less per batch) */
+    c->queues.sky_at_end = known_iterations != 0 ? 1u : 0u;
     c->queues.known_length = known_iterations != 0 ? 1u : 0u;
     std::vector<hipEvent_t> async_events;
     std::vector<hipEvent_t> *ev = c->stage_timing ? (async ? &async_events : &c->timing_events) : nullptr;
@@ -1189,10 +1266,10 @@ static int render_impl(rpt_ctx *c, uint32_t n_samples, bool allow_async) {
 
     uint64_t it = 0, full_iterations = 0;
     bool drained = c->cfg.c.max_bounces == 0u;
-    /* RPT_TEST_SHORT_BATCH=1 (test aid): enqueue one iteration too few in an asynchronous batch, to prove that the
+    /* rpt_debug_short_batch (test aid): enqueue one iteration too few in an asynchronous batch, to prove that the
      * completion checks of rpt_wait / k_generate_first notice */
     uint64_t short_batch = 0;
-    if (async && known_iterations > 1) { const char *e = getenv("RPT_TEST_SHORT_BATCH"); if (e && e[0] == '1') short_batch = 1; }
+    if (async && known_iterations > 1 && c->test_short_batch) short_batch = 1;
     /* Run-ahead: it only has to cover the enqueue latency (tens of microseconds).  Launches over millions of slots
      * last far longer than that, and every surplus iteration still dispatches its (instantly returning) workgroups. */
     const int lag = c->n_slots >= (512u << 10) ? 2 : (c->n_slots >= (128u << 10) ? 3 : LAG);
@@ -1388,7 +1465,13 @@ int rpt_get_stats(rpt_ctx *c, rpt_stats *out) {
     return RPT_OK;
 }
 
-/* ------------------------------------------------------------ test hooks -- */
+/* ------------------------------------------------------------ test hooks (include/rpt/rpt_debug.h) -- */
+int rpt_debug_short_batch(rpt_ctx *c, int on) {
+    if (!c) return RPT_EINVAL;
+    c->test_short_batch = on != 0;
+    return RPT_OK;
+}
+
 __global__ void k_debug_math(int op, const float *x, const float *y, float *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1520,25 +1603,8 @@ int rpt_debug_trace_rays(rpt_ctx *c, int any_hit, size_t n, const float *origins
     if (e == hipSuccess) e = hipMemcpy(d_d.p, dirs, 12 * n, hipMemcpyHostToDevice);
     if (e == hipSuccess && max_t) e = hipMemcpy(d_m.p, max_t, 4 * n, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        unsigned blocks = (unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK);
         hipStream_t s = c->stream;
-#define LAUNCH_DBG(ST)                                                                                                      \
-    if (any_hit) k_trace_debug<ST, true, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p); \
-    else k_trace_debug<ST, false, false, RPT_BLOCK><<<blocks, RPT_BLOCK, 0, s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p)
-        switch (c->stack_cap) {
-            case 16:
-                if (c->scene.lds_scene) {
-                    unsigned bl = (unsigned)((n + LDS_THREADS - 1) / LDS_THREADS);
-                    if (any_hit) k_trace_debug<16, true, true, LDS_THREADS><<<bl, LDS_THREADS, (size_t)c->scene.lds_vecs * sizeof(float4), s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
-                    else k_trace_debug<16, false, true, LDS_THREADS><<<bl, LDS_THREADS, (size_t)c->scene.lds_vecs * sizeof(float4), s>>>(c->scene, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
-                } else {
-                    LAUNCH_DBG(16);
-                }
-                break;
-            case 24: LAUNCH_DBG(24); break;
-            default: LAUNCH_DBG(32); break;
-        }
-#undef LAUNCH_DBG
+        rpt_launch_trace_debug(c, any_hit != 0, (uint32_t)n, d_o.p, d_d.p, d_m.p, d_t.p, d_tri.p, d_fl.p);
         e = hipStreamSynchronize(s);
     }
     if (e == hipSuccess) e = hipMemcpy(out_t, d_t.p, 4 * n, hipMemcpyDeviceToHost);
@@ -1580,11 +1646,7 @@ int rpt_debug_trace_rays_production(rpt_ctx *c, size_t n, const float *origins, 
     HIP_TRY(c, hipMemsetAsync(c->q_count.p, 0, Q_WORDS * sizeof(uint32_t), s));
     k_fill_idle<<<(c->n_slots + RPT_BLOCK - 1) / RPT_BLOCK, RPT_BLOCK, 0, s>>>(c->hit.p, c->n_slots);
     k_debug_load_rays<<<(unsigned)((n + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK, 0, s>>>(c->state, (uint32_t)n, d_o.p, d_d.p);
-    switch (c->stack_cap) {
-        case 16: launch_nearest<16>(c, 0u); break;
-        case 24: launch_nearest<24>(c, 0u); break;
-        default: launch_nearest<32>(c, 0u); break;
-    }
+    rpt_launch_nearest(c, 0u, false, false);
     std::vector<float2> hits(n);
     hipError_t e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();
@@ -1653,10 +1715,9 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     DevBuf<uint32_t> d_team_nodes, d_inner, d_rank, d_oidx;
     DevBuf<rpt_bvh_node> d_out;
     std::vector<std::pair<uint32_t, uint32_t>> levels;          /* build-order id ranges, root level first */
-    const char *no_teams = getenv("RPT_BVH_NO_TEAMS");
-    const bool use_teams = !(no_teams && no_teams[0] == '1');
+    const bool use_teams = true;
     uint32_t team_min = BVB_TEAM_MIN_COUNT;           /* RPT_BVH_TEAM_MIN: test aid, lets small nodes take the team path */
-    if (const char *e = getenv("RPT_BVH_TEAM_MIN")) team_min = (uint32_t)std::max(2, atoi(e));
+    if (const int forced = rpt_read_knobs().bvh_team_min) team_min = (uint32_t)forced;
     std::vector<BvbNode> bn;
     std::vector<uint32_t> order;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

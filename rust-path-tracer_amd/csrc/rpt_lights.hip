@@ -12,7 +12,8 @@
  *   6  "robin hood": walk the bins upwards, top each up to `average` from the current most probable bin, which steps down when it is used up
  *                                                                                                    a two-cursor f32 recurrence
  *   7  the table: areas / pdfs gathered through index_a / index_b, ratio = p_a / (p_a + p_b)         independent
- * 1, 3, 5, 7 are kernels (5 = rocPRIM's radix sort on order-preserving keys).  The three chains — 2, 4, 6 — run on the HOST between the
+ * 1, 3, 5, 7 are kernels (5 = a stable LSD radix sort on order-preserving keys: lt_radix_sort_pairs below; rounds 4-5 used rocPRIM's, whose 156 kernel
+ * instantiations were more than half of librpt_hip.so).  The three chains — 2, 4, 6 — run on the HOST between the
  * device passes: each of their steps waits for the rounded result of the one before, so what runs them is a question of latency per
  * dependent operation, not of width.  Measured on MI355X (profiles/r05_light_table.txt): one wave adding a million floats in index order —
  * values through the scalar cache, one v_add_f32 per element — takes 10.5 ms, 22 cycles per element on a GPU that idles around that one wave
@@ -27,7 +28,6 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <chrono>
 #include <string>
@@ -52,6 +52,85 @@ struct Arena {
     hipError_t reserve(size_t bytes) { size = bytes; used = 0; return hipMalloc(reinterpret_cast<void **>(&base), bytes ? bytes : 256); }
     template <typename T> T *take(size_t count) { T *p = reinterpret_cast<T *>(base + used); used += pad(count * sizeof(T)); return p; }
 };
+
+/* ---- stable LSD radix sort of (u32 key, u32 value) pairs: four passes over 8-bit digits, 1 024 pairs per workgroup ----------------------------------------
+ * pass: k_rs_count (digits of a workgroup's tile) -> k_rs_scan (exclusive scan over [digit][workgroup]: where every tile's pairs of every digit go) -> k_rs_scatter
+ * (tile in order, four rounds of 256: a pair's rank among the equal digits before it = lanes before it in its wave (ballots per digit bit), waves before it in the
+ * round, rounds before it in the tile).  Stable by construction: equal probabilities keep their triangle-index order, as Rust's sort_by does (light_pick.rs:84-88).
+ * A few hundred microseconds per million pairs; the table build is scene preparation. */
+constexpr uint32_t RS_TILE = 1024u, RS_DIGITS = 256u;
+__global__ __launch_bounds__(256) void k_rs_count(const uint32_t *keys, uint32_t n, uint32_t shift, uint32_t n_tiles, uint32_t *hist /* [digit][tile] */) {
+    __shared__ uint32_t cnt[RS_DIGITS];
+    cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+    for (uint32_t r = 0; r < RS_TILE / 256u; ++r) {
+        const uint32_t i = base + r * 256u + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_tiles + blockIdx.x] = cnt[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t *hist, uint32_t count) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (count + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < count ? lo + per : count;
+    uint32_t s = 0u;
+    for (uint32_t k = lo; k < hi; ++k) s += hist[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t run = 0u;
+        for (int k = 0; k < 1024; ++k) { const uint32_t v = part[k]; part[k] = run; run += v; }
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t k = lo; k < hi; ++k) { const uint32_t v = hist[k]; hist[k] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t *keys, const uint32_t *vals, uint32_t n, uint32_t shift, uint32_t n_tiles, const uint32_t *offsets /* scanned hist */,
+                                                    uint32_t *keys_out, uint32_t *vals_out) {
+    __shared__ uint32_t next[RS_DIGITS];                 /* where the tile's next pair of every digit goes */
+    __shared__ uint32_t wave_cnt[4][RS_DIGITS];          /* pairs of every digit in every wave of the current round */
+    next[threadIdx.x] = offsets[threadIdx.x * n_tiles + blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, base = blockIdx.x * RS_TILE;
+    for (uint32_t r = 0; r < RS_TILE / 256u; ++r) {
+        for (uint32_t w = 0; w < 4u; ++w) wave_cnt[w][threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t i = base + r * 256u + threadIdx.x;
+        const bool have = i < n;
+        const uint32_t key = have ? keys[i] : 0u, val = have ? vals[i] : 0u, digit = (key >> shift) & 255u;
+        /* the lanes of this wave that hold a pair of the same digit */
+        unsigned long long same = __ballot(have);
+        for (uint32_t b = 0; b < 8u; ++b) {
+            const unsigned long long with_bit = __ballot(have && ((digit >> b) & 1u) != 0u);
+            same &= ((digit >> b) & 1u) != 0u ? with_bit : ~with_bit;
+        }
+        const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (have && before == 0u) wave_cnt[wave][digit] = (uint32_t)__popcll(same);
+        __syncthreads();
+        if (have) {
+            uint32_t at = next[digit] + before;
+            for (uint32_t w = 0; w < wave; ++w) at += wave_cnt[w][digit];
+            keys_out[at] = key;
+            vals_out[at] = val;
+        }
+        __syncthreads();
+        next[threadIdx.x] += (wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x]) + (wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x]);
+        __syncthreads();
+    }
+}
+size_t lt_sort_tmp_bytes(uint32_t n) { return (size_t)RS_DIGITS * ((n + RS_TILE - 1u) / RS_TILE) * sizeof(uint32_t); }
+/* ascending by key, stable; the sorted pairs end in (keys, vals) — four passes, ping-pong through (keys_tmp, vals_tmp) */
+hipError_t lt_radix_sort_pairs(uint32_t *hist, uint32_t *keys, uint32_t *keys_tmp, uint32_t *vals, uint32_t *vals_tmp, uint32_t n) {
+    const uint32_t n_tiles = (n + RS_TILE - 1u) / RS_TILE;
+    for (uint32_t pass = 0; pass < 4u; ++pass) {
+        const uint32_t *ki = pass & 1u ? keys_tmp : keys, *vi = pass & 1u ? vals_tmp : vals;
+        uint32_t *ko = pass & 1u ? keys : keys_tmp, *vo = pass & 1u ? vals : vals_tmp;
+        k_rs_count<<<n_tiles, 256>>>(ki, n, pass * 8u, n_tiles, hist);
+        k_rs_scan<<<1, 1024>>>(hist, RS_DIGITS * n_tiles);
+        k_rs_scatter<<<n_tiles, 256>>>(ki, vi, n, pass * 8u, n_tiles, hist, ko, vo);
+    }
+    return hipGetLastError();
+}
 
 struct LtScalars {
     float total_power, average, prob_sum;
@@ -252,24 +331,23 @@ extern "C" int rpt_light_table_build_gpu(int device_id, const float *vertices_xy
     const uint32_t n = sc.n_bins;
     if (n == 0u) return sentinel(sc.total_tris);       /* every emissive triangle is degenerate: the reference would index bins[usize::MAX] and panic */
     if ((size_t)n > entries_capacity) { err = "rpt_light_table_build_gpu: the table needs " + std::to_string(n) + " entries"; return RPT_EINVAL; }
-    size_t tmp_bytes = 0;
-    LT_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u, 32u, (hipStream_t)0));
+    const size_t tmp_bytes = lt_sort_tmp_bytes(n);
     LT_TRY(phase2.reserve(7 * Arena::pad((size_t)n * sizeof(uint32_t)) + Arena::pad((size_t)n * sizeof(rpt_light_pick_entry)) + Arena::pad(tmp_bytes ? tmp_bytes : 1)));
     d_keys.p = phase2.take<uint32_t>(n); d_keys2.p = phase2.take<uint32_t>(n); d_vals.p = phase2.take<uint32_t>(n); d_vals2.p = phase2.take<uint32_t>(n);
     d_pa.p = phase2.take<float>(n); d_pb.p = phase2.take<float>(n); d_ib.p = phase2.take<uint32_t>(n);
     d_out.p = phase2.take<rpt_light_pick_entry>(n);
     d_tmp.p = phase2.take<char>(tmp_bytes ? tmp_bytes : 1);
     k_lt_bins<<<nb, LT_BLOCK>>>(d_prob.p, nt, d_counts.p, d_keys.p, d_vals.p);
-    LT_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, (size_t)n, 0u, 32u, (hipStream_t)0));   /* LSD radix sort: stable */
+    LT_TRY(lt_radix_sort_pairs(reinterpret_cast<uint32_t *>(d_tmp.p), d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, n));   /* stable; sorted pairs in (d_keys, d_vals) */
     const uint32_t nbn = (n + LT_BLOCK - 1) / LT_BLOCK;
-    k_lt_unkey<<<nbn, LT_BLOCK>>>(d_keys2.p, n, d_pa.p);
+    k_lt_unkey<<<nbn, LT_BLOCK>>>(d_keys.p, n, d_pa.p);
 
     /* step 6, :89-104, on the host: (pa, index_a) of the sorted bins down, (pa', index_b, pb) up */
     std::vector<float> pa(n), pb(n, 0.0f);
     std::vector<uint32_t> ia(n), ib(n, 0u);
     t0 = std::chrono::steady_clock::now();
     LT_TRY(hipMemcpy(pa.data(), d_pa.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    LT_TRY(hipMemcpy(ia.data(), d_vals2.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    LT_TRY(hipMemcpy(ia.data(), d_vals.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     ms_transfer += since(t0);
     t0 = std::chrono::steady_clock::now();
     {
@@ -293,7 +371,7 @@ extern "C" int rpt_light_table_build_gpu(int device_id, const float *vertices_xy
     LT_TRY(hipMemcpy(d_pb.p, pb.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     LT_TRY(hipMemcpy(d_ib.p, ib.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
     ms_transfer += since(t0);
-    k_lt_table<<<nbn, LT_BLOCK>>>(d_pa.p, d_pb.p, d_vals2.p, d_ib.p, d_area.p, d_prob.p, n, d_out.p);
+    k_lt_table<<<nbn, LT_BLOCK>>>(d_pa.p, d_pb.p, d_vals.p, d_ib.p, d_area.p, d_prob.p, n, d_out.p);
     LT_TRY(hipGetLastError());
     t0 = std::chrono::steady_clock::now();
     LT_TRY(hipMemcpy(entries_out, d_out.p, (size_t)n * sizeof(rpt_light_pick_entry), hipMemcpyDeviceToHost));

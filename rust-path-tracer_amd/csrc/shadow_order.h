@@ -26,7 +26,7 @@
  * needs fewer than SHADOW_FIXED_GAIN of near-first's, the shadow kernels walk a copy of the tree whose child pairs are flipped so that the preferred
  * child sits in the left slot, in fixed left-first order (no `tl > tr`, no swap); otherwise they keep the reference's near-first order.
  * Deterministic (ray i draws from its own generator), and whatever it decides the image is the same.  RPT_SHADOW_ORDER=near|fixed overrides (tests
- * run every NEE case both ways).
+ * run every NEE case both ways; the library's knobs are read in one place, rpt_ctx.h rpt_knobs).
  *
  * Round 6: the probes run as kernels.  On a 1 M-triangle scene the sequential probe was 17 - 40 ms of rpt_upload_scene — triangle areas, the
  * per-node sums, a cumulative distribution over all triangles, 8 192 walks through cold memory.  Now: per-node sums level by level on the device
@@ -81,6 +81,7 @@ struct LastOrder {
 
 namespace order_probe {
 
+struct float4_like { float x, y, z, w; };       /* (float4 without <hip/hip_runtime.h>: this header is plain C++ for the host driver) */
 struct V { float x, y, z; };
 RPT_HD V sub(V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; }
 RPT_HD V cross(V a, V b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
@@ -100,6 +101,8 @@ struct View {
     const double *area_all;       /* triangle surface below every node */
     const double *area_ne;        /* ... of the triangles whose material does not emit */
     const double *count;          /* nodes of every subtree */
+    const float4_like *geom;      /* device driver: 3 x float4 per triangle — a, e1 = b - a, e2 = c - a as k_derive_triangles computed them (the same subtractions
+                                     tri() makes: one 48-byte record instead of the index record and three 64-byte vertices); host driver: null */
 };
 
 RPT_HD bool emissive(const View &s, uint32_t t) {
@@ -140,8 +143,7 @@ RPT_HD bool box(const rpt_bvh_node &n, V o, V id, float &tmin) {
     tmin = lo;
     return hi >= lo && hi > 0.0f && lo < 1000000.0f;
 }
-RPT_HD bool tri(const rpt_per_vertex_data *pv, const rpt_triangle &t, V o, V d, float max_t) {
-    V a = vtx(pv[t.v0]), e1 = sub(vtx(pv[t.v1]), a), e2 = sub(vtx(pv[t.v2]), a);
+RPT_HD bool tri_test(V a, V e1, V e2, V o, V d, float max_t) {
     V p = cross(d, e2);
     float det = dot(e1, p);
     if (absf(det) < 1e-6f) return false;
@@ -154,6 +156,30 @@ RPT_HD bool tri(const rpt_per_vertex_data *pv, const rpt_triangle &t, V o, V d, 
     if (v < 0.0f || u + v > 1.0f) return false;
     float tt = dot(e2, q) * inv;
     return tt > 0.001f && tt <= max_t;
+}
+/* does the ray pass any triangle of a leaf?  (device driver: the records of eight triangles are in flight before the first is tested — one thread walks
+ * a ray, and a leaf of the clustered stand-in holds sixty triangles: tested one load at a time the probe was 8 ms of memory latency) */
+RPT_HD bool leaf_test(const View &s, uint32_t first, uint32_t count, V o, V d, float max_t) {
+    if (s.geom) {
+        for (uint32_t k0 = 0; k0 < count; k0 += 8u) {
+            float4_like g[24];
+            const uint32_t m = count - k0 < 8u ? count - k0 : 8u;
+            RPT_UNROLL
+            for (uint32_t j = 0; j < 8u; ++j)
+                if (j < m) { const float4_like *r = s.geom + 3u * (size_t)(first + k0 + j); g[3 * j] = r[0]; g[3 * j + 1] = r[1]; g[3 * j + 2] = r[2]; }
+            RPT_UNROLL
+            for (uint32_t j = 0; j < 8u; ++j)
+                if (j < m && tri_test(V{g[3 * j].x, g[3 * j].y, g[3 * j].z}, V{g[3 * j + 1].x, g[3 * j + 1].y, g[3 * j + 1].z}, V{g[3 * j + 2].x, g[3 * j + 2].y, g[3 * j + 2].z}, o, d, max_t))
+                    return true;
+        }
+        return false;
+    }
+    for (uint32_t k = 0; k < count; ++k) {
+        const rpt_triangle &t = s.idx[first + k];
+        const V a = vtx(s.pv[t.v0]);
+        if (tri_test(a, sub(vtx(s.pv[t.v1]), a), sub(vtx(s.pv[t.v2]), a), o, d, max_t)) return true;
+    }
+    return false;
 }
 
 /* ray i of a probe draws from its own generator (the kernels run one thread per ray) */
@@ -264,8 +290,7 @@ RPT_HD uint32_t walk(const View &s, const uint8_t *flip, V o, V d, float max_t, 
         const rpt_bvh_node &n = s.nodes[node];
         bool descend = false;
         if (n.triangle_count != 0u) {
-            for (uint32_t k = 0; k < n.triangle_count; ++k)
-                if (tri(s.pv, s.idx[n.left_or_first + k], o, d, max_t)) { occluded = true; return visits; }
+            if (leaf_test(s, n.left_or_first, n.triangle_count, o, d, max_t)) { occluded = true; return visits; }
         } else {
             const uint32_t L = n.left_or_first, R = L + 1u;
             float tl, tr;
@@ -321,7 +346,7 @@ inline void host_sums(const rpt_per_vertex_data *pv, const rpt_triangle *idx, si
 }
 
 /* the decisions, from the counters of either driver */
-inline void decide_shadow(ShadowOrder &so, uint64_t visits_near, uint64_t visits_fixed, uint32_t rays, uint32_t occluded) {
+inline void decide_shadow(ShadowOrder &so, uint64_t visits_near, uint64_t visits_fixed, uint32_t rays, uint32_t occluded, int forced /* RPT_SHADOW_ORDER: 0 near, 1 fixed, -1 the probe's */) {
     so.probe_rays = rays;
     so.probe_occluded = occluded;
     if (rays == 0) { so.why = "no probe ray could be formed"; return; }
@@ -329,12 +354,10 @@ inline void decide_shadow(ShadowOrder &so, uint64_t visits_near, uint64_t visits
     so.visits_fixed = (double)visits_fixed / rays;
     so.fixed = so.visits_fixed < SHADOW_FIXED_GAIN * so.visits_near;
     so.why = so.fixed ? "opaque-first needs fewer node visits on the probe rays" : "near-first needs no more node visits on the probe rays";
-    if (const char *env = getenv("RPT_SHADOW_ORDER")) {
-        if (!strcmp(env, "fixed")) { so.fixed = true; so.why = "RPT_SHADOW_ORDER=fixed"; }
-        else if (!strcmp(env, "near")) { so.fixed = false; so.why = "RPT_SHADOW_ORDER=near"; }
-    }
+    if (forced == 1) { so.fixed = true; so.why = "RPT_SHADOW_ORDER=fixed"; }
+    else if (forced == 0) { so.fixed = false; so.why = "RPT_SHADOW_ORDER=near"; }
 }
-inline void decide_last(LastOrder &lo, const uint64_t v[4], uint32_t rays, uint32_t hits) {
+inline void decide_last(LastOrder &lo, const uint64_t v[4], uint32_t rays, uint32_t hits, int forced /* RPT_LAST_ORDER: 0 near, 1 opaque, 2 small, 3 ratio; -1 (and 4 = off, decided elsewhere): the probe's */) {
     lo.probe_rays = rays;
     lo.probe_hits = hits;
     if (rays == 0) return;
@@ -342,9 +365,7 @@ inline void decide_last(LastOrder &lo, const uint64_t v[4], uint32_t rays, uint3
     int best = 1;
     for (int q = 2; q <= 3; ++q) if (lo.visits[q] < lo.visits[best]) best = q;
     lo.rule = lo.visits[best] < SHADOW_FIXED_GAIN * lo.visits[0] ? best : 0;
-    if (const char *env = getenv("RPT_LAST_ORDER")) {              /* near | opaque | small | ratio: tests and A/B */
-        if (!strcmp(env, "near")) lo.rule = 0; else if (!strcmp(env, "opaque")) lo.rule = 1; else if (!strcmp(env, "small")) lo.rule = 2; else if (!strcmp(env, "ratio")) lo.rule = 3;
-    }
+    if (forced >= 0 && forced <= 3) lo.rule = forced;              /* tests and A/B */
 }
 
 struct Clock {
@@ -358,7 +379,7 @@ struct Clock {
  * every inner node are the nodes (2p + 1, 2p + 2) of one pair — what the flipped copies can express; otherwise near-first stays. */
 inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
                                        const rpt_material_data *mats, const rpt_light_pick_entry *lp, size_t nlp, bool pair_shaped,
-                                       const float *cross_sq = nullptr /* optional: |(b - a) x (c - a)|^2 per triangle */) {
+                                       const float *cross_sq = nullptr /* optional: |(b - a) x (c - a)|^2 per triangle */, int forced = -1) {
     using namespace order_probe;
     ShadowOrder so;
     const Clock clock;
@@ -366,7 +387,7 @@ inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_
     if (!pair_shaped || nn < 3) { so.why = "node pool is not pair-shaped"; so.probe_ms = clock.ms(); return so; }
     std::vector<double> tri_area, area_all, area_ne, count;
     host_sums(pv, idx, nt, nodes, nn, mats, cross_sq, tri_area, area_all, area_ne, count);
-    const View s{pv, idx, nodes, mats, lp, (uint32_t)nt, (uint32_t)nn, (uint32_t)nlp, tri_area.data(), area_all.data(), area_ne.data(), count.data()};
+    const View s{pv, idx, nodes, mats, lp, (uint32_t)nt, (uint32_t)nn, (uint32_t)nlp, tri_area.data(), area_all.data(), area_ne.data(), count.data(), nullptr};
     so.flip.assign((nn - 1) / 2, 0);
     for (size_t p = 0; p < so.flip.size(); ++p) so.flip[p] = prefers_right(s, (uint32_t)p, 1) ? 1 : 0;
     const bool all = !(area_ne[0] > 0.0);
@@ -384,20 +405,20 @@ inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_
         rays += 1;
         occluded += occ_n ? 1u : 0u;
     }
-    decide_shadow(so, vn, vf, rays, occluded);
+    decide_shadow(so, vn, vf, rays, occluded, forced);
     so.probe_ms = clock.ms();
     return so;
 }
 
 inline LastOrder choose_last_order(const rpt_per_vertex_data *pv, const rpt_triangle *idx, size_t nt, const rpt_bvh_node *nodes, size_t nn,
-                                   const rpt_material_data *mats, bool pair_shaped) {
+                                   const rpt_material_data *mats, bool pair_shaped, int forced = -1) {
     using namespace order_probe;
     LastOrder lo;
     const Clock clock;
     if (!pair_shaped || nn < 3 || nt == 0) { lo.probe_ms = clock.ms(); return lo; }
     std::vector<double> tri_area, area_all, area_ne, count;
     host_sums(pv, idx, nt, nodes, nn, mats, nullptr, tri_area, area_all, area_ne, count);
-    const View s{pv, idx, nodes, mats, nullptr, (uint32_t)nt, (uint32_t)nn, 0u, tri_area.data(), area_all.data(), area_ne.data(), count.data()};
+    const View s{pv, idx, nodes, mats, nullptr, (uint32_t)nt, (uint32_t)nn, 0u, tri_area.data(), area_all.data(), area_ne.data(), count.data(), nullptr};
     const size_t P = (nn - 1) / 2;
     std::vector<uint8_t> flips[4];
     for (int r = 1; r <= 3; ++r) {
@@ -417,7 +438,7 @@ inline LastOrder choose_last_order(const rpt_per_vertex_data *pv, const rpt_tria
         rays += 1;
         hits += hit ? 1u : 0u;
     }
-    decide_last(lo, v, rays, hits);
+    decide_last(lo, v, rays, hits, forced);
     if (lo.rule != 0) lo.flip = flips[lo.rule];
     lo.probe_ms = clock.ms();
     return lo;

@@ -23,7 +23,7 @@ EXPORTS = [
     "rpt_map_accum", "rpt_comm_unique_id", "rpt_comm_init", "rpt_comm_world", "rpt_gather_async", "rpt_gather_wait", "rpt_read_gathered",
     "rpt_gathered_device_ptr", "rpt_multi_create", "rpt_multi_size", "rpt_multi_ctx", "rpt_multi_upload_scene", "rpt_multi_set_config",
     "rpt_multi_reset", "rpt_multi_render", "rpt_multi_wait", "rpt_multi_read_accum", "rpt_multi_get_stats", "rpt_multi_destroy",
-    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_build_fingerprint", "rpt_debug_comm_selftest", "rpt_device_info", "rpt_shadow_order", "rpt_debug_shadow_order_host", "rpt_last_bounce_order", "rpt_debug_last_order_host",
+    "rpt_multi_last_error", "rpt_comm_library", "rpt_debug_trace_rays_production", "rpt_build_fingerprint", "rpt_debug_comm_selftest", "rpt_device_info", "rpt_shadow_order", "rpt_debug_shadow_order_host", "rpt_last_bounce_order", "rpt_debug_last_order_host", "rpt_debug_short_batch",
 ]
 COMM_ID_BYTES = 128
 MULTI_ALLOW_SHARED_DEVICE = 1
@@ -321,7 +321,12 @@ class Renderer:
         self._check(lib().rpt_read_gathered(self._h, ptr(out), C.byref(samples)))
         return out, samples.value
 
-    # -- test hooks
+    # -- test hooks (include/rpt/rpt_debug.h)
+    def debug_short_batch(self, on=True):
+        """rpt_debug_short_batch: asynchronous batches enqueue one iteration too few (the completion checks must notice)."""
+        lib().rpt_debug_short_batch.argtypes = [C.c_void_p, C.c_int]
+        self._check(lib().rpt_debug_short_batch(self._h, 1 if on else 0))
+
     def debug_math(self, op, x, y=None):
         x = np.ascontiguousarray(x, np.float32)
         y = x if y is None else np.ascontiguousarray(y, np.float32)
@@ -540,7 +545,7 @@ def light_table_build_gpu(vertices_xyzw, triangles, materials, device=0):
     v = np.ascontiguousarray(vertices_xyzw, np.float32).reshape(-1, 4)
     t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE)
     m = np.ascontiguousarray(materials, MATERIAL_DTYPE)
-    table = np.zeros(max(1, len(t)), LIGHT_PICK_DTYPE)
+    table = np.empty(max(1, len(t)), LIGHT_PICK_DTYPE)          # (np.zeros would fault in 28 bytes per triangle of pages the call overwrites)
     n, n_em = C.c_size_t(0), C.c_uint32(0)
     ms = (C.c_double * 4)()
     L = lib()
@@ -550,7 +555,7 @@ def light_table_build_gpu(vertices_xyzw, triangles, materials, device=0):
                                      C.byref(n), C.byref(n_em), ms)
     if rc != 0:
         raise RptError(rc, L.rpt_last_error(None).decode())
-    return table[: n.value].copy(), n_em.value, {"total": ms[0], "device": ms[1], "host_chains": ms[2], "transfers": ms[3]}
+    return table[: n.value], n_em.value, {"total": ms[0], "device": ms[1], "host_chains": ms[2], "transfers": ms[3]}
 
 
 def bvh_build_gpu(vertices_xyzw, triangles, sah_samples=128, device=0):
@@ -560,11 +565,11 @@ def bvh_build_gpu(vertices_xyzw, triangles, sah_samples=128, device=0):
     from ._ffi import BVH_NODE_DTYPE, TRIANGLE_DTYPE
     v = np.ascontiguousarray(vertices_xyzw, np.float32).reshape(-1, 4)
     t = np.ascontiguousarray(triangles, TRIANGLE_DTYPE).copy()
-    nodes = np.zeros(max(1, 2 * len(t) - 1), BVH_NODE_DTYPE)
+    nodes = np.empty(max(1, 2 * len(t) - 1), BVH_NODE_DTYPE)      # (written by the call; zeroing and copying 64 MB of node pool was 25 ms of a 1 M-triangle "startup" in this harness)
     n_nodes = C.c_size_t(0)
     ms = C.c_double(0.0)
     rc = lib().rpt_bvh_build_gpu(device, v.ctypes.data, len(v), t.ctypes.data, len(t), sah_samples, nodes.ctypes.data, len(nodes),
                                  C.byref(n_nodes), C.byref(ms))
     if rc != 0:
         raise RptError(rc, lib().rpt_last_error(None).decode())
-    return nodes[: n_nodes.value].copy(), t, ms.value
+    return nodes[: n_nodes.value], t, ms.value

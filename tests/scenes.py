@@ -283,6 +283,23 @@ def fat_leaf_scene(n_stack=300, seed=3):
     return rpt.World.from_buffers(verts, normals.astype(np.float32), None, tris, m)
 
 
+def foreign_pool(w):
+    """The same tree as another builder might lay it out: an unused node at index 1, so every child pair sits at (even, odd) — not the (2p + 1, 2p + 2)
+    pairs of the reference's builder (src/bvh.rs:296-320: node_count starts at 1).  A valid node buffer of the boundary (children adjacent, links in range)."""
+    import copy
+    out = copy.copy(w)
+    nodes = w.nodes
+    new = np.zeros(len(nodes) + 1, nodes.dtype)
+    new[0] = nodes[0]
+    new[2:] = nodes[1:]
+    new[1] = nodes[len(nodes) - 1]                        # (never reached: a copy of some leaf)
+    inner = new["triangle_count"] == 0
+    inner[1] = False
+    new["left_or_first"][inner] += 1
+    out.nodes = new
+    return out
+
+
 def write_glb(path, positions, indices, *, normals=None, uvs=None, materials=None, images=None, textures=None, accessor_patch=None,
               node_extra=None):
     """Minimal glTF 2.0 binary writer for tests: one mesh, one primitive, optional embedded PNG images.

@@ -43,8 +43,10 @@ def test_headers_compile_as_c11_and_cxx(tmp_path):
 
 def test_hip_library_exports_every_declared_symbol(hipmod):
     L = hipmod.lib()
-    declared = _declared("rpt.h")
-    assert len(declared) >= 20
+    boundary, hooks = _declared("rpt.h"), _declared("rpt_debug.h")
+    assert len(boundary) >= 20 and not [s for s in boundary if s.startswith("rpt_debug_")]      # the test hooks live in rpt_debug.h, outside the boundary
+    assert hooks and all(s.startswith("rpt_debug_") for s in hooks)
+    declared = sorted(boundary + hooks)
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(hipmod.EXPORTS) == declared

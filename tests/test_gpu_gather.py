@@ -233,7 +233,7 @@ def test_multi_driver_with_rccl_on_the_devices_present(hipmod, rpt, world):
 
 def test_async_batches_are_checked_for_completion(monkeypatch, hipmod, rpt, world):
     """An asynchronous batch enqueues a fixed number of iterations and never looks at a progress report.  rpt_wait (and
-    every next batch) verifies that all samples finished; RPT_TEST_SHORT_BATCH=1 enqueues one iteration too few and
+    every next batch) verifies that all samples finished; rpt_debug_short_batch enqueues one iteration too few and
     must be caught — by rpt_wait for the last batch, by the following batch for an earlier one."""
     w = world("DarkCornell")
     W, H = 96, 64
@@ -246,9 +246,9 @@ def test_async_batches_are_checked_for_completion(monkeypatch, hipmod, rpt, worl
     r.wait()                                           # complete batches pass
     assert r.read_accum()[1] == 24
     r.close()
-    monkeypatch.setenv("RPT_TEST_SHORT_BATCH", "1")
     for batches in (1, 2):
         r = hipmod.Renderer(0)
+        r.debug_short_batch(True)
         r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
         for _ in range(batches):
             r.render_async(8)

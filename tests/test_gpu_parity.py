@@ -99,18 +99,19 @@ def test_ray_parity_nearest_and_any(renderer, oracle, world, scene):
     assert np.array_equal(afl_g & 1, afl_c & 1)
 
 
-@pytest.mark.parametrize("scene,knob", [("DarkCornell", None), ("DarkCornell", "RPT_LDS_STREAM=0"), ("DarkCornell", "RPT_NO_LDS_SCENE=1"),
-                                        ("VeachMIS", None), ("VeachMIS", "RPT_GSTREAM=0"), ("FurnaceTest", None), ("PBRTest", None),
+@pytest.mark.parametrize("scene,knob", [("DarkCornell", None), ("DarkCornell", "RPT_NO_LDS_SCENE=1"),
+                                        ("VeachMIS", None), ("VeachMIS", "foreign_pool"), ("FurnaceTest", None), ("PBRTest", None),
                                         ("PBRTest", "RPT_COOP_LEAVES=1"), ("deep_bvh", None), ("deep_bvh", "RPT_COOP_LEAVES=0"),
                                         ("deep_bvh", "RPT_STACK_BITS=21"), ("scatter", None)])
 def test_ray_parity_through_the_production_traversal_stage(monkeypatch, hipmod, oracle, rpt, world, scene, knob):
     """intersect_front_to_back (intersection.rs:177-234) per ray — t, triangle, backface bit for bit against the oracle — through
     the kernels rpt_render itself launches (rpt_debug_trace_rays_production): the persistent LDS-pool stream for DarkCornell, the
     streamed global-memory walks for the others (without the cooperative leaf code for thin-leaf scenes, with it for the fat-leaf
-    stand-in, and each forced the other way), the one-shot kernels behind their knobs, 21-bit stack entries.  The rays are
+    stand-in, and each forced the other way), the generic one-ray-per-lane walk for a node pool that is not pair-shaped (a foreign
+    builder's: scenes.foreign_pool), 21-bit stack entries.  The rays are
     incoherent (random origins inside the scene, random directions) and include axis-parallel directions with exact zeros,
     which leave the exact-division fast path."""
-    if knob:
+    if knob and "=" in knob:
         k, v = knob.split("=")
         monkeypatch.setenv(k, v)
     if scene == "deep_bvh":
@@ -121,6 +122,9 @@ def test_ray_parity_through_the_production_traversal_stage(monkeypatch, hipmod, 
         w = scatter_scene(80_000)                                # > 65 536 nodes: stack entries wider than 16 bits
     else:
         w = world(scene)
+    if knob == "foreign_pool":
+        from scenes import foreign_pool
+        w = foreign_pool(w)
     n = 150_000
     rng = np.random.default_rng(17)
     o, d = _random_rays(rng, n, w)
@@ -283,6 +287,44 @@ def test_the_library_chooses_the_shadow_order_per_scene(monkeypatch, hipmod, rpt
         r.close()
 
 
+@pytest.mark.parametrize("scene", ["DarkCornell", "VeachMIS", "FurnaceTest", "PBRTest", "deep_bvh", "scatter", "textured", "fat_leaf"])
+def test_the_probe_kernels_decide_exactly_as_the_host_loop_does(monkeypatch, hipmod, rpt, world, scene):
+    """Round 6: rpt_upload_scene runs both order probes as kernels (per-node sums level by level, one thread per probe ray); the sequential host loop over the
+    same core (rpt_debug_shadow_order_host / rpt_debug_last_order_host) is the checker.  Same rays, same node visits — the averages are EQUAL, digit for digit,
+    and so are the probe-ray counts and the decisions — on the four shipped scenes, the two 1 M-triangle stand-ins' smaller brothers (deep tree with fat
+    leaves; more than 65 536 nodes), a textured open scene and a leaf of 300 triangles."""
+    for k in ("RPT_SHADOW_ORDER", "RPT_LAST_ORDER"):
+        monkeypatch.delenv(k, raising=False)
+    if scene == "deep_bvh":
+        from scenes import deep_bvh_scene
+        w = deep_bvh_scene(120_000)
+    elif scene == "scatter":
+        from scenes import scatter_scene
+        w = scatter_scene(70_000)
+    elif scene == "textured":
+        from scenes import textured_scene
+        w = textured_scene()[0]
+    elif scene == "fat_leaf":
+        from scenes import fat_leaf_scene
+        w = fat_leaf_scene(300)
+    else:
+        w = world(scene)
+    r = hipmod.Renderer(0)
+    try:
+        r.upload_scene(w)
+        dev_s, dev_l = r.shadow_order(), r.last_bounce_order()
+    finally:
+        r.close()
+    host_s, host_l = hipmod.shadow_order_host(w), hipmod.last_order_host(w)
+    assert (dev_s["fixed"], dev_s["visits_near"], dev_s["visits_fixed"], dev_s["probe_rays"]) == (host_s["fixed"], host_s["visits_near"], host_s["visits_fixed"], host_s["probe_rays"])
+    assert dev_s["probe_ms"] > 0
+    if host_s["probe_rays"]:                                   # (no lights: no shadow probe; a leaf of 255+ triangles: no pair records, near-first stays)
+        assert dev_s["probe_rays"] > 1000 and dev_s["visits_near"] > 1.0
+    if dev_l["mode"] != 0 or scene == "DarkCornell":                            # (only scenes that live in LDS with few emitters probe the last rays)
+        assert dev_l["mode"] == 1 + host_l["rule"] and dev_l["probe_rays"] == host_l["probe_rays"] > 500
+        assert list(dev_l["probe_node_visits"].values()) == host_l["visits"]
+
+
 def _with_emissive_materials(rpt, w, how_many_triangles):
     """a copy of the world in which the materials of the first few non-emissive triangles (in material order) emit as well: nee = 0 reads no light table"""
     import copy
@@ -302,7 +344,7 @@ def _with_emissive_materials(rpt, w, how_many_triangles):
     return w2, have
 
 
-LAST_MODES = {"off": ("RPT_LAST_BOUNCE_HIT_OR_MISS", "0", 0), "near": ("RPT_LAST_ORDER", "near", 1), "opaque": ("RPT_LAST_ORDER", "opaque", 2),
+LAST_MODES = {"off": ("RPT_LAST_ORDER", "off", 0), "near": ("RPT_LAST_ORDER", "near", 1), "opaque": ("RPT_LAST_ORDER", "opaque", 2),
               "small": ("RPT_LAST_ORDER", "small", 3), "ratio": ("RPT_LAST_ORDER", "ratio", 4)}
 
 
@@ -316,7 +358,6 @@ def test_last_extension_rays_may_stop_at_their_first_hit(monkeypatch, hipmod, or
     with an image skybox, two bounces (the last ray is the second), roulette from the first bounce on, more emitters to test against."""
     var, val, expect = LAST_MODES[mode]
     monkeypatch.delenv("RPT_LAST_ORDER", raising=False)
-    monkeypatch.delenv("RPT_LAST_BOUNCE_HIT_OR_MISS", raising=False)
     monkeypatch.setenv(var, val)
     skybox = None
     over = {}
@@ -357,15 +398,13 @@ def test_last_extension_rays_may_stop_at_their_first_hit(monkeypatch, hipmod, or
     assert np.array_equal(acc_g.view(np.uint32), acc_c.view(np.uint32))
 
 
-@pytest.mark.parametrize("presub", ["0", "1"])
 @pytest.mark.parametrize("scene,nee,over", [("DarkCornell", 0, {}), ("DarkCornell", 1, {"cam_position": (-0.0, 1.0, -3.5, 0.0)}), ("textured", 2, {"cam_position": (0.0, 1.6, -4.0, 0.0)}),
                                             ("DarkCornell", 0, {"cam_position": (0.0, 1e6, -3e7, 0.0)})])
-def test_camera_rays_walk_planes_with_the_origin_already_subtracted(monkeypatch, hipmod, oracle, rpt, world, scene, nee, over, presub):
+def test_camera_rays_walk_planes_with_the_origin_already_subtracted(hipmod, oracle, rpt, world, scene, nee, over):
     """Iteration 0 of a render call traces camera rays only, all from cfg.cam_position: the streamed LDS walk of that launch stages `plane - origin`
-    once per workgroup instead of computing it per lane and node (k_traverse_nearest_stream FIRST).  On or off (RPT_FIRST_PRESUB), the image is the
+    once per workgroup instead of computing it per lane and node (k_traverse_nearest_stream FIRST).  The image is the
     oracle's — with NEE, with a zero of either sign and with a far-away value in the camera position (the exact-division guard's other path), and for a
     call whose slots take more than one sample (only its first iteration is such a launch)."""
-    monkeypatch.setenv("RPT_FIRST_PRESUB", presub)
     skybox = None
     if scene == "textured":
         from scenes import textured_scene
@@ -394,7 +433,6 @@ def test_the_library_chooses_the_order_of_the_last_rays_per_scene(monkeypatch, h
     """rpt_last_bounce_order after rpt_upload_scene: DarkCornell (two emissive triangles, lives in LDS) walks those rays in a fixed order its probe favoured;
     a scene that does not live in LDS keeps the whole walk; the decision is the host probe's (rpt_debug_last_order_host) and is re-taken on every upload."""
     monkeypatch.delenv("RPT_LAST_ORDER", raising=False)
-    monkeypatch.delenv("RPT_LAST_BOUNCE_HIT_OR_MISS", raising=False)
     r = hipmod.Renderer(0)
     try:
         r.upload_scene(world("DarkCornell"))
@@ -539,7 +577,7 @@ def test_baseline_configs_at_their_own_sample_counts(hipmod, oracle, rpt, world,
 @pytest.mark.parametrize("scene,nee,spp", [("DarkCornell", 0, 7), ("VeachMIS", 1, 5), ("PBRTest", 2, 3)])
 def test_samples_in_flight_invisible(hipmod, oracle, rpt, world, scene, nee, spp):
     """Any number of samples of a pixel in flight gives the sequential sample-order sum, bit for bit
-    (k_path.h: k_complete) — including sample counts that are not a multiple of it."""
+    (k_complete.h) — including sample counts that are not a multiple of it."""
     w = world(scene)
     W, H = 96, 80
     cfg = rpt.default_config(W, H, nee=nee)
@@ -599,25 +637,25 @@ def test_up_to_256_samples_of_a_pixel_in_flight(monkeypatch, hipmod, oracle, rpt
             r.close()
 
 
-def test_sky_stage_per_iteration_or_once_per_batch(monkeypatch, hipmod, oracle, rpt, world):
-    """A batch of known length shades its misses in ONE sky launch after its last iteration (a miss only ends a path, lib.rs:79);
-    RPT_SKY_AT_END=0 shades them in the iteration that found them, as calls with several samples per slot always do.  Same image,
-    same ray and sky counts, on the scene where most paths end in the sky."""
+def test_sky_stage_once_per_batch_or_per_iteration(hipmod, oracle, rpt, world):
+    """A batch of known length shades its misses in ONE sky launch after its last iteration (a miss only ends a path, lib.rs:79); a call whose slots
+    take several samples shades them in the iteration that found them (the slot must be free for its next sample).  Same image, same ray and sky
+    counts either way, on the scene where most paths end in the sky."""
     w = world("PBRTest")
     W, H, spp = 128, 96, 8
     cfg = rpt.default_config(W, H, nee=1)
     seeds = rpt.blue_noise_seeds(W, H)
     ref, rng_ref, st = oracle.trace_cpu(cfg, oracle.scene(w), seeds, spp)
-    for at_end in ("1", "0"):
-        monkeypatch.setenv("RPT_SKY_AT_END", at_end)
+    for in_flight in (0, 2):
         r = hipmod.Renderer(0)
+        r.set_samples_in_flight(in_flight)
         r.upload_scene(w); r.set_config(cfg); r.reset(seeds)
         r.render_async(5); r.render_async(3); r.wait()
         acc, n = r.read_accum()
         g = r.stats()
-        assert n == spp and np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"RPT_SKY_AT_END={at_end}"
+        assert n == spp and np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), in_flight
         assert g["extension_rays"] == st.extension_rays and g["shadow_rays"] == st.shadow_rays and g["sky_evals"] == st.sky_evals
-        assert g["kernel_launches"]["sky"] == (2 if at_end == "1" else 2 * cfg.max_bounces)
+        assert (g["kernel_launches"]["sky"] == 2) if in_flight == 0 else (g["kernel_launches"]["sky"] > 2 * cfg.max_bounces)
         r.close()
 
 
@@ -874,19 +912,18 @@ def test_host_dispatch_trace_gpu_furnace(rpt):
         state.close()
 
 
-@pytest.mark.parametrize("knob", ["RPT_LDS_STREAM=0", "RPT_NO_LDS_SCENE=1", "RPT_NO_FASTDIV=1", "RPT_SKY_THRESHOLD=4096",
-                                  "RPT_SKY_WIDE_LIMIT=0", "RPT_STREAM_MAX_BLOCKS=7", "RPT_STREAM_SPAN=1024", "RPT_GSTREAM=0",
-                                  "RPT_SHADE_COMPACT=1", "RPT_LDS_SHADOW_STREAM=0", "RPT_MAX_SLOTS=65536",
-                                  "RPT_SAMPLES_IN_FLIGHT=4", "RPT_STAGE_TIMING=2", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=3",
-                                  "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=5,RPT_SKY_WIDE_LIMIT=1000000", "RPT_SKY_STRIDED=0", "RPT_GSTREAM=1,RPT_STACK_BITS=21", "RPT_GSTREAM=1,RPT_STACK_BITS=24", "RPT_GSTREAM=1,RPT_STACK_BITS=32"])
+@pytest.mark.parametrize("knob", ["RPT_NO_LDS_SCENE=1", "RPT_SHADE_COMPACT=1", "RPT_SHADE_COMPACT=0", "RPT_STAGE_TIMING=1", "RPT_STAGE_TIMING=2", "RPT_UPLOAD_TIMING=1",
+                                  "RPT_SKY_STRIDED=3", "RPT_SKY_STRIDED=1", "RPT_SKY_STRIDED=0", "RPT_STACK_BITS=21", "RPT_STACK_BITS=24", "RPT_STACK_BITS=32",
+                                  "RPT_COOP_LEAVES=1", "RPT_SLOT_Q_SHIFT=3", "RPT_SHADOW_ORDER=near", "RPT_SHADOW_ORDER=fixed", "RPT_LAST_ORDER=off"])
 def test_developer_knobs_do_not_change_the_image(monkeypatch, hipmod, rpt, world, knob):
-    """README: every tuning knob leaves the image bit-identical (they select kernels / schedules, never arithmetic)."""
+    """Every environment variable the library reads (rpt_ctx.h rpt_knobs — one place, eleven of them + the test stand-in for RCCL) leaves the image
+    bit-identical: they select kernels / schedules / diagnostics, never arithmetic."""
     W, H, spp = 160, 96, 6
     cfg = rpt.default_config(W, H, nee=1)
     seeds = rpt.blue_noise_seeds(W, H)
 
     # (the global-memory walk / a scene open to the sky / the LDS walk)
-    scene = "VeachMIS" if knob.startswith("RPT_GSTREAM") else "PBRTest" if knob.startswith("RPT_SKY_STRIDED") else "DarkCornell"
+    scene = "VeachMIS" if knob.startswith(("RPT_STACK_BITS", "RPT_COOP_LEAVES")) else "PBRTest" if knob.startswith("RPT_SKY_STRIDED") else "DarkCornell"
 
     def render():
         r = hipmod.Renderer(0)
@@ -1048,21 +1085,25 @@ def test_more_than_65536_nodes_parity(renderer, oracle, rpt, nee):
     assert err == 0 and np.array_equal(afl_g & 1, afl_c & 1)
 
 
-@pytest.mark.parametrize("knobs", ["RPT_SHADE_COMPACT=1", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=3", "RPT_SKY_STRIDED=1,RPT_SKY_BLOCKS=2,RPT_SKY_WIDE_LIMIT=0",
-                                   "RPT_SHADE_COMPACT=1,RPT_SAMPLES_IN_FLIGHT=2"])
+@pytest.mark.parametrize("knobs", ["RPT_SHADE_COMPACT=1", "RPT_SKY_STRIDED=3", "RPT_SKY_STRIDED=2", "RPT_SHADE_COMPACT=1,samples_in_flight=2"])
 @pytest.mark.parametrize("nee,has_skybox", [(0, 1), (1, 1), (2, 0)])
 def test_kernel_variants_on_the_textured_scene(monkeypatch, hipmod, oracle, rpt, knobs, nee, has_skybox):
     """The template instantiations no shipped scene reaches together: TEXTURED x packed shade stage, and the strided sky
     stage on the image-skybox branch (lib.rs:70-78) as well as on the procedural sky — forced on, against the oracle."""
     from scenes import textured_scene
+    in_flight = 0
     for one in knobs.split(","):
         name, value = one.split("=")
-        monkeypatch.setenv(name, value)
+        if name == "samples_in_flight":
+            in_flight = int(value)
+        else:
+            monkeypatch.setenv(name, value)
     w, skybox = textured_scene()
     W, H, spp = 136, 88, 5
     cfg = rpt.default_config(W, H, nee=nee, has_skybox=has_skybox, cam_position=(0.0, 1.6, -4.0, 0.0), cam_rotation=(0.05, 0.1, 0.0, 0.0))
     seeds = rpt.blue_noise_seeds(W, H)
     r = hipmod.Renderer(0)
+    r.set_samples_in_flight(in_flight)
     r.upload_scene(w, skybox_f32=skybox)
     r.set_config(cfg)
     r.reset(seeds)
@@ -1096,11 +1137,11 @@ def test_deep_tree_with_wide_stack_entries(renderer, oracle, rpt):
     assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
 
 
-def test_one_ray_per_lane_walk_with_32_bit_stack_entries(monkeypatch, hipmod, oracle, rpt):
-    """RPT_GSTREAM=0 (k_traverse_nearest / k_traverse_shadow, one ray per lane) on the scene of more than 65 536 nodes."""
-    from scenes import scatter_scene
-    monkeypatch.setenv("RPT_GSTREAM", "0")
-    w = scatter_scene()
+def test_one_ray_per_lane_walk_of_a_foreign_node_pool(hipmod, oracle, rpt):
+    """A tree whose children are not the nodes (2p + 1, 2p + 2) of a pair — no pool of the reference's builder, but a valid buffer of the boundary — keeps the
+    generic walks (k_traverse_nearest / k_traverse_shadow, one ray per lane, 32-bit stack entries): the scene of more than 65 536 nodes, NEE on."""
+    from scenes import scatter_scene, foreign_pool
+    w = foreign_pool(scatter_scene())
     W, H, spp = 96, 64, 2
     cfg = rpt.default_config(W, H, nee=1, cam_position=(0.0, 1.8, -0.9, 0.0))
     seeds = rpt.blue_noise_seeds(W, H)

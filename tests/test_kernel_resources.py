@@ -25,7 +25,7 @@ def resources():
         m = re.match(r"\s*(\d+) vgpr\s+(\d+) sgpr\s+(\d+) scratch\s+(\d+) lds\s+(.*)", line)
         if m:
             table.setdefault(m.group(5).strip(), []).append(tuple(int(m.group(k)) for k in (1, 2, 3, 4)))
-    assert len(table) > 50
+    assert len(table) > 40
     return table
 
 
@@ -54,8 +54,8 @@ def test_eight_waves_per_simd_where_asked(resources, kernel):
 def test_no_kernel_of_the_library_spills(resources):
     """Round 3 left two (the cooperative nearest-hit walk with 24-bit stack entries asked for 8 waves per SIMD and spilled three registers);
     they ask for 7 now.  A spill in any kernel — stage, set-up, debug — fails the build check."""
-    # (rocPRIM's radix-sort kernels — the library sort of rpt_light_table_build_gpu, scene preparation — are the library's own business)
-    bad = {k: v for k, vs in resources.items() for v in vs if v[2] != 0 and "rocprim::" not in k}
+    bad = {k: v for k, vs in resources.items() for v in vs if v[2] != 0}
+    assert not [k for k in resources if "rocprim" in k]                   # (rounds 4-5 carried rocPRIM's radix sort: 156 kernels, half of the library; round 6 sorts with its own three)
     assert not bad, bad
 
 
@@ -106,7 +106,7 @@ def test_scalar_cache_path_of_the_global_walks_survives_the_compiler(tmp_path):
     subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=work, capture_output=True, check=True)
     co = [f for f in os.listdir(work) if "gfx950" in f]
     assert co
-    text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co[0]], cwd=work, capture_output=True, text=True, check=True).stdout
+    text = "".join(subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", one], cwd=work, capture_output=True, text=True, check=True).stdout for one in sorted(co))     # (one code object per translation unit)
     m = re.search(r"<_Z26k_traverse_nearest_gstreamILi24ELi16ELb0EEv[^>]*>:\n(.*?)s_endpgm", text, re.S)
     assert m, "kernel not found in the disassembly"
     lines = [l.strip() for l in m.group(1).splitlines() if l.startswith("\t")]
