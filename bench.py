@@ -176,6 +176,12 @@ def stage_roofline(hip, workload, s0, s1, steps, elapsed_s, cus, clock_mhz, pipe
     if ta:
         # the streamed global-memory walks are bound by the CU's texture-address unit, not by HBM: its busy share from the kept TA pass
         roofline["ta"] = ta
+    # `bound` is the contract's label (achieved algorithmic bytes / s against the HBM peak); what the kept counters say limits the stage is named beside it,
+    # so that `frac` is not read as headroom that does not exist
+    if valu or ta:
+        busy = (ta or {}).get("busy_frac")
+        roofline["limiter_measured"] = ("texture-address unit (global-memory walk: TA busy %.0f %%)" % (100 * busy) if busy and busy > 0.5 else
+                                        "VALU issue at %.0f %% live lanes (see valu / pipeline_roofline.valu.issue_frac), not HBM" % (100 * valu["lane_utilisation"]) if valu else None)
     simds = cus * 4
     if valu:
         # not an HBM kernel: the VALU issue figures of the kept SQ pass (same fingerprint rule as `traffic`), and from them

@@ -113,9 +113,9 @@ void build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, st
 void rpt_build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world, std::vector<uint32_t> &out) { build_pixel_order(W, H, rank, world, out); }
 namespace {
 
-int validate_scene(rpt_ctx *ctx, const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt,
-                   const rpt_bvh_node *nodes, size_t nn, const rpt_material_data *mats, size_t nm,
-                   const rpt_light_pick_entry *lp, size_t nlp, uint32_t &max_depth) {
+/* what needs no walk: sizes, and every index of the triangle and light-pick buffers in range */
+int validate_scene_flat(rpt_ctx *ctx, const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt, size_t nn, const rpt_material_data *mats, size_t nm,
+                        const rpt_light_pick_entry *lp, size_t nlp) {
     (void)pv; (void)mats;
     if (!nv || !nt || !nn || !nm || !nlp) { ctx->error = "empty scene buffer"; return RPT_ESCENE; }
     if (nt >= 0x7ffffff0ull || nn >= 0x7ffffff0ull) { ctx->error = "scene too large for 31-bit indices"; return RPT_ESCENE; }
@@ -131,14 +131,25 @@ int validate_scene(rpt_ctx *ctx, const rpt_per_vertex_data *pv, size_t nv, const
                 ctx->error = "light pick entry out of range";
                 return RPT_ESCENE;
             }
-    /* BVH: children in range, every node reached at most once, depth bounded */
+    return RPT_OK;
+}
+
+/* The whole validation on the host (the debug hooks, which have no device): the flat part + the node pool as a TREE — children in range, no node reached twice
+ * (a cycle, or a subtree with two parents), leaf ranges inside the index buffer, depth bounded.  rpt_upload_scene checks the tree on the device (device_validate_tree:
+ * the same four conditions, level by level; the DFS over the 2 M nodes of the scattered stand-in was 16 - 20 ms of its upload). */
+int validate_scene(rpt_ctx *ctx, const rpt_per_vertex_data *pv, size_t nv, const rpt_triangle *idx, size_t nt,
+                   const rpt_bvh_node *nodes, size_t nn, const rpt_material_data *mats, size_t nm,
+                   const rpt_light_pick_entry *lp, size_t nlp, uint32_t &max_depth) {
+    int rc = validate_scene_flat(ctx, pv, nv, idx, nt, nn, mats, nm, lp, nlp);
+    if (rc) return rc;
     std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 0u}};
-    size_t visited = 0;
+    std::vector<bool> seen(nn, false);
     max_depth = 0;
     while (!stack.empty()) {
         auto [n, d] = stack.back();
         stack.pop_back();
-        if (++visited > nn) { ctx->error = "BVH is not a tree"; return RPT_ESCENE; }
+        if (seen[n]) { ctx->error = "BVH is not a tree"; return RPT_ESCENE; }
+        seen[n] = true;
         if (d > max_depth) max_depth = d;
         const rpt_bvh_node &node = nodes[n];
         if (node.triangle_count > 0) {
@@ -453,6 +464,71 @@ __global__ __launch_bounds__(RPT_BLOCK) void k_derive_triangles(const float4 *pe
     cross_sq[i] = (cx * cx + cy * cy) + cz * cz;
 }
 
+/* ---- the node pool as a tree, checked on the device (rpt_upload_scene) ------------------------------------------------------------------------------------------- */
+struct NodeFacts {
+    uint32_t error;        /* 1 child index out of bounds, 2 leaf range out of bounds, 4 a node reached twice, 8 deeper than 31 levels */
+    uint32_t max_depth;
+    uint32_t flags;        /* over ALL nodes of the pool: 1 a leaf of more than RPT_COOP_LEAF_MIN triangles, 2 a node the pair records cannot express, 4 a bound outside the exact-division guard */
+};
+constexpr uint32_t DEPTH_UNSET = 0xffffffffu;
+/* pass p: the nodes at depth p claim their children for depth p + 1 (a child somebody already claimed: not a tree) */
+__global__ __launch_bounds__(RPT_BLOCK) void k_validate_pass(const rpt_bvh_node *nodes, uint32_t nn, uint32_t nt, uint32_t *depth_of, uint32_t pass, NodeFacts *facts) {
+    const uint32_t n = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    uint32_t err = 0u;
+    const bool mine = n < nn && depth_of[n] == pass;
+    if (mine) {
+        const rpt_bvh_node node = nodes[n];
+        if (pass > 31u) err = 8u;                  /* reference: FixedVec<usize, 32> would overflow (intersection.rs:178) */
+        else if (node.triangle_count != 0u) { if ((size_t)node.left_or_first + node.triangle_count > nt) err = 2u; }
+        else if ((size_t)node.left_or_first + 1 >= nn) err = 1u;
+        else {
+            if (atomicCAS(&depth_of[node.left_or_first], DEPTH_UNSET, pass + 1u) != DEPTH_UNSET) err = 4u;
+            if (atomicCAS(&depth_of[node.left_or_first + 1u], DEPTH_UNSET, pass + 1u) != DEPTH_UNSET) err = 4u;
+        }
+    }
+    const unsigned long long any = rpt_ballot(mine);
+    if (any != 0ull && __lane_id() == (uint32_t)__ffsll((long long)any) - 1u && pass < 32u) facts->max_depth = pass;      /* (every writer of a launch stores the same value) */
+    if (err != 0u) atomicOr(&facts->error, err);
+}
+__global__ __launch_bounds__(RPT_BLOCK) void k_node_flags(const rpt_bvh_node *nodes, uint32_t nn, NodeFacts *facts) {
+    const uint32_t n = blockIdx.x * RPT_BLOCK + threadIdx.x;
+    uint32_t bits = 0u;
+    if (n < nn) {
+        const rpt_bvh_node node = nodes[n];
+        if (node.triangle_count > (uint32_t)RPT_COOP_LEAF_MIN) bits |= 1u;
+        if (node.triangle_count >= 255u || node.left_or_first >= (1u << 24) || (node.triangle_count == 0u && ((node.left_or_first & 1u) == 0u || (size_t)node.left_or_first + 1 >= nn))) bits |= 2u;
+        for (int k = 0; k < 3; ++k)
+            if (!rptm::fastdiv_operand_ok(node.aabb_min[k]) || !rptm::fastdiv_operand_ok(node.aabb_max[k])) bits |= 4u;
+    }
+    uint32_t wave_bits = 0u;
+    for (uint32_t b = 1u; b <= 4u; b <<= 1) if (rpt_ballot((bits & b) != 0u) != 0ull) wave_bits |= b;
+    if (wave_bits != 0u && __lane_id() == 0u) atomicOr(&facts->flags, wave_bits);
+}
+/* nodes already on the device (not yet the context's); on RPT_OK `out` holds depth and flags */
+static int device_validate_tree(rpt_ctx *c, const rpt_bvh_node *d_nodes, size_t nn, size_t nt, NodeFacts &out) {
+    DevBuf<uint32_t> depth_of;
+    DevBuf<NodeFacts> facts;
+    hipError_t e = depth_of.alloc(nn);
+    if (e == hipSuccess) e = facts.alloc(1);
+    if (e == hipSuccess) e = hipMemsetAsync(depth_of.p, 0xff, nn * sizeof(uint32_t), nullptr);
+    if (e == hipSuccess) e = hipMemsetAsync(depth_of.p, 0, sizeof(uint32_t), nullptr);              /* the root: depth 0 */
+    if (e == hipSuccess) e = hipMemsetAsync(facts.p, 0, sizeof(NodeFacts), nullptr);
+    if (e == hipSuccess) {
+        const unsigned blocks = (unsigned)((nn + RPT_BLOCK - 1) / RPT_BLOCK);
+        for (uint32_t pass = 0; pass <= 32u; ++pass) k_validate_pass<<<blocks, RPT_BLOCK>>>(d_nodes, (uint32_t)nn, (uint32_t)nt, depth_of.p, pass, facts.p);
+        k_node_flags<<<blocks, RPT_BLOCK>>>(d_nodes, (uint32_t)nn, facts.p);
+        e = hipMemcpy(&out, facts.p, sizeof(out), hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    depth_of.release(); facts.release();
+    HIP_TRY(c, e);
+    if (out.error & 1u) { c->error = "BVH child index out of bounds"; return RPT_ESCENE; }
+    if (out.error & 2u) { c->error = "BVH leaf range out of bounds"; return RPT_ESCENE; }
+    if (out.error & 4u) { c->error = "BVH is not a tree"; return RPT_ESCENE; }
+    if (out.error & 8u) { c->error = "BVH deeper than the reference's 32-entry traversal stack"; return RPT_ESCENE; }
+    return RPT_OK;
+}
+
 /* what the pair records of the streamed global-memory walks (k_traverse.h SceneViewPairsT) and the flipped copies can express: children of every inner node
  * are the nodes (2p + 1, 2p + 2) of one pair — every pool the reference's builder makes (src/bvh.rs:296-320) —, leaves of fewer than 255 triangles, links in 24 bits */
 static bool pool_is_pair_shaped(const rpt_bvh_node *nodes, size_t nn) {
@@ -560,18 +636,19 @@ static int device_order_probes(rpt_ctx *c, const float *d_cross_sq, uint32_t dep
     const uint32_t nt = c->scene.n_triangles, nn = c->scene.n_nodes, P = nn >= 3u ? (nn - 1u) / 2u : 0u;
     if (nt == 0u || (!lights && !want_last)) { so.probe_ms = lo.probe_ms = clock.ms(); return RPT_OK; }
     if (!pair_shaped || nn < 3u) { if (lights) so.why = "node pool is not pair-shaped"; so.probe_ms = lo.probe_ms = clock.ms(); return RPT_OK; }
-    DevBuf<double> tri_area, sums;
-    DevBuf<uint32_t> level;
-    DevBuf<uint8_t> flips;
-    DevBuf<unsigned long long> counters;
-    auto release = [&]() { tri_area.release(); sums.release(); level.release(); flips.release(); counters.release(); };
+    /* ONE allocation, carved up (five hipMalloc / hipFree pairs were a third of the probe's 5 ms on a 1 M-triangle scene) */
+    DevBuf<unsigned char> arena;
+    auto pad = [](size_t bytes) { return (bytes + 255u) & ~(size_t)255u; };
+    const size_t o_tri = 0, o_sums = o_tri + pad((size_t)nt * sizeof(double)), o_level = o_sums + pad(3 * (size_t)nn * sizeof(double)),
+                 o_flips = o_level + pad((size_t)nn * sizeof(uint32_t)), o_counters = o_flips + pad(3 * (size_t)P), total = o_counters + pad(10 * sizeof(unsigned long long));
+    auto release = [&]() { arena.release(); };
 #define PROBE_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { release(); c->error = std::string("order probes: ") + hipGetErrorString(e_); return RPT_EHIP; } } while (0)
-    PROBE_TRY(tri_area.alloc(nt));
-    PROBE_TRY(sums.alloc(3 * (size_t)nn));
-    PROBE_TRY(level.alloc(nn));
-    PROBE_TRY(flips.alloc(3 * (size_t)P));
-    PROBE_TRY(counters.alloc(10));
-    PROBE_TRY(hipMemset(counters.p, 0, 10 * sizeof(unsigned long long)));
+    PROBE_TRY(arena.alloc(total));
+    struct { double *p; } tri_area{reinterpret_cast<double *>(arena.p + o_tri)}, sums{reinterpret_cast<double *>(arena.p + o_sums)};
+    struct { uint32_t *p; } level{reinterpret_cast<uint32_t *>(arena.p + o_level)};
+    struct { uint8_t *p; } flips{arena.p + o_flips};
+    struct { unsigned long long *p; } counters{reinterpret_cast<unsigned long long *>(arena.p + o_counters)};
+    PROBE_TRY(hipMemsetAsync(counters.p, 0, 10 * sizeof(unsigned long long), nullptr));
     double *area_all = sums.p, *area_ne = sums.p + nn, *count = sums.p + 2 * (size_t)nn;
     const View s{reinterpret_cast<const rpt_per_vertex_data *>(c->per_vertex.p), reinterpret_cast<const rpt_triangle *>(c->indices.p),
                  reinterpret_cast<const rpt_bvh_node *>(c->nodes.p), reinterpret_cast<const rpt_material_data *>(c->materials.p), c->light_pick.p, nt, nn,
@@ -781,8 +858,8 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         const rpt_knobs now = rpt_read_knobs();
         c->knobs.shadow_order = now.shadow_order; c->knobs.last_order = now.last_order; c->knobs.coop_leaves = now.coop_leaves; c->knobs.no_lds_scene = now.no_lds_scene;
     }
-    uint32_t depth = 0;
-    int rc = validate_scene(c, pv, nv, idx, nt, nodes, nn, mats, nm, lp, nlp, depth);
+    SectionTimer sections("rpt_upload_scene");
+    int rc = validate_scene_flat(c, pv, nv, idx, nt, nn, mats, nm, lp, nlp);
     if (rc) return rc;
     for (size_t i = 0; i < nm; ++i)
         if ((mats[i].has_albedo_texture | mats[i].has_metallic_texture | mats[i].has_roughness_texture | mats[i].has_normal_texture) &&
@@ -795,13 +872,21 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         c->error = "atlas larger than 2^30 texels / skybox larger than 2^28 texels";
         return RPT_ESCENE;
     }
-    SectionTimer sections("rpt_upload_scene");
-    sections.mark("validate");
+    sections.mark("validate_flat");
+    /* the node pool goes up first, into a buffer of its own: it is checked on the device (a tree, in range, at most 31 levels: device_validate_tree) before the
+     * context's scene is touched — a rejected upload leaves the previous scene in place */
+    DevBuf<float4> new_nodes;
+    struct NodesGuard { DevBuf<float4> &b; ~NodesGuard() { b.release(); } } nodes_guard{new_nodes};
+    HIP_TRY(c, new_nodes.alloc(2 * nn));
+    HIP_TRY(c, hipMemcpy(new_nodes.p, nodes, nn * sizeof(rpt_bvh_node), hipMemcpyHostToDevice));
+    NodeFacts facts{};
+    rc = device_validate_tree(c, reinterpret_cast<const rpt_bvh_node *>(new_nodes.p), nn, nt, facts);
+    if (rc) return rc;
+    const uint32_t depth = facts.max_depth;
+    sections.mark("validate_tree_device");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;
-    c->fat_leaves = false;
-    for (size_t i = 0; i < nn; ++i)
-        if (nodes[i].triangle_count > (uint32_t)RPT_COOP_LEAF_MIN) c->fat_leaves = true;
+    c->fat_leaves = (facts.flags & 1u) != 0u;
     if (c->knobs.coop_leaves >= 0) c->fat_leaves = c->knobs.coop_leaves != 0;
 
     /* derived per-triangle records, computed with the very f32 operations the reference performs per hit:
@@ -836,7 +921,9 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
         if (mats[i].has_albedo_texture | mats[i].has_metallic_texture | mats[i].has_roughness_texture | mats[i].has_normal_texture) textured = 1;
     }
     sections.mark("derive_host");
-    HIP_TRY(c, c->nodes.alloc(2 * nn));
+    c->nodes.release();
+    std::swap(c->nodes.p, new_nodes.p);
+    std::swap(c->nodes.n, new_nodes.n);
     HIP_TRY(c, c->tri_geom.alloc(3 * nt));
     HIP_TRY(c, c->tri_shade.alloc(4 * nt));
     HIP_TRY(c, c->tri_isect.alloc(9 * nt));
@@ -854,7 +941,6 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     if (nt) k_derive_triangles<<<(unsigned)((nt + RPT_BLOCK - 1) / RPT_BLOCK), RPT_BLOCK>>>(c->per_vertex.p, c->indices.p, (uint32_t)nt, c->tri_geom.p, c->tri_isect.p,
                                                                                          c->tri_shade.p, c->tri_tangent.p, d_cross_sq.p);
     HIP_TRY(c, hipMemcpy(c->mat_lite.p, lite.data(), lite.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->nodes.p, nodes, nn * sizeof(rpt_bvh_node), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->materials.p, mats, nm * sizeof(rpt_material_data), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->light_pick.p, lp, nlp * sizeof(rpt_light_pick_entry), hipMemcpyHostToDevice));
     HIP_TRY(c, hipGetLastError());
@@ -915,7 +1001,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     if (c->knobs.no_lds_scene) s.lds_scene = 0u;
     /* pair records for the streamed global-memory walks (k_traverse.h SceneViewPairsT); a pool they cannot express keeps the one-shot walks */
     s.gpairs = nullptr; s.glinks = nullptr;
-    const bool pair_shaped = pool_is_pair_shaped(nodes, nn);
+    const bool pair_shaped = (nn & 1u) == 1u && nn >= 3 && nodes[0].triangle_count == 0u && (facts.flags & 2u) == 0u;      /* (= pool_is_pair_shaped(nodes, nn), its per-node conditions from k_node_flags) */
     const uint32_t n_pairs = pair_shaped ? (uint32_t)((nn - 1) / 2) : 0u;
     if (pair_shaped) {
         HIP_TRY(c, c->gpairs.alloc(std::max<size_t>(1, 4 * (size_t)n_pairs)));
@@ -1018,10 +1104,7 @@ int rpt_upload_scene(rpt_ctx *c, const rpt_per_vertex_data *pv, size_t nv, const
     if (!s.lds_image_last) c->lds_image_last.release();
     sections.mark("last_order");
     s.no_lights = lp[0].ratio < 0.0f ? 1u : 0u;
-    s.fastdiv_ok = 1u;
-    for (size_t i = 0; i < nn && s.fastdiv_ok; ++i)
-        for (int k = 0; k < 3; ++k)
-            if (!rptm::fastdiv_operand_ok(nodes[i].aabb_min[k]) || !rptm::fastdiv_operand_ok(nodes[i].aabb_max[k])) s.fastdiv_ok = 0u;
+    s.fastdiv_ok = (facts.flags & 4u) == 0u ? 1u : 0u;          /* every node bound is 0 or in [2^-60, 2^40) (k_node_flags) */
     s.atlas = DevImage{c->atlas.p, aw, ah};
     s.skybox = DevImage{c->skybox.p, sw, sh};
     sections.mark("fastdiv_check");
