@@ -104,7 +104,7 @@ def main(steps=None, seed=None, quiet=False):
         elif op == "scene":
             new_scene(); reset()
         elif op == "in_flight":
-            r.set_samples_in_flight(int(rng.choice([0, 1, 2, 4, 8, 32])))
+            r.set_samples_in_flight(int(rng.choice([0, 1, 2, 4, 8, 32, 64, 256])))
             reset()
         elif op == "gather" and local_comm:
             r.gather_async()

@@ -18,7 +18,7 @@ hip = importlib.import_module("rust-path-tracer_amd.hip")
 from oracle_ffi import Oracle  # noqa: E402
 from scenes import textured_scene  # noqa: E402
 
-MODES = [None, ("RPT_LAST_BOUNCE_HIT_OR_MISS", "0"), ("RPT_LAST_ORDER", "near"), ("RPT_LAST_ORDER", "opaque"), ("RPT_LAST_ORDER", "small"), ("RPT_LAST_ORDER", "ratio")]
+MODES = [None, ("RPT_LAST_ORDER", "off"), ("RPT_LAST_ORDER", "near"), ("RPT_LAST_ORDER", "opaque"), ("RPT_LAST_ORDER", "small"), ("RPT_LAST_ORDER", "ratio")]
 
 
 def main():
@@ -30,7 +30,7 @@ def main():
     bad = 0
     seen_modes = {}
     for case in range(n_cases):
-        for var in ("RPT_LAST_BOUNCE_HIT_OR_MISS", "RPT_LAST_ORDER"):
+        for var in ("RPT_LAST_ORDER",):
             os.environ.pop(var, None)
         mode = MODES[rng.integers(len(MODES))]
         if mode:

@@ -35,6 +35,9 @@ def main(n_cases=None, seed=None, quiet=False):
         min_b = int(rng.integers(0, 5))
         spp = int(rng.integers(1, 9))
         s_in_flight = int(rng.choice([0, 1, 2, 4, 8, 16]))
+        if rng.integers(0, 10) == 0:                   # round 6: more than 32 samples of a pixel in flight (k_complete counts a pixel's finished slots)
+            spp, s_in_flight = int(rng.integers(33, 90)), int(rng.choice([0, 64, 128, 256]))
+            W, H = min(W, 72), min(H, 56)
         cam = (float(rng.uniform(-2, 2)), float(rng.uniform(0.3, 3)), float(rng.uniform(-6, 0)), 0.0)
         rot = (float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.8, 0.8)), 0.0, 0.0)
         has_sky = int(sky is not None and rng.integers(0, 2))
