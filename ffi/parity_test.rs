@@ -54,7 +54,8 @@ fn load_scene(path: &Path) -> Scene {
     let materials = pod_vec::<MaterialData>(take(nm * std::mem::size_of::<MaterialData>()));
     let light_pick = pod_vec::<LightPickEntry>(take(nl * std::mem::size_of::<LightPickEntry>()));
     // CPU atlas texel = (r, g, b, 255) / 255 (dynamic_image_to_cpu_buffer, src/asset.rs:266-273); no atlas in the file: the
-    // kit's scenes have no textures and the image is never sampled — the reference's 2x2 fallback stands in (asset.rs:283-290)
+    // kit's file scenes have no textures and the image is never sampled — the reference's 2x2 fallback stands in (asset.rs:283-290);
+    // Textured.rptscene carries a 64 x 64 atlas
     let (atlas, atlas_size) = if aw > 0 && ah > 0 {
         let px = take(aw as usize * ah as usize * 4);
         (px.chunks(4).map(|p| Vec4::new(p[0] as f32, p[1] as f32, p[2] as f32, 255.0) / 255.0).collect(), (aw, ah))
@@ -162,6 +163,14 @@ fn darkcornell_mis() {
 #[test]
 fn veachmis_mis() {
     run_case("veachmis_mis", "VeachMIS.rptscene", 128, 128, 32);
+}
+
+/// The texture path (round 6): a procedural scene with a 64 x 64 RGBA8 atlas — albedo / metallic / roughness / normal-map lookups through
+/// `CpuImage::sample_by_lod` (shared_structs/src/image_polyfill.rs:38-55), uv wrap (kernels/src/lib.rs:127-129), the tangent frame (:132-141).
+/// No shipped scene file carries a texture; the `.rptscene` holds the atlas bytes, `load_scene` turns them into the CPU texels.
+#[test]
+fn textured_mis() {
+    run_case("textured_mis", "Textured.rptscene", 128, 128, 32);
 }
 
 /// The buffers themselves: does the reference's own importer + BVH builder + light table produce the kit's `.rptscene`?

@@ -48,7 +48,7 @@ def test_kit_accumulators_hold_the_references_furnace_assertion(rpt):
         err = np.linalg.norm(acc[..., :3].astype(np.float64) - libm[..., :3]) / np.linalg.norm(libm[..., :3].astype(np.float64))
         assert err < (1e-5 if case["scene"].startswith("VeachMIS") else 1e-6), (case["name"], err)
         cfg = np.fromfile(os.path.join(KIT, case["config"]), np.uint8)
-        assert cfg.size == 80 and bytes(cfg) == bytes(rpt.default_config(W, H, nee=case["nee"]))
+        assert cfg.size == 80 and bytes(cfg) == bytes(rpt.default_config(W, H, nee=case["nee"], **{k: tuple(v) for k, v in case["config_overrides"].items()}))
         seeds = np.fromfile(os.path.join(KIT, case["seeds"]), np.uint32).reshape(H, W, 2)
         assert not seeds[..., 0].any() and seeds[0, 0, 1] == 1448498816 and seeds[75 % 256, 65 % 256, 1] == 50529028
         if case["scene"].startswith("FurnaceTest"):

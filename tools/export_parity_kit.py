@@ -40,6 +40,10 @@ CASES = [
     # an OPEN scene: most paths end in skybox::scatter (skybox.rs:18-94) — the one function whose exp the oracle evaluates with the kernels'
     # float-only exp_sky instead of a correctly rounded one — and the glossy plates exercise the specular lobe and MIS
     ("veachmis_mis", "VeachMIS", 128, 128, 32, 1),
+    # round 6: the texture path — atlas lookups with the CPU polyfill's semantics (image_polyfill.rs:32-55), uv wrap (lib.rs:127-129), the normal-map frame
+    # (lib.rs:132-141) and get_pbr_bsdf's three lookups (bsdf.rs:354-387) — on a procedural scene with a 64 x 64 RGBA8 atlas (tests/scenes.py textured_scene):
+    # no shipped scene file carries a texture, and BASELINE config[3] names four kinds of them
+    ("textured_mis", "procedural:Textured", 128, 128, 32, 1, {"cam_position": (0.0, 1.6, -4.0, 0.0), "cam_rotation": (0.05, 0.1, 0.0, 0.0)}),
 ]
 
 
@@ -63,7 +67,17 @@ def export(out_dir):
             f.write(data)
         files[name] = {"bytes": len(data), "sha256": hashlib.sha256(data).hexdigest()}
 
-    for name, scene, W, H, spp, nee in CASES:
+    for name, scene, W, H, spp, nee, *rest in CASES:
+        over = rest[0] if rest else {}
+        if scene.startswith("procedural:"):
+            scene = scene.split(":")[1]
+            if scene not in worlds:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from scenes import textured_scene
+                worlds[scene] = textured_scene()[0]
+                path = os.path.join(out_dir, scene + ".rptscene")
+                worlds[scene].save(path)
+                files[scene + ".rptscene"] = {"bytes": os.path.getsize(path), "sha256": sha256(path)}
         if scene not in worlds:
             worlds[scene] = rpt.World.from_path(rpt.fixture(scene + ".glb"))
             path = os.path.join(out_dir, scene + ".rptscene")
@@ -73,7 +87,7 @@ def export(out_dir):
         seeds = rpt.blue_noise_seeds(W, H)
         if seeds_name not in files:
             put(seeds_name, seeds.tobytes())
-        cfg = rpt.default_config(W, H, nee=nee)
+        cfg = rpt.default_config(W, H, nee=nee, **over)
         put(name + ".config.bin", bytes(cfg))
         accum, rng_after, st = orc.trace_cpu(cfg, orc.scene(worlds[scene]), seeds, spp)
         assert np.all(rng_after["n"] == spp) and np.all(accum[..., 3] == spp)
@@ -83,7 +97,7 @@ def export(out_dir):
         case = {"name": name, "scene": scene + ".rptscene", "seeds": seeds_name, "config": name + ".config.bin", "accum": name + ".accum.bin",
                 "accum_libm": name + ".accum_libm.bin",
                 "width": W, "height": H, "spp": spp, "nee": nee, "extension_rays": int(st.extension_rays), "shadow_rays": int(st.shadow_rays),
-                "tolerance_rel_l2": 1e-4}
+                "tolerance_rel_l2": 1e-4, "config_overrides": {k: list(v) for k, v in over.items()}}
         if scene == "FurnaceTest":
             px = accum[75, 65, :3] / np.float32(spp)             # the reference's assertion: pixel (65, 75) ^ (1/2.2) = 0.8 +- 0.02
             case["furnace_pixel_65_75_gamma"] = [float(v) for v in np.power(px.astype(np.float64), 1 / 2.2)]
