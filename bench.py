@@ -609,6 +609,9 @@ def main():
                     help="N > 1 without a launcher: ranks = one process per GPU under torch.distributed.run; multi = ONE process through rpt_multi_* "
                          "(ncclCommInitAll); auto = ranks, and multi only if that failed or hung")
     ap.add_argument("--launch-timeout", type=float, default=600.0, help="watchdog (seconds) around each self-launched child")
+    ap.add_argument("--rehearsal-fail-ranks", action="store_true",
+                    help="test aid, with --rehearsal only: every rank of the one-process-per-GPU driver exits at once (code 5), so that the launcher's second attempt — "
+                         "the one-process driver — is exercised end to end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -637,6 +640,9 @@ def main():
     in_launcher = int(os.environ.get("WORLD_SIZE", "1") or "1") > 1      # (an inherited WORLD_SIZE=1 is no launcher either)
     if os.environ.get("RPT_BENCH_CHILD") == "multi" and args.gpus > 1 and not in_launcher:
         return run_multi_driver(args)
+    if args.rehearsal_fail_ranks and args.rehearsal and in_launcher:
+        print(f"bench: rank {os.environ.get('RANK')}: --rehearsal-fail-ranks: failing on purpose", file=sys.stderr)
+        raise SystemExit(5)
     if args.gpus > 1 and not in_launcher:
         raise SystemExit(launch(args, sys.argv[1:]))
 

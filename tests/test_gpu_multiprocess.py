@@ -169,6 +169,24 @@ def test_bench_dress_rehearsal_of_the_scaling_run(tmp_path, ranks, launcher):
     assert p2.returncode != 0 and "RPT_RCCL_LIBRARY" in (p2.stderr + p2.stdout)
 
 
+def test_a_failing_rank_run_falls_back_to_the_one_process_driver(tmp_path):
+    """The launcher's whole chain on a GPU: the one-process-per-GPU child fails (every rank exits with code 5: --rehearsal-fail-ranks), the launcher says so and starts the
+    one-process driver (rpt_multi_*) as a second fresh child, whose line — bitwise parity against the oracle included — is relayed with `config.fallback_from` naming
+    what happened.  (That the first child is killed when it HANGS instead: tests/test_bench_launch.py, no GPU needed.)"""
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--rehearsal", "--rehearsal-fail-ranks"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "failing on purpose" in p.stderr and "second attempt with ONE process driving all 2 GPUs" in p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["driver"].startswith("multi") and "exited with code" in out["config"]["fallback_from"]
+    assert out["parity_check"]["bitwise"] is True and out["parity_check"]["image_spp"] == 2 * 64
+
+
 def test_bench_line_carries_the_other_single_gpu_workloads(tmp_path):
     """`bench.py --gpus 1` as the driver runs it: after the headline's timed loop the other single-GPU BASELINE workloads run on fresh
     contexts and appear under "workloads", each with its own value, roofline (dominant kernel, HIP-event timed), pipeline_roofline and a
