@@ -101,6 +101,8 @@ struct View {
     const double *area_all;       /* triangle surface below every node */
     const double *area_ne;        /* ... of the triangles whose material does not emit */
     const double *count;          /* nodes of every subtree */
+    uint32_t sub, lanes;          /* device driver: this thread is lane `sub` of the `lanes` (a power of two, adjacent lanes of one wave) that walk one ray together — they
+                                     share every decision and split the triangles of a leaf; host driver: 0, 1 */
     const float4_like *geom;      /* device driver: 3 x float4 per triangle — a, e1 = b - a, e2 = c - a as k_derive_triangles computed them (the same subtractions
                                      tri() makes: one 48-byte record instead of the index record and three 64-byte vertices); host driver: null */
 };
@@ -161,18 +163,24 @@ RPT_HD bool tri_test(V a, V e1, V e2, V o, V d, float max_t) {
  * a ray, and a leaf of the clustered stand-in holds sixty triangles: tested one load at a time the probe was 8 ms of memory latency) */
 RPT_HD bool leaf_test(const View &s, uint32_t first, uint32_t count, V o, V d, float max_t) {
     if (s.geom) {
-        for (uint32_t k0 = 0; k0 < count; k0 += 8u) {
-            float4_like g[24];
-            const uint32_t m = count - k0 < 8u ? count - k0 : 8u;
+        bool found = false;
+        for (uint32_t k0 = s.sub; k0 < count && !found; k0 += 4u * s.lanes) {
+            float4_like g[12];
             RPT_UNROLL
-            for (uint32_t j = 0; j < 8u; ++j)
-                if (j < m) { const float4_like *r = s.geom + 3u * (size_t)(first + k0 + j); g[3 * j] = r[0]; g[3 * j + 1] = r[1]; g[3 * j + 2] = r[2]; }
+            for (uint32_t j = 0; j < 4u; ++j)
+                if (k0 + j * s.lanes < count) { const float4_like *r = s.geom + 3u * (size_t)(first + k0 + j * s.lanes); g[3 * j] = r[0]; g[3 * j + 1] = r[1]; g[3 * j + 2] = r[2]; }
             RPT_UNROLL
-            for (uint32_t j = 0; j < 8u; ++j)
-                if (j < m && tri_test(V{g[3 * j].x, g[3 * j].y, g[3 * j].z}, V{g[3 * j + 1].x, g[3 * j + 1].y, g[3 * j + 1].z}, V{g[3 * j + 2].x, g[3 * j + 2].y, g[3 * j + 2].z}, o, d, max_t))
-                    return true;
+            for (uint32_t j = 0; j < 4u; ++j)
+                if (k0 + j * s.lanes < count && tri_test(V{g[3 * j].x, g[3 * j].y, g[3 * j].z}, V{g[3 * j + 1].x, g[3 * j + 1].y, g[3 * j + 1].z}, V{g[3 * j + 2].x, g[3 * j + 2].y, g[3 * j + 2].z}, o, d, max_t))
+                    found = true;
         }
-        return false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (s.lanes > 1u) {          /* the lanes of a ray walk in lockstep: whoever found a triangle tells the others */
+            const uint32_t lane = __lane_id();
+            found = ((__builtin_amdgcn_ballot_w64(found) >> (lane & ~(s.lanes - 1u))) & ((1ull << s.lanes) - 1ull)) != 0ull;
+        }
+#endif
+        return found;
     }
     for (uint32_t k = 0; k < count; ++k) {
         const rpt_triangle &t = s.idx[first + k];
@@ -387,7 +395,7 @@ inline ShadowOrder choose_shadow_order(const rpt_per_vertex_data *pv, const rpt_
     if (!pair_shaped || nn < 3) { so.why = "node pool is not pair-shaped"; so.probe_ms = clock.ms(); return so; }
     std::vector<double> tri_area, area_all, area_ne, count;
     host_sums(pv, idx, nt, nodes, nn, mats, cross_sq, tri_area, area_all, area_ne, count);
-    const View s{pv, idx, nodes, mats, lp, (uint32_t)nt, (uint32_t)nn, (uint32_t)nlp, tri_area.data(), area_all.data(), area_ne.data(), count.data(), nullptr};
+    const View s{pv, idx, nodes, mats, lp, (uint32_t)nt, (uint32_t)nn, (uint32_t)nlp, tri_area.data(), area_all.data(), area_ne.data(), count.data(), 0u, 1u, nullptr};
     so.flip.assign((nn - 1) / 2, 0);
     for (size_t p = 0; p < so.flip.size(); ++p) so.flip[p] = prefers_right(s, (uint32_t)p, 1) ? 1 : 0;
     const bool all = !(area_ne[0] > 0.0);
@@ -418,7 +426,7 @@ inline LastOrder choose_last_order(const rpt_per_vertex_data *pv, const rpt_tria
     if (!pair_shaped || nn < 3 || nt == 0) { lo.probe_ms = clock.ms(); return lo; }
     std::vector<double> tri_area, area_all, area_ne, count;
     host_sums(pv, idx, nt, nodes, nn, mats, nullptr, tri_area, area_all, area_ne, count);
-    const View s{pv, idx, nodes, mats, nullptr, (uint32_t)nt, (uint32_t)nn, 0u, tri_area.data(), area_all.data(), area_ne.data(), count.data(), nullptr};
+    const View s{pv, idx, nodes, mats, nullptr, (uint32_t)nt, (uint32_t)nn, 0u, tri_area.data(), area_all.data(), area_ne.data(), count.data(), 0u, 1u, nullptr};
     const size_t P = (nn - 1) / 2;
     std::vector<uint8_t> flips[4];
     for (int r = 1; r <= 3; ++r) {
