@@ -123,13 +123,99 @@ __device__ __forceinline__ uint32_t bvb_block_rank(bool flag, uint32_t *wave_tot
     return before + within;
 }
 
-/* THREADS = 1024 for the few huge nodes at the top of the tree (a workgroup walks its node's whole range), 256 below */
+/* ---- the sweep over the bins of one axis (bvh.rs:214-253) as two wave scans ---------------------------------------------------------------------------
+ * The sequential sweep folds the bins' boxes upwards (left boxes) and downwards (right boxes) with encapsulate = (f32::min, f32::max) per component, skipping empty
+ * bins, and takes the first candidate of least cost.  `bvb_min(a, b)` keeps the LATER operand on a tie (only the sign of a zero can differ), which is an associative
+ * rule — the fold of a run is "the last of its least elements" however it is bracketed — and an empty bin behaves like the identity (+inf, -inf): so the left boxes are
+ * an inclusive scan in ascending bin order and the right boxes one in descending order, two bins per lane, earlier operand first.  Round 6: the three-thread serial sweep
+ * (127 dependent steps per axis) was most of the 60 us a workgroup spends on a small node (profiles/r06_bvh_levels_scatter.txt). */
+__device__ __forceinline__ BvbBox bvb_box_identity() {
+    BvbBox b;
+    for (int j = 0; j < 3; ++j) { b.mn[j] = __builtin_inff(); b.mx[j] = -__builtin_inff(); }
+    return b;
+}
+__device__ __forceinline__ BvbBox bvb_box_join(const BvbBox &earlier, const BvbBox &later) {
+    BvbBox b;
+    for (int j = 0; j < 3; ++j) { b.mn[j] = bvb_min(earlier.mn[j], later.mn[j]); b.mx[j] = bvb_max(earlier.mx[j], later.mx[j]); }
+    return b;
+}
+__device__ __forceinline__ BvbBox bvb_box_shfl(const BvbBox &b, int from) {
+    BvbBox o;
+    for (int j = 0; j < 3; ++j) { o.mn[j] = __shfl(b.mn[j], from, 64); o.mx[j] = __shfl(b.mx[j], from, 64); }
+    return o;
+}
+/* one wave, one axis: best candidate (least cost, lowest index on ties; none: +inf, 0) over candidates 0 .. S - 2 */
+__device__ __forceinline__ void bvb_wave_sweep(const unsigned long long (*key)[6], const uint32_t *cnt, uint32_t S, float &best_cost, uint32_t &best_i) {
+    const int lane = (int)(threadIdx.x & 63u);
+    BvbBox e[2];
+    uint32_t c[2];
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t b = 2u * (uint32_t)lane + (uint32_t)k;
+        e[k] = bvb_box_identity();
+        c[k] = 0u;
+        if (b < S) {
+            c[k] = cnt[b];
+            if (c[k] != 0u && bvb_key_value(key[b][0]) != __builtin_inff())                /* encapsulate_node skips an empty box */
+                for (int j = 0; j < 3; ++j) { e[k].mn[j] = bvb_key_value(key[b][j]); e[k].mx[j] = bvb_key_value(key[b][3 + j]); }
+        }
+    }
+    /* left: bins ascending.  up = join of the bins of all lanes below */
+    BvbBox up = bvb_box_join(e[0], e[1]);
+    uint32_t up_c = c[0] + c[1];
+    for (int d = 1; d < 64; d <<= 1) {
+        const BvbBox o = bvb_box_shfl(up, lane - d < 0 ? lane : lane - d);
+        const uint32_t oc = (uint32_t)__shfl((int)up_c, lane - d < 0 ? lane : lane - d, 64);
+        if (lane >= d) { up = bvb_box_join(o, up); up_c += oc; }
+    }
+    BvbBox below = bvb_box_shfl(up, lane == 0 ? 0 : lane - 1);
+    uint32_t below_c = (uint32_t)__shfl((int)up_c, lane == 0 ? 0 : lane - 1, 64);
+    if (lane == 0) { below = bvb_box_identity(); below_c = 0u; }
+    const BvbBox left0 = bvb_box_join(below, e[0]), left1 = bvb_box_join(left0, e[1]);
+    const uint32_t lc0 = below_c + c[0], lc1 = lc0 + c[1];
+    /* right: bins descending.  dn = join of the bins of all lanes above, highest first */
+    BvbBox dn = bvb_box_join(e[1], e[0]);
+    uint32_t dn_c = c[0] + c[1];
+    for (int d = 1; d < 64; d <<= 1) {
+        const BvbBox o = bvb_box_shfl(dn, lane + d > 63 ? lane : lane + d);
+        const uint32_t oc = (uint32_t)__shfl((int)dn_c, lane + d > 63 ? lane : lane + d, 64);
+        if (lane + d <= 63) { dn = bvb_box_join(o, dn); dn_c += oc; }
+    }
+    BvbBox above = bvb_box_shfl(dn, lane == 63 ? 63 : lane + 1);                          /* bins 2 lane + 2 and up */
+    uint32_t above_c = (uint32_t)__shfl((int)dn_c, lane == 63 ? 63 : lane + 1, 64);
+    if (lane == 63) { above = bvb_box_identity(); above_c = 0u; }
+    const BvbBox right_of_0 = bvb_box_join(above, e[1]);                                   /* bins 2 lane + 1 and up: right side of candidate 2 lane */
+    const uint32_t rc_of_0 = above_c + c[1];
+    /* candidates 2 lane (right side: bins 2 lane + 1 ...) and 2 lane + 1 (right side: bins 2 lane + 2 ...), in index order */
+    float cost = __builtin_inff();
+    uint32_t at = 0u;
+    {
+        const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
+        if (i0 + 1u < S) {
+            const float v = (float)lc0 * bvb_area(left0) + (float)rc_of_0 * bvb_area(right_of_0);
+            if (v < cost) { cost = v; at = i0; }
+        }
+        if (i1 + 1u < S) {
+            const float v = (float)lc1 * bvb_area(left1) + (float)above_c * bvb_area(above);
+            if (v < cost) { cost = v; at = i1; }
+        }
+    }
+    /* the first least cost of the wave (`cost < best` in index order: a NaN or +inf candidate is never taken) */
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float oc = __shfl_xor(cost, d, 64);
+        const uint32_t oa = (uint32_t)__shfl_xor((int)at, d, 64);
+        if (oc < cost || (oc == cost && oc != __builtin_inff() && oa < at)) { cost = oc; at = oa; }
+    }
+    best_cost = cost;
+    best_i = cost == __builtin_inff() ? 0u : at;
+}
+
+/* THREADS = 1024 for the few huge nodes at the top of the tree (a workgroup walks its node's whole range), 256 below, 64 — one wave per node — for levels whose
+ * largest node has at most 64 triangles (the deep levels of a tree with small leaves: 0.4 M nodes of two to eight triangles each on the scattered stand-in) */
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level_begin) {
-    __shared__ unsigned long long s_key[3][BVB_MAX_BINS][6];      /* [axis][bin]: min x,y,z  max x,y,z */
-    __shared__ uint32_t s_cnt[3][BVB_MAX_BINS];
-    __shared__ float s_la[3][BVB_MAX_BINS], s_ra[3][BVB_MAX_BINS];
-    __shared__ uint32_t s_lc[3][BVB_MAX_BINS], s_rc[3][BVB_MAX_BINS];
+    constexpr uint32_t AXES = THREADS >= 192 ? 3u : 1u;            /* axes binned at once */
+    __shared__ unsigned long long s_key[AXES][BVB_MAX_BINS][6];   /* [axis][bin]: min x,y,z  max x,y,z */
+    __shared__ uint32_t s_cnt[AXES][BVB_MAX_BINS];
     __shared__ unsigned long long s_red[6];
     __shared__ uint32_t s_cb[6];                                  /* centroid bounds: ord(min) x3, ord(max) x3 */
     __shared__ float s_best_cost[3];
@@ -192,78 +278,60 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
     const float nmn[3] = {bvb_key_value(s_red[0]), bvb_key_value(s_red[1]), bvb_key_value(s_red[2])};
     const float nmx[3] = {bvb_key_value(s_red[3]), bvb_key_value(s_red[4]), bvb_key_value(s_red[5])};
 
-    /* ---- find_best_split_segmented (bvh.rs:178-255): all three axes binned in one pass */
-    for (uint32_t k = tid; k < 3u * BVB_MAX_BINS; k += THREADS) {
-        const uint32_t ax = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
-        for (int j = 0; j < 6; ++j) s_key[ax][b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
-        s_cnt[ax][b] = 0u;
-    }
-    __syncthreads();
+    /* ---- find_best_split_segmented (bvh.rs:178-255): all three axes binned in one pass by a wide workgroup; the one-wave build bins and sweeps one axis at a
+     * time through ONE set of bins (6 KB instead of 18 KB of LDS: more than twice the nodes in flight per CU, and a small node is all latency) */
     float scale[3];
     bool axis_on[3];
     for (int j = 0; j < 3; ++j) {
         axis_on[j] = !(bmin[j] == bmax[j]);
         scale[j] = (float)S / (bmax[j] - bmin[j]);
     }
-    for (uint32_t i = tid; i < count; i += THREADS) {
-        const uint32_t tri = a.order[first + i];
-        const uint4 t = a.tris[tri];
-        const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
-        const float4 ce = a.centroid[tri];
-        const float cc[3] = {ce.x, ce.y, ce.z};
-        for (int ax = 0; ax < 3; ++ax) {
-            if (!axis_on[ax]) continue;
-            const float x = (cc[ax] - bmin[ax]) * scale[ax];
-            uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;      /* `as usize` then min(S-1) */
-            if (si > S - 1u) si = S - 1u;
-            for (uint32_t k = 0; k < 3u; ++k) {
-                const uint32_t seq = i * 3u + k;
-                const float c[3] = {v[k].x, v[k].y, v[k].z};
-                for (int j = 0; j < 3; ++j) {
-                    atomicMin(&s_key[ax][si][j], bvb_min_key(c[j], seq));
-                    atomicMax(&s_key[ax][si][3 + j], bvb_max_key(c[j], seq));
-                }
-            }
-            atomicAdd(&s_cnt[ax][si], 1u);
+    for (uint32_t pass = 0; pass < 3u / AXES; ++pass) {
+        for (uint32_t k = tid; k < AXES * BVB_MAX_BINS; k += THREADS) {
+            const uint32_t slot = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
+            for (int j = 0; j < 6; ++j) s_key[slot][b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
+            s_cnt[slot][b] = 0u;
         }
-    }
-    __syncthreads();
-    if (tid < 3u) {
-        const uint32_t ax = tid;
-        float best_cost = __builtin_inff();
-        uint32_t best_i = 0u;
-        if (axis_on[ax]) {
-            BvbBox lb, rb;
-            for (int j = 0; j < 3; ++j) { lb.mn[j] = rb.mn[j] = __builtin_inff(); lb.mx[j] = rb.mx[j] = -__builtin_inff(); }
-            uint32_t lsum = 0u, rsum = 0u;
-            for (uint32_t i = 0; i + 1u < S; ++i) {
-                lsum += s_cnt[ax][i];
-                s_lc[ax][i] = lsum;
-                if (s_cnt[ax][i] != 0u && bvb_key_value(s_key[ax][i][0]) != __builtin_inff()) {     /* encapsulate_node skips an empty box */
+        __syncthreads();
+        for (uint32_t i = tid; i < count; i += THREADS) {
+            const uint32_t tri = a.order[first + i];
+            const uint4 t = a.tris[tri];
+            const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
+            const float4 ce = a.centroid[tri];
+            const float cc[3] = {ce.x, ce.y, ce.z};
+            for (uint32_t slot = 0; slot < AXES; ++slot) {
+                const uint32_t ax = AXES == 3u ? slot : pass;
+                if (!axis_on[ax]) continue;
+                const float x = (cc[ax] - bmin[ax]) * scale[ax];
+                uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;      /* `as usize` then min(S-1) */
+                if (si > S - 1u) si = S - 1u;
+                for (uint32_t k = 0; k < 3u; ++k) {
+                    const uint32_t seq = i * 3u + k;
+                    const float c[3] = {v[k].x, v[k].y, v[k].z};
                     for (int j = 0; j < 3; ++j) {
-                        lb.mn[j] = bvb_min(lb.mn[j], bvb_key_value(s_key[ax][i][j]));
-                        lb.mx[j] = bvb_max(lb.mx[j], bvb_key_value(s_key[ax][i][3 + j]));
+                        atomicMin(&s_key[slot][si][j], bvb_min_key(c[j], seq));
+                        atomicMax(&s_key[slot][si][3 + j], bvb_max_key(c[j], seq));
                     }
                 }
-                s_la[ax][i] = bvb_area(lb);
-                const uint32_t r = S - 1u - i;
-                rsum += s_cnt[ax][r];
-                s_rc[ax][S - 2u - i] = rsum;
-                if (s_cnt[ax][r] != 0u && bvb_key_value(s_key[ax][r][0]) != __builtin_inff()) {
-                    for (int j = 0; j < 3; ++j) {
-                        rb.mn[j] = bvb_min(rb.mn[j], bvb_key_value(s_key[ax][r][j]));
-                        rb.mx[j] = bvb_max(rb.mx[j], bvb_key_value(s_key[ax][r][3 + j]));
-                    }
-                }
-                s_ra[ax][S - 2u - i] = bvb_area(rb);
-            }
-            for (uint32_t i = 0; i + 1u < S; ++i) {
-                const float cost = (float)s_lc[ax][i] * s_la[ax][i] + (float)s_rc[ax][i] * s_ra[ax][i];
-                if (cost < best_cost) { best_cost = cost; best_i = i; }
+                atomicAdd(&s_cnt[slot][si], 1u);
             }
         }
-        s_best_cost[ax] = best_cost;
-        s_best_i[ax] = best_i;
+        __syncthreads();
+        if (AXES == 3u) {
+            if (tid < 192u) {                                  /* waves 0, 1, 2: one axis each (bvb_wave_sweep) */
+                const uint32_t ax = tid >> 6;
+                float best_cost = __builtin_inff();
+                uint32_t best_i = 0u;
+                if (axis_on[ax]) bvb_wave_sweep(s_key[ax], s_cnt[ax], S, best_cost, best_i);
+                if ((tid & 63u) == 0u) { s_best_cost[ax] = best_cost; s_best_i[ax] = best_i; }
+            }
+        } else {
+            float best_cost = __builtin_inff();
+            uint32_t best_i = 0u;
+            if (axis_on[pass]) bvb_wave_sweep(s_key[0], s_cnt[0], S, best_cost, best_i);
+            if (tid == 0u) { s_best_cost[pass] = best_cost; s_best_i[pass] = best_i; }
+            __syncthreads();                                   /* the bins are about to be cleared for the next axis */
+        }
     }
     __syncthreads();
     if (tid == 0u) {
@@ -384,6 +452,7 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
             node.left = BVB_NONE;                               /* bvh.rs:294-296: stays a leaf, triangles already permuted */
         } else {
             const uint32_t id = atomicAdd(a.node_count, 2u);
+            atomicMax(a.node_count + 1, nl > count - nl ? nl : count - nl);      /* the largest node of the next level: the host picks that level's workgroup size by it */
             node.left = id;
             a.nodes[id].first = first;          a.nodes[id].count = nl;              a.nodes[id].left = BVB_NONE;   a.nodes[id].pad[0] = 0u;
             a.nodes[id + 1u].first = first + nl; a.nodes[id + 1u].count = count - nl; a.nodes[id + 1u].left = BVB_NONE; a.nodes[id + 1u].pad[0] = 0u;

@@ -1825,7 +1825,7 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BVB_TRY(d_order_tmp.alloc(nt));
         BVB_TRY(d_tmp_a.alloc(nt));
         BVB_TRY(d_tmp_b.alloc(nt));
-        BVB_TRY(d_count.alloc(1));
+        BVB_TRY(d_count.alloc(2));                       /* [0] nodes so far, [1] the largest child created by the level just built */
         BVB_TRY(d_nodes.alloc(2 * (size_t)nt - 1));
         BVB_TRY(d_scratch.alloc(BVB_MAX_TEAMS));
         BVB_TRY(d_team_nodes.alloc(BVB_MAX_TEAMS));
@@ -1834,8 +1834,8 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BvbNode root{};
         root.first = 0; root.count = nt; root.left = BVB_NONE;
         BVB_TRY(hipMemcpy(d_nodes.p, &root, sizeof(root), hipMemcpyHostToDevice));
-        uint32_t one = 1;
-        BVB_TRY(hipMemcpy(d_count.p, &one, 4, hipMemcpyHostToDevice));
+        const uint32_t count_init[2] = {1u, 0u};
+        BVB_TRY(hipMemcpy(d_count.p, count_init, 8, hipMemcpyHostToDevice));
         BVB_TRY(hipEventCreate(&ev0));
         BVB_TRY(hipEventCreate(&ev1));
         sections.mark("alloc_h2d");
@@ -1858,10 +1858,11 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
                 max_teams = 0;
             }
         }
-        uint32_t begin = 0, end = 1;
+        uint32_t begin = 0, end = 1, level_max = nt;        /* level_max: the largest node of the level about to be built */
         std::vector<BvbNode> level_nodes;
         std::vector<uint32_t> team_nodes;
         while (begin < end) {                               /* one launch per tree level */
+            bool teams_here = false;
             /* the huge nodes of this level (if any) are split by teams of workgroups first */
             if (use_teams && max_teams != 0u && end - begin <= 4096u) {
                 level_nodes.resize(end - begin);
@@ -1873,15 +1874,19 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
                     BVB_TRY(hipMemcpy(d_team_nodes.p, team_nodes.data(), team_nodes.size() * 4, hipMemcpyHostToDevice));
                     k_bvb_team_init<<<(unsigned)team_nodes.size(), BVB_TEAM_THREADS>>>(d_scratch.p, d_team_nodes.p);
                     k_bvb_team<<<(unsigned)team_nodes.size() * BVB_TEAM, BVB_TEAM_THREADS>>>(a, d_scratch.p);
+                    teams_here = true;                      /* (their children are not in level_max: the next level keeps the wide workgroups) */
                 }
             }
             if (end - begin < 64u) k_bvb_level<1024><<<end - begin, 1024>>>(a, begin);      /* top of the tree: few, big nodes */
+            else if (level_max <= 256u) k_bvb_level<64><<<end - begin, 64>>>(a, begin);     /* small nodes: one wave each (measured: 64 / 256 / 1024 as the limit) */
             else k_bvb_level<BVB_THREADS><<<end - begin, BVB_THREADS>>>(a, begin);
-            uint32_t total = 0;
-            BVB_TRY(hipMemcpy(&total, d_count.p, 4, hipMemcpyDeviceToHost));
+            uint32_t total[2] = {0u, 0u};
+            BVB_TRY(hipMemcpy(total, d_count.p, 8, hipMemcpyDeviceToHost));
+            BVB_TRY(hipMemsetAsync(d_count.p + 1, 0, 4, nullptr));
+            level_max = teams_here ? nt : total[1];
             levels.push_back({begin, end});
             begin = end;
-            end = total;
+            end = total[0];
         }
         BVB_TRY(hipEventRecord(ev1, nullptr));
         BVB_TRY(hipEventSynchronize(ev1));
