@@ -22,9 +22,16 @@
  *     where the element AT first+nl is met first.  (Checked against the sequential loop on 200 000 random inputs
  *     before it was written down here; tests/test_gpu_bvh_build.py compares whole builds.)
  *
- * One workgroup walks its node's range with a stride loop (k_bvb_level); nodes of 65 536+ triangles — the top of a
- * large tree, where a level is only as fast as its largest node — are split by a team of 64 workgroups (k_bvb_team,
- * end of this file).
+ * Who splits a node, by its size (a level is one launch of each kernel that has work on it, then k_bvb_children):
+ *   16 384+ triangles   k_bvb_team: a team of 2 ... 256 workgroups, one per 8 192 triangles — the top of a large tree, where a level is only as
+ *                       fast as its largest node;
+ *   above 256           k_bvb_level<1024 | 256>: one workgroup walks the node's range with a stride loop;
+ *   65 ... 256          k_bvb_level<64>: one wave, one axis at a time through one set of bins;
+ *   9 ... 64            k_bvb_small: one wave, the node's triangles fetched once and kept in registers;
+ *   up to 8             k_bvb_tiny: eight nodes per wave, no bins.
+ * The children of a level are numbered by k_bvb_children (one atomic per 1 024 nodes: the two hot words — next free id, largest child — cost 11 ns per
+ * wave-atomic device-wide, which was most of a deep level's time).  Round 6, 1 M triangles: 40 -> 12 ms (64-triangle leaves, input in spatial order)
+ * and 40 -> 10 ms (2 M nodes); profiles/r06_bvh_levels_*.txt.
  */
 #ifndef RPT_K_BVH_BUILD_H
 #define RPT_K_BVH_BUILD_H
@@ -123,6 +130,57 @@ __device__ __forceinline__ uint32_t bvb_block_rank(bool flag, uint32_t *wave_tot
     return before + within;
 }
 
+/* ---- a triangle into the bins --------------------------------------------------------------------------------------------------------------------------------
+ * bvh.rs:214-229 grows the bin's box by the triangle's three vertices: nine coordinates, eighteen min / max folds.  The fold over a triangle's own three vertices
+ * can be taken first (bvb_tri_keys: six keys per triangle, the same for every axis); and where the triangles a wave holds fall into ONE bin of an axis — the rule
+ * for an input in spatial order, such as a scene file's meshes or an earlier build's leaf order — the wave folds its six keys (bvb_wave_fold) and one lane
+ * updates the bin: 7 LDS atomics per wave instead of 64 x 19 on one address, which serialise (the clustered 1 M-triangle stand-in in leaf order took 40 ms against
+ * 20 ms shuffled, profiles/r06_bvh_input_order.txt). */
+__device__ __forceinline__ void bvb_tri_keys(const float4 v[3], uint32_t i, bool valid, unsigned long long k6[6]) {
+    for (int j = 0; j < 3; ++j) { k6[j] = BVB_MIN_IDENT; k6[3 + j] = BVB_MAX_IDENT; }
+    if (!valid) return;
+    for (uint32_t k = 0; k < 3u; ++k) {
+        const uint32_t seq = i * 3u + k;
+        const float c[3] = {v[k].x, v[k].y, v[k].z};
+        for (int j = 0; j < 3; ++j) {
+            const unsigned long long lo = bvb_min_key(c[j], seq), hi = bvb_max_key(c[j], seq);
+            k6[j] = lo < k6[j] ? lo : k6[j];
+            k6[3 + j] = hi > k6[3 + j] ? hi : k6[3 + j];
+        }
+    }
+}
+__device__ __forceinline__ unsigned long long bvb_shfl_xor_u64(unsigned long long v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void bvb_wave_fold(const unsigned long long k6[6], unsigned long long out[6]) {
+    for (int j = 0; j < 6; ++j) out[j] = k6[j];
+    for (int d = 32; d >= 1; d >>= 1)
+        for (int j = 0; j < 3; ++j) {
+            const unsigned long long a = bvb_shfl_xor_u64(out[j], d), b = bvb_shfl_xor_u64(out[3 + j], d);
+            out[j] = a < out[j] ? a : out[j];
+            out[3 + j] = b > out[3 + j] ? b : out[3 + j];
+        }
+}
+/* every lane of the wave calls (valid: the lane holds a triangle whose bin on this axis is si); folded: bvb_wave_fold of the wave's keys, computed by the caller
+ * once for all axes when it may be needed */
+__device__ __forceinline__ void bvb_bin_add(unsigned long long (*key)[6], uint32_t *cnt, bool valid, uint32_t si, const unsigned long long k6[6],
+                                            const unsigned long long folded[6], bool folded_ok) {
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
+    if (act == 0ull) return;
+    const int lead = __ffsll((long long)act) - 1;
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)si, lead);
+    if (folded_ok && __builtin_amdgcn_ballot_w64(valid && si == b0) == act) {
+        if ((int)(threadIdx.x & 63u) == lead) {
+            for (int j = 0; j < 3; ++j) { atomicMin(&key[b0][j], folded[j]); atomicMax(&key[b0][3 + j], folded[3 + j]); }
+            atomicAdd(&cnt[b0], (uint32_t)__popcll(act));
+        }
+    } else if (valid) {
+        for (int j = 0; j < 3; ++j) { atomicMin(&key[si][j], k6[j]); atomicMax(&key[si][3 + j], k6[3 + j]); }
+        atomicAdd(&cnt[si], 1u);
+    }
+}
+
 /* ---- the sweep over the bins of one axis (bvh.rs:214-253) as two wave scans ---------------------------------------------------------------------------
  * The sequential sweep folds the bins' boxes upwards (left boxes) and downwards (right boxes) with encapsulate = (f32::min, f32::max) per component, skipping empty
  * bins, and takes the first candidate of least cost.  `bvb_min(a, b)` keeps the LATER operand on a tie (only the sign of a zero can differ), which is an associative
@@ -212,7 +270,7 @@ __device__ __forceinline__ void bvb_wave_sweep(const unsigned long long (*key)[6
 /* THREADS = 1024 for the few huge nodes at the top of the tree (a workgroup walks its node's whole range), 256 below, 64 — one wave per node — for levels whose
  * largest node has at most 64 triangles (the deep levels of a tree with small leaves: 0.4 M nodes of two to eight triangles each on the scattered stand-in) */
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level_begin) {
+__global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level_begin, uint32_t skip_upto) {
     constexpr uint32_t AXES = THREADS >= 192 ? 3u : 1u;            /* axes binned at once */
     __shared__ unsigned long long s_key[AXES][BVB_MAX_BINS][6];   /* [axis][bin]: min x,y,z  max x,y,z */
     __shared__ uint32_t s_cnt[AXES][BVB_MAX_BINS];
@@ -231,6 +289,7 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
     if (node.pad[0] != 0u) return;                 /* already split at this level by a team (k_bvb_team) */
     const uint32_t first = node.first, count = node.count, S = a.bins;
     const uint32_t last = first + count - 1u;
+    if (count <= skip_upto) return;                /* a node k_bvb_tiny has taken (0: none) */
 
     /* ---- update_node_aabb (bvh.rs:85-103), sequential tie-breaking reproduced by the keys */
     if (tid < 6u) s_red[tid] = tid < 3u ? BVB_MIN_IDENT : BVB_MAX_IDENT;
@@ -293,27 +352,30 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
             s_cnt[slot][b] = 0u;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < count; i += THREADS) {
-            const uint32_t tri = a.order[first + i];
-            const uint4 t = a.tris[tri];
-            const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
-            const float4 ce = a.centroid[tri];
-            const float cc[3] = {ce.x, ce.y, ce.z};
+        for (uint32_t base = 0; base < count; base += THREADS) {
+            const uint32_t i = base + tid;
+            const bool have = i < count;
+            float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+            float cc[3] = {0.0f, 0.0f, 0.0f};
+            if (have) {
+                const uint32_t tri = a.order[first + i];
+                const uint4 t = a.tris[tri];
+                v[0] = a.verts[t.x]; v[1] = a.verts[t.y]; v[2] = a.verts[t.z];
+                const float4 ce = a.centroid[tri];
+                cc[0] = ce.x; cc[1] = ce.y; cc[2] = ce.z;
+            }
+            unsigned long long k6[6], folded[6];
+            bvb_tri_keys(v, i, have, k6);
+            /* (a full wave of triangles: the fold is worth its 72 shuffles only if some axis then finds the wave in one bin — decided per axis below) */
+            const bool fold = __builtin_amdgcn_ballot_w64(have) == ~0ull;
+            if (fold) bvb_wave_fold(k6, folded);
             for (uint32_t slot = 0; slot < AXES; ++slot) {
                 const uint32_t ax = AXES == 3u ? slot : pass;
                 if (!axis_on[ax]) continue;
                 const float x = (cc[ax] - bmin[ax]) * scale[ax];
                 uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;      /* `as usize` then min(S-1) */
                 if (si > S - 1u) si = S - 1u;
-                for (uint32_t k = 0; k < 3u; ++k) {
-                    const uint32_t seq = i * 3u + k;
-                    const float c[3] = {v[k].x, v[k].y, v[k].z};
-                    for (int j = 0; j < 3; ++j) {
-                        atomicMin(&s_key[slot][si][j], bvb_min_key(c[j], seq));
-                        atomicMax(&s_key[slot][si][3 + j], bvb_max_key(c[j], seq));
-                    }
-                }
-                atomicAdd(&s_cnt[slot][si], 1u);
+                bvb_bin_add(s_key[slot], s_cnt[slot], have, si, k6, folded, fold);
             }
         }
         __syncthreads();
@@ -447,34 +509,373 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
     __threadfence_block();
     for (uint32_t i = tid; i < count; i += THREADS) a.order[first + i] = a.order_tmp[first + i];
 
+    /* bvh.rs:294-296: with an empty side the node stays a leaf, its triangles already permuted; otherwise k_bvb_children makes the two children */
+    if (tid == 0u) node.pad[1] = (nl == 0u || nl == count) ? 0u : nl;
+}
+
+/* ---- the children of a level's nodes (bvh.rs:296-320) -----------------------------------------------------------------------------------------------------
+ * The split kernels leave `nl` (triangles on the left side) in pad[1] of a node that gets children; this pass numbers them: a workgroup ranks its 1 024 nodes and
+ * takes its ids with ONE atomic.  (An atomic on one address costs 11.3 ns device-wide however many lanes of the wave take part — tools/atomic_probe.hip — so the
+ * 0.2-0.4 M nodes of a deep level, each fetching its own pair of ids and raising the level's largest-child word, spent 2-5 ms per level on those two words.) */
+__global__ __launch_bounds__(1024) void k_bvb_children(BvbArgs a, uint32_t level_begin, uint32_t level_end) {
+    __shared__ uint32_t s_wave_tot[16], s_wave_big[16], s_base;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t node_id = level_begin + blockIdx.x * 1024u + tid;
+    uint32_t nl = 0u, first = 0u, count = 0u;
+    if (node_id < level_end) {
+        nl = a.nodes[node_id].pad[1];
+        first = a.nodes[node_id].first; count = a.nodes[node_id].count;
+    }
+    uint32_t total;
+    const uint32_t rank = bvb_block_rank<1024>(nl != 0u, s_wave_tot, total);
+    if (total == 0u) return;
+    uint32_t big = nl != 0u ? (nl > count - nl ? nl : count - nl) : 0u;
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)big, d, 64); big = o > big ? o : big; }
+    if ((tid & 63u) == 0u) s_wave_big[tid >> 6] = big;
+    __syncthreads();
     if (tid == 0u) {
-        if (nl == 0u || nl == count) {
-            node.left = BVB_NONE;                               /* bvh.rs:294-296: stays a leaf, triangles already permuted */
-        } else {
-            const uint32_t id = atomicAdd(a.node_count, 2u);
-            atomicMax(a.node_count + 1, nl > count - nl ? nl : count - nl);      /* the largest node of the next level: the host picks that level's workgroup size by it */
-            node.left = id;
-            a.nodes[id].first = first;          a.nodes[id].count = nl;              a.nodes[id].left = BVB_NONE;   a.nodes[id].pad[0] = 0u;
-            a.nodes[id + 1u].first = first + nl; a.nodes[id + 1u].count = count - nl; a.nodes[id + 1u].left = BVB_NONE; a.nodes[id + 1u].pad[0] = 0u;
-        }
+        s_base = atomicAdd(a.node_count, 2u * total);
+        for (int w = 1; w < 16; ++w) big = s_wave_big[w] > big ? s_wave_big[w] : big;
+        /* the largest node of the next level: the host picks that level's kernels by it */
+        if (big > __hip_atomic_load(a.node_count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.node_count + 1, big);
+    }
+    __syncthreads();
+    if (nl != 0u) {
+        const uint32_t id = s_base + 2u * rank;
+        a.nodes[node_id].left = id;
+        a.nodes[node_id].pad[1] = 0u;
+        BvbNode l{}, r{};
+        l.first = first;      l.count = nl;         l.left = BVB_NONE;
+        r.first = first + nl; r.count = count - nl; r.left = BVB_NONE;
+        a.nodes[id] = l;
+        a.nodes[id + 1u] = r;
     }
 }
 
 /* ---------------------------------------------------------------------------------------------------------------
- * The few HUGE nodes at the top of a large tree: a TEAM of BVB_TEAM workgroups per node instead of one.
+ * The deep levels of a tree with small leaves: every node of the level holds at most 64 triangles (0.2-0.4 M nodes of one to eight triangles on each of six levels of
+ * the scattered stand-in).  One wave per node as in k_bvb_level<64>, but the node's triangles are fetched ONCE — lane i keeps triangle first + i: index, six keys,
+ * centroid — and every pass of k_bvb_level (bounds, three binnings, the partition's count and its three ranking passes, the copy back) works out of registers: a small
+ * node is nothing but latency, and the stride-loop kernel walks order -> triangle -> vertices eight times per node (5.4 ms for a level of 0.4 M nodes).  Same keys,
+ * same bins, same sweep, same closed-form partition (its prefix counts are ballots here): the same tree. */
+__global__ __launch_bounds__(64) void k_bvb_small(BvbArgs a, uint32_t level_begin, uint32_t skip_upto) {
+    __shared__ unsigned long long s_key[BVB_MAX_BINS][6];
+    __shared__ uint32_t s_cnt[BVB_MAX_BINS];
+    __shared__ uint32_t s_rb[64], s_hole_at[64];
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t node_id = level_begin + blockIdx.x;
+    BvbNode &node = a.nodes[node_id];
+    if (node.pad[0] != 0u) return;
+    const uint32_t first = node.first, count = node.count, S = a.bins;       /* count <= 64: the host launches this kernel only then */
+    if (count <= skip_upto) return;
+    const bool have = lane < count;
+    uint32_t tri = 0u;
+    float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    float cc[3] = {0.0f, 0.0f, 0.0f};
+    if (have) {
+        tri = a.order[first + lane];
+        const uint4 t = a.tris[tri];
+        v[0] = a.verts[t.x]; v[1] = a.verts[t.y]; v[2] = a.verts[t.z];
+        const float4 ce = a.centroid[tri];
+        cc[0] = ce.x; cc[1] = ce.y; cc[2] = ce.z;
+    }
+    /* ---- update_node_aabb: the fold of the wave's keys */
+    unsigned long long k6[6], red[6];
+    bvb_tri_keys(v, lane, have, k6);
+    bvb_wave_fold(k6, red);
+    uint32_t cb[6];
+    for (int j = 0; j < 3; ++j) {
+        uint32_t nz;
+        const uint32_t o = bvb_ord(cc[j], nz);
+        cb[j] = have ? o : 0xffffffffu;
+        cb[3 + j] = have ? o : 0u;
+    }
+    for (int d = 32; d >= 1; d >>= 1)
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)cb[j], d, 64), hi = (uint32_t)__shfl_xor((int)cb[3 + j], d, 64);
+            cb[j] = lo < cb[j] ? lo : cb[j];
+            cb[3 + j] = hi > cb[3 + j] ? hi : cb[3 + j];
+        }
+    if (lane < 3u) {
+        node.mn[lane] = bvb_key_value(lane == 0u ? red[0] : (lane == 1u ? red[1] : red[2]));
+        node.mx[lane] = bvb_key_value(lane == 0u ? red[3] : (lane == 1u ? red[4] : red[5]));
+    }
+    float bmin[3], bmax[3], nmn[3], nmx[3];
+    for (int j = 0; j < 3; ++j) {
+        bmin[j] = bvb_unord(cb[j], 0u); bmax[j] = bvb_unord(cb[3 + j], 0u);
+        nmn[j] = bvb_key_value(red[j]); nmx[j] = bvb_key_value(red[3 + j]);
+    }
+    /* ---- find_best_split_segmented, one axis at a time through one set of bins */
+    int axis = 0;
+    float split = 0.0f, cost = __builtin_inff();
+    for (int ax = 0; ax < 3; ++ax) {
+        if (bmin[ax] == bmax[ax]) continue;                          /* (uniform: every lane holds the same bounds) */
+        for (uint32_t b = lane; b < BVB_MAX_BINS; b += 64u) {
+            for (int j = 0; j < 6; ++j) s_key[b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
+            s_cnt[b] = 0u;
+        }
+        __syncthreads();
+        if (have) {
+            const float x = (cc[ax] - bmin[ax]) * ((float)S / (bmax[ax] - bmin[ax]));
+            uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;
+            if (si > S - 1u) si = S - 1u;
+            for (int j = 0; j < 3; ++j) { atomicMin(&s_key[si][j], k6[j]); atomicMax(&s_key[si][3 + j], k6[3 + j]); }
+            atomicAdd(&s_cnt[si], 1u);
+        }
+        __syncthreads();
+        float best_cost;
+        uint32_t best_i;
+        bvb_wave_sweep(s_key, s_cnt, S, best_cost, best_i);
+        __syncthreads();
+        if (best_cost < cost) {
+            cost = best_cost;
+            axis = ax;
+            const float scale2 = (bmax[ax] - bmin[ax]) / (float)S;
+            split = bmin[ax] + scale2 * (float)(best_i + 1u);
+        }
+    }
+    {
+        BvbBox nb;
+        for (int j = 0; j < 3; ++j) { nb.mn[j] = nmn[j]; nb.mx[j] = nmx[j]; }
+        if (bvb_area(nb) * (float)count <= cost) {                   /* bvh.rs:272-277 */
+            if (lane == 0u) node.left = BVB_NONE;
+            return;
+        }
+    }
+    /* ---- the partition in closed form (file header), its running counts as ballots */
+    const float c = axis == 0 ? cc[0] : (axis == 1 ? cc[1] : cc[2]);
+    const bool L = have && c < split;
+    const unsigned long long all_l = __builtin_amdgcn_ballot_w64(L), all = __builtin_amdgcn_ballot_w64(have);
+    const uint32_t nl = (uint32_t)__popcll(all_l);
+    const unsigned long long below_nl = nl >= 64u ? ~0ull : ((1ull << nl) - 1ull);
+    const unsigned long long pre_r = all & ~all_l & below_nl, suf_l = all_l & ~below_nl, suf_r = all & ~all_l & ~below_nl;
+    const unsigned long long above = lane >= 63u ? 0ull : (~0ull << (lane + 1u)), under = (1ull << lane) - 1ull;
+    const uint32_t H = (uint32_t)__popcll(suf_l);
+    const bool in_prefix = lane < nl;
+    const uint32_t m = (uint32_t)__popcll(suf_l & above), rb = (uint32_t)__popcll(suf_r & above);        /* suffix lanes: left / right elements above */
+    const uint32_t hole = (uint32_t)__popcll(pre_r & under);                                             /* prefix lanes: holes below */
+    if (have && !in_prefix && L) s_rb[m] = rb;
+    if (have && in_prefix && !L) s_hole_at[hole] = lane;
+    __syncthreads();
+    uint32_t dest = lane;                                             /* a left-side element of the prefix stays */
+    if (have) {
+        const uint32_t last_i = count - 1u;
+        if (in_prefix && !L) {
+            dest = last_i - (hole + (hole >= 1u ? s_rb[hole - 1u] : 0u));
+        } else if (!in_prefix && L) {
+            dest = s_hole_at[m];
+        } else if (!in_prefix) {
+            const uint32_t base_rb = H >= 1u ? s_rb[H - 1u] : 0u;
+            uint32_t rank;
+            if (m == H) rank = lane == nl ? H + base_rb : H + rb + 1u;
+            else rank = (m + 1u) + rb;
+            dest = last_i - rank;
+        }
+        a.order[first + dest] = tri;
+    }
+    if (lane == 0u) node.pad[1] = (nl == 0u || nl == count) ? 0u : nl;          /* -> k_bvb_children */
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Nodes of at most BVB_TINY triangles — 87 % of the nodes of the scattered stand-in's level 18, all of them from level 21 down, two triangles on average: EIGHT nodes
+ * per wave, eight lanes each, and no bins at all.  With n <= 8 triangles at most 8 of the S bins hold anything, and the sweep's candidates between two occupied bins
+ * cost the same (same left set, same right set: the first of them is the candidate AT the lower occupied bin), those before the first occupied bin or from the last
+ * one on have an empty side (0 x area(empty) = NaN: never taken, bvh.rs:246-250 as k_bvb_level's sweep).  So lane t prices candidate i = bin(t) by folding the keys of
+ * the group's members u with bin(u) <= bin(t) into the left box and the others into the right box: n steps of one shuffle round each.  The sequential fold is by
+ * triangle inside a bin, then by bin — ascending for the left boxes, descending for the right ones, the LATER operand winning a tie (which only the sign of a zero can
+ * tell) — so the tie-break word of a key gets the bin on top of the triangle's sequence number, for the left boxes the other way round than for the right boxes.  A
+ * bin whose least x is +inf is skipped by the sweep (encapsulate_node of an "empty" box) though its triangles count: `excluded`.  Nodes of more than BVB_TINY
+ * triangles are left to the launch that follows (k_bvb_small / k_bvb_level<64> with skip_upto = BVB_TINY). */
+#define BVB_TINY 8u
+__device__ __forceinline__ float bvb_select3(const float v[3], uint32_t j) { return j == 0u ? v[0] : (j == 1u ? v[1] : v[2]); }
+__global__ __launch_bounds__(64) void k_bvb_tiny(BvbArgs a, uint32_t level_begin, uint32_t level_end) {
+    __shared__ uint32_t s_rb[64], s_hole_at[64];
+    const uint32_t lane = threadIdx.x, g0 = lane & ~7u, l = lane & 7u;
+    const uint32_t node_id = level_begin + blockIdx.x * 8u + (lane >> 3);
+    BvbNode *node = a.nodes + (node_id < level_end ? node_id : level_begin);
+    uint32_t first = 0u, count = 0u;
+    bool mine = false;
+    if (node_id < level_end && node->pad[0] == 0u) {
+        first = node->first; count = node->count;
+        mine = count <= BVB_TINY;
+    }
+    const uint32_t S = a.bins;
+    const bool have = mine && l < count;
+    uint32_t tri = 0u;
+    float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    float cc[3] = {0.0f, 0.0f, 0.0f};
+    if (have) {
+        tri = a.order[first + l];
+        const uint4 t = a.tris[tri];
+        v[0] = a.verts[t.x]; v[1] = a.verts[t.y]; v[2] = a.verts[t.z];
+        const float4 ce = a.centroid[tri];
+        cc[0] = ce.x; cc[1] = ce.y; cc[2] = ce.z;
+    }
+    /* ---- update_node_aabb over the group */
+    unsigned long long k6[6], red[6];
+    bvb_tri_keys(v, l, have, k6);
+    uint32_t cb[6];
+    for (int j = 0; j < 3; ++j) {
+        uint32_t nz;
+        const uint32_t o = bvb_ord(cc[j], nz);
+        cb[j] = have ? o : 0xffffffffu;
+        cb[3 + j] = have ? o : 0u;
+    }
+    for (int j = 0; j < 6; ++j) red[j] = k6[j];
+    for (int d = 4; d >= 1; d >>= 1)
+        for (int j = 0; j < 3; ++j) {
+            const unsigned long long x = bvb_shfl_xor_u64(red[j], d), y = bvb_shfl_xor_u64(red[3 + j], d);
+            red[j] = x < red[j] ? x : red[j];
+            red[3 + j] = y > red[3 + j] ? y : red[3 + j];
+            const uint32_t lo = (uint32_t)__shfl_xor((int)cb[j], d, 64), hi = (uint32_t)__shfl_xor((int)cb[3 + j], d, 64);
+            cb[j] = lo < cb[j] ? lo : cb[j];
+            cb[3 + j] = hi > cb[3 + j] ? hi : cb[3 + j];
+        }
+    float bmin[3], bmax[3], nmn[3], nmx[3];
+    for (int j = 0; j < 3; ++j) {
+        bmin[j] = bvb_unord(cb[j], 0u); bmax[j] = bvb_unord(cb[3 + j], 0u);
+        nmn[j] = bvb_key_value(red[j]); nmx[j] = bvb_key_value(red[3 + j]);
+    }
+    if (mine && l < 3u) { node->mn[l] = bvb_select3(nmn, l); node->mx[l] = bvb_select3(nmx, l); }
+    /* the longest group of the wave bounds the member loops */
+    uint32_t n_max = mine ? count : 0u;
+    for (int d = 32; d >= 8; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)n_max, d, 64); n_max = o > n_max ? o : n_max; }
+    n_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_max);
+    /* ---- find_best_split_segmented without bins */
+    int axis = 0;
+    float split = 0.0f, cost = __builtin_inff();
+    for (int ax = 0; ax < 3; ++ax) {
+        const bool on = mine && !(bmin[ax] == bmax[ax]);
+        if (__builtin_amdgcn_ballot_w64(on) == 0ull) continue;
+        uint32_t si = 0u;
+        if (on && have) {
+            const float x = (cc[ax] - bmin[ax]) * ((float)S / (bmax[ax] - bmin[ax]));
+            si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;
+            if (si > S - 1u) si = S - 1u;
+        }
+        /* bins the sweep skips: least x of the bin's triangles is +inf */
+        bool excluded = false;
+        if (__builtin_amdgcn_ballot_w64(on && have && bvb_key_value(k6[0]) == __builtin_inff()) != 0ull) {
+            unsigned long long bin_min_x = k6[0];
+            for (uint32_t u = 0; u < n_max; ++u) {
+                const uint32_t su = (uint32_t)__shfl((int)si, (int)(g0 + u), 64);
+                const unsigned long long ku = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)k6[0], (int)(g0 + u), 64) |
+                                              ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(k6[0] >> 32), (int)(g0 + u), 64) << 32);
+                if (u < count && su == si && ku < bin_min_x) bin_min_x = ku;
+            }
+            excluded = bvb_key_value(bin_min_x) == __builtin_inff();
+        }
+        const uint32_t tag = si | (excluded ? 0x80000000u : 0u);
+        unsigned long long Lk[6], Rk[6];
+        for (int j = 0; j < 3; ++j) { Lk[j] = Rk[j] = BVB_MIN_IDENT; Lk[3 + j] = Rk[3 + j] = BVB_MAX_IDENT; }
+        uint32_t lc = 0u, rc = 0u;
+        for (uint32_t u = 0; u < n_max; ++u) {
+            const uint32_t tu = (uint32_t)__shfl((int)tag, (int)(g0 + u), 64);
+            uint32_t hi[6], lo[6];
+            for (int j = 0; j < 6; ++j) {
+                lo[j] = (uint32_t)__shfl((int)(uint32_t)k6[j], (int)(g0 + u), 64);
+                hi[j] = (uint32_t)__shfl((int)(uint32_t)(k6[j] >> 32), (int)(g0 + u), 64);
+            }
+            const uint32_t su = tu & 0x7fffffffu;
+            const bool member = u < count, is_left = su <= si;
+            lc += member && is_left ? 1u : 0u;
+            rc += member && !is_left ? 1u : 0u;
+            const bool to_l = member && !(tu & 0x80000000u) && is_left, to_r = member && !(tu & 0x80000000u) && !is_left;
+            /* the later operand of the fold wins a tie: a higher bin for the left boxes (ascending), a lower one for the right boxes (descending) */
+            const uint32_t up = su << 24, down = (127u - su) << 24;
+            for (int j = 0; j < 3; ++j) {
+                const unsigned long long kmin = ((unsigned long long)hi[j] << 32) | ((is_left ? down : up) | (lo[j] & 0xffffffu));
+                const unsigned long long kmax = ((unsigned long long)hi[3 + j] << 32) | ((is_left ? up : down) | (lo[3 + j] & 0xffffffu));
+                Lk[j] = to_l && kmin < Lk[j] ? kmin : Lk[j];
+                Lk[3 + j] = to_l && kmax > Lk[3 + j] ? kmax : Lk[3 + j];
+                Rk[j] = to_r && kmin < Rk[j] ? kmin : Rk[j];
+                Rk[3 + j] = to_r && kmax > Rk[3 + j] ? kmax : Rk[3 + j];
+            }
+        }
+        BvbBox lb = bvb_box_identity(), rb = bvb_box_identity();
+        if (Lk[0] != BVB_MIN_IDENT) for (int j = 0; j < 3; ++j) { lb.mn[j] = bvb_key_value(Lk[j]); lb.mx[j] = bvb_key_value(Lk[3 + j]); }
+        if (Rk[0] != BVB_MIN_IDENT) for (int j = 0; j < 3; ++j) { rb.mn[j] = bvb_key_value(Rk[j]); rb.mx[j] = bvb_key_value(Rk[3 + j]); }
+        float c_here = __builtin_inff();
+        uint32_t at = 0u;
+        if (on && have && si + 1u < S) {
+            const float v = (float)lc * bvb_area(lb) + (float)rc * bvb_area(rb);
+            if (v < c_here) { c_here = v; at = si; }
+        }
+        for (int d = 4; d >= 1; d >>= 1) {
+            const float oc = __shfl_xor(c_here, d, 64);
+            const uint32_t oa = (uint32_t)__shfl_xor((int)at, d, 64);
+            if (oc < c_here || (oc == c_here && oc != __builtin_inff() && oa < at)) { c_here = oc; at = oa; }
+        }
+        if (c_here < cost) {
+            cost = c_here;
+            axis = ax;
+            const float scale2 = (bmax[ax] - bmin[ax]) / (float)S;
+            split = bmin[ax] + scale2 * (float)(at + 1u);
+        }
+    }
+    bool splits = false;
+    if (mine) {
+        BvbBox nb;
+        for (int j = 0; j < 3; ++j) { nb.mn[j] = nmn[j]; nb.mx[j] = nmx[j]; }
+        splits = !(bvb_area(nb) * (float)count <= cost);             /* bvh.rs:272-277 */
+        if (!splits && l == 0u) node->left = BVB_NONE;
+    }
+    /* ---- the partition in closed form, the running counts as bits of a ballot */
+    const float c = axis == 0 ? cc[0] : (axis == 1 ? cc[1] : cc[2]);
+    const bool L = splits && have && c < split;
+    const uint32_t grp_l = (uint32_t)(__builtin_amdgcn_ballot_w64(L) >> g0) & 0xffu;
+    const uint32_t grp = (uint32_t)(__builtin_amdgcn_ballot_w64(splits && have) >> g0) & 0xffu;
+    const uint32_t nl = (uint32_t)__popc(grp_l);
+    const uint32_t below_nl = (1u << nl) - 1u;
+    const uint32_t pre_r = grp & ~grp_l & below_nl, suf_l = grp_l & ~below_nl, suf_r = grp & ~grp_l & ~below_nl;
+    const uint32_t above = (~0u << (l + 1u)) & 0xffu, under = (1u << l) - 1u;
+    const uint32_t H = (uint32_t)__popc(suf_l);
+    const bool in_prefix = l < nl;
+    const uint32_t m = (uint32_t)__popc(suf_l & above), rb_above = (uint32_t)__popc(suf_r & above);
+    const uint32_t hole = (uint32_t)__popc(pre_r & under);
+    if (splits && have && !in_prefix && L) s_rb[g0 + m] = rb_above;
+    if (splits && have && in_prefix && !L) s_hole_at[g0 + hole] = l;
+    __syncthreads();
+    if (splits && have) {
+        const uint32_t last_i = count - 1u;
+        uint32_t dest = l;
+        if (in_prefix && !L) {
+            dest = last_i - (hole + (hole >= 1u ? s_rb[g0 + hole - 1u] : 0u));
+        } else if (!in_prefix && L) {
+            dest = s_hole_at[g0 + m];
+        } else if (!in_prefix) {
+            const uint32_t base_rb = H >= 1u ? s_rb[g0 + H - 1u] : 0u;
+            uint32_t rank;
+            if (m == H) rank = l == nl ? H + base_rb : H + rb_above + 1u;
+            else rank = (m + 1u) + rb_above;
+            dest = last_i - rank;
+        }
+        a.order[first + dest] = tri;
+    }
+    if (splits && l == 0u) node->pad[1] = (nl == 0u || nl == count) ? 0u : nl;          /* -> k_bvb_children (bvh.rs:294-296: an empty side, and the node stays a leaf) */
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The big nodes at the top of a large tree: a TEAM of 2 ... BVB_TEAM workgroups per node (one per BVB_TEAM_CHUNK triangles) instead of one.
  * Same arithmetic, same keys, same closed-form partition — the passes are cut into contiguous chunks of the node's
  * range, partial results meet in global memory (64-bit atomic min/max on the same keys, per-chunk left counts), and
- * the workgroups of a team meet at a counter barrier between passes (all of them are resident: the host launches at
- * most BVB_MAX_TEAMS teams).  With L(p) = number of left-side elements at positions < p (chunk prefix + local rank)
+ * the workgroups of a team meet at a counter barrier between passes (all of them are resident: the host launches no
+ * more workgroups than the device holds at once).  With L(p) = number of left-side elements at positions < p (chunk prefix + local rank)
  * every quantity of the closed form is local:  hole rank of p = (p - first) - L(p);  for a suffix position q:
  * m(q) = nl - L(q+1) left-side elements above it, rb(q) = (last - q) - m(q) right-side elements above it.
  * Measured on the 1 M-triangle stand-in: the levels that hold a 0.5-1 M-triangle node took 7-15 ms each with one
  * workgroup per node. */
-#define BVB_TEAM 64
+#define BVB_TEAM 256               /* the largest team */
 #define BVB_TEAM_THREADS 256
-#define BVB_MAX_TEAMS 16          /* x 64 workgroups of ~26 KB LDS: all resident at once (the barrier needs that) */
-#define BVB_TEAM_MIN_COUNT 65536u
+#define BVB_TEAM_CHUNK 8192u       /* triangles per workgroup a team is sized for (a power of two of workgroups, 2 ... BVB_TEAM): measured 1 024 ... 32 768 */
+#define BVB_MAX_TEAMS 128          /* all workgroups of all teams of a launch are resident at once (the barrier needs that): the host counts them */
+#define BVB_TEAM_MIN_COUNT 16384u  /* measured on both 1 M-triangle stand-ins, 4 096 ... 32 768 (profiles/r06_bvh_team_sweep.txt) */
+#define BVB_WIDE_MIN_COUNT 16384u  /* a level whose largest node is at least this big gets 1 024 threads per node (4 waves per SIMD walk a 30 k-triangle node 4 x faster) */
 
+struct BvbTeamRef {
+    uint32_t node_id, size, first_block;
+};
 struct BvbTeamScratch {
     unsigned long long red[6];
     unsigned long long key[3][BVB_MAX_BINS][6];
@@ -484,10 +885,10 @@ struct BvbTeamScratch {
     uint32_t barrier;
     int axis;
     float split;
-    uint32_t node_id;
+    uint32_t node_id, size, first_block;
 };
 
-__global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team_init(BvbTeamScratch *scratch, const uint32_t *team_nodes) {
+__global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team_init(BvbTeamScratch *scratch, const BvbTeamRef *refs) {
     BvbTeamScratch &t = scratch[blockIdx.x];
     const uint32_t tid = threadIdx.x;
     if (tid < 6u) { t.red[tid] = tid < 3u ? BVB_MIN_IDENT : BVB_MAX_IDENT; t.cb[tid] = tid < 3u ? 0xffffffffu : 0u; }
@@ -496,28 +897,29 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team_init(BvbTeamScrat
         for (int j = 0; j < 6; ++j) t.key[ax][b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
         t.cnt[ax][b] = 0u;
     }
-    if (tid < BVB_TEAM) { t.chunk_l[tid] = 0u; t.chunk_lf[tid] = 0u; }
-    if (tid == 0u) { t.barrier = 0u; t.axis = -1; t.split = 0.0f; t.node_id = team_nodes[blockIdx.x]; }
+    for (uint32_t k = tid; k < BVB_TEAM; k += BVB_TEAM_THREADS) { t.chunk_l[k] = 0u; t.chunk_lf[k] = 0u; }
+    if (tid == 0u) {
+        t.barrier = 0u; t.axis = -1; t.split = 0.0f;
+        t.node_id = refs[blockIdx.x].node_id; t.size = refs[blockIdx.x].size; t.first_block = refs[blockIdx.x].first_block;
+    }
 }
 
-/* all BVB_TEAM workgroups of a team arrive; `phase` counts the barriers passed so far */
-__device__ __forceinline__ void bvb_team_sync(uint32_t *counter, uint32_t &phase) {
+/* all workgroups of a team arrive; `phase` counts the barriers passed so far */
+__device__ __forceinline__ void bvb_team_sync(uint32_t *counter, uint32_t &phase, uint32_t team_size) {
     __syncthreads();
     phase += 1u;
     if (threadIdx.x == 0u) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < phase * BVB_TEAM) __builtin_amdgcn_s_sleep(4);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < phase * team_size) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-__global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTeamScratch *scratch) {
+__global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTeamScratch *scratch, const uint16_t *block_team) {
     constexpr int THREADS = BVB_TEAM_THREADS;
     __shared__ unsigned long long s_key[3][BVB_MAX_BINS][6];
     __shared__ uint32_t s_cnt[3][BVB_MAX_BINS];
-    __shared__ float s_la[3][BVB_MAX_BINS], s_ra[3][BVB_MAX_BINS];
-    __shared__ uint32_t s_lc[3][BVB_MAX_BINS], s_rc[3][BVB_MAX_BINS];
     __shared__ unsigned long long s_red[6];
     __shared__ uint32_t s_cb[6];
     __shared__ float s_best_cost[3];
@@ -526,12 +928,12 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
     __shared__ uint32_t s_misc[4];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t team = blockIdx.x / BVB_TEAM, member = blockIdx.x % BVB_TEAM;
-    BvbTeamScratch &T = scratch[team];
+    BvbTeamScratch &T = scratch[block_team[blockIdx.x]];
+    const uint32_t team_size = T.size, member = blockIdx.x - T.first_block;
     BvbNode &node = a.nodes[T.node_id];
     const uint32_t first = node.first, count = node.count, S = a.bins;
     const uint32_t last = first + count - 1u;
-    const uint32_t chunk = (count + BVB_TEAM - 1u) / BVB_TEAM;
+    const uint32_t chunk = (count + team_size - 1u) / team_size;
     const uint32_t c_begin = first + member * chunk < first + count ? first + member * chunk : first + count;
     const uint32_t c_end = c_begin + chunk < first + count ? c_begin + chunk : first + count;      /* positions [c_begin, c_end) */
     uint32_t phase = 0u;
@@ -579,7 +981,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         atomicMin(&T.cb[tid], s_cb[tid]);
         atomicMax(&T.cb[3u + tid], s_cb[3u + tid]);
     }
-    bvb_team_sync(&T.barrier, phase);
+    bvb_team_sync(&T.barrier, phase, team_size);
     float bmin[3], bmax[3], nmn[3], nmx[3];
     for (int j = 0; j < 3; ++j) {
         bmin[j] = bvb_unord(__hip_atomic_load(&T.cb[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0u);
@@ -602,27 +1004,29 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         axis_on[j] = !(bmin[j] == bmax[j]);
         scale[j] = (float)S / (bmax[j] - bmin[j]);
     }
-    for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) {
+    for (uint32_t base = c_begin; base < c_end; base += THREADS) {
+        const uint32_t pos = base + tid;
+        const bool have = pos < c_end;
         const uint32_t i = pos - first;
-        const uint32_t tri = a.order[pos];
-        const uint4 t = a.tris[tri];
-        const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
-        const float4 ce = a.centroid[tri];
-        const float cc[3] = {ce.x, ce.y, ce.z};
+        float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+        float cc[3] = {0.0f, 0.0f, 0.0f};
+        if (have) {
+            const uint32_t tri = a.order[pos];
+            const uint4 t = a.tris[tri];
+            v[0] = a.verts[t.x]; v[1] = a.verts[t.y]; v[2] = a.verts[t.z];
+            const float4 ce = a.centroid[tri];
+            cc[0] = ce.x; cc[1] = ce.y; cc[2] = ce.z;
+        }
+        unsigned long long k6[6], folded[6];
+        bvb_tri_keys(v, i, have, k6);
+        const bool fold = __builtin_amdgcn_ballot_w64(have) == ~0ull;
+        if (fold) bvb_wave_fold(k6, folded);
         for (int ax = 0; ax < 3; ++ax) {
             if (!axis_on[ax]) continue;
             const float x = (cc[ax] - bmin[ax]) * scale[ax];
             uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;
             if (si > S - 1u) si = S - 1u;
-            for (uint32_t k = 0; k < 3u; ++k) {
-                const uint32_t seq = i * 3u + k;
-                const float c[3] = {v[k].x, v[k].y, v[k].z};
-                for (int j = 0; j < 3; ++j) {
-                    atomicMin(&s_key[ax][si][j], bvb_min_key(c[j], seq));
-                    atomicMax(&s_key[ax][si][3 + j], bvb_max_key(c[j], seq));
-                }
-            }
-            atomicAdd(&s_cnt[ax][si], 1u);
+            bvb_bin_add(s_key[ax], s_cnt[ax], have, si, k6, folded, fold);
         }
     }
     __syncthreads();
@@ -637,7 +1041,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
             }
         }
     }
-    bvb_team_sync(&T.barrier, phase);
+    bvb_team_sync(&T.barrier, phase, team_size);
 
     /* ---- pass 3: member 0 evaluates the splits exactly as the single-workgroup kernel does */
     if (member == 0u) {
@@ -647,42 +1051,12 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
             s_cnt[ax][b] = __hip_atomic_load(&T.cnt[ax][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (tid < 3u) {
-            const uint32_t ax = tid;
+        if (tid < 192u) {                                      /* waves 0, 1, 2: one axis each (bvb_wave_sweep) */
+            const uint32_t ax = tid >> 6;
             float best_cost = __builtin_inff();
             uint32_t best_i = 0u;
-            if (axis_on[ax]) {
-                BvbBox lb, rb;
-                for (int j = 0; j < 3; ++j) { lb.mn[j] = rb.mn[j] = __builtin_inff(); lb.mx[j] = rb.mx[j] = -__builtin_inff(); }
-                uint32_t lsum = 0u, rsum = 0u;
-                for (uint32_t i = 0; i + 1u < S; ++i) {
-                    lsum += s_cnt[ax][i];
-                    s_lc[ax][i] = lsum;
-                    if (s_cnt[ax][i] != 0u && bvb_key_value(s_key[ax][i][0]) != __builtin_inff()) {
-                        for (int j = 0; j < 3; ++j) {
-                            lb.mn[j] = bvb_min(lb.mn[j], bvb_key_value(s_key[ax][i][j]));
-                            lb.mx[j] = bvb_max(lb.mx[j], bvb_key_value(s_key[ax][i][3 + j]));
-                        }
-                    }
-                    s_la[ax][i] = bvb_area(lb);
-                    const uint32_t r = S - 1u - i;
-                    rsum += s_cnt[ax][r];
-                    s_rc[ax][S - 2u - i] = rsum;
-                    if (s_cnt[ax][r] != 0u && bvb_key_value(s_key[ax][r][0]) != __builtin_inff()) {
-                        for (int j = 0; j < 3; ++j) {
-                            rb.mn[j] = bvb_min(rb.mn[j], bvb_key_value(s_key[ax][r][j]));
-                            rb.mx[j] = bvb_max(rb.mx[j], bvb_key_value(s_key[ax][r][3 + j]));
-                        }
-                    }
-                    s_ra[ax][S - 2u - i] = bvb_area(rb);
-                }
-                for (uint32_t i = 0; i + 1u < S; ++i) {
-                    const float cost = (float)s_lc[ax][i] * s_la[ax][i] + (float)s_rc[ax][i] * s_ra[ax][i];
-                    if (cost < best_cost) { best_cost = cost; best_i = i; }
-                }
-            }
-            s_best_cost[ax] = best_cost;
-            s_best_i[ax] = best_i;
+            if (axis_on[ax]) bvb_wave_sweep(s_key[ax], s_cnt[ax], S, best_cost, best_i);
+            if ((tid & 63u) == 0u) { s_best_cost[ax] = best_cost; s_best_i[ax] = best_i; }
         }
         __syncthreads();
         if (tid == 0u) {
@@ -703,7 +1077,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
             T.split = split;
         }
     }
-    bvb_team_sync(&T.barrier, phase);
+    bvb_team_sync(&T.barrier, phase, team_size);
     const int axis = T.axis;
     if (axis < 0) {
         if (member == 0u && tid == 0u) { node.left = BVB_NONE; node.pad[0] = 1u; }
@@ -726,9 +1100,9 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         __syncthreads();
         if (tid == 0u) T.chunk_l[member] = s_misc[0];
     }
-    bvb_team_sync(&T.barrier, phase);
+    bvb_team_sync(&T.barrier, phase, team_size);
     uint32_t nl = 0u, pref_l = 0u;
-    for (uint32_t b = 0; b < BVB_TEAM; ++b) {
+    for (uint32_t b = 0; b < team_size; ++b) {
         const uint32_t n = __hip_atomic_load(&T.chunk_l[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pref_l += b < member ? n : 0u;
         nl += n;
@@ -745,9 +1119,9 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         __syncthreads();
         if (tid == 0u) T.chunk_lf[member] = s_misc[0];
     }
-    bvb_team_sync(&T.barrier, phase);
+    bvb_team_sync(&T.barrier, phase, team_size);
     uint32_t l_in_prefix = 0u;
-    for (uint32_t b = 0; b < BVB_TEAM; ++b) l_in_prefix += __hip_atomic_load(&T.chunk_lf[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t b = 0; b < team_size; ++b) l_in_prefix += __hip_atomic_load(&T.chunk_lf[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t H = nl - l_in_prefix;
 
     /* ---- pass 6 (B1): rb_at_L for the suffix left-side elements of this chunk */
@@ -766,7 +1140,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
             run += tot;
         }
     }
-    bvb_team_sync(&T.barrier, phase);
+    bvb_team_sync(&T.barrier, phase, team_size);
     const uint32_t base_rb = H >= 1u ? __hip_atomic_load(&a.tmp_b[first + H - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     /* ---- pass 7 (F): the prefix */
     {
@@ -790,7 +1164,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
             run += tot;
         }
     }
-    bvb_team_sync(&T.barrier, phase);
+    bvb_team_sync(&T.barrier, phase, team_size);
     /* ---- pass 8 (B2): the suffix */
     {
         uint32_t run = pref_l;
@@ -816,7 +1190,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
             run += tot;
         }
     }
-    bvb_team_sync(&T.barrier, phase);
+    bvb_team_sync(&T.barrier, phase, team_size);
     for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS)
         a.order[pos] = __hip_atomic_load(&a.order_tmp[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (member == 0u && tid == 0u) {
@@ -826,8 +1200,8 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         } else {
             const uint32_t id = atomicAdd(a.node_count, 2u);
             node.left = id;
-            a.nodes[id].first = first;          a.nodes[id].count = nl;              a.nodes[id].left = BVB_NONE;   a.nodes[id].pad[0] = 0u;
-            a.nodes[id + 1u].first = first + nl; a.nodes[id + 1u].count = count - nl; a.nodes[id + 1u].left = BVB_NONE; a.nodes[id + 1u].pad[0] = 0u;
+            a.nodes[id].first = first;          a.nodes[id].count = nl;              a.nodes[id].left = BVB_NONE;   a.nodes[id].pad[0] = 0u;   a.nodes[id].pad[1] = 0u;
+            a.nodes[id + 1u].first = first + nl; a.nodes[id + 1u].count = count - nl; a.nodes[id + 1u].left = BVB_NONE; a.nodes[id + 1u].pad[0] = 0u; a.nodes[id + 1u].pad[1] = 0u;
         }
     }
 }

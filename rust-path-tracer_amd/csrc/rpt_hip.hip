@@ -1805,12 +1805,15 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     DevBuf<uint32_t> d_order, d_order_tmp, d_tmp_a, d_tmp_b, d_count;
     DevBuf<BvbNode> d_nodes;
     DevBuf<BvbTeamScratch> d_scratch;
-    DevBuf<uint32_t> d_team_nodes, d_inner, d_rank, d_oidx;
+    DevBuf<BvbTeamRef> d_team_refs;
+    DevBuf<uint16_t> d_block_team;
+    DevBuf<uint32_t> d_inner, d_rank, d_oidx;
     DevBuf<rpt_bvh_node> d_out;
     std::vector<std::pair<uint32_t, uint32_t>> levels;          /* build-order id ranges, root level first */
     const bool use_teams = true;
     uint32_t team_min = BVB_TEAM_MIN_COUNT;           /* RPT_BVH_TEAM_MIN: test aid, lets small nodes take the team path */
     if (const int forced = rpt_read_knobs().bvh_team_min) team_min = (uint32_t)forced;
+    const uint32_t team_chunk = BVB_TEAM_CHUNK;
     std::vector<BvbNode> bn;
     std::vector<uint32_t> order;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1828,7 +1831,8 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BVB_TRY(d_count.alloc(2));                       /* [0] nodes so far, [1] the largest child created by the level just built */
         BVB_TRY(d_nodes.alloc(2 * (size_t)nt - 1));
         BVB_TRY(d_scratch.alloc(BVB_MAX_TEAMS));
-        BVB_TRY(d_team_nodes.alloc(BVB_MAX_TEAMS));
+        BVB_TRY(d_team_refs.alloc(BVB_MAX_TEAMS));
+        BVB_TRY(d_block_team.alloc(BVB_MAX_TEAMS * BVB_TEAM));
         BVB_TRY(hipMemcpy(d_verts.p, vertices_xyzw, n_vertices * sizeof(float4), hipMemcpyHostToDevice));
         BVB_TRY(hipMemcpy(d_tris.p, triangles, nt * sizeof(uint4), hipMemcpyHostToDevice));
         BvbNode root{};
@@ -1842,44 +1846,59 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BvbArgs a{d_verts.p, d_tris.p, d_centroid.p, d_order.p, d_order_tmp.p, d_tmp_a.p, d_tmp_b.p, d_nodes.p, d_count.p, nt, sah_samples};
         BVB_TRY(hipEventRecord(ev0, nullptr));
         k_bvb_init<<<(nt + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(a);
-        /* a team's 64 workgroups meet at counter barriers (bvb_team_sync): every workgroup of the launch must be resident at
-         * once, so the number of teams is capped by what the device can hold (a CU-masked or partitioned device holds fewer;
+        /* a team's workgroups meet at counter barriers (bvb_team_sync): every workgroup of the launch must be resident at
+         * once, so the teams of a launch are capped by what the device can hold (a CU-masked or partitioned device holds fewer;
          * with room for none the big nodes simply take the one-workgroup path) */
-        uint32_t max_teams = BVB_MAX_TEAMS;
+        uint32_t resident = 0u;
         {
             int per_cu = 0;
             hipDeviceProp_t prop;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bvb_team, BVB_TEAM_THREADS, 0) == hipSuccess &&
                 hipGetDeviceProperties(&prop, device_id) == hipSuccess && per_cu > 0 && prop.multiProcessorCount > 0) {
                 /* one block per CU less than the API says: it over-reports by one at some register counts (MI355X_MICROARCH.md) */
-                const uint32_t resident = (uint32_t)std::max(0, per_cu - 1) * (uint32_t)prop.multiProcessorCount;
-                max_teams = std::min<uint32_t>(BVB_MAX_TEAMS, resident / BVB_TEAM);
-            } else {
-                max_teams = 0;
+                resident = std::min<uint32_t>((uint32_t)std::max(0, per_cu - 1) * (uint32_t)prop.multiProcessorCount, BVB_MAX_TEAMS * BVB_TEAM);
             }
         }
         uint32_t begin = 0, end = 1, level_max = nt;        /* level_max: the largest node of the level about to be built */
         std::vector<BvbNode> level_nodes;
-        std::vector<uint32_t> team_nodes;
+        std::vector<BvbTeamRef> team_refs;
+        std::vector<uint16_t> block_team;
         while (begin < end) {                               /* one launch per tree level */
             bool teams_here = false;
-            /* the huge nodes of this level (if any) are split by teams of workgroups first */
-            if (use_teams && max_teams != 0u && end - begin <= 4096u) {
+            /* the big nodes of this level (if any) are split by teams of workgroups first: one workgroup per BVB_TEAM_CHUNK triangles */
+            if (use_teams && resident >= 2u && end - begin <= 4096u && level_max >= team_min) {
                 level_nodes.resize(end - begin);
                 BVB_TRY(hipMemcpy(level_nodes.data(), d_nodes.p + begin, (size_t)(end - begin) * sizeof(BvbNode), hipMemcpyDeviceToHost));
-                team_nodes.clear();
-                for (uint32_t k = 0; k < end - begin && team_nodes.size() < max_teams; ++k)
-                    if (level_nodes[k].count >= team_min) team_nodes.push_back(begin + k);
-                if (!team_nodes.empty()) {
-                    BVB_TRY(hipMemcpy(d_team_nodes.p, team_nodes.data(), team_nodes.size() * 4, hipMemcpyHostToDevice));
-                    k_bvb_team_init<<<(unsigned)team_nodes.size(), BVB_TEAM_THREADS>>>(d_scratch.p, d_team_nodes.p);
-                    k_bvb_team<<<(unsigned)team_nodes.size() * BVB_TEAM, BVB_TEAM_THREADS>>>(a, d_scratch.p);
+                team_refs.clear();
+                block_team.clear();
+                for (uint32_t k = 0; k < end - begin && team_refs.size() < BVB_MAX_TEAMS; ++k) {
+                    if (level_nodes[k].count < team_min) continue;
+                    uint32_t size = 2u;
+                    while (size < BVB_TEAM && (size_t)size * team_chunk < level_nodes[k].count) size *= 2u;
+                    while (size > 2u && block_team.size() + size > resident) size /= 2u;
+                    if (block_team.size() + size > resident) break;
+                    team_refs.push_back(BvbTeamRef{begin + k, size, (uint32_t)block_team.size()});
+                    block_team.insert(block_team.end(), size, (uint16_t)(team_refs.size() - 1));
+                }
+                if (!team_refs.empty()) {
+                    BVB_TRY(hipMemcpy(d_team_refs.p, team_refs.data(), team_refs.size() * sizeof(BvbTeamRef), hipMemcpyHostToDevice));
+                    BVB_TRY(hipMemcpy(d_block_team.p, block_team.data(), block_team.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                    k_bvb_team_init<<<(unsigned)team_refs.size(), BVB_TEAM_THREADS>>>(d_scratch.p, d_team_refs.p);
+                    k_bvb_team<<<(unsigned)block_team.size(), BVB_TEAM_THREADS>>>(a, d_scratch.p, d_block_team.p);
                     teams_here = true;                      /* (their children are not in level_max: the next level keeps the wide workgroups) */
                 }
             }
-            if (end - begin < 64u) k_bvb_level<1024><<<end - begin, 1024>>>(a, begin);      /* top of the tree: few, big nodes */
-            else if (level_max <= 256u) k_bvb_level<64><<<end - begin, 64>>>(a, begin);     /* small nodes: one wave each (measured: 64 / 256 / 1024 as the limit) */
-            else k_bvb_level<BVB_THREADS><<<end - begin, BVB_THREADS>>>(a, begin);
+            if (end - begin < 64u || level_max >= BVB_WIDE_MIN_COUNT) k_bvb_level<1024><<<end - begin, 1024>>>(a, begin, 0u);    /* few nodes, or big ones */
+            else if (level_max <= 256u) {
+                /* small nodes: those of up to 8 triangles eight to a wave, the others one wave each — out of registers up to 64 triangles
+                 * (measured: 64 / 256 / 1024 as the limit of the one-wave kernel) */
+                k_bvb_tiny<<<(end - begin + 7u) / 8u, 64>>>(a, begin, end);
+                if (level_max > BVB_TINY) {
+                    if (level_max <= 64u) k_bvb_small<<<end - begin, 64>>>(a, begin, BVB_TINY);
+                    else k_bvb_level<64><<<end - begin, 64>>>(a, begin, BVB_TINY);
+                }
+            } else k_bvb_level<BVB_THREADS><<<end - begin, BVB_THREADS>>>(a, begin, 0u);
+            k_bvb_children<<<(end - begin + 1023u) / 1024u, 1024>>>(a, begin, end);
             uint32_t total[2] = {0u, 0u};
             BVB_TRY(hipMemcpy(total, d_count.p, 8, hipMemcpyDeviceToHost));
             BVB_TRY(hipMemsetAsync(d_count.p + 1, 0, 4, nullptr));
@@ -1921,14 +1940,14 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
-    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_nodes.release();
+    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_refs.release(); d_block_team.release();
     d_inner.release(); d_rank.release(); d_oidx.release(); d_out.release();
     return RPT_OK;
 fail:
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
-    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_nodes.release();
+    d_tmp_a.release(); d_tmp_b.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_refs.release(); d_block_team.release();
     d_inner.release(); d_rank.release(); d_oidx.release(); d_out.release();
     return RPT_EHIP;
 #undef BVB_TRY

@@ -189,3 +189,72 @@ def test_gpu_build_on_hostile_coordinates():
         hip.bvh_build_gpu(v, t.copy())
     assert "NaN" in str(e.value)
     assert len(_oracle_build(v, t.copy())[0]) >= 1          # (host and oracle builders agree on the NaN soup too: f32::min / max skip it)
+
+
+def _soup_of(v3):
+    ffi = importlib.import_module("rust-path-tracer_amd._ffi")
+    n = len(v3) // 3
+    v = np.concatenate([v3.astype(np.float32), np.ones((len(v3), 1), np.float32)], 1)
+    t = np.zeros(n, ffi.TRIANGLE_DTYPE)
+    idx = np.arange(n * 3, dtype=np.uint32).reshape(n, 3)
+    nm = t.dtype.names
+    t[nm[0]], t[nm[1]], t[nm[2]] = idx[:, 0], idx[:, 1], idx[:, 2]
+    return v, t
+
+
+@pytest.mark.parametrize("bins", [5, 128])
+def test_gpu_build_bins_the_sweep_skips(bins):
+    """A bin whose least x is +inf is an "empty box" to the sweep (bvh.rs:214-229 via encapsulate_node) though its triangles count.  Such a bin only
+    changes a decision where the +inf triangles sit ALONE in their bins (one that shares a bin with finite triangles makes that bin's box, and every
+    fold over it, infinite): a dense strip of finite triangles and a few isolated ones with x = +inf beyond its end.  The node at the end of the strip
+    keeps them down to the smallest sizes: the binned kernels, the register kernel and the eight-nodes-per-wave kernel, which has no bins and must
+    skip them by name (checked by mutation: without its `excluded` this test fails)."""
+    rpt, hip, host = _mods()
+    rng = np.random.default_rng(bins)
+    deepest = 0
+    for n_inf in (1, 2, 3, 5, 7):
+        for axis in (1, 2):
+            n = 400
+            c = np.zeros((n, 1, 3), np.float32)
+            c[:, 0, axis] = np.sort(rng.random(n)).astype(np.float32)
+            c[:, 0, 3 - axis] = rng.random(n).astype(np.float32) * 0.01
+            v3 = (c + rng.normal(size=(n, 3, 3)).astype(np.float32) * 0.0005).reshape(n, 3, 3)
+            far = np.zeros((n_inf, 3, 3), np.float32)
+            far[:, :, axis] = (2.0 + np.arange(n_inf, dtype=np.float32))[:, None] + rng.normal(size=(n_inf, 3)).astype(np.float32) * 0.0005
+            far[:, :, 0] = np.inf
+            if n_inf >= 3:
+                far[1, :, 3 - axis] = -np.inf
+            v, t = _soup_of(np.concatenate([v3, far]).reshape(-1, 3))
+            t = t[rng.permutation(len(t))]
+            hn, ht = _oracle_build(v, t.copy(), bins)
+            gn, gt, _ = hip.bvh_build_gpu(v, t.copy(), bins)
+            _assert_same(gn, gt, hn, ht)
+            deepest = max(deepest, len(hn))
+    assert deepest > 400         # (with 5 bins and 5+ far triangles the strip shares a bin with one of them: a single leaf, on both sides)
+
+
+def test_gpu_build_of_input_in_spatial_order():
+    """What a scene file or an earlier build gives: neighbours in the index buffer are neighbours in space, so a wave's 64 triangles
+    fall into one bin (the wave folds its keys and updates the bin once, k_bvh_build.h bvb_bin_add) — and so do teams' chunks."""
+    rpt, hip, host = _mods()
+    from scenes import deep_bvh_scene, scatter_scene
+    for w in (deep_bvh_scene(120_000), scatter_scene(60_000)):
+        v = np.ascontiguousarray(w.per_vertex["vertex"], np.float32).reshape(-1, 4)
+        t = w.indices.copy()                              # leaf order of the build that made the scene
+        hn, ht = _oracle_build(v, t.copy())
+        gn, gt, _ = hip.bvh_build_gpu(v, t.copy())
+        _assert_same(gn, gt, hn, ht)
+
+
+@pytest.mark.parametrize("team_min", ["2", "9", "300"])
+def test_teams_of_every_size(monkeypatch, team_min):
+    """Teams are sized by their node (one workgroup per 8 192 triangles, 2 ... 256): with the threshold at 2 / 9 / 300 triangles up to 128 two-
+    workgroup teams run beside the one-workgroup kernels of the same level, the eight-per-wave kernel takes what is left."""
+    monkeypatch.setenv("RPT_BVH_TEAM_MIN", team_min)
+    rpt, hip, host = _mods()
+    from scenes import scatter_scene
+    w = scatter_scene(20_000)
+    v, t = _original_soup(w)
+    hn, ht = _oracle_build(v, t.copy())
+    gn, gt, _ = hip.bvh_build_gpu(v, t.copy())
+    _assert_same(gn, gt, hn, ht)
