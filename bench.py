@@ -293,7 +293,7 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
             # "Startup time (GPU)" of the reference's own bench (benches/benchmark.rs:11-13: trace_gpu(scene, 0 samples) = load the scene, build the BVH
             # and the light table, create the buffers) for this scene, scene-preparation steps on the device: BVH (rpt_bvh_build_gpu) + light table
             # (rpt_light_table_build_gpu) from the raw triangles, then rpt_upload_scene (upload-time derivations + the shadow-order probe), set_config,
-            # reset; the first batch (which also touches every page of the path state) is reported beside it.  File parsing has no counterpart here:
+            # reset; the first batch (which also allocates the path state) is reported beside it, with the steady batch.  File parsing has no counterpart here:
             # the stand-in is generated.
             torch.cuda.synchronize()
             v = np.ascontiguousarray(world.per_vertex["vertex"], np.float32).reshape(-1, 4)
@@ -372,6 +372,9 @@ def measure_single_gpu_workload(rpt, hip, name, steps, warmup, spp_per_step, dev
         par.pop("against", None)
     if "valu" in pipeline:
         pipeline["valu"].pop("issue_frac_is", None)
+    if startup:
+        # (the first batch also allocates the path state; beside it the batch of the timed loop, so that nobody reads the batch itself as a start-up cost)
+        startup["steady_batch_ms"] = round(elapsed / steps * 1e3, 2)
     return {"value": round((n_ext + n_shadow) / elapsed / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
             "value_as_the_reference_counts": round((n_ext + n_shadow + n_elided) / elapsed / 1e6, 3),   # + the shadow rays the reference traces and this build proves irrelevant
             "steps": steps, "warmup": warmup, "samples_per_s": round(n_samples / elapsed, 1),
