@@ -12,7 +12,7 @@ CXX      ?= g++
 
 HOST_SRCS := $(CSRC)/host/host_api.cpp $(CSRC)/host/glb_scene.cpp $(CSRC)/host/bvh_build.cpp \
              $(CSRC)/host/light_table.cpp $(CSRC)/host/bluenoise.cpp $(CSRC)/host/image_io.cpp $(CSRC)/host/textures.cpp $(CSRC)/host/obj_scene.cpp $(CSRC)/host/jpeg_decode.cpp
-HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_traverse.hip $(CSRC)/rpt_comm.hip $(CSRC)/rpt_lights.hip
+HIP_SRCS  := $(CSRC)/rpt_hip.hip $(CSRC)/rpt_traverse.hip $(CSRC)/rpt_comm.hip $(CSRC)/rpt_lights.hip $(CSRC)/rpt_bvh.hip
 HIP_OBJS  := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
 HIP_DEPS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hip) $(wildcard include/rpt/*.h)
 
@@ -52,7 +52,7 @@ build/%.o: $(CSRC)/%.hip $(HIP_DEPS) tools/source_fingerprint.py Makefile
 
 $(LIBDIR)/librpt_hip.so: $(HIP_SRCS) $(HIP_DEPS) tools/source_fingerprint.py Makefile
 	@mkdir -p $(LIBDIR)
-	$(MAKE) -j4 $(HIP_OBJS)
+	$(MAKE) -j5 $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(HIP_OBJS) -ldl
 
 # test infrastructure: a stand-in for RCCL's point-to-point calls over shared memory, so that N PROCESSES on a one-GPU test box run

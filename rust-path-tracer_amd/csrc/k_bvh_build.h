@@ -58,8 +58,9 @@ struct BvbArgs {
     float4 *centroid;           /* per original triangle */
     uint32_t *order;            /* position -> original triangle */
     uint32_t *order_tmp, *tmp_a, *tmp_b;
+    uint8_t *side;              /* per position: 1 = left of the node's split (written by the partition's counting pass, read by its three ranking passes) */
     BvbNode *nodes;
-    uint32_t *node_count;
+    uint32_t *node_count;       /* [0] nodes so far, [1] the largest child the level just built has made, [2] a kernel met a node it was not built for */
     uint32_t n_tris, bins;
 };
 
@@ -430,7 +431,11 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
     uint32_t nl;
     {
         uint32_t mine = 0u;
-        for (uint32_t i = tid; i < count; i += THREADS) mine += is_left(first + i) ? 1u : 0u;
+        for (uint32_t i = tid; i < count; i += THREADS) {
+            const bool l = is_left(first + i);
+            a.side[first + i] = l ? 1u : 0u;
+            mine += l ? 1u : 0u;
+        }
         if (tid == 0u) s_misc[0] = 0u;
         __syncthreads();
         atomicAdd(&s_misc[0], mine);
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
             const uint32_t i = base + tid;
             const bool valid = i < back_n;
             const uint32_t q = last - i;
-            const bool L = valid && is_left(q);
+            const bool L = valid && (a.side[q] != 0u);
             const bool R = valid && !L;
             uint32_t tot_l, tot_r;
             const uint32_t m = run_l + bvb_block_rank<THREADS>(L, s_wave_tot, tot_l);
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
             const uint32_t i = base + tid;
             const bool valid = i < nl;
             const uint32_t p = first + i;
-            const bool L = valid && is_left(p);
+            const bool L = valid && (a.side[p] != 0u);
             const bool R = valid && !L;
             uint32_t tot;
             const uint32_t hole = run + bvb_block_rank<THREADS>(R, s_wave_tot, tot);
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
             const uint32_t i = base + tid;
             const bool valid = i < back_n;
             const uint32_t q = last - i;
-            const bool L = valid && is_left(q);
+            const bool L = valid && (a.side[q] != 0u);
             const bool R = valid && !L;
             uint32_t tot_l, tot_r;
             const uint32_t m = run_l + bvb_block_rank<THREADS>(L, s_wave_tot, tot_l);
@@ -569,6 +574,10 @@ __global__ __launch_bounds__(64) void k_bvb_small(BvbArgs a, uint32_t level_begi
     if (node.pad[0] != 0u) return;
     const uint32_t first = node.first, count = node.count, S = a.bins;       /* count <= 64: the host launches this kernel only then */
     if (count <= skip_upto) return;
+    if (count > 64u) {                             /* (cannot happen: the host picks the kernel by the level's largest node — said aloud rather than built wrong) */
+        if (lane == 0u) atomicOr(a.node_count + 2, 1u);
+        return;
+    }
     const bool have = lane < count;
     uint32_t tri = 0u;
     float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
@@ -1093,7 +1102,11 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
     /* ---- pass 4: left counts per chunk -> nl and this chunk's prefix */
     {
         uint32_t mine = 0u;
-        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) mine += is_left(pos) ? 1u : 0u;
+        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) {
+            const bool l = is_left(pos);
+            a.side[pos] = l ? 1u : 0u;                             /* (read back by this workgroup only: its chunk) */
+            mine += l ? 1u : 0u;
+        }
         if (tid == 0u) s_misc[0] = 0u;
         __syncthreads();
         atomicAdd(&s_misc[0], mine);
@@ -1111,7 +1124,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
     /* ---- pass 5: left-side elements inside the prefix -> H (holes) */
     {
         uint32_t mine = 0u;
-        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) mine += (pos < split_pos && is_left(pos)) ? 1u : 0u;
+        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) mine += (pos < split_pos && (a.side[pos] != 0u)) ? 1u : 0u;
         __syncthreads();
         if (tid == 0u) s_misc[0] = 0u;
         __syncthreads();
@@ -1130,7 +1143,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         for (uint32_t base = c_begin; base < c_end; base += THREADS) {
             const uint32_t q = base + tid;
             const bool valid = q < c_end;
-            const bool L = valid && is_left(q);
+            const bool L = valid && (a.side[q] != 0u);
             uint32_t tot;
             const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
             if (L && q >= split_pos) {
@@ -1148,7 +1161,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         for (uint32_t base = c_begin; base < c_end; base += THREADS) {
             const uint32_t p = base + tid;
             const bool valid = p < c_end;
-            const bool L = valid && is_left(p);
+            const bool L = valid && (a.side[p] != 0u);
             uint32_t tot;
             const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
             if (valid && p < split_pos) {
@@ -1171,7 +1184,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         for (uint32_t base = c_begin; base < c_end; base += THREADS) {
             const uint32_t q = base + tid;
             const bool valid = q < c_end;
-            const bool L = valid && is_left(q);
+            const bool L = valid && (a.side[q] != 0u);
             uint32_t tot;
             const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
             if (valid && q >= split_pos) {

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -173,5 +175,26 @@ void rpt_build_pixel_order(uint32_t W, uint32_t H, uint32_t rank, uint32_t world
 void rpt_comm_release(rpt_ctx *c);
 void rpt_image_release(rpt_ctx *c);
 std::string &rpt_create_error();
+
+/* RPT_UPLOAD_TIMING=1: host-side section times of rpt_upload_scene / rpt_bvh_build_gpu on stderr (where the start-up time of a large scene goes) */
+struct SectionTimer {
+    bool on;
+    const char *title;
+    std::chrono::steady_clock::time_point last;
+    std::string line;
+    explicit SectionTimer(const char *t) : on(false), title(t) {
+        on = rpt_read_knobs().upload_timing;
+        last = std::chrono::steady_clock::now();
+    }
+    void mark(const char *name) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof buf, " %s %.1f", name, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~SectionTimer() { if (on) fprintf(stderr, "%s (ms):%s\n", title, line.c_str()); }
+};
 
 #endif /* RPT_CTX_H */
