@@ -13,4 +13,10 @@ for seed in ${FUZZ_API_SEEDS:-31 32 33 34}; do
   echo "## tools/fuzz_api.py 500 $seed" >> $OUT
   timeout 1500 python3 tools/fuzz_api.py 500 $seed 2>&1 | tail -3 >> $OUT
 done
+echo "## tools/fuzz_last_bounce.py 120 ${FUZZ_LAST_SEED:-78}" >> $OUT
+timeout 1500 python3 tools/fuzz_last_bounce.py 120 ${FUZZ_LAST_SEED:-78} 2>&1 | tail -3 >> $OUT
+for seed in ${FUZZ_BVH_SEEDS:-7 99}; do
+  echo "## tools/fuzz_bvh_build.py 8000 $seed" >> $OUT
+  timeout 1500 python3 tools/fuzz_bvh_build.py 8000 $seed 2>&1 | tail -3 >> $OUT
+done
 cat $OUT
