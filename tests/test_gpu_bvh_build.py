@@ -128,7 +128,7 @@ def test_world_loader_with_gpu_builder_gives_the_same_world():
 
 @pytest.mark.parametrize("team_min", ["64", "1000"])
 def test_team_kernels_on_small_nodes(monkeypatch, team_min):
-    """k_bvb_team (64 workgroups per node, chunked passes, counter barriers) is meant for nodes of 65 536+ triangles;
+    """k_bvb_team (a team of workgroups per node, chunked passes, counter barriers) is meant for nodes of 16 384+ triangles;
     with the threshold lowered every upper node of the shipped scenes and of the signed-zero stress soup goes through
     it — chunks shorter than a tile, empty chunks, empty-side partitions included."""
     monkeypatch.setenv("RPT_BVH_TEAM_MIN", team_min)
