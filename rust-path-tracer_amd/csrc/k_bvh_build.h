@@ -30,8 +30,8 @@
  *   9 ... 64            k_bvb_small: one wave, the node's triangles fetched once and kept in registers;
  *   up to 8             k_bvb_tiny: eight nodes per wave, no bins.
  * The children of a level are numbered by k_bvb_children (one atomic per 1 024 nodes: the two hot words — next free id, largest child — cost 11 ns per
- * wave-atomic device-wide, which was most of a deep level's time).  Round 6, 1 M triangles: 40 -> 12 ms (64-triangle leaves, input in spatial order)
- * and 40 -> 10 ms (2 M nodes); profiles/r06_bvh_levels_*.txt.
+ * wave-atomic device-wide, which was most of a deep level's time).  Round 6, 1 M triangles: 40 -> 5.8 ms (64-triangle leaves, input in spatial order)
+ * and 38 -> 6.0 ms (2 M nodes); profiles/r06_bvh_levels_*.txt, r06_bvh_input_order.txt (step by step).
  */
 #ifndef RPT_K_BVH_BUILD_H
 #define RPT_K_BVH_BUILD_H
@@ -52,16 +52,28 @@ struct BvbNode {
     uint32_t pad[3];
 };
 
+/* What the build reads of a triangle — its box, which of its three vertices the sequential fold of the bounds would have kept per component (the tie-break of the
+ * keys: the LAST vertex that attains the minimum / maximum, -0 == +0), its centroid — gathered once by k_bvb_init into one 64-byte line: every pass over a node is
+ * position -> triangle -> this line instead of position -> triangle -> vertex indices -> three vertices (+ the centroid): five random 16-byte reads over 48 MB became
+ * one, three dependent round trips two (a big node's bounds and bin passes are nothing else). */
+struct BvbRec {
+    float4 mn;                  /* least x, y, z over the vertices (as the winner holds it: the sign of a zero is the winner's); w: 2 bits per key = the winner's vertex, keys 0-5 */
+    float4 mx;
+    float4 ce;                  /* (v0 + v1 + v2) / 3.0 (bvh.rs:66-69) */
+    float4 pad;
+};
+
 struct BvbArgs {
     const float4 *verts;
     const uint4 *tris;          /* original order */
-    float4 *centroid;           /* per original triangle */
+    struct BvbRec *recs;        /* per original triangle: everything the build reads of it, in one 64-byte line (k_bvb_init) */
     uint32_t *order;            /* position -> original triangle */
     uint32_t *order_tmp, *tmp_a, *tmp_b;
-    uint8_t *side;              /* per position: 1 = left of the node's split (written by the partition's counting pass, read by its three ranking passes) */
+    uint32_t *lpre;             /* per position of a node being partitioned: (left-side elements before it << 1) | it is one — written by the partition's counting pass;
+                                   every later quantity of the closed form follows from it without another scan (teams: counted inside the workgroup's chunk) */
     BvbNode *nodes;
-    uint32_t *node_count;       /* [0] nodes so far, [1] the largest child the level just built has made, [2] a kernel met a node it was not built for */
-    uint32_t n_tris, bins;
+    uint32_t *node_count;       /* [0] nodes so far, [1] the largest child the level just built has made, [2] bits: 1 a kernel met a node it was not built for, 2 a vertex index out of range, 4 a NaN coordinate */
+    uint32_t n_tris, bins, n_verts;
 };
 
 /* monotone float -> u32 with both zeros on the same code; the sign of a zero travels separately */
@@ -96,10 +108,40 @@ __global__ __launch_bounds__(BVB_THREADS) void k_bvb_init(BvbArgs a) {
     uint32_t i = blockIdx.x * BVB_THREADS + threadIdx.x;
     if (i >= a.n_tris) return;
     uint4 t = a.tris[i];
-    float4 v0 = a.verts[t.x], v1 = a.verts[t.y], v2 = a.verts[t.z];
-    /* (v0 + v1 + v2) / 3.0 (bvh.rs:66-69) */
-    a.centroid[i] = make_float4(((v0.x + v1.x) + v2.x) / 3.0f, ((v0.y + v1.y) + v2.y) / 3.0f, ((v0.z + v1.z) + v2.z) / 3.0f, 0.0f);
     a.order[i] = i;
+    if (t.x >= a.n_verts || t.y >= a.n_verts || t.z >= a.n_verts) {      /* said to the host (node_count[2]); the build runs on over a point at the origin and is thrown away */
+        atomicOr(a.node_count + 2, 2u);
+        BvbRec z;
+        z.mn = z.mx = z.ce = z.pad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        a.recs[i] = z;
+        return;
+    }
+    const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
+    {   /* the ordered keys have no place for a NaN (which f32::min / max skip): refused, see rpt_bvh_build_gpu */
+        bool nan = false;
+        for (int k = 0; k < 3; ++k) nan = nan || v[k].x != v[k].x || v[k].y != v[k].y || v[k].z != v[k].z;
+        if (nan) atomicOr(a.node_count + 2, 4u);
+    }
+    BvbRec r;
+    /* (v0 + v1 + v2) / 3.0 (bvh.rs:66-69) */
+    r.ce = make_float4(((v[0].x + v[1].x) + v[2].x) / 3.0f, ((v[0].y + v[1].y) + v[2].y) / 3.0f, ((v[0].z + v[1].z) + v[2].z) / 3.0f, 0.0f);
+    /* the fold of the three vertices under the keys' order: value first, then the later vertex (bvb_min_key / bvb_max_key with seq = 3 i + k) */
+    float lo[3], hi[3];
+    uint32_t who = 0u;
+    for (int j = 0; j < 3; ++j) {
+        const float c[3] = {j == 0 ? v[0].x : (j == 1 ? v[0].y : v[0].z), j == 0 ? v[1].x : (j == 1 ? v[1].y : v[1].z), j == 0 ? v[2].x : (j == 1 ? v[2].y : v[2].z)};
+        uint32_t kl = 0u, kh = 0u;
+        for (uint32_t k = 1; k < 3u; ++k) {
+            if (bvb_min_key(c[k], k) < bvb_min_key(c[kl], kl)) kl = k;
+            if (bvb_max_key(c[k], k) > bvb_max_key(c[kh], kh)) kh = k;
+        }
+        lo[j] = c[kl]; hi[j] = c[kh];
+        who |= (kl << (2 * j)) | (kh << (2 * (3 + j)));
+    }
+    r.mn = make_float4(lo[0], lo[1], lo[2], __uint_as_float(who));
+    r.mx = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    r.pad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    a.recs[i] = r;
 }
 
 struct BvbBox {
@@ -131,23 +173,72 @@ __device__ __forceinline__ uint32_t bvb_block_rank(bool flag, uint32_t *wave_tot
     return before + within;
 }
 
+/* exclusive prefix, in thread order, of a small per-thread count over the workgroup (+ the workgroup's total); every thread calls */
+template <int THREADS>
+__device__ __forceinline__ uint32_t bvb_block_scan(uint32_t v, uint32_t *wave_tot, uint32_t &block_total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    __syncthreads();                       /* wave_tot free again */
+    if (lane == 63u) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0u, total = 0u;
+    for (uint32_t w = 0; w < (uint32_t)THREADS / 64u; ++w) {
+        const uint32_t n = wave_tot[w];
+        before += w < wave ? n : 0u;
+        total += n;
+    }
+    block_total = total;
+    return before + inc - v;
+}
+
+/* The partition's counting pass over positions [begin, end): each thread takes BVB_RUN consecutive positions per trip (their gathers — position -> triangle ->
+ * centroid — in flight together), one workgroup scan per trip; leaves (left-side elements before the position, counted from `begin`) << 1 | is-left in a.lpre
+ * and returns the number of left-side elements (bvh.rs:283: centroid[axis] < split).  Everything the closed-form partition needs afterwards is a function of
+ * that word (the first form ranked the elements again in each of the three passes, two workgroup barriers per trip; one scan is simpler and 3 % faster —
+ * a big node's time is in its bounds and bin passes, 0.10 ms each of the 0.24 ms a 16 k-triangle node takes under 1 024 threads: random gathers, position ->
+ * triangle -> vertices, over 48 MB). */
+#define BVB_RUN 4
+template <int THREADS>
+__device__ __forceinline__ uint32_t bvb_count_left(const BvbArgs &a, uint32_t begin, uint32_t end, int axis, float split, uint32_t *wave_tot) {
+    uint32_t run = 0u;
+    for (uint32_t base = begin; base < end; base += (uint32_t)THREADS * BVB_RUN) {
+        uint32_t tri[BVB_RUN];
+        bool have[BVB_RUN], left[BVB_RUN];
+        const uint32_t p0 = base + threadIdx.x * BVB_RUN;
+        _Pragma("unroll") for (int e = 0; e < BVB_RUN; ++e) { have[e] = p0 + (uint32_t)e < end; tri[e] = a.order[have[e] ? p0 + (uint32_t)e : begin]; }
+        uint32_t mine = 0u;
+        _Pragma("unroll") for (int e = 0; e < BVB_RUN; ++e) {
+            const float4 ce = a.recs[tri[e]].ce;
+            const float c = axis == 0 ? ce.x : (axis == 1 ? ce.y : ce.z);
+            left[e] = have[e] && c < split;
+            mine += left[e] ? 1u : 0u;
+        }
+        uint32_t total;
+        uint32_t before = run + bvb_block_scan<THREADS>(mine, wave_tot, total);
+        _Pragma("unroll") for (int e = 0; e < BVB_RUN; ++e)
+            if (have[e]) { a.lpre[p0 + (uint32_t)e] = (before << 1) | (left[e] ? 1u : 0u); before += left[e] ? 1u : 0u; }
+        run += total;
+    }
+    return run;
+}
+
 /* ---- a triangle into the bins --------------------------------------------------------------------------------------------------------------------------------
  * bvh.rs:214-229 grows the bin's box by the triangle's three vertices: nine coordinates, eighteen min / max folds.  The fold over a triangle's own three vertices
- * can be taken first (bvb_tri_keys: six keys per triangle, the same for every axis); and where the triangles a wave holds fall into ONE bin of an axis — the rule
- * for an input in spatial order, such as a scene file's meshes or an earlier build's leaf order — the wave folds its six keys (bvb_wave_fold) and one lane
- * updates the bin: 7 LDS atomics per wave instead of 64 x 19 on one address, which serialise (the clustered 1 M-triangle stand-in in leaf order took 40 ms against
- * 20 ms shuffled, profiles/r06_bvh_input_order.txt). */
-__device__ __forceinline__ void bvb_tri_keys(const float4 v[3], uint32_t i, bool valid, unsigned long long k6[6]) {
+ * is taken once, by k_bvb_init (BvbRec; bvb_rec_keys: six keys per triangle, the same for every axis): 7 LDS atomics per triangle and axis instead of 19.  What
+ * they cost is decided by how many lanes of a wave meet on one address — an LDS atomic is served lane by lane —, hence bvb_scatter_index below, and the wave's
+ * own fold (bvb_wave_fold) before anything that every thread of a workgroup would add to the same word (the node's bounds). */
+__device__ __forceinline__ void bvb_rec_keys(const float4 &mn, const float4 &mx, uint32_t i, bool valid, unsigned long long k6[6]) {
     for (int j = 0; j < 3; ++j) { k6[j] = BVB_MIN_IDENT; k6[3 + j] = BVB_MAX_IDENT; }
     if (!valid) return;
-    for (uint32_t k = 0; k < 3u; ++k) {
-        const uint32_t seq = i * 3u + k;
-        const float c[3] = {v[k].x, v[k].y, v[k].z};
-        for (int j = 0; j < 3; ++j) {
-            const unsigned long long lo = bvb_min_key(c[j], seq), hi = bvb_max_key(c[j], seq);
-            k6[j] = lo < k6[j] ? lo : k6[j];
-            k6[3 + j] = hi > k6[3 + j] ? hi : k6[3 + j];
-        }
+    const uint32_t who = __float_as_uint(mn.w);
+    const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+    for (int j = 0; j < 3; ++j) {
+        k6[j] = bvb_min_key(lo[j], i * 3u + ((who >> (2 * j)) & 3u));
+        k6[3 + j] = bvb_max_key(hi[j], i * 3u + ((who >> (2 * (3 + j))) & 3u));
     }
 }
 __device__ __forceinline__ unsigned long long bvb_shfl_xor_u64(unsigned long long v, int d) {
@@ -163,23 +254,22 @@ __device__ __forceinline__ void bvb_wave_fold(const unsigned long long k6[6], un
             out[3 + j] = b > out[3 + j] ? b : out[3 + j];
         }
 }
-/* every lane of the wave calls (valid: the lane holds a triangle whose bin on this axis is si); folded: bvb_wave_fold of the wave's keys, computed by the caller
- * once for all axes when it may be needed */
-__device__ __forceinline__ void bvb_bin_add(unsigned long long (*key)[6], uint32_t *cnt, bool valid, uint32_t si, const unsigned long long k6[6],
-                                            const unsigned long long folded[6], bool folded_ok) {
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
-    if (act == 0ull) return;
-    const int lead = __ffsll((long long)act) - 1;
-    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)si, lead);
-    if (folded_ok && __builtin_amdgcn_ballot_w64(valid && si == b0) == act) {
-        if ((int)(threadIdx.x & 63u) == lead) {
-            for (int j = 0; j < 3; ++j) { atomicMin(&key[b0][j], folded[j]); atomicMax(&key[b0][3 + j], folded[3 + j]); }
-            atomicAdd(&cnt[b0], (uint32_t)__popcll(act));
-        }
-    } else if (valid) {
-        for (int j = 0; j < 3; ++j) { atomicMin(&key[si][j], k6[j]); atomicMax(&key[si][3 + j], k6[3 + j]); }
-        atomicAdd(&cnt[si], 1u);
-    }
+/* the element a thread takes in the bin pass: NOT its neighbour's neighbour.  In spatially ordered input (a scene file's meshes, an earlier build's leaf order)
+ * the 64 triangles at consecutive positions fall into one or two bins of every axis, and an LDS atomic on one address is served lane by lane: the bin pass took
+ * twice as long as on shuffled input.  An affine bijection of [0, 2^k) (odd multiplier), cycle-walked into [0, n), deals the node's positions to the lanes
+ * like a shuffle; the keys carry the element's own position, so who folds an element into its bin is immaterial. */
+__device__ __forceinline__ uint32_t bvb_scatter_index(uint32_t i, uint32_t n, uint32_t mask /* 2^k - 1 >= n - 1 */) {
+    uint32_t j = i;
+    do { j = (j * 0x9E3779B1u + 0x7F4A7C15u) & mask; } while (j >= n);
+    return j;
+}
+__device__ __forceinline__ uint32_t bvb_mask_for(uint32_t n) { return n <= 1u ? 0u : (0xffffffffu >> __builtin_clz(n - 1u)); }
+
+/* a triangle (six keys) into bin si of one axis */
+__device__ __forceinline__ void bvb_bin_add(unsigned long long (*key)[6], uint32_t *cnt, bool valid, uint32_t si, const unsigned long long k6[6]) {
+    if (!valid) return;
+    for (int j = 0; j < 3; ++j) { atomicMin(&key[si][j], k6[j]); atomicMax(&key[si][3 + j], k6[3 + j]); }
+    atomicAdd(&cnt[si], 1u);
 }
 
 /* ---- the sweep over the bins of one axis (bvh.rs:214-253) as two wave scans ---------------------------------------------------------------------------
@@ -268,8 +358,8 @@ __device__ __forceinline__ void bvb_wave_sweep(const unsigned long long (*key)[6
     best_i = cost == __builtin_inff() ? 0u : at;
 }
 
-/* THREADS = 1024 for the few huge nodes at the top of the tree (a workgroup walks its node's whole range), 256 below, 64 — one wave per node — for levels whose
- * largest node has at most 64 triangles (the deep levels of a tree with small leaves: 0.4 M nodes of two to eight triangles each on the scattered stand-in) */
+/* THREADS = 1024 for levels whose largest node has 16 384+ triangles or that have fewer than 64 nodes (a workgroup walks its node's whole range), 256 below, 64 — one
+ * wave per node — for levels whose largest node has at most 256 triangles (nodes of up to 64 go to k_bvb_small, of up to 8 to k_bvb_tiny) */
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level_begin, uint32_t skip_upto) {
     constexpr uint32_t AXES = THREADS >= 192 ? 3u : 1u;            /* axes binned at once */
@@ -280,7 +370,6 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
     __shared__ float s_best_cost[3];
     __shared__ uint32_t s_best_i[3];
     __shared__ uint32_t s_wave_tot[THREADS / 64];
-    __shared__ uint32_t s_misc[4];
     __shared__ float s_split;
     __shared__ int s_axis;
 
@@ -301,18 +390,13 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
         uint32_t cmin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, cmax[3] = {0u, 0u, 0u};
         for (uint32_t i = tid; i < count; i += THREADS) {
             const uint32_t tri = a.order[first + i];
-            const uint4 t = a.tris[tri];
-            const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
-            for (uint32_t k = 0; k < 3u; ++k) {
-                const uint32_t seq = i * 3u + k;
-                const float c[3] = {v[k].x, v[k].y, v[k].z};
-                for (int j = 0; j < 3; ++j) {
-                    unsigned long long lo = bvb_min_key(c[j], seq), hi = bvb_max_key(c[j], seq);
-                    kmin[j] = lo < kmin[j] ? lo : kmin[j];
-                    kmax[j] = hi > kmax[j] ? hi : kmax[j];
-                }
+            const float4 r_mn = a.recs[tri].mn, r_mx = a.recs[tri].mx, ce = a.recs[tri].ce;
+            unsigned long long k6[6];
+            bvb_rec_keys(r_mn, r_mx, i, true, k6);
+            for (int j = 0; j < 3; ++j) {
+                kmin[j] = k6[j] < kmin[j] ? k6[j] : kmin[j];
+                kmax[j] = k6[3 + j] > kmax[j] ? k6[3 + j] : kmax[j];
             }
-            const float4 ce = a.centroid[tri];
             const float cc[3] = {ce.x, ce.y, ce.z};
             for (int j = 0; j < 3; ++j) {
                 uint32_t nz;
@@ -321,12 +405,24 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
                 cmax[j] = o > cmax[j] ? o : cmax[j];
             }
         }
-        for (int j = 0; j < 3; ++j) {
-            atomicMin(&s_red[j], kmin[j]);
-            atomicMax(&s_red[3 + j], kmax[j]);
-            atomicMin(&s_cb[j], cmin[j]);
-            atomicMax(&s_cb[3 + j], cmax[j]);
-        }
+        /* the wave's fold by shuffles, then ONE lane per wave into the workgroup's words: an LDS atomic on one address is served lane by lane — 1 024 threads
+         * x 12 of them were 0.10 of the 0.24 ms a 16 k-triangle node took */
+        for (int d = 32; d >= 1; d >>= 1)
+            for (int j = 0; j < 3; ++j) {
+                const unsigned long long x = bvb_shfl_xor_u64(kmin[j], d), y = bvb_shfl_xor_u64(kmax[j], d);
+                kmin[j] = x < kmin[j] ? x : kmin[j];
+                kmax[j] = y > kmax[j] ? y : kmax[j];
+                const uint32_t lo = (uint32_t)__shfl_xor((int)cmin[j], d, 64), hi = (uint32_t)__shfl_xor((int)cmax[j], d, 64);
+                cmin[j] = lo < cmin[j] ? lo : cmin[j];
+                cmax[j] = hi > cmax[j] ? hi : cmax[j];
+            }
+        if ((tid & 63u) == 0u)
+            for (int j = 0; j < 3; ++j) {
+                atomicMin(&s_red[j], kmin[j]);
+                atomicMax(&s_red[3 + j], kmax[j]);
+                atomicMin(&s_cb[j], cmin[j]);
+                atomicMax(&s_cb[3 + j], cmax[j]);
+            }
     }
     __syncthreads();
     if (tid < 3u) {
@@ -346,6 +442,7 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
         axis_on[j] = !(bmin[j] == bmax[j]);
         scale[j] = (float)S / (bmax[j] - bmin[j]);
     }
+    const uint32_t deal_mask = bvb_mask_for(count);
     for (uint32_t pass = 0; pass < 3u / AXES; ++pass) {
         for (uint32_t k = tid; k < AXES * BVB_MAX_BINS; k += THREADS) {
             const uint32_t slot = k / BVB_MAX_BINS, b = k % BVB_MAX_BINS;
@@ -354,29 +451,25 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
         }
         __syncthreads();
         for (uint32_t base = 0; base < count; base += THREADS) {
-            const uint32_t i = base + tid;
-            const bool have = i < count;
-            float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+            const bool have = base + tid < count;
+            const uint32_t i = have ? bvb_scatter_index(base + tid, count, deal_mask) : 0u;
+            float4 r_mn = make_float4(0, 0, 0, 0), r_mx = make_float4(0, 0, 0, 0);
             float cc[3] = {0.0f, 0.0f, 0.0f};
             if (have) {
                 const uint32_t tri = a.order[first + i];
-                const uint4 t = a.tris[tri];
-                v[0] = a.verts[t.x]; v[1] = a.verts[t.y]; v[2] = a.verts[t.z];
-                const float4 ce = a.centroid[tri];
+                r_mn = a.recs[tri].mn; r_mx = a.recs[tri].mx;
+                const float4 ce = a.recs[tri].ce;
                 cc[0] = ce.x; cc[1] = ce.y; cc[2] = ce.z;
             }
-            unsigned long long k6[6], folded[6];
-            bvb_tri_keys(v, i, have, k6);
-            /* (a full wave of triangles: the fold is worth its 72 shuffles only if some axis then finds the wave in one bin — decided per axis below) */
-            const bool fold = __builtin_amdgcn_ballot_w64(have) == ~0ull;
-            if (fold) bvb_wave_fold(k6, folded);
+            unsigned long long k6[6];
+            bvb_rec_keys(r_mn, r_mx, i, have, k6);
             for (uint32_t slot = 0; slot < AXES; ++slot) {
                 const uint32_t ax = AXES == 3u ? slot : pass;
                 if (!axis_on[ax]) continue;
                 const float x = (cc[ax] - bmin[ax]) * scale[ax];
                 uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;      /* `as usize` then min(S-1) */
                 if (si > S - 1u) si = S - 1u;
-                bvb_bin_add(s_key[slot], s_cnt[slot], have, si, k6, folded, fold);
+                bvb_bin_add(s_key[slot], s_cnt[slot], have, si, k6);
             }
         }
         __syncthreads();
@@ -422,92 +515,52 @@ __global__ __launch_bounds__(THREADS) void k_bvb_level(BvbArgs a, uint32_t level
     }
     const float split = s_split;
 
-    /* ---- the partition (bvh.rs:281-292) in closed form (file header) */
-    auto is_left = [&](uint32_t pos) {
-        const float4 ce = a.centroid[a.order[pos]];
-        const float c = axis == 0 ? ce.x : (axis == 1 ? ce.y : ce.z);
-        return c < split;
-    };
-    uint32_t nl;
-    {
-        uint32_t mine = 0u;
-        for (uint32_t i = tid; i < count; i += THREADS) {
-            const bool l = is_left(first + i);
-            a.side[first + i] = l ? 1u : 0u;
-            mine += l ? 1u : 0u;
+    /* ---- the partition (bvh.rs:281-292) in closed form (file header), every quantity from L(p) = left-side elements before p (bvb_count_left):
+     * hole rank of a prefix position p = (p - first) - L(p);  for a suffix position q: m(q) = nl - L(q + 1) left-side elements above it, rb(q) = (last - q) - m(q)
+     * right-side elements above it */
+    const uint32_t nl = bvb_count_left<THREADS>(a, first, first + count, axis, split, s_wave_tot);
+    __syncthreads();
+    __threadfence_block();
+    const uint32_t split_pos = first + nl;                         /* prefix = [first, split_pos), suffix = [split_pos, last] */
+    const uint32_t H = nl - (nl < count ? (a.lpre[split_pos] >> 1) : nl);      /* holes: right-side elements in the prefix */
+    /* pass B1: rb_at_L[m] = right-side elements above the m-th left-side element of the suffix (counted from the top) */
+    for (uint32_t q = split_pos + tid; q <= last; q += THREADS) {
+        const uint32_t w = a.lpre[q];
+        if (w & 1u) {
+            const uint32_t m = nl - ((w >> 1) + 1u);
+            a.tmp_b[first + m] = (last - q) - m;
         }
-        if (tid == 0u) s_misc[0] = 0u;
-        __syncthreads();
-        atomicAdd(&s_misc[0], mine);
-        __syncthreads();
-        nl = s_misc[0];
-    }
-    const uint32_t back_n = count - nl;                 /* suffix positions first+nl .. last */
-    /* pass B1: suffix, descending — rb_at_L[m] = right-side elements above the m-th left-side element */
-    uint32_t H = 0u;
-    {
-        uint32_t run_l = 0u, run_r = 0u;
-        for (uint32_t base = 0; base < back_n; base += THREADS) {
-            const uint32_t i = base + tid;
-            const bool valid = i < back_n;
-            const uint32_t q = last - i;
-            const bool L = valid && (a.side[q] != 0u);
-            const bool R = valid && !L;
-            uint32_t tot_l, tot_r;
-            const uint32_t m = run_l + bvb_block_rank<THREADS>(L, s_wave_tot, tot_l);
-            const uint32_t rb = run_r + bvb_block_rank<THREADS>(R, s_wave_tot, tot_r);
-            if (L) a.tmp_b[first + m] = rb;
-            run_l += tot_l;
-            run_r += tot_r;
-        }
-        H = run_l;
     }
     __syncthreads();
     __threadfence_block();
     const uint32_t base_rb = H >= 1u ? a.tmp_b[first + H - 1u] : 0u;
-    /* pass F: prefix, ascending */
-    {
-        uint32_t run = 0u;
-        for (uint32_t base = 0; base < nl; base += THREADS) {
-            const uint32_t i = base + tid;
-            const bool valid = i < nl;
-            const uint32_t p = first + i;
-            const bool L = valid && (a.side[p] != 0u);
-            const bool R = valid && !L;
-            uint32_t tot;
-            const uint32_t hole = run + bvb_block_rank<THREADS>(R, s_wave_tot, tot);
-            if (L) a.order_tmp[p] = a.order[p];
-            if (R) {
-                const uint32_t rank = hole + (hole >= 1u ? a.tmp_b[first + hole - 1u] : 0u);
-                a.order_tmp[last - rank] = a.order[p];
-                a.tmp_a[first + hole] = p;
-            }
-            run += tot;
+    /* pass F: the prefix */
+    for (uint32_t p = first + tid; p < split_pos; p += THREADS) {
+        const uint32_t w = a.lpre[p];
+        if (w & 1u) {
+            a.order_tmp[p] = a.order[p];
+        } else {
+            const uint32_t hole = (p - first) - (w >> 1);
+            const uint32_t rank = hole + (hole >= 1u ? a.tmp_b[first + hole - 1u] : 0u);
+            a.order_tmp[last - rank] = a.order[p];
+            a.tmp_a[first + hole] = p;
         }
     }
     __syncthreads();
     __threadfence_block();
-    /* pass B2: suffix again, now every destination is known */
-    {
-        uint32_t run_l = 0u, run_r = 0u;
-        for (uint32_t base = 0; base < back_n; base += THREADS) {
-            const uint32_t i = base + tid;
-            const bool valid = i < back_n;
-            const uint32_t q = last - i;
-            const bool L = valid && (a.side[q] != 0u);
-            const bool R = valid && !L;
-            uint32_t tot_l, tot_r;
-            const uint32_t m = run_l + bvb_block_rank<THREADS>(L, s_wave_tot, tot_l);
-            const uint32_t rb = run_r + bvb_block_rank<THREADS>(R, s_wave_tot, tot_r);
-            if (L) a.order_tmp[a.tmp_a[first + m]] = a.order[q];
-            if (R) {
-                uint32_t rank;
-                if (m == H) rank = (q == first + nl) ? H + base_rb : H + rb + 1u;
-                else rank = (m + 1u) + rb;
-                a.order_tmp[last - rank] = a.order[q];
-            }
-            run_l += tot_l;
-            run_r += tot_r;
+    /* pass B2: the suffix, now every destination is known */
+    for (uint32_t q = split_pos + tid; q <= last; q += THREADS) {
+        const uint32_t w = a.lpre[q];
+        if (w & 1u) {
+            const uint32_t m = nl - ((w >> 1) + 1u);
+            a.order_tmp[a.tmp_a[first + m]] = a.order[q];
+        } else {
+            const uint32_t m = nl - (w >> 1);
+            const uint32_t rb = (last - q) - m;
+            uint32_t rank;
+            if (m == H) rank = (q == split_pos) ? H + base_rb : H + rb + 1u;
+            else rank = (m + 1u) + rb;
+            a.order_tmp[last - rank] = a.order[q];
         }
     }
     __syncthreads();
@@ -580,18 +633,17 @@ __global__ __launch_bounds__(64) void k_bvb_small(BvbArgs a, uint32_t level_begi
     }
     const bool have = lane < count;
     uint32_t tri = 0u;
-    float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    float4 r_mn = make_float4(0, 0, 0, 0), r_mx = make_float4(0, 0, 0, 0);
     float cc[3] = {0.0f, 0.0f, 0.0f};
     if (have) {
         tri = a.order[first + lane];
-        const uint4 t = a.tris[tri];
-        v[0] = a.verts[t.x]; v[1] = a.verts[t.y]; v[2] = a.verts[t.z];
-        const float4 ce = a.centroid[tri];
+        r_mn = a.recs[tri].mn; r_mx = a.recs[tri].mx;
+        const float4 ce = a.recs[tri].ce;
         cc[0] = ce.x; cc[1] = ce.y; cc[2] = ce.z;
     }
     /* ---- update_node_aabb: the fold of the wave's keys */
     unsigned long long k6[6], red[6];
-    bvb_tri_keys(v, lane, have, k6);
+    bvb_rec_keys(r_mn, r_mx, lane, have, k6);
     bvb_wave_fold(k6, red);
     uint32_t cb[6];
     for (int j = 0; j < 3; ++j) {
@@ -712,18 +764,17 @@ __global__ __launch_bounds__(64) void k_bvb_tiny(BvbArgs a, uint32_t level_begin
     const uint32_t S = a.bins;
     const bool have = mine && l < count;
     uint32_t tri = 0u;
-    float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    float4 r_mn = make_float4(0, 0, 0, 0), r_mx = make_float4(0, 0, 0, 0);
     float cc[3] = {0.0f, 0.0f, 0.0f};
     if (have) {
         tri = a.order[first + l];
-        const uint4 t = a.tris[tri];
-        v[0] = a.verts[t.x]; v[1] = a.verts[t.y]; v[2] = a.verts[t.z];
-        const float4 ce = a.centroid[tri];
+        r_mn = a.recs[tri].mn; r_mx = a.recs[tri].mx;
+        const float4 ce = a.recs[tri].ce;
         cc[0] = ce.x; cc[1] = ce.y; cc[2] = ce.z;
     }
     /* ---- update_node_aabb over the group */
     unsigned long long k6[6], red[6];
-    bvb_tri_keys(v, l, have, k6);
+    bvb_rec_keys(r_mn, r_mx, l, have, k6);
     uint32_t cb[6];
     for (int j = 0; j < 3; ++j) {
         uint32_t nz;
@@ -890,7 +941,7 @@ struct BvbTeamScratch {
     unsigned long long key[3][BVB_MAX_BINS][6];
     uint32_t cb[6];
     uint32_t cnt[3][BVB_MAX_BINS];
-    uint32_t chunk_l[BVB_TEAM], chunk_lf[BVB_TEAM];
+    uint32_t chunk_l[BVB_TEAM];
     uint32_t barrier;
     int axis;
     float split;
@@ -906,7 +957,7 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team_init(BvbTeamScrat
         for (int j = 0; j < 6; ++j) t.key[ax][b][j] = j < 3 ? BVB_MIN_IDENT : BVB_MAX_IDENT;
         t.cnt[ax][b] = 0u;
     }
-    for (uint32_t k = tid; k < BVB_TEAM; k += BVB_TEAM_THREADS) { t.chunk_l[k] = 0u; t.chunk_lf[k] = 0u; }
+    for (uint32_t k = tid; k < BVB_TEAM; k += BVB_TEAM_THREADS) t.chunk_l[k] = 0u;
     if (tid == 0u) {
         t.barrier = 0u; t.axis = -1; t.split = 0.0f;
         t.node_id = refs[blockIdx.x].node_id; t.size = refs[blockIdx.x].size; t.first_block = refs[blockIdx.x].first_block;
@@ -934,7 +985,6 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
     __shared__ float s_best_cost[3];
     __shared__ uint32_t s_best_i[3];
     __shared__ uint32_t s_wave_tot[THREADS / 64];
-    __shared__ uint32_t s_misc[4];
 
     const uint32_t tid = threadIdx.x;
     BvbTeamScratch &T = scratch[block_team[blockIdx.x]];
@@ -956,18 +1006,13 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) {
             const uint32_t i = pos - first;
             const uint32_t tri = a.order[pos];
-            const uint4 t = a.tris[tri];
-            const float4 v[3] = {a.verts[t.x], a.verts[t.y], a.verts[t.z]};
-            for (uint32_t k = 0; k < 3u; ++k) {
-                const uint32_t seq = i * 3u + k;
-                const float c[3] = {v[k].x, v[k].y, v[k].z};
-                for (int j = 0; j < 3; ++j) {
-                    unsigned long long lo = bvb_min_key(c[j], seq), hi = bvb_max_key(c[j], seq);
-                    kmin[j] = lo < kmin[j] ? lo : kmin[j];
-                    kmax[j] = hi > kmax[j] ? hi : kmax[j];
-                }
+            const float4 r_mn = a.recs[tri].mn, r_mx = a.recs[tri].mx, ce = a.recs[tri].ce;
+            unsigned long long k6[6];
+            bvb_rec_keys(r_mn, r_mx, i, true, k6);
+            for (int j = 0; j < 3; ++j) {
+                kmin[j] = k6[j] < kmin[j] ? k6[j] : kmin[j];
+                kmax[j] = k6[3 + j] > kmax[j] ? k6[3 + j] : kmax[j];
             }
-            const float4 ce = a.centroid[tri];
             const float cc[3] = {ce.x, ce.y, ce.z};
             for (int j = 0; j < 3; ++j) {
                 uint32_t nz;
@@ -976,12 +1021,24 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
                 cmax[j] = o > cmax[j] ? o : cmax[j];
             }
         }
-        for (int j = 0; j < 3; ++j) {
-            atomicMin(&s_red[j], kmin[j]);
-            atomicMax(&s_red[3 + j], kmax[j]);
-            atomicMin(&s_cb[j], cmin[j]);
-            atomicMax(&s_cb[3 + j], cmax[j]);
-        }
+        /* the wave's fold by shuffles, then ONE lane per wave into the workgroup's words: an LDS atomic on one address is served lane by lane — 1 024 threads
+         * x 12 of them were 0.10 of the 0.24 ms a 16 k-triangle node took */
+        for (int d = 32; d >= 1; d >>= 1)
+            for (int j = 0; j < 3; ++j) {
+                const unsigned long long x = bvb_shfl_xor_u64(kmin[j], d), y = bvb_shfl_xor_u64(kmax[j], d);
+                kmin[j] = x < kmin[j] ? x : kmin[j];
+                kmax[j] = y > kmax[j] ? y : kmax[j];
+                const uint32_t lo = (uint32_t)__shfl_xor((int)cmin[j], d, 64), hi = (uint32_t)__shfl_xor((int)cmax[j], d, 64);
+                cmin[j] = lo < cmin[j] ? lo : cmin[j];
+                cmax[j] = hi > cmax[j] ? hi : cmax[j];
+            }
+        if ((tid & 63u) == 0u)
+            for (int j = 0; j < 3; ++j) {
+                atomicMin(&s_red[j], kmin[j]);
+                atomicMax(&s_red[3 + j], kmax[j]);
+                atomicMin(&s_cb[j], cmin[j]);
+                atomicMax(&s_cb[3 + j], cmax[j]);
+            }
     }
     __syncthreads();
     if (tid < 3u) {
@@ -1013,29 +1070,27 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         axis_on[j] = !(bmin[j] == bmax[j]);
         scale[j] = (float)S / (bmax[j] - bmin[j]);
     }
-    for (uint32_t base = c_begin; base < c_end; base += THREADS) {
-        const uint32_t pos = base + tid;
-        const bool have = pos < c_end;
+    const uint32_t c_n = c_end - c_begin, deal_mask = bvb_mask_for(c_n);
+    for (uint32_t base = 0; base < c_n; base += THREADS) {
+        const bool have = base + tid < c_n;
+        const uint32_t pos = c_begin + (have ? bvb_scatter_index(base + tid, c_n, deal_mask) : 0u);
         const uint32_t i = pos - first;
-        float4 v[3] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+        float4 r_mn = make_float4(0, 0, 0, 0), r_mx = make_float4(0, 0, 0, 0);
         float cc[3] = {0.0f, 0.0f, 0.0f};
         if (have) {
             const uint32_t tri = a.order[pos];
-            const uint4 t = a.tris[tri];
-            v[0] = a.verts[t.x]; v[1] = a.verts[t.y]; v[2] = a.verts[t.z];
-            const float4 ce = a.centroid[tri];
+            r_mn = a.recs[tri].mn; r_mx = a.recs[tri].mx;
+            const float4 ce = a.recs[tri].ce;
             cc[0] = ce.x; cc[1] = ce.y; cc[2] = ce.z;
         }
-        unsigned long long k6[6], folded[6];
-        bvb_tri_keys(v, i, have, k6);
-        const bool fold = __builtin_amdgcn_ballot_w64(have) == ~0ull;
-        if (fold) bvb_wave_fold(k6, folded);
+        unsigned long long k6[6];
+        bvb_rec_keys(r_mn, r_mx, i, have, k6);
         for (int ax = 0; ax < 3; ++ax) {
             if (!axis_on[ax]) continue;
             const float x = (cc[ax] - bmin[ax]) * scale[ax];
             uint32_t si = x > 0.0f ? (x >= (float)S ? S - 1u : (uint32_t)x) : 0u;
             if (si > S - 1u) si = S - 1u;
-            bvb_bin_add(s_key[ax], s_cnt[ax], have, si, k6, folded, fold);
+            bvb_bin_add(s_key[ax], s_cnt[ax], have, si, k6);
         }
     }
     __syncthreads();
@@ -1093,27 +1148,15 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         return;                                                   /* team-uniform */
     }
     const float split = T.split;
-    auto is_left = [&](uint32_t pos) {
-        const float4 ce = a.centroid[a.order[pos]];
-        const float c = axis == 0 ? ce.x : (axis == 1 ? ce.y : ce.z);
-        return c < split;
-    };
 
-    /* ---- pass 4: left counts per chunk -> nl and this chunk's prefix */
+    /* ---- pass 4: left-side elements before every position of the chunk (bvb_count_left) -> this chunk's count */
     {
-        uint32_t mine = 0u;
-        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) {
-            const bool l = is_left(pos);
-            a.side[pos] = l ? 1u : 0u;                             /* (read back by this workgroup only: its chunk) */
-            mine += l ? 1u : 0u;
-        }
-        if (tid == 0u) s_misc[0] = 0u;
-        __syncthreads();
-        atomicAdd(&s_misc[0], mine);
-        __syncthreads();
-        if (tid == 0u) T.chunk_l[member] = s_misc[0];
+        const uint32_t mine = bvb_count_left<THREADS>(a, c_begin, c_end, axis, split, s_wave_tot);
+        if (tid == 0u) T.chunk_l[member] = mine;
     }
     bvb_team_sync(&T.barrier, phase, team_size);
+    /* nl, this chunk's prefix, and L(split position) = the left-side elements inside the prefix: the count before the chunk that holds the split position
+     * + that position's own word (written by that chunk's workgroup before the barrier) */
     uint32_t nl = 0u, pref_l = 0u;
     for (uint32_t b = 0; b < team_size; ++b) {
         const uint32_t n = __hip_atomic_load(&T.chunk_l[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1121,86 +1164,51 @@ __global__ __launch_bounds__(BVB_TEAM_THREADS) void k_bvb_team(BvbArgs a, BvbTea
         nl += n;
     }
     const uint32_t split_pos = first + nl;                       /* prefix = [first, split_pos), suffix = [split_pos, last] */
-    /* ---- pass 5: left-side elements inside the prefix -> H (holes) */
-    {
-        uint32_t mine = 0u;
-        for (uint32_t pos = c_begin + tid; pos < c_end; pos += THREADS) mine += (pos < split_pos && (a.side[pos] != 0u)) ? 1u : 0u;
-        __syncthreads();
-        if (tid == 0u) s_misc[0] = 0u;
-        __syncthreads();
-        atomicAdd(&s_misc[0], mine);
-        __syncthreads();
-        if (tid == 0u) T.chunk_lf[member] = s_misc[0];
+    uint32_t l_in_prefix = nl;
+    if (nl < count) {
+        const uint32_t c_split = nl / chunk;
+        l_in_prefix = __hip_atomic_load(&a.lpre[split_pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 1;
+        for (uint32_t b = 0; b < c_split; ++b) l_in_prefix += __hip_atomic_load(&T.chunk_l[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    bvb_team_sync(&T.barrier, phase, team_size);
-    uint32_t l_in_prefix = 0u;
-    for (uint32_t b = 0; b < team_size; ++b) l_in_prefix += __hip_atomic_load(&T.chunk_lf[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t H = nl - l_in_prefix;
 
     /* ---- pass 6 (B1): rb_at_L for the suffix left-side elements of this chunk */
-    {
-        uint32_t run = pref_l;                                    /* left-side elements before the current tile */
-        for (uint32_t base = c_begin; base < c_end; base += THREADS) {
-            const uint32_t q = base + tid;
-            const bool valid = q < c_end;
-            const bool L = valid && (a.side[q] != 0u);
-            uint32_t tot;
-            const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
-            if (L && q >= split_pos) {
-                const uint32_t m = nl - (l_before + 1u);
-                a.tmp_b[first + m] = (last - q) - m;
-            }
-            run += tot;
+    for (uint32_t q = (c_begin > split_pos ? c_begin : split_pos) + tid; q < c_end; q += THREADS) {
+        const uint32_t w = a.lpre[q];
+        if (w & 1u) {
+            const uint32_t m = nl - (pref_l + (w >> 1) + 1u);
+            a.tmp_b[first + m] = (last - q) - m;
         }
     }
     bvb_team_sync(&T.barrier, phase, team_size);
     const uint32_t base_rb = H >= 1u ? __hip_atomic_load(&a.tmp_b[first + H - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     /* ---- pass 7 (F): the prefix */
-    {
-        uint32_t run = pref_l;
-        for (uint32_t base = c_begin; base < c_end; base += THREADS) {
-            const uint32_t p = base + tid;
-            const bool valid = p < c_end;
-            const bool L = valid && (a.side[p] != 0u);
-            uint32_t tot;
-            const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
-            if (valid && p < split_pos) {
-                if (L) {
-                    a.order_tmp[p] = a.order[p];
-                } else {
-                    const uint32_t hole = (p - first) - l_before;
-                    const uint32_t rank = hole + (hole >= 1u ? __hip_atomic_load(&a.tmp_b[first + hole - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
-                    a.order_tmp[last - rank] = a.order[p];
-                    a.tmp_a[first + hole] = p;
-                }
-            }
-            run += tot;
+    for (uint32_t p = c_begin + tid; p < c_end && p < split_pos; p += THREADS) {
+        const uint32_t w = a.lpre[p];
+        if (w & 1u) {
+            a.order_tmp[p] = a.order[p];
+        } else {
+            const uint32_t hole = (p - first) - (pref_l + (w >> 1));
+            const uint32_t rank = hole + (hole >= 1u ? __hip_atomic_load(&a.tmp_b[first + hole - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u);
+            a.order_tmp[last - rank] = a.order[p];
+            a.tmp_a[first + hole] = p;
         }
     }
     bvb_team_sync(&T.barrier, phase, team_size);
     /* ---- pass 8 (B2): the suffix */
-    {
-        uint32_t run = pref_l;
-        for (uint32_t base = c_begin; base < c_end; base += THREADS) {
-            const uint32_t q = base + tid;
-            const bool valid = q < c_end;
-            const bool L = valid && (a.side[q] != 0u);
-            uint32_t tot;
-            const uint32_t l_before = run + bvb_block_rank<THREADS>(L, s_wave_tot, tot);
-            if (valid && q >= split_pos) {
-                if (L) {
-                    const uint32_t m = nl - (l_before + 1u);
-                    a.order_tmp[__hip_atomic_load(&a.tmp_a[first + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = a.order[q];
-                } else {
-                    const uint32_t m = nl - l_before;
-                    const uint32_t rb = (last - q) - m;
-                    uint32_t rank;
-                    if (m == H) rank = (q == split_pos) ? H + base_rb : H + rb + 1u;
-                    else rank = (m + 1u) + rb;
-                    a.order_tmp[last - rank] = a.order[q];
-                }
-            }
-            run += tot;
+    for (uint32_t q = (c_begin > split_pos ? c_begin : split_pos) + tid; q < c_end; q += THREADS) {
+        const uint32_t w = a.lpre[q];
+        const uint32_t l_before = pref_l + (w >> 1);
+        if (w & 1u) {
+            const uint32_t m = nl - (l_before + 1u);
+            a.order_tmp[__hip_atomic_load(&a.tmp_a[first + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = a.order[q];
+        } else {
+            const uint32_t m = nl - l_before;
+            const uint32_t rb = (last - q) - m;
+            uint32_t rank;
+            if (m == H) rank = (q == split_pos) ? H + base_rb : H + rb + 1u;
+            else rank = (m + 1u) + rb;
+            a.order_tmp[last - rank] = a.order[q];
         }
     }
     bvb_team_sync(&T.barrier, phase, team_size);

@@ -28,20 +28,12 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     if (sah_samples < 2) sah_samples = 2;
     if (sah_samples > BVB_MAX_BINS) { rpt_create_error() = "rpt_bvh_build_gpu: at most 128 SAH bins"; return RPT_EINVAL; }
     if (n_triangles >= (1u << 28)) { rpt_create_error() = "rpt_bvh_build_gpu: too many triangles"; return RPT_EINVAL; }
+    if (n_vertices > 0xffffffffull) { rpt_create_error() = "rpt_bvh_build_gpu: too many vertices"; return RPT_EINVAL; }
     if (nodes_capacity < 2 * n_triangles - 1) { rpt_create_error() = "rpt_bvh_build_gpu: node buffer needs 2N-1 entries"; return RPT_EINVAL; }
-    for (size_t i = 0; i < n_triangles; ++i)
-        if (triangles[i].v0 >= n_vertices || triangles[i].v1 >= n_vertices || triangles[i].v2 >= n_vertices) {
-            rpt_create_error() = "rpt_bvh_build_gpu: vertex index out of range";
-            return RPT_ESCENE;
-        }
-    /* The ordered 64-bit keys that reproduce the builder's f32::min / max folds (k_bvh_build.h) have no place for a NaN, which
-     * those folds SKIP (src/bvh.rs via f32::min): with a NaN coordinate this build and the sequential one part ways (found by
-     * tools/bvh_nan_probe.py; infinities, denormals and coincident points are fine).  Said, not built around. */
-    for (size_t i = 0; i < n_vertices; ++i)
-        if (vertices_xyzw[4 * i] != vertices_xyzw[4 * i] || vertices_xyzw[4 * i + 1] != vertices_xyzw[4 * i + 1] || vertices_xyzw[4 * i + 2] != vertices_xyzw[4 * i + 2]) {
-            rpt_create_error() = "rpt_bvh_build_gpu: a vertex coordinate is NaN — such a scene must be built by the host builder (rpt_bvh_build)";
-            return RPT_ESCENE;
-        }
+    /* (vertex indices in range, no NaN coordinate: checked by k_bvb_init where the triangles are gathered anyway — two host loops over the scene were 1.8 ms of a
+     *  1 M-triangle build.  The ordered 64-bit keys that reproduce the builder's f32::min / max folds (k_bvh_build.h) have no place for a NaN, which those folds
+     *  SKIP (src/bvh.rs via f32::min): with a NaN coordinate this build and the sequential one part ways (found by tools/bvh_nan_probe.py; infinities, denormals
+     *  and coincident points are fine).  Said, not built around: such a scene is refused.) */
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev == 0) { rpt_create_error() = "no HIP device"; return RPT_ENODEV; }
@@ -54,10 +46,11 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
             goto fail;                                                                                  \
         }                                                                                               \
     } while (0)
-    DevBuf<float4> d_verts, d_centroid;
+    DevBuf<float4> d_verts;
+    DevBuf<BvbRec> d_recs;
     DevBuf<uint4> d_tris;
     DevBuf<uint32_t> d_order, d_order_tmp, d_tmp_a, d_tmp_b, d_count;
-    DevBuf<uint8_t> d_side;
+    DevBuf<uint32_t> d_lpre;
     DevBuf<BvbNode> d_nodes;
     DevBuf<BvbTeamScratch> d_scratch;
     DevBuf<BvbTeamRef> d_team_refs;
@@ -72,18 +65,19 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     std::vector<BvbNode> bn;
     std::vector<uint32_t> order;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int fail_code = RPT_EHIP;
     sections.mark("validate");
     const uint32_t nt = (uint32_t)n_triangles;
     {
         BVB_TRY(hipSetDevice(device_id));
         BVB_TRY(d_verts.alloc(n_vertices));
         BVB_TRY(d_tris.alloc(nt));
-        BVB_TRY(d_centroid.alloc(nt));
+        BVB_TRY(d_recs.alloc(nt));
         BVB_TRY(d_order.alloc(nt));
         BVB_TRY(d_order_tmp.alloc(nt));
         BVB_TRY(d_tmp_a.alloc(nt));
         BVB_TRY(d_tmp_b.alloc(nt));
-        BVB_TRY(d_side.alloc(nt));
+        BVB_TRY(d_lpre.alloc(nt));
         BVB_TRY(d_count.alloc(3));                       /* BvbArgs::node_count */
         BVB_TRY(d_nodes.alloc(2 * (size_t)nt - 1));
         BVB_TRY(d_scratch.alloc(BVB_MAX_TEAMS));
@@ -99,7 +93,7 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
         BVB_TRY(hipEventCreate(&ev0));
         BVB_TRY(hipEventCreate(&ev1));
         sections.mark("alloc_h2d");
-        BvbArgs a{d_verts.p, d_tris.p, d_centroid.p, d_order.p, d_order_tmp.p, d_tmp_a.p, d_tmp_b.p, d_side.p, d_nodes.p, d_count.p, nt, sah_samples};
+        BvbArgs a{d_verts.p, d_tris.p, d_recs.p, d_order.p, d_order_tmp.p, d_tmp_a.p, d_tmp_b.p, d_lpre.p, d_nodes.p, d_count.p, nt, sah_samples, (uint32_t)n_vertices};
         BVB_TRY(hipEventRecord(ev0, nullptr));
         k_bvb_init<<<(nt + BVB_THREADS - 1) / BVB_THREADS, BVB_THREADS>>>(a);
         /* a team's workgroups meet at counter barriers (bvb_team_sync): every workgroup of the launch must be resident at
@@ -158,7 +152,10 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
             uint32_t total[3] = {0u, 0u, 0u};
             BVB_TRY(hipMemcpy(total, d_count.p, sizeof total, hipMemcpyDeviceToHost));
             if (total[2] != 0u) {
-                rpt_create_error() = "rpt_bvh_build_gpu: internal error, a level's largest node was misjudged";
+                if (total[2] & 2u) rpt_create_error() = "rpt_bvh_build_gpu: vertex index out of range";
+                else if (total[2] & 4u) rpt_create_error() = "rpt_bvh_build_gpu: a vertex coordinate is NaN — such a scene must be built by the host builder (rpt_bvh_build)";
+                else rpt_create_error() = "rpt_bvh_build_gpu: internal error, a level's largest node was misjudged";
+                fail_code = (total[2] & 6u) ? RPT_ESCENE : RPT_EHIP;
                 goto fail;
             }
             BVB_TRY(hipMemsetAsync(d_count.p + 1, 0, 4, nullptr));
@@ -199,17 +196,17 @@ int rpt_bvh_build_gpu(int device_id, const float *vertices_xyzw, size_t n_vertic
     }
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
-    d_tmp_a.release(); d_tmp_b.release(); d_side.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_refs.release(); d_block_team.release();
+    d_verts.release(); d_tris.release(); d_recs.release(); d_order.release(); d_order_tmp.release();
+    d_tmp_a.release(); d_tmp_b.release(); d_lpre.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_refs.release(); d_block_team.release();
     d_inner.release(); d_rank.release(); d_oidx.release(); d_out.release();
     return RPT_OK;
 fail:
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    d_verts.release(); d_tris.release(); d_centroid.release(); d_order.release(); d_order_tmp.release();
-    d_tmp_a.release(); d_tmp_b.release(); d_side.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_refs.release(); d_block_team.release();
+    d_verts.release(); d_tris.release(); d_recs.release(); d_order.release(); d_order_tmp.release();
+    d_tmp_a.release(); d_tmp_b.release(); d_lpre.release(); d_count.release(); d_nodes.release(); d_scratch.release(); d_team_refs.release(); d_block_team.release();
     d_inner.release(); d_rank.release(); d_oidx.release(); d_out.release();
-    return RPT_EHIP;
+    return fail_code;
 #undef BVB_TRY
 }
 
