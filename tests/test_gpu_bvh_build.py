@@ -258,3 +258,17 @@ def test_teams_of_every_size(monkeypatch, team_min):
     hn, ht = _oracle_build(v, t.copy())
     gn, gt, _ = hip.bvh_build_gpu(v, t.copy())
     _assert_same(gn, gt, hn, ht)
+
+
+def test_big_nodes_without_teams(monkeypatch):
+    """A device with no room for a team (CU-masked, partitioned) splits even the root with one workgroup: the threshold out of reach, 120 000 triangles in
+    spatial order — one 1 024-thread workgroup over the whole range, its bin pass dealing 120 000 positions to the lanes (bvb_scatter_index)."""
+    monkeypatch.setenv("RPT_BVH_TEAM_MIN", str(1 << 30))
+    rpt, hip, host = _mods()
+    from scenes import deep_bvh_scene
+    w = deep_bvh_scene(120_000)
+    v = np.ascontiguousarray(w.per_vertex["vertex"], np.float32).reshape(-1, 4)
+    for t in (w.indices.copy(), _original_soup(w)[1]):
+        hn, ht = _oracle_build(v, t.copy())
+        gn, gt, _ = hip.bvh_build_gpu(v, t.copy())
+        _assert_same(gn, gt, hn, ht)
